@@ -1,0 +1,101 @@
+"""ctypes binding of libfloodseg.so (the C ABI declared in include/floodseg.h).
+
+The product path has no CPU fallback: if the HIP library is missing or fails to load, importing
+the ops raises.  torch is imported first on purpose -- torch ships its own libamdhip64 (same
+soname), and device pointers / streams are only interchangeable inside ONE HIP runtime instance.
+"""
+import ctypes
+import os
+
+import torch  # noqa: F401  (must precede CDLL so both share torch's HIP runtime)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfloodseg.so")
+
+c_float_p = ctypes.POINTER(ctypes.c_float)
+c_void = ctypes.c_void_p
+c_int = ctypes.c_int
+c_i64 = ctypes.c_int64
+c_f32 = ctypes.c_float
+
+
+class FsConfig(ctypes.Structure):
+    _fields_ = [("arch", c_int), ("layers", c_int), ("classes", c_int)]
+
+
+ARCH_PSPNET = 0
+ARCH_DEEPLABV3 = 1
+
+# name -> (restype, argtypes); must list every symbol of include/floodseg.h
+_SIGNATURES = {
+    "fs_version": (c_int, []),
+    "fs_last_error": (ctypes.c_char_p, []),
+    "fs_create": (c_int, [ctypes.POINTER(FsConfig), ctypes.POINTER(c_void)]),
+    "fs_destroy": (c_int, [c_void]),
+    "fs_load_weight": (c_int, [c_void, ctypes.c_char_p, c_void, ctypes.POINTER(c_i64), c_int, c_int, c_void]),
+    "fs_finalize": (c_int, [c_void, c_void]),
+    "fs_feature_shape": (c_int, [c_void, c_int, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
+    "fs_workspace_bytes": (ctypes.c_size_t, [c_void, c_int, c_int, c_int]),
+    "fs_encoder_forward": (c_int, [c_void, c_void, c_int, c_int, c_int, c_void, c_void]),
+    "fs_decoder_forward": (c_int, [c_void, c_void, c_int, c_int, c_int, c_void, c_void]),
+    "fs_profile_enable": (c_int, [c_void, c_int]),
+    "fs_profile_dump": (c_int, [c_void, ctypes.c_char_p, ctypes.c_size_t]),
+    "fs_grid_sample_nchw": (c_int, [c_void, c_int, c_int, c_int, c_int, c_void, c_int, c_int, c_void, c_int, c_void]),
+    "fs_grid_sample_nhwc": (c_int, [c_void, c_int, c_int, c_int, c_int, c_int, c_void, c_int, c_int, c_void, c_int, c_int, c_void]),
+    "fs_resize_bilinear_nchw": (c_int, [c_void, c_int, c_int, c_int, c_void, c_int, c_int, c_int, c_void]),
+    "fs_resize_bilinear_nhwc": (c_int, [c_void, c_int, c_int, c_int, c_int, c_int, c_void, c_int, c_int, c_int, c_int, c_void]),
+    "fs_blend": (c_int, [c_void, c_f32, c_void, c_f32, c_void, c_i64, c_void]),
+    "fs_seg_tail": (c_int, [c_void, c_void, ctypes.POINTER(c_void), ctypes.POINTER(c_void), c_int, c_int, c_int, c_int, c_int,
+                            c_int, c_int, c_int, c_int, c_void, c_void, c_void, c_void]),
+    "fs_argmax_u8": (c_int, [c_void, c_int, c_int, c_i64, c_void, c_void]),
+    "fs_resize_argmax_u8": (c_int, [c_void, c_int, c_int, c_int, c_int, c_void, c_int, c_int, c_void]),
+    "fs_iou_hist": (c_int, [c_void, c_void, c_i64, c_int, c_int, c_void, c_void]),
+    "fs_pack_conv_weight": (c_int, [c_void, c_void, c_int, c_int, c_int, c_int, c_void]),
+    "fs_conv2d_nhwc": (c_int, [c_void, c_int, c_void, c_void, c_void, c_void, c_int, c_void, c_int] + [c_int] * 12 + [c_void]),
+    "fs_stem_conv_nchw": (c_int, [c_void, c_void, c_void, c_void, c_void] + [c_int] * 8 + [c_void]),
+    "fs_maxpool3x3s2_nhwc": (c_int, [c_void, c_void, c_int, c_int, c_int, c_int, c_void]),
+    "fs_adaptive_avgpool_nhwc": (c_int, [c_void, c_int, c_void, c_int, c_int, c_int, c_int, c_int, c_void]),
+    "fs_nchw_to_nhwc": (c_int, [c_void, c_void, c_int, c_int, c_int, c_void]),
+    "fs_nhwc_to_nchw": (c_int, [c_void, c_void, c_int, c_int, c_int, c_void]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libfloodseg.so once; raise loudly when it is absent (no fallback path exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950); there is no CPU fallback for this path")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def exported_symbols():
+    return sorted(_SIGNATURES)
+
+
+def check(rc):
+    if rc != 0:
+        msg = load().fs_last_error()
+        raise RuntimeError("floodseg: " + (msg.decode() if msg else f"error {rc}"))
+
+
+def stream_ptr():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    """Device (or host) pointer of a tensor; None -> NULL."""
+    if t is None:
+        return ctypes.c_void_p(0)
+    return ctypes.c_void_p(t.data_ptr())

@@ -1,0 +1,173 @@
+// extern "C" surface declared in include/floodseg.h.  Plain pointers and sizes only.
+#include "../../include/floodseg.h"
+#include "kernels.h"
+#include "net.h"
+
+#define FS_API extern "C" __attribute__((visibility("default")))
+
+static inline hipStream_t S(fs_stream s) { return reinterpret_cast<hipStream_t>(s); }
+
+FS_API int fs_version(void) { return 100; }
+FS_API const char* fs_last_error(void) { return fs::last_error().c_str(); }
+
+FS_API int fs_create(const fs_config* cfg, fs_handle* out) { return fs::net_create(cfg, out); }
+FS_API int fs_destroy(fs_handle h) { return fs::net_destroy(h); }
+FS_API int fs_load_weight(fs_handle h, const char* name, const float* data, const int64_t* shape, int ndim, int on_device,
+                          fs_stream stream) {
+    return fs::net_load_weight(h, name, data, shape, ndim, on_device, S(stream));
+}
+FS_API int fs_finalize(fs_handle h, fs_stream stream) { return fs::net_finalize(h, S(stream)); }
+FS_API int fs_feature_shape(fs_handle h, int H, int W, int* C, int* fh, int* fw) { return fs::net_feature_shape(h, H, W, C, fh, fw); }
+FS_API size_t fs_workspace_bytes(fs_handle h, int B, int H, int W) { return fs::net_workspace_bytes(h, B, H, W); }
+FS_API int fs_encoder_forward(fs_handle h, const float* in_nchw, int B, int H, int W, float* out_nhwc, fs_stream stream) {
+    return fs::net_encoder(h, in_nchw, B, H, W, out_nhwc, S(stream));
+}
+FS_API int fs_decoder_forward(fs_handle h, const float* feat_nhwc, int B, int fh, int fw, float* out_nchw, fs_stream stream) {
+    return fs::net_decoder(h, feat_nhwc, B, fh, fw, out_nchw, S(stream));
+}
+FS_API int fs_profile_enable(fs_handle h, int on) {
+    if (!h) return fs::fail("fs_profile_enable: null handle");
+    h->profiling = on != 0;
+    return 0;
+}
+FS_API int fs_profile_dump(fs_handle h, char* buf, size_t buflen) { return fs::net_profile_dump(h, buf, buflen); }
+
+FS_API int fs_grid_sample_nchw(const float* in, int B, int C, int Hi, int Wi, const float* grid, int Hg, int Wg, float* out,
+                               int align_corners, fs_stream stream) {
+    if (!in || !grid || !out || B < 1 || C < 1 || Hi < 1 || Wi < 1 || Hg < 1 || Wg < 1) return fs::fail("fs_grid_sample_nchw: bad arguments");
+    return fs::launch_grid_sample_nchw(in, B, C, Hi, Wi, grid, Hg, Wg, out, align_corners, S(stream));
+}
+FS_API int fs_grid_sample_nhwc(const float* in, int ld_in, int B, int C, int Hi, int Wi, const float* grid, int Hg, int Wg,
+                               float* out, int ld_out, int align_corners, fs_stream stream) {
+    if (!in || !grid || !out || B < 1 || C < 1 || Hi < 1 || Wi < 1 || Hg < 1 || Wg < 1) return fs::fail("fs_grid_sample_nhwc: bad arguments");
+    return fs::launch_grid_sample_nhwc(in, ld_in, B, C, Hi, Wi, grid, Hg, Wg, out, ld_out, align_corners, S(stream));
+}
+FS_API int fs_resize_bilinear_nchw(const float* in, int BC, int Hi, int Wi, float* out, int Ho, int Wo, int align_corners,
+                                   fs_stream stream) {
+    if (!in || !out || BC < 1 || Hi < 1 || Wi < 1 || Ho < 1 || Wo < 1) return fs::fail("fs_resize_bilinear_nchw: bad arguments");
+    return fs::launch_resize_bilinear_nchw(in, BC, Hi, Wi, out, Ho, Wo, align_corners, S(stream));
+}
+FS_API int fs_resize_bilinear_nhwc(const float* in, int ld_in, int B, int C, int Hi, int Wi, float* out, int ld_out, int Ho,
+                                   int Wo, int align_corners, fs_stream stream) {
+    if (!in || !out || B < 1 || C < 1 || Hi < 1 || Wi < 1 || Ho < 1 || Wo < 1) return fs::fail("fs_resize_bilinear_nhwc: bad arguments");
+    return fs::launch_resize_bilinear_nhwc(in, ld_in, B, C, Hi, Wi, out, ld_out, Ho, Wo, align_corners, S(stream));
+}
+FS_API int fs_blend(const float* a, float wa, const float* b, float wb, float* out, int64_t numel, fs_stream stream) {
+    if (!a || !out || numel < 0) return fs::fail("fs_blend: bad arguments");
+    if (numel == 0) return 0;
+    return fs::launch_blend(a, wa, b, wb, out, numel, S(stream));
+}
+
+FS_API int fs_seg_tail(const float* lo_prev, const float* lo_next, const float* const* grids_left,
+                       const float* const* grids_right, int K, int h, int w, int Hg, int Wg, int H, int W, int n, int no_warp,
+                       float* out_logits, uint8_t* out_mask, float* scratch, fs_stream stream) {
+    if (!lo_prev || h < 1 || w < 1 || H < 1 || W < 1) return fs::fail("fs_seg_tail: bad arguments");
+    fs::SegTailParams p{};
+    p.lo_prev = lo_prev;
+    p.lo_next = lo_next;
+    p.grids_left = grids_left;
+    p.grids_right = grids_right;
+    p.K = K;
+    p.h = h;
+    p.w = w;
+    p.Hg = Hg;
+    p.Wg = Wg;
+    p.H = H;
+    p.W = W;
+    p.n = n;
+    p.no_warp = no_warp;
+    p.out_logits = out_logits;
+    p.out_mask = out_mask;
+    p.scratch = scratch;
+    return fs::launch_seg_tail(p, S(stream));
+}
+
+FS_API int fs_argmax_u8(const float* in, int B, int K, int64_t HW, uint8_t* out, fs_stream stream) {
+    if (!in || !out || B < 1 || HW < 1) return fs::fail("fs_argmax_u8: bad arguments");
+    return fs::launch_argmax_u8(in, B, K, HW, out, S(stream));
+}
+FS_API int fs_resize_argmax_u8(const float* in, int B, int K, int Hi, int Wi, uint8_t* out, int Ho, int Wo, fs_stream stream) {
+    if (!in || !out || B < 1 || Hi < 1 || Wi < 1 || Ho < 1 || Wo < 1) return fs::fail("fs_resize_argmax_u8: bad arguments");
+    return fs::launch_resize_argmax_u8(in, B, K, Hi, Wi, out, Ho, Wo, S(stream));
+}
+FS_API int fs_iou_hist(const uint8_t* pred, const uint8_t* target, int64_t numel, int K, int ignore_index, long long* hist3K,
+                       fs_stream stream) {
+    if (!pred || !target || !hist3K || numel < 0) return fs::fail("fs_iou_hist: bad arguments");
+    if (numel == 0) return 0;
+    return fs::launch_iou_hist(pred, target, numel, K, ignore_index, hist3K, S(stream));
+}
+
+FS_API int fs_pack_conv_weight(const float* oihw, float* ohwi, int O, int I, int KH, int KW, fs_stream stream) {
+    if (!oihw || !ohwi || O < 1 || I < 1 || KH < 1 || KW < 1) return fs::fail("fs_pack_conv_weight: bad arguments");
+    return fs::launch_pack_oihw_to_ohwi(oihw, ohwi, O, I, KH, KW, S(stream));
+}
+FS_API int fs_conv2d_nhwc(const float* in, int ld_in, const float* wgt_ohwi, const float* scale, const float* shift,
+                          const float* res, int ld_res, float* out, int ld_out, int B, int H, int W, int Cin, int Cout, int KH,
+                          int KW, int stride, int pad, int dil, int relu, int tile, fs_stream stream) {
+    if (!in || !wgt_ohwi || !out || B < 1 || H < 1 || W < 1 || stride < 1 || dil < 1 || pad < 0)
+        return fs::fail("fs_conv2d_nhwc: bad arguments");
+    fs::ConvParams p{};
+    p.in = in;
+    p.ld_in = ld_in;
+    p.wgt = wgt_ohwi;
+    p.scale = scale;
+    p.shift = shift;
+    p.res = res;
+    p.ld_res = ld_res;
+    p.out = out;
+    p.ld_out = ld_out;
+    p.B = B;
+    p.H = H;
+    p.W = W;
+    p.Cin = Cin;
+    p.Cout = Cout;
+    p.KH = KH;
+    p.KW = KW;
+    p.stride = stride;
+    p.pad = pad;
+    p.dil = dil;
+    p.relu = relu;
+    p.Ho = (H + 2 * pad - dil * (KH - 1) - 1) / stride + 1;
+    p.Wo = (W + 2 * pad - dil * (KW - 1) - 1) / stride + 1;
+    if (p.Ho < 1 || p.Wo < 1) return fs::fail("fs_conv2d_nhwc: empty output");
+    return fs::launch_conv_igemm(p, S(stream), tile);
+}
+FS_API int fs_stem_conv_nchw(const float* in_nchw, const float* wgt_hwio, const float* scale, const float* shift,
+                             float* out_nhwc, int B, int H, int W, int Cout, int KH, int KW, int stride, int pad,
+                             fs_stream stream) {
+    if (!in_nchw || !wgt_hwio || !scale || !shift || !out_nhwc || B < 1) return fs::fail("fs_stem_conv_nchw: bad arguments");
+    fs::StemParams p{};
+    p.in = in_nchw;
+    p.wgt = wgt_hwio;
+    p.scale = scale;
+    p.shift = shift;
+    p.out = out_nhwc;
+    p.ld_out = Cout;
+    p.B = B;
+    p.H = H;
+    p.W = W;
+    p.Ho = (H + 2 * pad - KH) / stride + 1;
+    p.Wo = (W + 2 * pad - KW) / stride + 1;
+    p.Cout = Cout;
+    p.KH = KH;
+    p.KW = KW;
+    p.stride = stride;
+    p.pad = pad;
+    return fs::launch_stem_conv(p, S(stream));
+}
+FS_API int fs_maxpool3x3s2_nhwc(const float* in, float* out, int B, int H, int W, int C, fs_stream stream) {
+    if (!in || !out || B < 1 || H < 1 || W < 1) return fs::fail("fs_maxpool3x3s2_nhwc: bad arguments");
+    return fs::launch_maxpool3x3s2(in, C, out, C, B, H, W, C, (H + 2 - 3) / 2 + 1, (W + 2 - 3) / 2 + 1, S(stream));
+}
+FS_API int fs_adaptive_avgpool_nhwc(const float* in, int ld_in, float* out, int B, int H, int W, int C, int bin, fs_stream stream) {
+    if (!in || !out || B < 1 || H < 1 || W < 1 || bin < 1) return fs::fail("fs_adaptive_avgpool_nhwc: bad arguments");
+    return fs::launch_adaptive_avgpool(in, ld_in, out, B, H, W, C, bin, S(stream));
+}
+FS_API int fs_nchw_to_nhwc(const float* in, float* out, int B, int C, int HW, fs_stream stream) {
+    if (!in || !out || B < 1 || C < 1 || HW < 1) return fs::fail("fs_nchw_to_nhwc: bad arguments");
+    return fs::launch_nchw_to_nhwc(in, out, C, B, C, HW, S(stream));
+}
+FS_API int fs_nhwc_to_nchw(const float* in, float* out, int B, int C, int HW, fs_stream stream) {
+    if (!in || !out || B < 1 || C < 1 || HW < 1) return fs::fail("fs_nhwc_to_nchw: bad arguments");
+    return fs::launch_nhwc_to_nchw(in, C, out, B, C, HW, S(stream));
+}

@@ -1,0 +1,253 @@
+// fp32 implicit-GEMM convolution on the CDNA4 matrix cores.
+//
+//   v_mfma_f32_32x32x2_f32: exact f32 fmaf-chain numerics at 64 FLOP/clk/SIMD (157 TFLOP/s chip peak).
+//
+// Mapping (one 256-thread workgroup = 4 waves, one per SIMD, 2x2 over the block tile):
+//   GEMM M = B*Ho*Wo output pixels (A rows, gathered NHWC pixels: 32 channels = one 128-B line)
+//   GEMM N = Cout                  (B rows, packed weights [Cout][KH*KW*Cin])
+//   GEMM K = KH*KW*Cin walked in 32-float chunks; Cin % 32 == 0 so a chunk never straddles a tap.
+// LDS image: [row][32 floats], the 16-B chunk index XOR-swizzled with (row>>1)&7 so that the
+// ds_read_b128 fragment reads (16-lane groups, 64-bank rows) are conflict-free.
+// MFMA operand trick: lane (i = l&31, h = l>>5) reads 4 consecutive k (one ds_read_b128) and
+// feeds element e to the e-th MFMA; A and B use the same k for the same (h, e), and the MFMA
+// sums over k, so any k permutation is legal.
+// D layout (32x32): col(n) = lane&31, row(m) = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+//   -> each store instruction writes two 128-B channel runs: coalesced NHWC epilogue.
+// Pipeline: register prefetch of chunk k+1 (global_load_dwordx4) is in flight while chunk k is
+// multiplied out of LDS (64 MFMAs = 4096 cycles per wave per chunk at 128x128).
+#include "kernels.h"
+
+namespace fs {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void conv_igemm_f32(ConvParams p, int tiles_m, int tiles_n) {
+    constexpr int BK = 32;
+    constexpr int WM = BM / 2, WN = BN / 2;
+    constexpr int TM = WM / 32, TN = WN / 32;
+    constexpr int RA = BM / 32, RB = BN / 32;  // staged rows per thread
+    constexpr int PM = 8;                      // m-tiles per raster panel
+
+    __shared__ __attribute__((aligned(16))) float lds[(BM + BN) * BK];
+    float* As = lds;
+    float* Bs = lds + BM * BK;
+
+    // ---- XCD-aware tile order: blocks b and b+8 share an XCD (and its L2); give each XCD a
+    // contiguous run of logical tiles, rastered m-fastest inside 8 x tiles_n panels so that
+    // the ~32 tiles resident on one XCD share 8 pixel slabs and 4 weight slabs.
+    const int nblk = gridDim.x;
+    const int bid = blockIdx.x;
+    const int q = nblk >> 3, rr = nblk & 7, xcd = bid & 7;
+    const int lid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (bid >> 3);
+    const int panel = lid / (PM * tiles_n);
+    const int within = lid - panel * (PM * tiles_n);
+    const int prow = min(PM, tiles_m - panel * PM);
+    const int m_tile = panel * PM + within % prow;
+    const int n_tile = within / prow;
+    const int m0 = m_tile * BM, n0 = n_tile * BN;
+
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wv = t >> 6;
+    const int wm = wv >> 1, wn = wv & 1;
+    const int l31 = lane & 31, hh = lane >> 5;
+
+    const int M = p.B * p.Ho * p.Wo;
+    const int K = p.KH * p.KW * p.Cin;
+    const int cpt = p.Cin >> 5;  // chunks per filter tap
+    const int nchunks = p.KH * p.KW * cpt;
+
+    // ---- staging assignment: thread (r0 = t>>3, c = t&7) moves the 16-B chunk c of rows r0+32j
+    const int sc = t & 7;
+    const int r0 = t >> 3;
+    int a_iy0[RA], a_ix0[RA], a_pix[RA];
+    unsigned a_valid = 0;
+#pragma unroll
+    for (int j = 0; j < RA; ++j) {
+        const int m = m0 + r0 + 32 * j;
+        const bool v = m < M;
+        const int mm = v ? m : 0;
+        const int hw = p.Ho * p.Wo;
+        const int b = mm / hw;
+        const int rem = mm - b * hw;
+        const int oy = rem / p.Wo;
+        const int ox = rem - oy * p.Wo;
+        a_iy0[j] = oy * p.stride - p.pad;
+        a_ix0[j] = ox * p.stride - p.pad;
+        a_pix[j] = b * p.H * p.W;
+        a_valid |= (v ? 1u : 0u) << j;
+    }
+    const float* b_src[RB];
+    unsigned b_valid = 0;
+#pragma unroll
+    for (int j = 0; j < RB; ++j) {
+        const int n = n0 + r0 + 32 * j;
+        const bool v = n < p.Cout;
+        b_src[j] = p.wgt + (size_t)(v ? n : 0) * K + sc * 4;
+        b_valid |= (v ? 1u : 0u) << j;
+    }
+
+    f32x4 ra[RA], rb[RB];
+    unsigned ra_ok = 0;
+    int tap_r = 0, tap_s = 0, cc = 0;  // position of the chunk being loaded
+
+    auto load_chunk = [&](int kc) {
+        const int dy = tap_r * p.dil, dx = tap_s * p.dil;
+        ra_ok = 0;
+#pragma unroll
+        for (int j = 0; j < RA; ++j) {
+            const int iy = a_iy0[j] + dy, ix = a_ix0[j] + dx;
+            const bool ok = ((a_valid >> j) & 1u) && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+            const size_t pix = ok ? (size_t)(a_pix[j] + iy * p.W + ix) : 0;
+            ra[j] = *reinterpret_cast<const f32x4*>(p.in + pix * p.ld_in + cc * 32 + sc * 4);
+            ra_ok |= (ok ? 1u : 0u) << j;
+        }
+#pragma unroll
+        for (int j = 0; j < RB; ++j) rb[j] = *reinterpret_cast<const f32x4*>(b_src[j] + (size_t)kc * 32);
+        // advance (cc, tap_s, tap_r) to the next chunk
+        if (++cc == cpt) {
+            cc = 0;
+            if (++tap_s == p.KW) { tap_s = 0; ++tap_r; }
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int sw = (l31 >> 1) & 7;  // read-side swizzle key (row base is a multiple of 32)
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+    load_chunk(0);
+    for (int kc = 0; kc < nchunks; ++kc) {
+        __syncthreads();  // everyone finished reading the previous chunk
+#pragma unroll
+        for (int j = 0; j < RA; ++j) {
+            const int row = r0 + 32 * j;
+            const f32x4 v = ((ra_ok >> j) & 1u) ? ra[j] : zero4;
+            *reinterpret_cast<f32x4*>(&As[row * BK + 4 * (sc ^ ((row >> 1) & 7))]) = v;
+        }
+#pragma unroll
+        for (int j = 0; j < RB; ++j) {
+            const int row = r0 + 32 * j;
+            const f32x4 v = ((b_valid >> j) & 1u) ? rb[j] : zero4;
+            *reinterpret_cast<f32x4*>(&Bs[row * BK + 4 * (sc ^ ((row >> 1) & 7))]) = v;
+        }
+        __syncthreads();
+        if (kc + 1 < nchunks) load_chunk(kc + 1);  // in flight under the MFMAs below
+
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int cidx = (2 * s + hh) ^ sw;
+            f32x4 a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                a[i] = *reinterpret_cast<const f32x4*>(&As[(wm * WM + i * 32 + l31) * BK + 4 * cidx]);
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                b[j] = *reinterpret_cast<const f32x4*>(&Bs[(wn * WN + j * 32 + l31) * BK + 4 * cidx]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
+        }
+    }
+
+    // ---- epilogue: scale/shift (eval BatchNorm or bias), residual, ReLU, NHWC store
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * WN + j * 32 + l31;
+        const bool nok = n < p.Cout;
+        const float sc_n = (nok && p.scale) ? p.scale[n] : 1.f;
+        const float sh_n = (nok && p.shift) ? p.shift[n] : 0.f;
+        const int nc = nok ? n : 0;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int mb = m0 + wm * WM + i * 32 + 4 * hh;
+            // all 16 residual loads are issued back to back on clamped (always valid) addresses,
+            // so the compiler does not serialise a vmcnt(0) round trip per element
+            float rv[16];
+            if (p.res) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int m = min(mb + (e & 3) + 8 * (e >> 2), M - 1);
+                    rv[e] = p.res[(size_t)m * p.ld_res + nc];
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) rv[e] = 0.f;
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = mb + (e & 3) + 8 * (e >> 2);
+                float v = acc[i][j][e] * sc_n + sh_n + rv[e];
+                if (p.relu) v = fmaxf(v, 0.f);
+                if (nok && m < M) p.out[(size_t)m * p.ld_out + n] = v;
+            }
+        }
+    }
+}
+
+namespace {
+struct TileCfg { int bm, bn; const char* name; };
+const TileCfg kTiles[5] = {{0, 0, "auto"}, {128, 128, "igemm128x128"}, {128, 64, "igemm128x64"},
+                           {64, 64, "igemm64x64"}, {64, 128, "igemm64x128"}};
+
+int pick_tile(const ConvParams& p) {
+    const int M = p.B * p.Ho * p.Wo;
+    // relative per-tile MFMA efficiency guesses; refined from rocprof later
+    const double eff[5] = {0, 1.00, 0.92, 0.80, 0.92};
+    int best = 1;
+    double best_t = 1e300;
+    for (int c = 1; c <= 4; ++c) {
+        const int bm = kTiles[c].bm, bn = kTiles[c].bn;
+        if (p.Cout < bn && bn > 64) continue;
+        const long tiles = (long)cdiv(M, bm) * cdiv(p.Cout, bn);
+        const long rounds = (tiles + 255) / 256;
+        const double t = (double)rounds * bm * bn / eff[c];
+        if (t < best_t) { best_t = t; best = c; }
+    }
+    return best;
+}
+}  // namespace
+
+const char* conv_igemm_tile_name(const ConvParams& p, int tile) {
+    if (tile <= 0 || tile > 4) tile = pick_tile(p);
+    return kTiles[tile].name;
+}
+
+int launch_conv_igemm(const ConvParams& p, hipStream_t s, int tile) {
+    FS_REQUIRE(p.Cin % 32 == 0, "conv_igemm: Cin=%d must be a multiple of 32", p.Cin);
+    FS_REQUIRE(p.ld_in % 4 == 0 && p.ld_in >= p.Cin, "conv_igemm: bad ld_in=%d (Cin=%d)", p.ld_in, p.Cin);
+    FS_REQUIRE(p.ld_out >= p.Cout, "conv_igemm: bad ld_out=%d (Cout=%d)", p.ld_out, p.Cout);
+    FS_REQUIRE(((uintptr_t)p.in & 15) == 0 && ((uintptr_t)p.wgt & 15) == 0, "conv_igemm: unaligned operand");
+    FS_REQUIRE(p.Ho == (p.H + 2 * p.pad - p.dil * (p.KH - 1) - 1) / p.stride + 1 &&
+               p.Wo == (p.W + 2 * p.pad - p.dil * (p.KW - 1) - 1) / p.stride + 1,
+               "conv_igemm: output geometry %dx%d inconsistent with input %dx%d", p.Ho, p.Wo, p.H, p.W);
+    FS_REQUIRE((int64_t)p.B * p.H * p.W * p.ld_in < (int64_t)1 << 31, "conv_igemm: input too large for 32-bit pixel index");
+    if (!(p.res == nullptr || p.ld_res >= p.Cout)) return fail("conv_igemm: bad ld_res");
+    if (tile <= 0 || tile > 4) tile = pick_tile(p);
+    const int M = p.B * p.Ho * p.Wo;
+    const int bm = kTiles[tile].bm, bn = kTiles[tile].bn;
+    const int tm = cdiv(M, bm), tn = cdiv(p.Cout, bn);
+    const dim3 grid(tm * tn), block(256);
+    switch (tile) {
+        case 1: hipLaunchKernelGGL((conv_igemm_f32<128, 128>), grid, block, 0, s, p, tm, tn); break;
+        case 2: hipLaunchKernelGGL((conv_igemm_f32<128, 64>), grid, block, 0, s, p, tm, tn); break;
+        case 3: hipLaunchKernelGGL((conv_igemm_f32<64, 64>), grid, block, 0, s, p, tm, tn); break;
+        default: hipLaunchKernelGGL((conv_igemm_f32<64, 128>), grid, block, 0, s, p, tm, tn); break;
+    }
+    FS_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace fs

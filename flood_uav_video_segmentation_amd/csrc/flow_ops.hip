@@ -1,0 +1,407 @@
+// Interpolation tail of the key-frame pipeline (all HBM/latency bound):
+//   warp = F.grid_sample(bilinear, border, align_corners=False)       flow/model.py:244-249
+//   up   = F.interpolate(bilinear, align_corners=True)                flow/model.py:193,206,218,228
+//   fuse = (n-p)/n * fwd[p-1] + p/n * bwd[n-p-1]                      flow/model.py:232-237
+//   post = F.interpolate(.., (1072,1920)) -> max(1)[1] -> uint8       flow/base.py:275-277
+// plus the metric histogram of util/util.py:52-63.
+#include "interp.h"
+#include "kernels.h"
+
+namespace fs {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ------------------------------------------------------------------ grid_sample, NCHW
+__global__ __launch_bounds__(256) void grid_sample_nchw_kernel(const float* __restrict__ in, int B, int C, int Hi, int Wi,
+                                                               const float* __restrict__ grid, int Hg, int Wg,
+                                                               float* __restrict__ out, int ac) {
+    const int64_t total = (int64_t)B * Hg * Wg;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int b = (int)(i / ((int64_t)Hg * Wg));
+        const int64_t g = i - (int64_t)b * Hg * Wg;
+        const float gx = grid[i * 2 + 0], gy = grid[i * 2 + 1];
+        const GsTaps t = gs_taps(gx, gy, Wi, Hi, ac);
+        const int x1 = t.x1ok ? t.x0 + 1 : t.x0, y1 = t.y1ok ? t.y0 + 1 : t.y0;
+        for (int c = 0; c < C; ++c) {
+            const float* pl = in + ((size_t)b * C + c) * Hi * Wi;
+            const float vnw = pl[(size_t)t.y0 * Wi + t.x0];
+            const float vne = t.x1ok ? pl[(size_t)t.y0 * Wi + x1] : 0.f;
+            const float vsw = t.y1ok ? pl[(size_t)y1 * Wi + t.x0] : 0.f;
+            const float vse = (t.x1ok && t.y1ok) ? pl[(size_t)y1 * Wi + x1] : 0.f;
+            out[((size_t)b * C + c) * Hg * Wg + g] = gs_combine(vnw, vne, vsw, vse, t);
+        }
+    }
+}
+
+int launch_grid_sample_nchw(const float* in, int B, int C, int Hi, int Wi, const float* grid, int Hg, int Wg, float* out,
+                            int align_corners, hipStream_t s) {
+    const int64_t total = (int64_t)B * Hg * Wg;
+    hipLaunchKernelGGL(grid_sample_nchw_kernel, dim3((unsigned)std::min<int64_t>(cdiv64(total, 256), 8192)), dim3(256), 0, s, in,
+                       B, C, Hi, Wi, grid, Hg, Wg, out, align_corners);
+    FS_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------ grid_sample, NHWC (C % 4 == 0)
+// One wave-sized group of float4 lanes sweeps the channels of one output pixel: every tap is a
+// contiguous C*4-byte run, so the gather is fully coalesced.
+__global__ __launch_bounds__(256) void grid_sample_nhwc_kernel(const float* __restrict__ in, int ld_in, int B, int C4, int Hi,
+                                                               int Wi, const float* __restrict__ grid, int Hg, int Wg,
+                                                               float* __restrict__ out, int ld_out, int ac) {
+    const int64_t total = (int64_t)B * Hg * Wg * C4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c4 = (int)(i % C4);
+        const int64_t m = i / C4;
+        const int b = (int)(m / ((int64_t)Hg * Wg));
+        const float gx = grid[m * 2 + 0], gy = grid[m * 2 + 1];
+        const GsTaps t = gs_taps(gx, gy, Wi, Hi, ac);
+        const int x1 = t.x1ok ? t.x0 + 1 : t.x0, y1 = t.y1ok ? t.y0 + 1 : t.y0;
+        const float* base = in + (size_t)b * Hi * Wi * ld_in + c4 * 4;
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        const f32x4 vnw = *reinterpret_cast<const f32x4*>(base + ((size_t)t.y0 * Wi + t.x0) * ld_in);
+        const f32x4 vne = t.x1ok ? *reinterpret_cast<const f32x4*>(base + ((size_t)t.y0 * Wi + x1) * ld_in) : z;
+        const f32x4 vsw = t.y1ok ? *reinterpret_cast<const f32x4*>(base + ((size_t)y1 * Wi + t.x0) * ld_in) : z;
+        const f32x4 vse = (t.x1ok && t.y1ok) ? *reinterpret_cast<const f32x4*>(base + ((size_t)y1 * Wi + x1) * ld_in) : z;
+        f32x4 r;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) r[e] = gs_combine(vnw[e], vne[e], vsw[e], vse[e], t);
+        *reinterpret_cast<f32x4*>(out + (size_t)m * ld_out + c4 * 4) = r;
+    }
+}
+
+int launch_grid_sample_nhwc(const float* in, int ld_in, int B, int C, int Hi, int Wi, const float* grid, int Hg, int Wg,
+                            float* out, int ld_out, int align_corners, hipStream_t s) {
+    FS_REQUIRE(C % 4 == 0 && ld_in % 4 == 0 && ld_out % 4 == 0, "grid_sample_nhwc: C/ld must be multiples of 4");
+    const int64_t total = (int64_t)B * Hg * Wg * (C / 4);
+    hipLaunchKernelGGL(grid_sample_nhwc_kernel, dim3((unsigned)std::min<int64_t>(cdiv64(total, 256), 8192)), dim3(256), 0, s, in,
+                       ld_in, B, C / 4, Hi, Wi, grid, Hg, Wg, out, ld_out, align_corners);
+    FS_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------ bilinear resize
+__global__ __launch_bounds__(256) void resize_bilinear_nchw_kernel(const float* __restrict__ in, int BC, int Hi, int Wi,
+                                                                   float* __restrict__ out, int Ho, int Wo, int ac, float sy,
+                                                                   float sx) {
+    const int64_t total = (int64_t)BC * Ho * Wo;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int ox = (int)(i % Wo);
+        const int oy = (int)((i / Wo) % Ho);
+        const int64_t pc = i / ((int64_t)Wo * Ho);
+        const LinCoord cy = lin_coord(oy, Hi, sy, ac), cx = lin_coord(ox, Wi, sx, ac);
+        const float* pl = in + (size_t)pc * Hi * Wi;
+        out[i] = bilerp(pl[cy.i0 * Wi + cx.i0], pl[cy.i0 * Wi + cx.i1], pl[cy.i1 * Wi + cx.i0], pl[cy.i1 * Wi + cx.i1], cy, cx);
+    }
+}
+
+int launch_resize_bilinear_nchw(const float* in, int BC, int Hi, int Wi, float* out, int Ho, int Wo, int align_corners,
+                                hipStream_t s) {
+    const int64_t total = (int64_t)BC * Ho * Wo;
+    hipLaunchKernelGGL(resize_bilinear_nchw_kernel, dim3((unsigned)std::min<int64_t>(cdiv64(total, 256), 16384)), dim3(256), 0, s,
+                       in, BC, Hi, Wi, out, Ho, Wo, align_corners, resize_scale(Hi, Ho, align_corners),
+                       resize_scale(Wi, Wo, align_corners));
+    FS_HIP(hipGetLastError());
+    return 0;
+}
+
+__global__ __launch_bounds__(256) void resize_bilinear_nhwc_kernel(const float* __restrict__ in, int ld_in, int B, int C4, int Hi,
+                                                                   int Wi, float* __restrict__ out, int ld_out, int Ho, int Wo,
+                                                                   int ac, float sy, float sx) {
+    const int64_t total = (int64_t)B * Ho * Wo * C4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c4 = (int)(i % C4);
+        const int64_t m = i / C4;
+        const int ox = (int)(m % Wo);
+        const int oy = (int)((m / Wo) % Ho);
+        const int b = (int)(m / ((int64_t)Wo * Ho));
+        const LinCoord cy = lin_coord(oy, Hi, sy, ac), cx = lin_coord(ox, Wi, sx, ac);
+        const float* base = in + (size_t)b * Hi * Wi * ld_in + c4 * 4;
+        const f32x4 v00 = *reinterpret_cast<const f32x4*>(base + ((size_t)cy.i0 * Wi + cx.i0) * ld_in);
+        const f32x4 v01 = *reinterpret_cast<const f32x4*>(base + ((size_t)cy.i0 * Wi + cx.i1) * ld_in);
+        const f32x4 v10 = *reinterpret_cast<const f32x4*>(base + ((size_t)cy.i1 * Wi + cx.i0) * ld_in);
+        const f32x4 v11 = *reinterpret_cast<const f32x4*>(base + ((size_t)cy.i1 * Wi + cx.i1) * ld_in);
+        f32x4 r;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) r[e] = bilerp(v00[e], v01[e], v10[e], v11[e], cy, cx);
+        *reinterpret_cast<f32x4*>(out + (size_t)m * ld_out + c4 * 4) = r;
+    }
+}
+
+int launch_resize_bilinear_nhwc(const float* in, int ld_in, int B, int C, int Hi, int Wi, float* out, int ld_out, int Ho, int Wo,
+                                int align_corners, hipStream_t s) {
+    FS_REQUIRE(C % 4 == 0 && ld_in % 4 == 0 && ld_out % 4 == 0, "resize_nhwc: C/ld must be multiples of 4");
+    const int64_t total = (int64_t)B * Ho * Wo * (C / 4);
+    hipLaunchKernelGGL(resize_bilinear_nhwc_kernel, dim3((unsigned)std::min<int64_t>(cdiv64(total, 256), 16384)), dim3(256), 0, s,
+                       in, ld_in, B, C / 4, Hi, Wi, out, ld_out, Ho, Wo, align_corners, resize_scale(Hi, Ho, align_corners),
+                       resize_scale(Wi, Wo, align_corners));
+    FS_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------ blend: out = wa*a + wb*b
+__global__ __launch_bounds__(256) void blend_kernel(const float* __restrict__ a, float wa, const float* __restrict__ b, float wb,
+                                                    float* __restrict__ out, int64_t n4, int64_t numel) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const f32x4 x = reinterpret_cast<const f32x4*>(a)[i];
+        f32x4 r;
+        if (b) {
+            const f32x4 y = reinterpret_cast<const f32x4*>(b)[i];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) r[e] = __fadd_rn(__fmul_rn(wa, x[e]), __fmul_rn(wb, y[e]));
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) r[e] = __fmul_rn(wa, x[e]);
+        }
+        reinterpret_cast<f32x4*>(out)[i] = r;
+    }
+    // scalar tail
+    if (blockIdx.x == 0) {
+        for (int64_t i = n4 * 4 + threadIdx.x; i < numel; i += 256)
+            out[i] = b ? __fadd_rn(__fmul_rn(wa, a[i]), __fmul_rn(wb, b[i])) : __fmul_rn(wa, a[i]);
+    }
+}
+
+int launch_blend(const float* a, float wa, const float* b, float wb, float* out, int64_t numel, hipStream_t s) {
+    FS_REQUIRE((((uintptr_t)a | (uintptr_t)b | (uintptr_t)out) & 15) == 0, "blend: operands must be 16-B aligned");
+    const int64_t n4 = numel / 4;
+    hipLaunchKernelGGL(blend_kernel, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>(cdiv64(n4, 256), 16384))), dim3(256), 0, s,
+                       a, wa, b, wb, out, n4, numel);
+    FS_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------ fused predict_segmentation tail
+// Virtual key-frame map: value of up_ac(lo)[k] at integer pixel (y, x) of the H x W frame.
+__device__ __forceinline__ float up_at(const float* __restrict__ pl, int h, int w, int y, int x, float sy, float sx) {
+    const LinCoord cy = lin_coord(y, h, sy, 1), cx = lin_coord(x, w, sx, 1);
+    return bilerp(pl[cy.i0 * w + cx.i0], pl[cy.i0 * w + cx.i1], pl[cy.i1 * w + cx.i0], pl[cy.i1 * w + cx.i1], cy, cx);
+}
+
+// One warp step for both directions (blockIdx.y = direction).  Step 0 samples the virtual
+// H x W map up_ac(lo) (flow/model.py:193 replaces o by its upsampled version before warping);
+// later steps sample the previous Hg x Wg result (the chain stays at grid resolution).
+__global__ __launch_bounds__(256) void seg_warp_step_kernel(const float* __restrict__ lo_prev, const float* __restrict__ lo_next,
+                                                            const float* __restrict__ src_f, const float* __restrict__ src_b,
+                                                            const float* __restrict__ grid_f, const float* __restrict__ grid_b,
+                                                            float* __restrict__ dst_f, float* __restrict__ dst_b, int K, int h,
+                                                            int w, int H, int W, int Hg, int Wg, int first, float sy, float sx) {
+    const int dir = blockIdx.y;
+    const float* lo = dir ? lo_next : lo_prev;
+    const float* src = dir ? src_b : src_f;
+    const float* grid = dir ? grid_b : grid_f;
+    float* dst = dir ? dst_b : dst_f;
+    const int G = Hg * Wg;
+    for (int g = blockIdx.x * 256 + threadIdx.x; g < G; g += gridDim.x * 256) {
+        const float gx = grid[g * 2 + 0], gy = grid[g * 2 + 1];
+        const int Hs = first ? H : Hg, Ws = first ? W : Wg;
+        const GsTaps t = gs_taps(gx, gy, Ws, Hs, 0);
+        const int x1 = t.x1ok ? t.x0 + 1 : t.x0, y1 = t.y1ok ? t.y0 + 1 : t.y0;
+        for (int k = 0; k < K; ++k) {
+            float vnw, vne, vsw, vse;
+            if (first) {
+                const float* pl = lo + (size_t)k * h * w;
+                vnw = up_at(pl, h, w, t.y0, t.x0, sy, sx);
+                vne = t.x1ok ? up_at(pl, h, w, t.y0, x1, sy, sx) : 0.f;
+                vsw = t.y1ok ? up_at(pl, h, w, y1, t.x0, sy, sx) : 0.f;
+                vse = (t.x1ok && t.y1ok) ? up_at(pl, h, w, y1, x1, sy, sx) : 0.f;
+            } else {
+                const float* pl = src + (size_t)k * G;
+                vnw = pl[t.y0 * Ws + t.x0];
+                vne = t.x1ok ? pl[t.y0 * Ws + x1] : 0.f;
+                vsw = t.y1ok ? pl[y1 * Ws + t.x0] : 0.f;
+                vse = (t.x1ok && t.y1ok) ? pl[y1 * Ws + x1] : 0.f;
+            }
+            dst[(size_t)k * G + g] = gs_combine(vnw, vne, vsw, vse, t);
+        }
+    }
+}
+
+// Fusion + upsample (+ argmax).  One thread per output pixel; KMAX classes kept in registers.
+template <int KMAX>
+__global__ __launch_bounds__(256) void seg_fuse_kernel(SegTailParams p, float sy_lo, float sx_lo, float sy_g, float sx_g) {
+    const int64_t HW = (int64_t)p.H * p.W;
+    const int K = p.K, n = p.n;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < HW; i += (int64_t)gridDim.x * 256) {
+        const int x = (int)(i % p.W), y = (int)(i / p.W);
+        float a[KMAX], b[KMAX];
+        // frame 0: the key frame itself
+        {
+            const LinCoord cy = lin_coord(y, p.h, sy_lo, 1), cx = lin_coord(x, p.w, sx_lo, 1);
+            float best = -INFINITY;
+            int arg = 0;
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k) {
+                if (k < K) {
+                    const float* pl = p.lo_prev + (size_t)k * p.h * p.w;
+                    a[k] = bilerp(pl[cy.i0 * p.w + cx.i0], pl[cy.i0 * p.w + cx.i1], pl[cy.i1 * p.w + cx.i0],
+                                  pl[cy.i1 * p.w + cx.i1], cy, cx);
+                    if (p.lo_next && p.no_warp) {
+                        const float* pn = p.lo_next + (size_t)k * p.h * p.w;
+                        b[k] = bilerp(pn[cy.i0 * p.w + cx.i0], pn[cy.i0 * p.w + cx.i1], pn[cy.i1 * p.w + cx.i0],
+                                      pn[cy.i1 * p.w + cx.i1], cy, cx);
+                    }
+                    if (p.out_logits) p.out_logits[(size_t)k * HW + i] = a[k];
+                    if (a[k] > best) { best = a[k]; arg = k; }
+                }
+            }
+            if (p.out_mask) p.out_mask[i] = (uint8_t)arg;
+        }
+        if (!p.lo_next) continue;
+        LinCoord gy_c, gx_c;
+        if (!p.no_warp) {
+            gy_c = lin_coord(y, p.Hg, sy_g, 1);
+            gx_c = lin_coord(x, p.Wg, sx_g, 1);
+        }
+        const int G = p.Hg * p.Wg;
+        for (int f = 1; f < n; ++f) {
+            const float wa = (float)((double)(n - f) / (double)n);
+            const float wb = (float)((double)f / (double)n);
+            float best = -INFINITY;
+            int arg = 0;
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k) {
+                if (k < K) {
+                    float va, vb;
+                    if (p.no_warp) {
+                        va = a[k];
+                        vb = b[k];
+                    } else {
+                        // scratch layout: [dir][step][K][Hg][Wg]; forward map f-1, backward map n-f-1
+                        const float* pf = p.scratch + ((size_t)(f - 1) * K + k) * G;
+                        const float* pb = p.scratch + ((size_t)(n - 1) * K + (size_t)(n - f - 1) * K + k) * G;
+                        va = bilerp(pf[gy_c.i0 * p.Wg + gx_c.i0], pf[gy_c.i0 * p.Wg + gx_c.i1], pf[gy_c.i1 * p.Wg + gx_c.i0],
+                                    pf[gy_c.i1 * p.Wg + gx_c.i1], gy_c, gx_c);
+                        vb = bilerp(pb[gy_c.i0 * p.Wg + gx_c.i0], pb[gy_c.i0 * p.Wg + gx_c.i1], pb[gy_c.i1 * p.Wg + gx_c.i0],
+                                    pb[gy_c.i1 * p.Wg + gx_c.i1], gy_c, gx_c);
+                    }
+                    const float v = __fadd_rn(__fmul_rn(wa, va), __fmul_rn(wb, vb));
+                    if (p.out_logits) p.out_logits[((size_t)f * K + k) * HW + i] = v;
+                    if (v > best) { best = v; arg = k; }
+                }
+            }
+            if (p.out_mask) p.out_mask[(size_t)f * HW + i] = (uint8_t)arg;
+        }
+    }
+}
+
+int launch_seg_tail(const SegTailParams& p, hipStream_t s) {
+    FS_REQUIRE(p.K >= 1 && p.K <= 32, "seg_tail: K=%d out of range (1..32)", p.K);
+    FS_REQUIRE(p.n >= 1, "seg_tail: n must be >= 1");
+    FS_REQUIRE(p.out_logits || p.out_mask, "seg_tail: no output requested");
+    const float sy_lo = resize_scale(p.h, p.H, 1), sx_lo = resize_scale(p.w, p.W, 1);
+    float sy_g = 0.f, sx_g = 0.f;
+    const bool warp = p.lo_next && !p.no_warp && p.n > 1;
+    if (warp) {
+        FS_REQUIRE(p.scratch && p.grids_left && p.grids_right, "seg_tail: warp mode needs grids and scratch");
+        sy_g = resize_scale(p.Hg, p.H, 1);
+        sx_g = resize_scale(p.Wg, p.W, 1);
+        const int G = p.Hg * p.Wg;
+        const size_t map = (size_t)p.K * G;
+        float* fwd = p.scratch;
+        float* bwd = p.scratch + (size_t)(p.n - 1) * map;
+        for (int j = 0; j < p.n - 1; ++j) {
+            hipLaunchKernelGGL(seg_warp_step_kernel, dim3(cdiv(G, 256), 2), dim3(256), 0, s, p.lo_prev, p.lo_next,
+                               j ? fwd + (size_t)(j - 1) * map : nullptr, j ? bwd + (size_t)(j - 1) * map : nullptr,
+                               p.grids_left[j], p.grids_right[j], fwd + (size_t)j * map, bwd + (size_t)j * map, p.K, p.h, p.w,
+                               p.H, p.W, p.Hg, p.Wg, j == 0 ? 1 : 0, sy_lo, sx_lo);
+        }
+    }
+    const int64_t HW = (int64_t)p.H * p.W;
+    const dim3 grid((unsigned)std::min<int64_t>(cdiv64(HW, 256), 16384)), block(256);
+    if (p.K <= 8)
+        hipLaunchKernelGGL((seg_fuse_kernel<8>), grid, block, 0, s, p, sy_lo, sx_lo, sy_g, sx_g);
+    else
+        hipLaunchKernelGGL((seg_fuse_kernel<32>), grid, block, 0, s, p, sy_lo, sx_lo, sy_g, sx_g);
+    FS_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------ argmax / fused resize+argmax
+__global__ __launch_bounds__(256) void argmax_u8_kernel(const float* __restrict__ in, int B, int K, int64_t HW,
+                                                        uint8_t* __restrict__ out) {
+    const int64_t total = (int64_t)B * HW;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t b = i / HW, px = i - b * HW;
+        const float* p = in + (size_t)b * K * HW + px;
+        float best = p[0];
+        int arg = 0;
+        for (int k = 1; k < K; ++k) {
+            const float v = p[(size_t)k * HW];
+            if (v > best) { best = v; arg = k; }
+        }
+        out[i] = (uint8_t)arg;
+    }
+}
+
+int launch_argmax_u8(const float* in, int B, int K, int64_t HW, uint8_t* out, hipStream_t s) {
+    FS_REQUIRE(K >= 1 && K <= 255, "argmax_u8: K out of range");
+    const int64_t total = (int64_t)B * HW;
+    hipLaunchKernelGGL(argmax_u8_kernel, dim3((unsigned)std::min<int64_t>(cdiv64(total, 256), 16384)), dim3(256), 0, s, in, B, K, HW,
+                       out);
+    FS_HIP(hipGetLastError());
+    return 0;
+}
+
+__global__ __launch_bounds__(256) void resize_argmax_u8_kernel(const float* __restrict__ in, int B, int K, int Hi, int Wi,
+                                                               uint8_t* __restrict__ out, int Ho, int Wo, float sy, float sx) {
+    const int64_t total = (int64_t)B * Ho * Wo;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int ox = (int)(i % Wo);
+        const int oy = (int)((i / Wo) % Ho);
+        const int64_t b = i / ((int64_t)Wo * Ho);
+        const LinCoord cy = lin_coord(oy, Hi, sy, 1), cx = lin_coord(ox, Wi, sx, 1);
+        float best = -INFINITY;
+        int arg = 0;
+        for (int k = 0; k < K; ++k) {
+            const float* pl = in + ((size_t)b * K + k) * Hi * Wi;
+            const float v = bilerp(pl[(size_t)cy.i0 * Wi + cx.i0], pl[(size_t)cy.i0 * Wi + cx.i1], pl[(size_t)cy.i1 * Wi + cx.i0],
+                                   pl[(size_t)cy.i1 * Wi + cx.i1], cy, cx);
+            if (v > best) { best = v; arg = k; }
+        }
+        out[i] = (uint8_t)arg;
+    }
+}
+
+int launch_resize_argmax_u8(const float* in, int B, int K, int Hi, int Wi, uint8_t* out, int Ho, int Wo, hipStream_t s) {
+    FS_REQUIRE(K >= 1 && K <= 255, "resize_argmax_u8: K out of range");
+    const int64_t total = (int64_t)B * Ho * Wo;
+    hipLaunchKernelGGL(resize_argmax_u8_kernel, dim3((unsigned)std::min<int64_t>(cdiv64(total, 256), 16384)), dim3(256), 0, s, in, B,
+                       K, Hi, Wi, out, Ho, Wo, resize_scale(Hi, Ho, 1), resize_scale(Wi, Wo, 1));
+    FS_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------ IoU histograms (util/util.py:52-63)
+// hist[0][k] = |pred==target==k|, hist[1][k] = |pred==k| (after ignore masking), hist[2][k] = |target==k|;
+// union = hist[1] + hist[2] - hist[0] is formed by the caller.
+__global__ __launch_bounds__(256) void iou_hist_kernel(const uint8_t* __restrict__ pred, const uint8_t* __restrict__ target,
+                                                       int64_t numel, int K, int ignore, unsigned long long* __restrict__ hist) {
+    extern __shared__ unsigned int h[];  // [3][K]
+    for (int i = threadIdx.x; i < 3 * K; i += 256) h[i] = 0;
+    __syncthreads();
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < numel; i += (int64_t)gridDim.x * 256) {
+        const int t = target[i];
+        int o = pred[i];
+        if (t == ignore) o = ignore;
+        if (o < K) {
+            atomicAdd(&h[K + o], 1u);
+            if (o == t) atomicAdd(&h[o], 1u);
+        }
+        if (t < K) atomicAdd(&h[2 * K + t], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 3 * K; i += 256)
+        if (h[i]) atomicAdd(&hist[i], (unsigned long long)h[i]);
+}
+
+int launch_iou_hist(const uint8_t* pred, const uint8_t* target, int64_t numel, int K, int ignore_index, long long* hist3K,
+                    hipStream_t s) {
+    FS_REQUIRE(K >= 1 && K <= 255, "iou_hist: K out of range");
+    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv64(numel, 256 * 16), 1024));
+    hipLaunchKernelGGL(iou_hist_kernel, dim3(grid), dim3(256), 3 * K * sizeof(unsigned int), s, pred, target, numel, K,
+                       ignore_index, reinterpret_cast<unsigned long long*>(hist3K));
+    FS_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace fs

@@ -1,0 +1,121 @@
+// Launcher declarations for the hand-written gfx950 kernels.
+// All tensors are fp32. Activations inside the library are NHWC ("pixel-major"):
+// element (b, y, x, c) lives at ((b*H + y)*W + x) * ld + c, ld >= C (ld > C when the
+// tensor is a channel slice of a wider concat buffer).
+#pragma once
+#include "common.h"
+
+namespace fs {
+
+// ---------------------------------------------------------------------------------
+// Implicit-GEMM convolution on the fp32 matrix cores (v_mfma_f32_32x32x2_f32).
+//   out[m][n] = act( scale[n] * sum_k A[m][k] * Wt[n][k] + shift[n] (+ res[m][n]) )
+//   m = (b, oy, ox) output pixel, n = output channel, k = (r, s, c) filter tap/channel.
+// Restates nn.Conv2d + eval BatchNorm2d + ReLU (+ residual add) of the reference's
+// Bottleneck (model/resnet.py:76-96) and PSPNet heads (model/pspnet.py:21-26, 70-76).
+// ---------------------------------------------------------------------------------
+struct ConvParams {
+    const float* in;    int ld_in;   // NHWC input
+    const float* wgt;                // [Cout][KH*KW*Cin], k ordered (r, s, c), c fastest
+    const float* scale;              // [Cout] or nullptr (=1)
+    const float* shift;              // [Cout] or nullptr (=0)
+    const float* res;   int ld_res;  // residual, NHWC at output resolution, or nullptr
+    float* out;         int ld_out;  // NHWC output
+    int B, H, W, Cin;
+    int Ho, Wo, Cout;
+    int KH, KW, stride, pad, dil;
+    int relu;
+};
+// tile: 0 = heuristic, 1 = 128x128, 2 = 128x64, 3 = 64x64, 4 = 64x128
+int launch_conv_igemm(const ConvParams& p, hipStream_t s, int tile = 0);
+const char* conv_igemm_tile_name(const ConvParams& p, int tile = 0);
+
+// ---------------------------------------------------------------------------------
+// Stem convolution with Cin = 3 read straight from the caller's NCHW frame
+// (model/resnet.py:110 3x3 s2 p1; torchvision ResNet 7x7 s2 p3), + BN + ReLU, NHWC out.
+// ---------------------------------------------------------------------------------
+struct StemParams {
+    const float* in;  // NCHW [B,3,H,W]
+    const float* wgt; // [KH*KW*3][Cout]  (tap-major, Cout fastest)
+    const float* scale; const float* shift;
+    float* out; int ld_out;  // NHWC [B,Ho,Wo,Cout]
+    int B, H, W, Ho, Wo, Cout, KH, KW, stride, pad;
+};
+int launch_stem_conv(const StemParams& p, hipStream_t s);
+
+// MaxPool2d(kernel 3, stride 2, padding 1) NHWC (model/resnet.py:117).
+int launch_maxpool3x3s2(const float* in, int ld_in, float* out, int ld_out, int B, int H, int W, int C,
+                        int Ho, int Wo, hipStream_t s);
+
+// AdaptiveAvgPool2d(bin) NHWC -> [B][bin*bin][C] (model/pspnet.py:22; torchvision ASPPPooling).
+int launch_adaptive_avgpool(const float* in, int ld_in, float* out, int B, int H, int W, int C, int bin,
+                            hipStream_t s);
+
+// Small-M 1x1 convolution (+scale/shift+ReLU): out[m][n] = act(scale[n]*dot(in[m], w[n]) + shift[n]).
+// Used for the pooled PPM / ASPP-pooling branches (M = B*bin*bin <= ~100).
+int launch_rowdot_1x1(const float* in, int ld_in, const float* wgt, const float* scale, const float* shift,
+                      float* out, int ld_out, int M, int K, int N, int relu, hipStream_t s);
+
+// Bilinear (align_corners as given) upsample of a tiny [B][hi*wi][C] map into a channel
+// slice of an NHWC buffer (PPM: model/pspnet.py:33, align_corners=True).
+int launch_upsample_into(const float* in, int hi, int wi, float* out, int ld_out, int B, int Ho, int Wo,
+                         int C, int align_corners, hipStream_t s);
+
+// Final classifier 1x1 conv with bias, NHWC in -> NCHW out (model/pspnet.py:75).
+int launch_classifier_nchw(const float* in, int ld_in, const float* wgt /*[K][C]*/, const float* bias,
+                           float* out /*[B,K,H,W]*/, int B, int HW, int C, int K, hipStream_t s);
+
+// ---------------------------------------------------------------------------------
+// Layout / weight packing
+// ---------------------------------------------------------------------------------
+int launch_pack_oihw_to_ohwi(const float* w, float* out, int O, int I, int KH, int KW, hipStream_t s);
+int launch_pack_oihw_to_hwio(const float* w, float* out, int O, int I, int KH, int KW, hipStream_t s);
+int launch_nchw_to_nhwc(const float* in, float* out, int ld_out, int B, int C, int HW, hipStream_t s);
+int launch_nhwc_to_nchw(const float* in, int ld_in, float* out, int B, int C, int HW, hipStream_t s);
+
+// ---------------------------------------------------------------------------------
+// Flow / interpolation tail (flow/model.py:184-249, flow/base.py:275-276)
+// ---------------------------------------------------------------------------------
+// F.grid_sample(mode=bilinear, padding_mode=border), NCHW in/out, N = 1..B.
+int launch_grid_sample_nchw(const float* in, int B, int C, int Hi, int Wi, const float* grid, int Hg, int Wg,
+                            float* out, int align_corners, hipStream_t s);
+// Same on NHWC tensors (feature-based mode, C = 4096).
+int launch_grid_sample_nhwc(const float* in, int ld_in, int B, int C, int Hi, int Wi, const float* grid, int Hg,
+                            int Wg, float* out, int ld_out, int align_corners, hipStream_t s);
+// F.interpolate(mode=bilinear), NCHW.
+int launch_resize_bilinear_nchw(const float* in, int BC, int Hi, int Wi, float* out, int Ho, int Wo,
+                                int align_corners, hipStream_t s);
+// NHWC bilinear resize (feature maps).
+int launch_resize_bilinear_nhwc(const float* in, int ld_in, int B, int C, int Hi, int Wi, float* out, int ld_out,
+                                int Ho, int Wo, int align_corners, hipStream_t s);
+// out = wa*a + wb*b  (b may be nullptr -> out = wa*a)
+int launch_blend(const float* a, float wa, const float* b, float wb, float* out, int64_t numel, hipStream_t s);
+
+// Fused predict_segmentation tail.
+struct SegTailParams {
+    const float* lo_prev;   // [K, h, w]   decoder logits of the previous key frame
+    const float* lo_next;   // [K, h, w]   or nullptr (single-frame)
+    const float* const* grids_left;   // n-1 device pointers [Hg,Wg,2] (ignored when no_warp)
+    const float* const* grids_right;  // n-1 device pointers
+    int K, h, w;            // low-res logits geometry
+    int Hg, Wg;             // grid geometry
+    int H, W;               // output frame size
+    int n;                  // frame_delta
+    int no_warp;
+    float* out_logits;      // [n, K, H, W] or nullptr
+    uint8_t* out_mask;      // [n, H, W] argmax or nullptr
+    float* scratch;         // >= 2*(n-1)*K*Hg*Wg floats when warping
+};
+int launch_seg_tail(const SegTailParams& p, hipStream_t s);
+
+// argmax over channel dim of NCHW logits -> uint8 (first max wins; flow/base.py:276).
+int launch_argmax_u8(const float* in, int B, int K, int64_t HW, uint8_t* out, hipStream_t s);
+// argmax of the align_corners=True bilinear upsample of NCHW logits, without materialising it
+// (flow/base.py:275-276: F.interpolate(output,(1072,1920)) then max(1)[1]).
+int launch_resize_argmax_u8(const float* in, int B, int K, int Hi, int Wi, uint8_t* out, int Ho, int Wo,
+                            hipStream_t s);
+// intersection / union / target histograms (util/util.py:52-63), int64[3][K] accumulated.
+int launch_iou_hist(const uint8_t* pred, const uint8_t* target, int64_t numel, int K, int ignore_index,
+                    long long* hist3K, hipStream_t s);
+
+}  // namespace fs

@@ -1,0 +1,511 @@
+// Host-side executor: builds the layer plan from the loaded state_dict and runs it with the
+// hand-written kernels.  No torch types; device memory is raw hipMalloc owned by the handle.
+#include "net.h"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstring>
+
+namespace fs {
+
+std::string& last_error() {
+    static thread_local std::string e;
+    return e;
+}
+int fail(const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    last_error() = buf;
+    return 1;
+}
+
+namespace {
+
+int dev_alloc(fs_net* h, float** p, size_t elems) {
+    FS_HIP(hipMalloc(reinterpret_cast<void**>(p), std::max<size_t>(elems, 4) * sizeof(float)));
+    h->owned.push_back(*p);
+    return 0;
+}
+
+int fetch(fs_net* h, const std::string& name, const RawTensor** out) {
+    auto it = h->raw.find(name);
+    if (it == h->raw.end()) return fail("missing weight '%s'", name.c_str());
+    *out = &it->second;
+    return 0;
+}
+
+int to_host(const RawTensor& t, std::vector<float>& v) {
+    v.resize((size_t)t.numel());
+    FS_HIP(hipMemcpy(v.data(), t.d, v.size() * sizeof(float), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// conv weight + BatchNorm prefix (or bias name, or neither)
+int make_conv(fs_net* h, ConvBN& c, const std::string& wname, const std::string& bn, const std::string& bias, int stride,
+              int pad, int dil, int relu, bool hwio, hipStream_t s) {
+    const RawTensor* w;
+    FS_TRY(fetch(h, wname, &w));
+    FS_REQUIRE(w->shape.size() == 4, "weight '%s' is not 4-D", wname.c_str());
+    c.name = wname;
+    c.Cout = (int)w->shape[0];
+    c.Cin = (int)w->shape[1];
+    c.KH = (int)w->shape[2];
+    c.KW = (int)w->shape[3];
+    c.stride = stride;
+    c.pad = pad;
+    c.dil = dil;
+    c.relu = relu;
+    FS_TRY(dev_alloc(h, &c.w, (size_t)w->numel()));
+    if (hwio)
+        FS_TRY(launch_pack_oihw_to_hwio(w->d, c.w, c.Cout, c.Cin, c.KH, c.KW, s));
+    else
+        FS_TRY(launch_pack_oihw_to_ohwi(w->d, c.w, c.Cout, c.Cin, c.KH, c.KW, s));
+    if (!bn.empty()) {
+        const RawTensor *g, *b, *m, *v;
+        FS_TRY(fetch(h, bn + ".weight", &g));
+        FS_TRY(fetch(h, bn + ".bias", &b));
+        FS_TRY(fetch(h, bn + ".running_mean", &m));
+        FS_TRY(fetch(h, bn + ".running_var", &v));
+        FS_REQUIRE(g->numel() == c.Cout && b->numel() == c.Cout && m->numel() == c.Cout && v->numel() == c.Cout,
+                   "BatchNorm '%s' does not match %d output channels", bn.c_str(), c.Cout);
+        std::vector<float> hg, hb, hm, hv, sc((size_t)c.Cout), sh((size_t)c.Cout);
+        FS_TRY(to_host(*g, hg));
+        FS_TRY(to_host(*b, hb));
+        FS_TRY(to_host(*m, hm));
+        FS_TRY(to_host(*v, hv));
+        for (int i = 0; i < c.Cout; ++i) {
+            // ATen eval batch_norm: alpha = invstd * weight; beta = bias - mean * alpha  (eps = 1e-5)
+            const float invstd = 1.0f / std::sqrt(hv[i] + 1e-5f);
+            sc[i] = invstd * hg[i];
+            sh[i] = hb[i] - hm[i] * sc[i];
+        }
+        FS_TRY(dev_alloc(h, &c.scale, (size_t)c.Cout));
+        FS_TRY(dev_alloc(h, &c.shift, (size_t)c.Cout));
+        FS_HIP(hipMemcpy(c.scale, sc.data(), sc.size() * sizeof(float), hipMemcpyHostToDevice));
+        FS_HIP(hipMemcpy(c.shift, sh.data(), sh.size() * sizeof(float), hipMemcpyHostToDevice));
+    } else if (!bias.empty()) {
+        const RawTensor* b;
+        FS_TRY(fetch(h, bias, &b));
+        FS_REQUIRE(b->numel() == c.Cout, "bias '%s' does not match %d output channels", bias.c_str(), c.Cout);
+        FS_TRY(dev_alloc(h, &c.shift, (size_t)c.Cout));
+        FS_HIP(hipMemcpy(c.shift, b->d, (size_t)c.Cout * sizeof(float), hipMemcpyDeviceToDevice));
+    }
+    return 0;
+}
+
+int prof_begin(fs_net* h, const std::string& name, const char* kernel, double flops, double bytes, hipStream_t s) {
+    if (!h->profiling) return 0;
+    ProfRec r;
+    r.name = name;
+    r.kernel = kernel;
+    r.flops = flops;
+    r.bytes = bytes;
+    FS_HIP(hipEventCreate(&r.e0));
+    FS_HIP(hipEventCreate(&r.e1));
+    FS_HIP(hipEventRecord(r.e0, s));
+    h->prof.push_back(r);
+    return 0;
+}
+int prof_end(fs_net* h, hipStream_t s) {
+    if (!h->profiling) return 0;
+    FS_HIP(hipEventRecord(h->prof.back().e1, s));
+    return 0;
+}
+
+int run_conv(fs_net* h, const ConvBN& c, const float* in, int ld_in, int B, int H, int W, float* out, int ld_out,
+             const float* res, int ld_res, hipStream_t s) {
+    ConvParams p{};
+    p.in = in;
+    p.ld_in = ld_in;
+    p.wgt = c.w;
+    p.scale = c.scale;
+    p.shift = c.shift;
+    p.res = res;
+    p.ld_res = ld_res;
+    p.out = out;
+    p.ld_out = ld_out;
+    p.B = B;
+    p.H = H;
+    p.W = W;
+    p.Cin = c.Cin;
+    p.Ho = c.out_size(H);
+    p.Wo = c.out_size(W);
+    p.Cout = c.Cout;
+    p.KH = c.KH;
+    p.KW = c.KW;
+    p.stride = c.stride;
+    p.pad = c.pad;
+    p.dil = c.dil;
+    p.relu = c.relu;
+    const double M = (double)B * p.Ho * p.Wo;
+    const double flops = 2.0 * M * c.Cout * c.KH * c.KW * c.Cin;
+    const double bytes = 4.0 * ((double)B * H * W * c.Cin + (double)c.Cout * c.KH * c.KW * c.Cin + M * c.Cout * (res ? 2 : 1));
+    FS_TRY(prof_begin(h, c.name, conv_igemm_tile_name(p), flops, bytes, s));
+    FS_TRY(launch_conv_igemm(p, s));
+    return prof_end(h, s);
+}
+
+int ensure_workspace(fs_net* h, size_t buf_elems, size_t small_elems) {
+    if (buf_elems > h->buf_elems) {
+        FS_HIP(hipDeviceSynchronize());
+        for (int i = 0; i < 4; ++i) {
+            if (h->buf[i]) FS_HIP(hipFree(h->buf[i]));
+            h->buf[i] = nullptr;
+            FS_HIP(hipMalloc(reinterpret_cast<void**>(&h->buf[i]), buf_elems * sizeof(float)));
+        }
+        h->buf_elems = buf_elems;
+    }
+    if (small_elems > h->small_elems) {
+        FS_HIP(hipDeviceSynchronize());
+        if (h->small) FS_HIP(hipFree(h->small));
+        h->small = nullptr;
+        FS_HIP(hipMalloc(reinterpret_cast<void**>(&h->small), small_elems * sizeof(float)));
+        h->small_elems = small_elems;
+    }
+    return 0;
+}
+
+struct Geometry {
+    int H1, W1, H2, W2, H3, W3;  // after stem conv, after maxpool, after layer2 (stride 8 map)
+};
+
+Geometry geometry(const fs_net* h, int H, int W) {
+    Geometry g;
+    g.H1 = h->stem[0].out_size(H);
+    g.W1 = h->stem[0].out_size(W);
+    g.H2 = (g.H1 + 2 - 3) / 2 + 1;
+    g.W2 = (g.W1 + 2 - 3) / 2 + 1;
+    g.H3 = (g.H2 + 2 - 3) / 2 + 1;
+    g.W3 = (g.W2 + 2 - 3) / 2 + 1;
+    return g;
+}
+
+size_t encoder_buf_elems(const fs_net* h, int B, int H, int W) {
+    const Geometry g = geometry(h, H, W);
+    const size_t a = (size_t)B * g.H1 * g.W1 * 128;
+    const size_t b = (size_t)B * g.H2 * g.W2 * 256;
+    const size_t c = (size_t)B * g.H3 * g.W3 * 2048;
+    return std::max(a, std::max(b, c));
+}
+
+size_t small_elems_for(int B) { return (size_t)B * 50 * (2048 + 512) + 1024; }
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+int net_create(const fs_config* cfg, fs_handle* out) {
+    FS_REQUIRE(cfg && out, "fs_create: null argument");
+    FS_REQUIRE(cfg->arch == FS_ARCH_PSPNET || cfg->arch == FS_ARCH_DEEPLABV3, "fs_create: unknown arch %d", cfg->arch);
+    FS_REQUIRE(cfg->layers == 50 || cfg->layers == 101 || cfg->layers == 152, "fs_create: layers must be 50, 101 or 152");
+    FS_REQUIRE(cfg->classes >= 1 && cfg->classes <= 255, "fs_create: classes out of range");
+    fs_net* h = new fs_net();
+    h->cfg = *cfg;
+    h->deep_stem = cfg->arch == FS_ARCH_PSPNET;
+    *out = h;
+    return 0;
+}
+
+int net_destroy(fs_handle h) {
+    if (!h) return 0;
+    (void)hipDeviceSynchronize();
+    for (auto& kv : h->raw)
+        if (kv.second.d) (void)hipFree(kv.second.d);
+    for (float* p : h->owned) (void)hipFree(p);
+    for (int i = 0; i < 4; ++i)
+        if (h->buf[i]) (void)hipFree(h->buf[i]);
+    if (h->small) (void)hipFree(h->small);
+    for (auto& r : h->prof) {
+        (void)hipEventDestroy(r.e0);
+        (void)hipEventDestroy(r.e1);
+    }
+    delete h;
+    return 0;
+}
+
+int net_load_weight(fs_handle h, const char* name, const float* data, const int64_t* shape, int ndim, int on_device,
+                    hipStream_t s) {
+    FS_REQUIRE(h && name && data && (shape || ndim == 0), "fs_load_weight: null argument");
+    FS_REQUIRE(!h->finalized, "fs_load_weight: network already finalized");
+    RawTensor t;
+    t.shape.assign(shape, shape + ndim);
+    const int64_t n = t.numel();
+    FS_REQUIRE(n > 0, "fs_load_weight: '%s' is empty", name);
+    auto it = h->raw.find(name);
+    if (it != h->raw.end()) {
+        (void)hipFree(it->second.d);
+        h->raw.erase(it);
+    }
+    FS_HIP(hipMalloc(reinterpret_cast<void**>(&t.d), (size_t)n * sizeof(float)));
+    FS_HIP(hipMemcpyAsync(t.d, data, (size_t)n * sizeof(float), on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
+    h->raw[name] = t;
+    return 0;
+}
+
+int net_finalize(fs_handle h, hipStream_t s) {
+    FS_REQUIRE(h, "fs_finalize: null handle");
+    FS_REQUIRE(!h->finalized, "fs_finalize: already finalized");
+    FS_HIP(hipStreamSynchronize(s));
+    const bool psp = h->cfg.arch == FS_ARCH_PSPNET;
+    const std::string bb = psp ? "" : "backbone.";
+    // ---- stem
+    if (psp) {
+        FS_TRY(make_conv(h, h->stem[0], "layer0.0.weight", "layer0.1", "", 2, 1, 1, 1, true, s));
+        FS_TRY(make_conv(h, h->stem[1], "layer0.3.weight", "layer0.4", "", 1, 1, 1, 1, false, s));
+        FS_TRY(make_conv(h, h->stem[2], "layer0.6.weight", "layer0.7", "", 1, 1, 1, 1, false, s));
+    } else {
+        FS_TRY(make_conv(h, h->stem[0], "backbone.conv1.weight", "backbone.bn1", "", 2, 3, 1, 1, true, s));
+    }
+    FS_REQUIRE(h->stem[0].Cin == 3, "stem conv must take 3 input channels");
+    // ---- residual stages
+    int nblk[4] = {3, 4, 6, 3};
+    if (h->cfg.layers == 101) nblk[2] = 23;
+    if (h->cfg.layers == 152) { nblk[1] = 8; nblk[2] = 36; }
+    h->blocks.clear();
+    h->layer_end.clear();
+    for (int L = 1; L <= 4; ++L) {
+        for (int b = 0; b < nblk[L - 1]; ++b) {
+            Bottleneck blk;
+            const std::string pre = bb + "layer" + std::to_string(L) + "." + std::to_string(b) + ".";
+            int stride = 1, dil = 1;
+            if (L == 2 && b == 0) stride = 2;
+            if (psp) {
+                // model/pspnet.py:55-64: every conv2 of layer3/4 gets dilation 2/4, stride 1
+                if (L == 3) dil = 2;
+                if (L == 4) dil = 4;
+            } else {
+                // torchvision replace_stride_with_dilation=[False, True, True]
+                if (L == 3) dil = b == 0 ? 1 : 2;
+                if (L == 4) dil = b == 0 ? 2 : 4;
+            }
+            FS_TRY(make_conv(h, blk.c1, pre + "conv1.weight", pre + "bn1", "", 1, 0, 1, 1, false, s));
+            FS_TRY(make_conv(h, blk.c2, pre + "conv2.weight", pre + "bn2", "", stride, dil, dil, 1, false, s));
+            FS_TRY(make_conv(h, blk.c3, pre + "conv3.weight", pre + "bn3", "", 1, 0, 1, 1, false, s));
+            blk.has_ds = b == 0;
+            if (blk.has_ds)
+                FS_TRY(make_conv(h, blk.ds, pre + "downsample.0.weight", pre + "downsample.1", "", stride, 0, 1, 0, false, s));
+            h->blocks.push_back(blk);
+        }
+        h->layer_end.push_back((int)h->blocks.size());
+    }
+    // ---- heads
+    const int K = h->cfg.classes;
+    if (psp) {
+        for (int i = 0; i < 4; ++i) {
+            const std::string pre = "ppm.features." + std::to_string(i) + ".";
+            FS_TRY(make_conv(h, h->ppm[i], pre + "1.weight", pre + "2", "", 1, 0, 1, 1, false, s));
+            FS_REQUIRE(h->ppm[i].Cin == 2048 && h->ppm[i].Cout == 512, "unexpected PPM conv shape");
+        }
+        FS_TRY(make_conv(h, h->cls_conv, "decoder.0.weight", "decoder.1", "", 1, 1, 1, 1, false, s));
+        FS_REQUIRE(h->cls_conv.Cin == 4096, "decoder.0 must take 4096 channels");
+        h->cls_cin = h->cls_conv.Cout;
+        const RawTensor *w, *b;
+        FS_TRY(fetch(h, "decoder.4.weight", &w));
+        FS_TRY(fetch(h, "decoder.4.bias", &b));
+        FS_REQUIRE(w->shape.size() == 4 && w->shape[0] == K && w->shape[1] == h->cls_cin, "decoder.4.weight has wrong shape");
+        FS_TRY(dev_alloc(h, &h->cls_w, (size_t)w->numel()));
+        FS_TRY(dev_alloc(h, &h->cls_b, (size_t)K));
+        FS_HIP(hipMemcpy(h->cls_w, w->d, (size_t)w->numel() * sizeof(float), hipMemcpyDeviceToDevice));
+        FS_HIP(hipMemcpy(h->cls_b, b->d, (size_t)K * sizeof(float), hipMemcpyDeviceToDevice));
+    } else {
+        const int rates[4] = {0, 12, 24, 36};
+        FS_TRY(make_conv(h, h->aspp[0], "classifier.0.convs.0.0.weight", "classifier.0.convs.0.1", "", 1, 0, 1, 1, false, s));
+        for (int i = 1; i < 4; ++i) {
+            const std::string pre = "classifier.0.convs." + std::to_string(i) + ".";
+            FS_TRY(make_conv(h, h->aspp[i], pre + "0.weight", pre + "1", "", 1, rates[i], rates[i], 1, false, s));
+        }
+        FS_TRY(make_conv(h, h->aspp_pool, "classifier.0.convs.4.1.weight", "classifier.0.convs.4.2", "", 1, 0, 1, 1, false, s));
+        FS_TRY(make_conv(h, h->project, "classifier.0.project.0.weight", "classifier.0.project.1", "", 1, 0, 1, 1, false, s));
+        FS_TRY(make_conv(h, h->head_conv, "classifier.1.weight", "classifier.2", "", 1, 1, 1, 1, false, s));
+        h->cls_cin = h->head_conv.Cout;
+        const RawTensor *w, *b;
+        FS_TRY(fetch(h, "classifier.4.weight", &w));
+        FS_TRY(fetch(h, "classifier.4.bias", &b));
+        FS_REQUIRE(w->shape.size() == 4 && w->shape[0] == K && w->shape[1] == h->cls_cin, "classifier.4.weight has wrong shape");
+        FS_TRY(dev_alloc(h, &h->cls_w, (size_t)w->numel()));
+        FS_TRY(dev_alloc(h, &h->cls_b, (size_t)K));
+        FS_HIP(hipMemcpy(h->cls_w, w->d, (size_t)w->numel() * sizeof(float), hipMemcpyDeviceToDevice));
+        FS_HIP(hipMemcpy(h->cls_b, b->d, (size_t)K * sizeof(float), hipMemcpyDeviceToDevice));
+    }
+    FS_HIP(hipStreamSynchronize(s));
+    FS_HIP(hipDeviceSynchronize());
+    for (auto& kv : h->raw) {
+        (void)hipFree(kv.second.d);
+        kv.second.d = nullptr;
+    }
+    h->raw.clear();
+    h->finalized = true;
+    return 0;
+}
+
+int net_feature_shape(fs_handle h, int H, int W, int* C, int* fh, int* fw) {
+    FS_REQUIRE(h && h->finalized, "fs_feature_shape: network not finalized");
+    const Geometry g = geometry(h, H, W);
+    if (C) *C = h->feat_channels();
+    if (fh) *fh = g.H3;
+    if (fw) *fw = g.W3;
+    return 0;
+}
+
+size_t net_workspace_bytes(fs_handle h, int B, int H, int W) {
+    if (!h || !h->finalized) return 0;
+    return (4 * encoder_buf_elems(h, B, H, W) + small_elems_for(B)) * sizeof(float);
+}
+
+// ---------------------------------------------------------------------------------------------
+int net_encoder(fs_handle h, const float* in_nchw, int B, int H, int W, float* out, hipStream_t s) {
+    FS_REQUIRE(h && h->finalized, "fs_encoder_forward: network not finalized");
+    FS_REQUIRE(in_nchw && out && B >= 1 && H >= 33 && W >= 33, "fs_encoder_forward: bad arguments (B=%d H=%d W=%d)", B, H, W);
+    const Geometry g = geometry(h, H, W);
+    FS_TRY(ensure_workspace(h, encoder_buf_elems(h, B, H, W), small_elems_for(B)));
+    const bool psp = h->cfg.arch == FS_ARCH_PSPNET;
+    float *X = h->buf[0], *F1 = h->buf[1], *F2 = h->buf[2], *F3 = h->buf[3];
+
+    // ---- stem
+    {
+        const ConvBN& c = h->stem[0];
+        StemParams p{};
+        p.in = in_nchw;
+        p.wgt = c.w;
+        p.scale = c.scale;
+        p.shift = c.shift;
+        p.out = X;
+        p.ld_out = c.Cout;
+        p.B = B;
+        p.H = H;
+        p.W = W;
+        p.Ho = g.H1;
+        p.Wo = g.W1;
+        p.Cout = c.Cout;
+        p.KH = c.KH;
+        p.KW = c.KW;
+        p.stride = c.stride;
+        p.pad = c.pad;
+        const double M = (double)B * g.H1 * g.W1;
+        FS_TRY(prof_begin(h, c.name, "stem_conv", 2.0 * M * c.Cout * c.KH * c.KW * 3, 4.0 * (B * 3.0 * H * W + M * c.Cout), s));
+        FS_TRY(launch_stem_conv(p, s));
+        FS_TRY(prof_end(h, s));
+    }
+    int C = h->stem[0].Cout;
+    if (h->deep_stem) {
+        FS_TRY(run_conv(h, h->stem[1], X, C, B, g.H1, g.W1, F1, h->stem[1].Cout, nullptr, 0, s));
+        FS_TRY(run_conv(h, h->stem[2], F1, h->stem[1].Cout, B, g.H1, g.W1, X, h->stem[2].Cout, nullptr, 0, s));
+        C = h->stem[2].Cout;
+    }
+    {
+        const double M = (double)B * g.H2 * g.W2;
+        FS_TRY(prof_begin(h, "maxpool", "maxpool3x3s2", 0, 4.0 * ((double)B * g.H1 * g.W1 * C + M * C), s));
+        FS_TRY(launch_maxpool3x3s2(X, C, F1, C, B, g.H1, g.W1, C, g.H2, g.W2, s));
+        FS_TRY(prof_end(h, s));
+        std::swap(X, F1);
+    }
+    // ---- residual stages.  X holds the block input; F1..F3 are free.
+    int curH = g.H2, curW = g.W2;
+    const int nblocks = (int)h->blocks.size();
+    for (int bi = 0; bi < nblocks; ++bi) {
+        const Bottleneck& blk = h->blocks[bi];
+        const bool last = bi == nblocks - 1;
+        const int oH = blk.c2.out_size(curH), oW = blk.c2.out_size(curW);
+        FS_TRY(run_conv(h, blk.c1, X, C, B, curH, curW, F1, blk.c1.Cout, nullptr, 0, s));
+        FS_TRY(run_conv(h, blk.c2, F1, blk.c1.Cout, B, curH, curW, F2, blk.c2.Cout, nullptr, 0, s));
+        const int Cn = blk.c3.Cout;
+        float* dst = last ? out : nullptr;
+        const int ld_dst = last ? h->feat_channels() : Cn;
+        ConvBN c3 = blk.c3;
+        c3.relu = 1;  // ReLU after the residual add (model/resnet.py:93-94)
+        if (blk.has_ds) {
+            FS_TRY(run_conv(h, blk.ds, X, C, B, curH, curW, F3, Cn, nullptr, 0, s));
+            if (!dst) dst = F3;  // in place over the shortcut
+            FS_TRY(run_conv(h, c3, F2, blk.c2.Cout, B, oH, oW, dst, ld_dst, F3, Cn, s));
+            if (!last) std::swap(X, F3);
+        } else {
+            if (!dst) dst = X;  // in place over the identity shortcut
+            FS_TRY(run_conv(h, c3, F2, blk.c2.Cout, B, oH, oW, dst, ld_dst, X, C, s));
+        }
+        C = Cn;
+        curH = oH;
+        curW = oW;
+    }
+    FS_REQUIRE(curH == g.H3 && curW == g.W3 && C == 2048, "encoder geometry mismatch");
+    if (!psp) return 0;
+
+    // ---- pyramid pooling: pooled -> 1x1 conv + BN + ReLU -> bilinear(ac=True) into channels 2048+512*i
+    float* pooled = h->small;
+    float* reduced = h->small + (size_t)B * 50 * 2048;
+    size_t poff = 0, roff = 0;
+    for (int i = 0; i < 4; ++i) {
+        const int bin = h->bins[i];
+        const int cells = bin * bin;
+        FS_TRY(prof_begin(h, "ppm.pool" + std::to_string(bin), "adaptive_avgpool", 0, 4.0 * B * curH * curW * 2048.0, s));
+        FS_TRY(launch_adaptive_avgpool(out, 4096, pooled + poff, B, curH, curW, 2048, bin, s));
+        FS_TRY(prof_end(h, s));
+        const ConvBN& c = h->ppm[i];
+        FS_TRY(prof_begin(h, c.name, "rowdot_1x1", 2.0 * B * cells * 2048.0 * 512.0, 4.0 * 2048.0 * 512.0, s));
+        FS_TRY(launch_rowdot_1x1(pooled + poff, 2048, c.w, c.scale, c.shift, reduced + roff, 512, B * cells, 2048, 512, 1, s));
+        FS_TRY(prof_end(h, s));
+        FS_TRY(prof_begin(h, "ppm.up" + std::to_string(bin), "upsample_into", 0, 4.0 * B * curH * curW * 512.0, s));
+        FS_TRY(launch_upsample_into(reduced + roff, bin, bin, out + 2048 + 512 * i, 4096, B, curH, curW, 512, 1, s));
+        FS_TRY(prof_end(h, s));
+        poff += (size_t)B * cells * 2048;
+        roff += (size_t)B * cells * 512;
+    }
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+int net_decoder(fs_handle h, const float* feat, int B, int fh, int fw, float* out_nchw, hipStream_t s) {
+    FS_REQUIRE(h && h->finalized, "fs_decoder_forward: network not finalized");
+    FS_REQUIRE(feat && out_nchw && B >= 1 && fh >= 1 && fw >= 1, "fs_decoder_forward: bad arguments");
+    const int K = h->cfg.classes;
+    const size_t px = (size_t)B * fh * fw;
+    if (h->cfg.arch == FS_ARCH_PSPNET) {
+        FS_TRY(ensure_workspace(h, px * 512, small_elems_for(B)));
+        float* T = h->buf[0];
+        FS_TRY(run_conv(h, h->cls_conv, feat, 4096, B, fh, fw, T, 512, nullptr, 0, s));
+        FS_TRY(prof_begin(h, "decoder.4", "classifier_nchw", 2.0 * px * 512.0 * K, 4.0 * px * 512.0, s));
+        FS_TRY(launch_classifier_nchw(T, 512, h->cls_w, h->cls_b, out_nchw, B, fh * fw, 512, K, s));
+        return prof_end(h, s);
+    }
+    // DeepLabv3 head (torchvision DeepLabHead): ASPP -> project -> 3x3 -> 1x1
+    FS_TRY(ensure_workspace(h, px * 1280, small_elems_for(B)));
+    float *cat = h->buf[0], *P = h->buf[1], *Q = h->buf[2];
+    for (int i = 0; i < 4; ++i) FS_TRY(run_conv(h, h->aspp[i], feat, 2048, B, fh, fw, cat + 256 * i, 1280, nullptr, 0, s));
+    float* pooled = h->small;
+    float* reduced = h->small + (size_t)B * 2048;
+    FS_TRY(prof_begin(h, "aspp.pool", "adaptive_avgpool", 0, 4.0 * px * 2048.0, s));
+    FS_TRY(launch_adaptive_avgpool(feat, 2048, pooled, B, fh, fw, 2048, 1, s));
+    FS_TRY(prof_end(h, s));
+    FS_TRY(prof_begin(h, h->aspp_pool.name, "rowdot_1x1", 2.0 * B * 2048.0 * 256.0, 4.0 * 2048.0 * 256.0, s));
+    FS_TRY(launch_rowdot_1x1(pooled, 2048, h->aspp_pool.w, h->aspp_pool.scale, h->aspp_pool.shift, reduced, 256, B, 2048, 256, 1, s));
+    FS_TRY(prof_end(h, s));
+    FS_TRY(prof_begin(h, "aspp.up", "upsample_into", 0, 4.0 * px * 256.0, s));
+    FS_TRY(launch_upsample_into(reduced, 1, 1, cat + 1024, 1280, B, fh, fw, 256, 0, s));
+    FS_TRY(prof_end(h, s));
+    FS_TRY(run_conv(h, h->project, cat, 1280, B, fh, fw, P, 256, nullptr, 0, s));
+    FS_TRY(run_conv(h, h->head_conv, P, 256, B, fh, fw, Q, 256, nullptr, 0, s));
+    FS_TRY(prof_begin(h, "classifier.4", "classifier_nchw", 2.0 * px * 256.0 * K, 4.0 * px * 256.0, s));
+    FS_TRY(launch_classifier_nchw(Q, 256, h->cls_w, h->cls_b, out_nchw, B, fh * fw, 256, K, s));
+    return prof_end(h, s);
+}
+
+int net_profile_dump(fs_handle h, char* buf, size_t n) {
+    FS_REQUIRE(h && buf && n > 0, "fs_profile_dump: bad arguments");
+    FS_HIP(hipDeviceSynchronize());
+    size_t off = 0;
+    buf[0] = 0;
+    for (auto& r : h->prof) {
+        float ms = 0.f;
+        FS_HIP(hipEventElapsedTime(&ms, r.e0, r.e1));
+        const int w = snprintf(buf + off, n - off, "%s %s %.0f %.0f %.6f\n", r.name.c_str(), r.kernel.c_str(), r.flops, r.bytes, ms);
+        if (w < 0 || (size_t)w >= n - off) return fail("fs_profile_dump: buffer too small");
+        off += (size_t)w;
+        (void)hipEventDestroy(r.e0);
+        (void)hipEventDestroy(r.e1);
+    }
+    h->prof.clear();
+    return 0;
+}
+
+}  // namespace fs

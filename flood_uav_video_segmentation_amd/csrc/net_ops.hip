@@ -1,0 +1,381 @@
+// Non-GEMM network kernels (HBM-bound or tiny): stem conv, pooling, PPM pieces, classifier,
+// weight packing and layout changes.  All NHWC unless the name says otherwise.
+#include "interp.h"
+#include "kernels.h"
+
+namespace fs {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// -------------------------------------------------------------------------------------------
+// Stem conv (Cin = 3) from NCHW, fused scale/shift + ReLU, NHWC out.
+// Block = 64 output pixels x 4 channel groups; filter bank lives in LDS ([tap*3+ci][Cout]).
+// Cout must be a multiple of 16 and <= 128.
+// -------------------------------------------------------------------------------------------
+template <int CPT /*channels per thread*/>
+__global__ __launch_bounds__(256) void stem_conv_kernel(StemParams p) {
+    extern __shared__ __attribute__((aligned(16))) float wlds[];
+    const int taps = p.KH * p.KW * 3;
+    for (int i = threadIdx.x; i < taps * p.Cout; i += 256) wlds[i] = p.wgt[i];
+    __syncthreads();
+
+    const int groups = p.Cout / CPT;           // threads per pixel
+    const int ppb = 256 / groups;              // pixels per block
+    const int cg = threadIdx.x % groups;
+    const int M = p.B * p.Ho * p.Wo;
+    const int m = blockIdx.x * ppb + threadIdx.x / groups;
+    if (m >= M) return;
+    const int hw = p.Ho * p.Wo;
+    const int b = m / hw;
+    const int rem = m - b * hw;
+    const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+    const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;
+
+    float acc[CPT];
+#pragma unroll
+    for (int c = 0; c < CPT; ++c) acc[c] = 0.f;
+    const size_t plane = (size_t)p.H * p.W;
+    const float* inb = p.in + (size_t)b * 3 * plane;
+    for (int ky = 0; ky < p.KH; ++ky) {
+        const int iy = iy0 + ky;
+        const bool yok = (unsigned)iy < (unsigned)p.H;
+        for (int kx = 0; kx < p.KW; ++kx) {
+            const int ix = ix0 + kx;
+            const bool ok = yok && (unsigned)ix < (unsigned)p.W;
+            const size_t off = ok ? (size_t)iy * p.W + ix : 0;
+            const float x0 = ok ? inb[off] : 0.f;
+            const float x1 = ok ? inb[plane + off] : 0.f;
+            const float x2 = ok ? inb[2 * plane + off] : 0.f;
+            const float* w = wlds + (size_t)((ky * p.KW + kx) * 3) * p.Cout + cg * CPT;
+#pragma unroll
+            for (int c = 0; c < CPT; c += 4) {
+                const f32x4 w0 = *reinterpret_cast<const f32x4*>(w + c);
+                const f32x4 w1 = *reinterpret_cast<const f32x4*>(w + p.Cout + c);
+                const f32x4 w2 = *reinterpret_cast<const f32x4*>(w + 2 * p.Cout + c);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[c + e] += x0 * w0[e] + x1 * w1[e] + x2 * w2[e];
+            }
+        }
+    }
+    float* o = p.out + (size_t)m * p.ld_out + cg * CPT;
+#pragma unroll
+    for (int c = 0; c < CPT; c += 4) {
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int ch = cg * CPT + c + e;
+            float y = acc[c + e] * p.scale[ch] + p.shift[ch];
+            v[e] = fmaxf(y, 0.f);
+        }
+        *reinterpret_cast<f32x4*>(o + c) = v;
+    }
+}
+
+int launch_stem_conv(const StemParams& p, hipStream_t s) {
+    FS_REQUIRE(p.Cout % 16 == 0 && p.Cout <= 256 && 256 % (p.Cout / 16) == 0, "stem_conv: unsupported Cout=%d", p.Cout);
+    FS_REQUIRE(p.ld_out % 4 == 0, "stem_conv: ld_out must be a multiple of 4");
+    const int M = p.B * p.Ho * p.Wo;
+    const int groups = p.Cout / 16, ppb = 256 / groups;
+    const size_t lds = (size_t)p.KH * p.KW * 3 * p.Cout * sizeof(float);
+    FS_REQUIRE(lds <= 64 * 1024, "stem_conv: filter bank %zu B exceeds LDS budget", lds);
+    hipLaunchKernelGGL((stem_conv_kernel<16>), dim3(cdiv(M, ppb)), dim3(256), lds, s, p);
+    FS_HIP(hipGetLastError());
+    return 0;
+}
+
+// -------------------------------------------------------------------------------------------
+// MaxPool 3x3 stride 2 pad 1 (padding never wins: -inf)
+// -------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const float* __restrict__ in, int ld_in, float* __restrict__ out,
+                                                           int ld_out, int B, int H, int W, int C4, int Ho, int Wo) {
+    const int64_t total = (int64_t)B * Ho * Wo * C4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c4 = (int)(i % C4);
+        const int64_t m = i / C4;
+        const int ox = (int)(m % Wo);
+        const int oy = (int)((m / Wo) % Ho);
+        const int b = (int)(m / ((int64_t)Wo * Ho));
+        f32x4 best = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int iy = oy * 2 - 1 + ky;
+            if ((unsigned)iy >= (unsigned)H) continue;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int ix = ox * 2 - 1 + kx;
+                if ((unsigned)ix >= (unsigned)W) continue;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(in + ((size_t)(b * H + iy) * W + ix) * ld_in + c4 * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) best[e] = fmaxf(best[e], v[e]);
+            }
+        }
+        *reinterpret_cast<f32x4*>(out + (size_t)m * ld_out + c4 * 4) = best;
+    }
+}
+
+int launch_maxpool3x3s2(const float* in, int ld_in, float* out, int ld_out, int B, int H, int W, int C, int Ho, int Wo,
+                        hipStream_t s) {
+    FS_REQUIRE(C % 4 == 0 && ld_in % 4 == 0 && ld_out % 4 == 0, "maxpool: C/ld must be multiples of 4");
+    const int64_t total = (int64_t)B * Ho * Wo * (C / 4);
+    const int grid = (int)std::min<int64_t>(cdiv64(total, 256), 256 * 32);
+    hipLaunchKernelGGL(maxpool3x3s2_kernel, dim3(grid), dim3(256), 0, s, in, ld_in, out, ld_out, B, H, W, C / 4, Ho, Wo);
+    FS_HIP(hipGetLastError());
+    return 0;
+}
+
+// -------------------------------------------------------------------------------------------
+// AdaptiveAvgPool2d(bin): windows [floor(i*H/bin), ceil((i+1)*H/bin)).
+// Block = 16 pixel lanes x 16 float4 channel lanes (64 channels); grid (bin*bin, C/64, B).
+// -------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void adaptive_avgpool_kernel(const float* __restrict__ in, int ld_in, float* __restrict__ out,
+                                                               int H, int W, int C, int bin) {
+    __shared__ f32x4 part[16][16];
+    const int cell = blockIdx.x, b = blockIdx.z;
+    const int by = cell / bin, bx = cell - by * bin;
+    const int ys = (by * H) / bin, ye = ((by + 1) * H + bin - 1) / bin;
+    const int xs = (bx * W) / bin, xe = ((bx + 1) * W + bin - 1) / bin;
+    const int wh = ye - ys, ww = xe - xs;
+    const int cl = threadIdx.x & 15, pg = threadIdx.x >> 4;
+    const int c = blockIdx.y * 64 + cl * 4;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int i = pg; i < wh * ww; i += 16) {
+        const int y = ys + i / ww, x = xs + i % ww;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(in + ((size_t)(b * H + y) * W + x) * ld_in + c);
+        acc += v;
+    }
+    part[pg][cl] = acc;
+    __syncthreads();
+    if (pg == 0) {
+        f32x4 sum = part[0][cl];
+#pragma unroll
+        for (int g = 1; g < 16; ++g) sum += part[g][cl];
+        const float inv = 1.f / (float)(wh * ww);
+        sum *= inv;
+        *reinterpret_cast<f32x4*>(out + ((size_t)b * bin * bin + cell) * C + c) = sum;
+    }
+}
+
+int launch_adaptive_avgpool(const float* in, int ld_in, float* out, int B, int H, int W, int C, int bin, hipStream_t s) {
+    FS_REQUIRE(C % 64 == 0 && ld_in % 4 == 0, "adaptive_avgpool: C=%d must be a multiple of 64", C);
+    hipLaunchKernelGGL(adaptive_avgpool_kernel, dim3(bin * bin, C / 64, B), dim3(256), 0, s, in, ld_in, out, H, W, C, bin);
+    FS_HIP(hipGetLastError());
+    return 0;
+}
+
+// -------------------------------------------------------------------------------------------
+// Small-M 1x1 conv: one wave per output channel n, weight row held in registers, loop over m.
+// -------------------------------------------------------------------------------------------
+template <int KV /* float4 per lane = K/256 */>
+__global__ __launch_bounds__(256) void rowdot_1x1_kernel(const float* __restrict__ in, int ld_in, const float* __restrict__ wgt,
+                                                         const float* __restrict__ scale, const float* __restrict__ shift,
+                                                         float* __restrict__ out, int ld_out, int M, int K, int N, int relu) {
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    f32x4 w[KV];
+#pragma unroll
+    for (int i = 0; i < KV; ++i) w[i] = *reinterpret_cast<const f32x4*>(wgt + (size_t)n * K + (i * 64 + lane) * 4);
+    const float sc = scale ? scale[n] : 1.f, sh = shift ? shift[n] : 0.f;
+    for (int m = 0; m < M; ++m) {
+        float acc = 0.f;
+#pragma unroll
+        for (int i = 0; i < KV; ++i) {
+            const f32x4 x = *reinterpret_cast<const f32x4*>(in + (size_t)m * ld_in + (i * 64 + lane) * 4);
+            acc += x[0] * w[i][0] + x[1] * w[i][1] + x[2] * w[i][2] + x[3] * w[i][3];
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+        if (lane == 0) {
+            float y = acc * sc + sh;
+            if (relu) y = fmaxf(y, 0.f);
+            out[(size_t)m * ld_out + n] = y;
+        }
+    }
+}
+
+int launch_rowdot_1x1(const float* in, int ld_in, const float* wgt, const float* scale, const float* shift, float* out,
+                      int ld_out, int M, int K, int N, int relu, hipStream_t s) {
+    FS_REQUIRE(K % 256 == 0 && K <= 4096, "rowdot_1x1: K=%d must be a multiple of 256 and <= 4096", K);
+    const dim3 grid(cdiv(N, 4)), block(256);
+#define FS_ROWDOT(KV)                                                                                             \
+    case KV:                                                                                                      \
+        hipLaunchKernelGGL((rowdot_1x1_kernel<KV>), grid, block, 0, s, in, ld_in, wgt, scale, shift, out, ld_out, M, K, N, relu); \
+        break;
+    switch (K / 256) {
+        FS_ROWDOT(1) FS_ROWDOT(2) FS_ROWDOT(3) FS_ROWDOT(4) FS_ROWDOT(5) FS_ROWDOT(6) FS_ROWDOT(7) FS_ROWDOT(8)
+        FS_ROWDOT(9) FS_ROWDOT(10) FS_ROWDOT(11) FS_ROWDOT(12) FS_ROWDOT(13) FS_ROWDOT(14) FS_ROWDOT(15) FS_ROWDOT(16)
+        default: return fail("rowdot_1x1: unsupported K");
+    }
+#undef FS_ROWDOT
+    FS_HIP(hipGetLastError());
+    return 0;
+}
+
+// -------------------------------------------------------------------------------------------
+// Bilinear upsample of a tiny pooled map [B][hi*wi][C] into a channel slice of an NHWC buffer.
+// -------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void upsample_into_kernel(const float* __restrict__ in, int hi, int wi, float* __restrict__ out,
+                                                            int ld_out, int B, int Ho, int Wo, int C4, int ac, float sy, float sx) {
+    const int64_t total = (int64_t)B * Ho * Wo * C4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c4 = (int)(i % C4);
+        const int64_t m = i / C4;
+        const int ox = (int)(m % Wo);
+        const int oy = (int)((m / Wo) % Ho);
+        const int b = (int)(m / ((int64_t)Wo * Ho));
+        const LinCoord cy = lin_coord(oy, hi, sy, ac), cx = lin_coord(ox, wi, sx, ac);
+        const float* base = in + (size_t)b * hi * wi * C4 * 4 + c4 * 4;
+        const f32x4 v00 = *reinterpret_cast<const f32x4*>(base + (size_t)(cy.i0 * wi + cx.i0) * C4 * 4);
+        const f32x4 v01 = *reinterpret_cast<const f32x4*>(base + (size_t)(cy.i0 * wi + cx.i1) * C4 * 4);
+        const f32x4 v10 = *reinterpret_cast<const f32x4*>(base + (size_t)(cy.i1 * wi + cx.i0) * C4 * 4);
+        const f32x4 v11 = *reinterpret_cast<const f32x4*>(base + (size_t)(cy.i1 * wi + cx.i1) * C4 * 4);
+        f32x4 r;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) r[e] = bilerp(v00[e], v01[e], v10[e], v11[e], cy, cx);
+        *reinterpret_cast<f32x4*>(out + (size_t)m * ld_out + c4 * 4) = r;
+    }
+}
+
+int launch_upsample_into(const float* in, int hi, int wi, float* out, int ld_out, int B, int Ho, int Wo, int C,
+                         int align_corners, hipStream_t s) {
+    FS_REQUIRE(C % 4 == 0 && ld_out % 4 == 0 && ((uintptr_t)out & 15) == 0, "upsample_into: C/ld_out must be multiples of 4");
+    const int64_t total = (int64_t)B * Ho * Wo * (C / 4);
+    const int grid = (int)std::min<int64_t>(cdiv64(total, 256), 256 * 32);
+    hipLaunchKernelGGL(upsample_into_kernel, dim3(grid), dim3(256), 0, s, in, hi, wi, out, ld_out, B, Ho, Wo, C / 4,
+                       align_corners, resize_scale(hi, Ho, align_corners), resize_scale(wi, Wo, align_corners));
+    FS_HIP(hipGetLastError());
+    return 0;
+}
+
+// -------------------------------------------------------------------------------------------
+// Classifier 1x1 conv + bias, NHWC -> NCHW.  16 lanes per pixel, 16 pixels per block.
+// -------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void classifier_nchw_kernel(const float* __restrict__ in, int ld_in, const float* __restrict__ wgt,
+                                                              const float* __restrict__ bias, float* __restrict__ out, int B,
+                                                              int HW, int C, int K) {
+    extern __shared__ __attribute__((aligned(16))) float wl[];  // [K][C]
+    for (int i = threadIdx.x; i < K * C; i += 256) wl[i] = wgt[i];
+    __syncthreads();
+    const int l16 = threadIdx.x & 15;
+    const int64_t M = (int64_t)B * HW;
+    const int64_t m = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+    const int64_t mc = m < M ? m : M - 1;  // keep all lanes alive for the shuffles
+    const float* x = in + (size_t)mc * ld_in;
+    for (int k0 = 0; k0 < K; k0 += 8) {
+        float acc[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+        for (int c = l16 * 4; c < C; c += 64) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(x + c);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                if (k0 + k < K) {
+                    const f32x4 w = *reinterpret_cast<const f32x4*>(wl + (size_t)(k0 + k) * C + c);
+                    acc[k] += v[0] * w[0] + v[1] * w[1] + v[2] * w[2] + v[3] * w[3];
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+#pragma unroll
+            for (int off = 8; off > 0; off >>= 1) acc[k] += __shfl_xor(acc[k], off, 64);
+        }
+        if (l16 == 0 && m < M) {
+            const int64_t b = m / HW, pix = m - b * HW;
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (k0 + k < K) out[((size_t)b * K + k0 + k) * HW + pix] = acc[k] + (bias ? bias[k0 + k] : 0.f);
+        }
+    }
+}
+
+int launch_classifier_nchw(const float* in, int ld_in, const float* wgt, const float* bias, float* out, int B, int HW,
+                           int C, int K, hipStream_t s) {
+    FS_REQUIRE(C % 4 == 0 && ld_in % 4 == 0, "classifier: C must be a multiple of 4");
+    const size_t lds = (size_t)K * C * sizeof(float);
+    FS_REQUIRE(lds <= 64 * 1024, "classifier: K*C too large for LDS");
+    const int64_t M = (int64_t)B * HW;
+    hipLaunchKernelGGL(classifier_nchw_kernel, dim3((unsigned)cdiv64(M, 16)), dim3(256), lds, s, in, ld_in, wgt, bias, out, B,
+                       HW, C, K);
+    FS_HIP(hipGetLastError());
+    return 0;
+}
+
+// -------------------------------------------------------------------------------------------
+// Weight packing (one-off at load time) and layout changes
+// -------------------------------------------------------------------------------------------
+__global__ void pack_weights_kernel(const float* __restrict__ w, float* __restrict__ out, int O, int I, int KH, int KW, int hwio) {
+    const int64_t total = (int64_t)O * I * KH * KW;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        // i indexes the source OIHW tensor
+        const int s = (int)(i % KW);
+        const int r = (int)((i / KW) % KH);
+        const int ci = (int)((i / ((int64_t)KW * KH)) % I);
+        const int o = (int)(i / ((int64_t)KW * KH * I));
+        const size_t dst = hwio ? ((size_t)((r * KW + s) * I + ci)) * O + o : ((size_t)((o * KH + r) * KW + s)) * I + ci;
+        out[dst] = w[i];
+    }
+}
+
+int launch_pack_oihw_to_ohwi(const float* w, float* out, int O, int I, int KH, int KW, hipStream_t s) {
+    const int64_t total = (int64_t)O * I * KH * KW;
+    hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)std::min<int64_t>(cdiv64(total, 256), 65535)), dim3(256), 0, s, w, out,
+                       O, I, KH, KW, 0);
+    FS_HIP(hipGetLastError());
+    return 0;
+}
+int launch_pack_oihw_to_hwio(const float* w, float* out, int O, int I, int KH, int KW, hipStream_t s) {
+    const int64_t total = (int64_t)O * I * KH * KW;
+    hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)std::min<int64_t>(cdiv64(total, 256), 65535)), dim3(256), 0, s, w, out,
+                       O, I, KH, KW, 1);
+    FS_HIP(hipGetLastError());
+    return 0;
+}
+
+// 32x32 LDS-tiled transposes between [B][C][HW] and [B][HW][ld]
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ in, float* __restrict__ out, int ld_out, int C,
+                                                           int HW) {
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z;
+    const int p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    for (int r = ty; r < 32; r += 8) {
+        const int c = c0 + r, px = p0 + tx;
+        tile[r][tx] = (c < C && px < HW) ? in[((size_t)b * C + c) * HW + px] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int px = p0 + r, c = c0 + tx;
+        if (px < HW && c < C) out[((size_t)b * HW + px) * ld_out + c] = tile[tx][r];
+    }
+}
+
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* __restrict__ in, int ld_in, float* __restrict__ out, int C,
+                                                           int HW) {
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z;
+    const int p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8) {
+        const int px = p0 + r, c = c0 + tx;
+        tile[r][tx] = (c < C && px < HW) ? in[((size_t)b * HW + px) * ld_in + c] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int c = c0 + r, px = p0 + tx;
+        if (px < HW && c < C) out[((size_t)b * C + c) * HW + px] = tile[tx][r];
+    }
+}
+
+int launch_nchw_to_nhwc(const float* in, float* out, int ld_out, int B, int C, int HW, hipStream_t s) {
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(cdiv(HW, 32), cdiv(C, 32), B), dim3(256), 0, s, in, out, ld_out, C, HW);
+    FS_HIP(hipGetLastError());
+    return 0;
+}
+int launch_nhwc_to_nchw(const float* in, int ld_in, float* out, int B, int C, int HW, hipStream_t s) {
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(cdiv(HW, 32), cdiv(C, 32), B), dim3(256), 0, s, in, ld_in, out, C, HW);
+    FS_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace fs

@@ -1,0 +1,186 @@
+"""Tensor-level wrappers over the C ABI (torch is only the allocator / stream provider here).
+
+Every function enqueues on torch's current HIP stream and returns freshly allocated tensors;
+inputs are never modified.  Reference ops restated: see include/floodseg.h.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import check, ptr, stream_ptr
+
+
+def _f32c(t, name="tensor"):
+    if not t.is_cuda:
+        raise RuntimeError(f"floodseg: {name} must live on the GPU (no CPU fallback exists)")
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+def is_channels_last_dense(t):
+    """True when a logical NCHW tensor is stored pixel-major with pixel stride == C."""
+    if t.dim() != 4:
+        return False
+    b, c, h, w = t.shape
+    return t.stride() == (h * w * c, 1, w * c, c) or (c == 1 and t.is_contiguous())
+
+
+def as_nhwc(t):
+    """Logical NCHW tensor -> dense channels_last storage (copy only if needed)."""
+    t = t if t.dtype == torch.float32 else t.float()
+    if is_channels_last_dense(t):
+        return t
+    return t.contiguous(memory_format=torch.channels_last)
+
+
+def empty_nhwc(b, c, h, w, device):
+    return torch.empty((b, c, h, w), dtype=torch.float32, device=device, memory_format=torch.channels_last)
+
+
+# ------------------------------------------------------------------------------------------ flow ops
+def grid_sample(inp, grid, align_corners=False):
+    """F.grid_sample(inp, grid, mode='bilinear', padding_mode='border') (flow/model.py:157,248)."""
+    lib = _lib.load()
+    b, c, hi, wi = inp.shape
+    gb, hg, wg, two = grid.shape
+    if two != 2 or gb != b:
+        raise RuntimeError(f"floodseg.grid_sample: grid shape {tuple(grid.shape)} does not match input batch {b}")
+    grid = _f32c(grid, "grid")
+    if inp.dim() == 4 and c % 4 == 0 and c >= 64 and is_channels_last_dense(inp):
+        src = inp if inp.dtype == torch.float32 else inp.float()
+        out = empty_nhwc(b, c, hg, wg, inp.device)
+        check(lib.fs_grid_sample_nhwc(ptr(src), c, b, c, hi, wi, ptr(grid), hg, wg, ptr(out), c, int(align_corners), stream_ptr()))
+        return out
+    src = _f32c(inp, "input")
+    out = torch.empty((b, c, hg, wg), dtype=torch.float32, device=inp.device)
+    check(lib.fs_grid_sample_nchw(ptr(src), b, c, hi, wi, ptr(grid), hg, wg, ptr(out), int(align_corners), stream_ptr()))
+    return out
+
+
+def resize_bilinear(inp, size, align_corners=True):
+    """F.interpolate(inp, size, mode='bilinear', align_corners=...) (flow/model.py:42..228)."""
+    lib = _lib.load()
+    b, c, hi, wi = inp.shape
+    ho, wo = int(size[0]), int(size[1])
+    if c % 4 == 0 and c >= 64 and is_channels_last_dense(inp):
+        src = inp if inp.dtype == torch.float32 else inp.float()
+        out = empty_nhwc(b, c, ho, wo, inp.device)
+        check(lib.fs_resize_bilinear_nhwc(ptr(src), c, b, c, hi, wi, ptr(out), c, ho, wo, int(align_corners), stream_ptr()))
+        return out
+    src = _f32c(inp, "input")
+    out = torch.empty((b, c, ho, wo), dtype=torch.float32, device=inp.device)
+    check(lib.fs_resize_bilinear_nchw(ptr(src), b * c, hi, wi, ptr(out), ho, wo, int(align_corners), stream_ptr()))
+    return out
+
+
+def blend(a, wa, b=None, wb=0.0):
+    """wa*a + wb*b with the reference's rounding order (flow/model.py:104,168,234-236)."""
+    lib = _lib.load()
+    if b is not None and (a.shape != b.shape or a.stride() != b.stride()):
+        b = b.contiguous(memory_format=torch.channels_last) if is_channels_last_dense(a) else b.contiguous()
+        if a.stride() != b.stride():
+            a = a.contiguous()
+            b = b.contiguous()
+    if not (a.is_contiguous() or is_channels_last_dense(a)):
+        a = a.contiguous()
+    a = a if a.dtype == torch.float32 else a.float()
+    out = torch.empty_like(a)
+    check(lib.fs_blend(ptr(a), float(wa), ptr(b), float(wb), ptr(out), a.numel(), stream_ptr()))
+    return out
+
+
+def _ptr_array(tensors):
+    arr = (ctypes.c_void_p * max(len(tensors), 1))()
+    for i, t in enumerate(tensors):
+        arr[i] = t.data_ptr()
+    return arr
+
+
+def seg_tail(lo_prev, lo_next, grids_left, grids_right, n, out_hw, no_warp, want_logits=True, want_mask=False):
+    """Fused predict_segmentation tail (flow/model.py:184-241 after the two decoder calls).
+
+    lo_prev/lo_next: [1,K,h,w] decoder logits; grids: lists of n-1 [1,Hg,Wg,2] tensors.
+    Returns (logits [n,K,H,W] or None, mask uint8 [n,H,W] or None).
+    """
+    lib = _lib.load()
+    lo_prev = _f32c(lo_prev, "lo_prev")
+    _, k, h, w = lo_prev.shape
+    hh, ww = out_hw
+    dev = lo_prev.device
+    frames = n if lo_next is not None else 1
+    logits = torch.empty((frames, k, hh, ww), dtype=torch.float32, device=dev) if want_logits else None
+    mask = torch.empty((frames, hh, ww), dtype=torch.uint8, device=dev) if want_mask else None
+    gl = gr = None
+    hg = wg = 1
+    scratch = None
+    keep = []
+    if lo_next is not None:
+        lo_next = _f32c(lo_next, "lo_next")
+        if not no_warp:
+            if len(grids_left) != n - 1 or len(grids_right) != n - 1:
+                raise RuntimeError("floodseg.seg_tail: need n-1 grids per direction")
+            keep = [_f32c(g, "grid") for g in list(grids_left) + list(grids_right)]
+            hg, wg = keep[0].shape[1], keep[0].shape[2]
+            for g in keep:
+                if tuple(g.shape) != (1, hg, wg, 2):
+                    raise RuntimeError("floodseg.seg_tail: all grids must be [1,Hg,Wg,2] of one size")
+            gl = _ptr_array(keep[: n - 1])
+            gr = _ptr_array(keep[n - 1:])
+            scratch = torch.empty(2 * (n - 1) * k * hg * wg, dtype=torch.float32, device=dev)
+    check(lib.fs_seg_tail(ptr(lo_prev), ptr(lo_next), gl, gr, k, h, w, hg, wg, hh, ww, int(n), int(bool(no_warp)),
+                          ptr(logits), ptr(mask), ptr(scratch), stream_ptr()))
+    return logits, mask
+
+
+def argmax_u8(logits):
+    """logits.max(1)[1] as uint8 (flow/base.py:276-277)."""
+    lib = _lib.load()
+    x = _f32c(logits)
+    b, k, h, w = x.shape
+    out = torch.empty((b, h, w), dtype=torch.uint8, device=x.device)
+    check(lib.fs_argmax_u8(ptr(x), b, k, h * w, ptr(out), stream_ptr()))
+    return out
+
+
+def resize_argmax_u8(logits, size):
+    """F.interpolate(logits, size, bilinear, align_corners=True).max(1)[1] without the big intermediate."""
+    lib = _lib.load()
+    x = _f32c(logits)
+    b, k, h, w = x.shape
+    out = torch.empty((b, int(size[0]), int(size[1])), dtype=torch.uint8, device=x.device)
+    check(lib.fs_resize_argmax_u8(ptr(x), b, k, h, w, ptr(out), int(size[0]), int(size[1]), stream_ptr()))
+    return out
+
+
+def iou_hist(pred_u8, target_u8, classes, ignore_index=255, hist=None):
+    """Accumulate int64[3,K] = (intersection, |pred|, |target|) (util/util.py:52-63)."""
+    lib = _lib.load()
+    p = pred_u8.contiguous()
+    t = target_u8.contiguous()
+    if p.dtype != torch.uint8 or t.dtype != torch.uint8 or p.shape != t.shape:
+        raise RuntimeError("floodseg.iou_hist: uint8 tensors of equal shape required")
+    if hist is None:
+        hist = torch.zeros((3, classes), dtype=torch.int64, device=p.device)
+    check(lib.fs_iou_hist(ptr(p), ptr(t), p.numel(), classes, ignore_index, ptr(hist), stream_ptr()))
+    return hist
+
+
+# ------------------------------------------------------------------------------------------ building blocks
+def conv2d_nhwc(x, weight, scale=None, shift=None, residual=None, stride=1, pad=0, dil=1, relu=False, tile=0, out=None):
+    """Conv2d on the fp32 matrix cores; x logical NCHW (stored NHWC), weight OIHW. Test/bring-up helper."""
+    lib = _lib.load()
+    x = as_nhwc(x)
+    b, cin, h, w = x.shape
+    o, i, kh, kw = weight.shape
+    wp = torch.empty((o, kh, kw, i), dtype=torch.float32, device=x.device)
+    check(lib.fs_pack_conv_weight(ptr(_f32c(weight)), ptr(wp), o, i, kh, kw, stream_ptr()))
+    ho = (h + 2 * pad - dil * (kh - 1) - 1) // stride + 1
+    wo = (w + 2 * pad - dil * (kw - 1) - 1) // stride + 1
+    if out is None:
+        out = empty_nhwc(b, o, ho, wo, x.device)
+    res = as_nhwc(residual) if residual is not None else None
+    check(lib.fs_conv2d_nhwc(ptr(x), cin, ptr(wp), ptr(scale), ptr(shift), ptr(res), o, ptr(out), o, b, h, w, cin, o, kh, kw,
+                             stride, pad, dil, int(relu), tile, stream_ptr()))
+    return out

@@ -1,0 +1,142 @@
+"""Seed-driven synthetic weights, frames and motion grids (numpy PCG64, so the GPU box regenerates
+bit-identical tensors).  Follows SURVEY.md 8(d): no real checkpoints, frames or motion vectors ship
+with the reference (dataset/flow/README.md:3), so every benchmark and parity input is synthetic.
+
+Weight names are the reference's state_dict keys (canonical, un-aliased):
+  PSPNet     model/pspnet.py:52-76, 113-141 + model/resnet.py:60-147
+  DeepLabv3  torchvision deeplabv3_resnet101 as wrapped by model/deeplabv3.py:47-54
+"""
+import math
+
+import numpy as np
+import torch
+
+RESNET_BLOCKS = {50: (3, 4, 6, 3), 101: (3, 4, 23, 3), 152: (3, 8, 36, 3)}
+
+
+def _rng(seed):
+    return np.random.Generator(np.random.PCG64(seed))
+
+
+def _conv(rng, cout, cin, k, gain=1.0):
+    std = gain * math.sqrt(2.0 / (cout * k * k))  # kaiming_normal_(fan_out), model/resnet.py:127
+    return torch.from_numpy((rng.standard_normal((cout, cin, k, k)) * std).astype(np.float32))
+
+
+def _bn(rng, state, prefix, c):
+    state[prefix + ".weight"] = torch.from_numpy(rng.uniform(0.5, 1.5, c).astype(np.float32))
+    state[prefix + ".bias"] = torch.from_numpy((rng.standard_normal(c) * 0.1).astype(np.float32))
+    state[prefix + ".running_mean"] = torch.from_numpy((rng.standard_normal(c) * 0.1).astype(np.float32))
+    state[prefix + ".running_var"] = torch.from_numpy(rng.uniform(0.5, 1.5, c).astype(np.float32))
+
+
+def _resnet_stages(rng, state, prefix, layers, inplanes):
+    for li, nblk in enumerate(RESNET_BLOCKS[layers]):
+        planes = 64 * 2 ** li
+        for b in range(nblk):
+            p = f"{prefix}layer{li + 1}.{b}."
+            cin = inplanes if b == 0 else planes * 4
+            state[p + "conv1.weight"] = _conv(rng, planes, cin, 1)
+            _bn(rng, state, p + "bn1", planes)
+            state[p + "conv2.weight"] = _conv(rng, planes, planes, 3)
+            _bn(rng, state, p + "bn2", planes)
+            # damp the residual branch so that depth does not blow activations up
+            state[p + "conv3.weight"] = _conv(rng, planes * 4, planes, 1, gain=0.5)
+            _bn(rng, state, p + "bn3", planes * 4)
+            if b == 0:
+                state[p + "downsample.0.weight"] = _conv(rng, planes * 4, cin, 1)
+                _bn(rng, state, p + "downsample.1", planes * 4)
+        inplanes = planes * 4
+
+
+def make_pspnet_state(layers=50, classes=5, seed=0):
+    """State dict of FlowPSPNet (canonical keys: layer0..4, ppm, decoder)."""
+    rng = _rng(seed)
+    s = {}
+    s["layer0.0.weight"] = _conv(rng, 64, 3, 3)
+    _bn(rng, s, "layer0.1", 64)
+    s["layer0.3.weight"] = _conv(rng, 64, 64, 3)
+    _bn(rng, s, "layer0.4", 64)
+    s["layer0.6.weight"] = _conv(rng, 128, 64, 3)
+    _bn(rng, s, "layer0.7", 128)
+    _resnet_stages(rng, s, "", layers, 128)
+    for i in range(4):
+        s[f"ppm.features.{i}.1.weight"] = _conv(rng, 512, 2048, 1)
+        _bn(rng, s, f"ppm.features.{i}.2", 512)
+    s["decoder.0.weight"] = _conv(rng, 512, 4096, 3)
+    _bn(rng, s, "decoder.1", 512)
+    s["decoder.4.weight"] = torch.from_numpy((rng.standard_normal((classes, 512, 1, 1)) * 0.05).astype(np.float32))
+    s["decoder.4.bias"] = torch.from_numpy((rng.standard_normal(classes) * 0.01).astype(np.float32))
+    return s
+
+
+def make_deeplab_state(layers=101, classes=5, seed=0):
+    """State dict of FlowDeepLabv3 (canonical keys: backbone.*, classifier.*)."""
+    rng = _rng(seed + 7919)
+    s = {}
+    s["backbone.conv1.weight"] = _conv(rng, 64, 3, 7)
+    _bn(rng, s, "backbone.bn1", 64)
+    _resnet_stages(rng, s, "backbone.", layers, 64)
+    s["classifier.0.convs.0.0.weight"] = _conv(rng, 256, 2048, 1)
+    _bn(rng, s, "classifier.0.convs.0.1", 256)
+    for i in (1, 2, 3):
+        s[f"classifier.0.convs.{i}.0.weight"] = _conv(rng, 256, 2048, 3)
+        _bn(rng, s, f"classifier.0.convs.{i}.1", 256)
+    s["classifier.0.convs.4.1.weight"] = _conv(rng, 256, 2048, 1)
+    _bn(rng, s, "classifier.0.convs.4.2", 256)
+    s["classifier.0.project.0.weight"] = _conv(rng, 256, 1280, 1)
+    _bn(rng, s, "classifier.0.project.1", 256)
+    s["classifier.1.weight"] = _conv(rng, 256, 256, 3)
+    _bn(rng, s, "classifier.2", 256)
+    s["classifier.4.weight"] = torch.from_numpy((rng.standard_normal((classes, 256, 1, 1)) * 0.05).astype(np.float32))
+    s["classifier.4.bias"] = torch.from_numpy((rng.standard_normal(classes) * 0.01).astype(np.float32))
+    return s
+
+
+def make_clip(frames, size, seed, shift=(2, 1)):
+    """[T,3,S,S] float32 normalised frames: a smooth random field translated by `shift` px/frame + noise."""
+    h = w = size
+    if isinstance(size, (tuple, list)):
+        h, w = size
+    rng = _rng(seed)
+    pad = max(abs(shift[0]), abs(shift[1])) * frames + 2
+    yy, xx = np.mgrid[0:h + 2 * pad, 0:w + 2 * pad].astype(np.float64)
+    base = np.zeros((3, h + 2 * pad, w + 2 * pad))
+    for c in range(3):
+        for _ in range(6):
+            fx, fy = rng.uniform(0.004, 0.05, 2)
+            ph = rng.uniform(0, 2 * np.pi, 2)
+            base[c] += rng.uniform(0.3, 1.0) * np.sin(2 * np.pi * fx * xx + ph[0]) * np.cos(2 * np.pi * fy * yy + ph[1])
+    out = np.empty((frames, 3, h, w), dtype=np.float32)
+    for t in range(frames):
+        oy, ox = pad + shift[1] * t, pad + shift[0] * t
+        out[t] = base[:, oy:oy + h, ox:ox + w] + rng.standard_normal((3, h, w)) * 0.1
+    return torch.from_numpy(out)
+
+
+def identity_grid(hg, wg):
+    """Identity sampling grid of block centres for a crop of hg x wg 16-px blocks (flow/model.py:10-21 semantics)."""
+    x = ((np.arange(wg) * 16 + 8) / (wg * 16)) * 2 - 1
+    y = ((np.arange(hg) * 16 + 8) / (hg * 16)) * 2 - 1
+    g = np.zeros((hg, wg, 2))
+    g[:, :, 0] = x[None, :]
+    g[:, :, 1] = y[:, None]
+    return g
+
+
+def make_grids(n, hg, wg, seed, shift=(2, 1), frame=(713, 713), jitter=0.02):
+    """(mvs_left, mvs_right): n-1 forward grids and n-1 backward grids ALREADY in the order FlowData emits
+    them (flow/dataset.py:138-146: inverse grids reversed).  Each [1,hg,wg,2] float32."""
+    rng = _rng(seed)
+    ident = identity_grid(hg, wg)
+    d = np.array([shift[0] / frame[1] * 2, shift[1] / frame[0] * 2])
+    left = [ident - d + rng.uniform(-jitter, jitter, ident.shape) for _ in range(n - 1)]
+    right = [ident + d + rng.uniform(-jitter, jitter, ident.shape) for _ in range(n - 1)]
+    right = right[::-1]
+    to_t = lambda a: torch.from_numpy(a.astype(np.float32))[None]  # noqa: E731
+    return [to_t(a) for a in left], [to_t(a) for a in right]
+
+
+def dummy_grids(n):
+    """no_warp placeholders: n-1 zeros(1) tensors whose count encodes n (flow/dataset.py:198-205)."""
+    return [torch.zeros(1, 1) for _ in range(n - 1)], [torch.zeros(1, 1) for _ in range(n - 1)]

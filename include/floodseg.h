@@ -1,0 +1,116 @@
+/*
+ * floodseg.h -- C ABI of the MI355X-native key-frame segmentation + flow-interpolation hot path.
+ *
+ * Drop-in boundary for lenke182/flood-uav-video-segmentation (citations are reference file:line):
+ *   - the two callables the reference's FlowModel invokes on its network,
+ *       self.model.encoder(x) / self.model.decoder(f)            flow/model.py:39-40,57-58,76-79,120,129,177,189-204
+ *     for FlowPSPNet (model/pspnet.py:113-141) and FlowDeepLabv3 (model/deeplabv3.py:47-54);
+ *   - the torch ops FlowModel applies around them,
+ *       F.grid_sample(bilinear, border)                          flow/model.py:157,248
+ *       F.interpolate(bilinear, align_corners=True)              flow/model.py:42,68,86,103,139,150,159,179,193,206,218,228
+ *       (n-p)/n * a + p/n * b                                    flow/model.py:104,168,170,234-236
+ *   - the post-processing inside the reference's timed region,
+ *       F.interpolate(.., (1072,1920)); max(1)[1]; uint8         flow/base.py:275-277
+ *   - the metric histogram intersectionAndUnionGPU               util/util.py:52-63
+ *
+ * Conventions
+ *   - every pointer named *_dev / in / out is a DEVICE pointer (tensor.data_ptr()); nothing is freed or
+ *     retained by the library except its own packed weights and workspace;
+ *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream); all work is
+ *     enqueued on it, no call synchronises the device except fs_finalize / fs_profile_dump;
+ *   - all functions return 0 on success; on failure a non-zero code, and fs_last_error() holds the text
+ *     (the Python shim raises RuntimeError with it -- the reference itself only raises/asserts);
+ *   - NCHW tensors are the reference's layout; "NHWC" tensors are pixel-major with an explicit pixel
+ *     stride `ld` (in floats) so that channel slices of wider buffers can be addressed.
+ */
+#ifndef FLOODSEG_H_
+#define FLOODSEG_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct fs_net* fs_handle;
+typedef void* fs_stream;
+
+enum { FS_ARCH_PSPNET = 0, FS_ARCH_DEEPLABV3 = 1 };
+
+typedef struct fs_config {
+    int arch;     /* FS_ARCH_*                                  flow/base.py:94-103            */
+    int layers;   /* 50 | 101 | 152                             model/pspnet.py:45-50          */
+    int classes;  /* K                                          dataset/flow/config.yaml:2     */
+} fs_config;
+
+int fs_version(void);
+const char* fs_last_error(void);
+
+/* ---- network lifecycle ------------------------------------------------------------------------- */
+int fs_create(const fs_config* cfg, fs_handle* out);
+int fs_destroy(fs_handle h);
+/* Copy one state_dict tensor (canonical name) into the library.
+ * on_device != 0: `data` is a device pointer. */
+int fs_load_weight(fs_handle h, const char* name, const float* data, const int64_t* shape, int ndim, int on_device,
+                   fs_stream stream);
+/* Fold eval-mode BatchNorm into per-channel scale/shift, repack filters OIHW -> OHWI. Synchronises. */
+int fs_finalize(fs_handle h, fs_stream stream);
+/* Feature-map geometry produced by fs_encoder_forward for an H x W frame. */
+int fs_feature_shape(fs_handle h, int H, int W, int* C, int* fh, int* fw);
+/* Bytes of library-owned workspace a forward at this geometry needs (allocated lazily). */
+size_t fs_workspace_bytes(fs_handle h, int B, int H, int W);
+
+/* model.encoder(x):  in NCHW [B,3,H,W]  ->  out NHWC [B,fh,fw,C] (ld = C; a channels_last torch tensor) */
+int fs_encoder_forward(fs_handle h, const float* in_nchw, int B, int H, int W, float* out_nhwc, fs_stream stream);
+/* model.decoder(f):  in NHWC [B,fh,fw,C]  ->  out NCHW [B,K,fh,fw] */
+int fs_decoder_forward(fs_handle h, const float* feat_nhwc, int B, int fh, int fw, float* out_nchw, fs_stream stream);
+
+/* ---- per-op profiling (HIP events on `stream` around every launch of the next forward calls) -- */
+int fs_profile_enable(fs_handle h, int on);
+/* Synchronises the recorded events; writes one line per op: "name kernel flops bytes ms\n". */
+int fs_profile_dump(fs_handle h, char* buf, size_t buflen);
+
+/* ---- flow / interpolation ops -------------------------------------------------------------------- */
+int fs_grid_sample_nchw(const float* in, int B, int C, int Hi, int Wi, const float* grid, int Hg, int Wg, float* out,
+                        int align_corners, fs_stream stream);
+int fs_grid_sample_nhwc(const float* in, int ld_in, int B, int C, int Hi, int Wi, const float* grid, int Hg, int Wg,
+                        float* out, int ld_out, int align_corners, fs_stream stream);
+int fs_resize_bilinear_nchw(const float* in, int BC, int Hi, int Wi, float* out, int Ho, int Wo, int align_corners,
+                            fs_stream stream);
+int fs_resize_bilinear_nhwc(const float* in, int ld_in, int B, int C, int Hi, int Wi, float* out, int ld_out, int Ho,
+                            int Wo, int align_corners, fs_stream stream);
+/* out = wa*a + wb*b (b may be NULL) */
+int fs_blend(const float* a, float wa, const float* b, float wb, float* out, int64_t numel, fs_stream stream);
+
+/* Fused tail of FlowModel.predict_segmentation (flow/model.py:184-241) from the two low-resolution
+ * decoder outputs: upsample, (optional) warp chains at grid resolution, linear fusion, and optionally
+ * the per-frame argmax.  grids_left/right: host arrays of n-1 device pointers [Hg,Wg,2] (ignored when
+ * no_warp).  scratch: >= 2*(n-1)*K*Hg*Wg floats (warp mode).  lo_next may be NULL (single frame). */
+int fs_seg_tail(const float* lo_prev, const float* lo_next, const float* const* grids_left,
+                const float* const* grids_right, int K, int h, int w, int Hg, int Wg, int H, int W, int n, int no_warp,
+                float* out_logits, uint8_t* out_mask, float* scratch, fs_stream stream);
+
+int fs_argmax_u8(const float* in, int B, int K, int64_t HW, uint8_t* out, fs_stream stream);
+int fs_resize_argmax_u8(const float* in, int B, int K, int Hi, int Wi, uint8_t* out, int Ho, int Wo, fs_stream stream);
+/* hist3K: int64[3][K] = {intersection, |pred|, |target|}, accumulated (caller zeroes). */
+int fs_iou_hist(const uint8_t* pred, const uint8_t* target, int64_t numel, int K, int ignore_index, long long* hist3K,
+                fs_stream stream);
+
+/* ---- building blocks (exposed for op-level parity tests and for other host code) ---------------- */
+int fs_pack_conv_weight(const float* oihw, float* ohwi, int O, int I, int KH, int KW, fs_stream stream);
+int fs_conv2d_nhwc(const float* in, int ld_in, const float* wgt_ohwi, const float* scale, const float* shift,
+                   const float* res, int ld_res, float* out, int ld_out, int B, int H, int W, int Cin, int Cout, int KH,
+                   int KW, int stride, int pad, int dil, int relu, int tile, fs_stream stream);
+/* wgt_hwio: [KH][KW][3][Cout] (weight.permute(2,3,1,0)) */
+int fs_stem_conv_nchw(const float* in_nchw, const float* wgt_hwio, const float* scale, const float* shift, float* out_nhwc,
+                      int B, int H, int W, int Cout, int KH, int KW, int stride, int pad, fs_stream stream);
+int fs_maxpool3x3s2_nhwc(const float* in, float* out, int B, int H, int W, int C, fs_stream stream);
+int fs_adaptive_avgpool_nhwc(const float* in, int ld_in, float* out, int B, int H, int W, int C, int bin, fs_stream stream);
+int fs_nchw_to_nhwc(const float* in, float* out, int B, int C, int HW, fs_stream stream);
+int fs_nhwc_to_nchw(const float* in, float* out, int B, int C, int HW, fs_stream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FLOODSEG_H_ */
