@@ -161,8 +161,20 @@ __global__ __launch_bounds__(256) void blend_kernel(const float* __restrict__ a,
     }
 }
 
+__global__ __launch_bounds__(256) void blend_scalar_kernel(const float* __restrict__ a, float wa, const float* __restrict__ b, float wb,
+                                                           float* __restrict__ out, int64_t numel) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < numel; i += (int64_t)gridDim.x * 256)
+        out[i] = b ? __fadd_rn(__fmul_rn(wa, a[i]), __fmul_rn(wb, b[i])) : __fmul_rn(wa, a[i]);
+}
+
 int launch_blend(const float* a, float wa, const float* b, float wb, float* out, int64_t numel, hipStream_t s) {
-    FS_REQUIRE((((uintptr_t)a | (uintptr_t)b | (uintptr_t)out) & 15) == 0, "blend: operands must be 16-B aligned");
+    if ((((uintptr_t)a | (uintptr_t)b | (uintptr_t)out) & 15) != 0) {
+        // batch slices of odd-sized maps are only 4-B aligned: scalar path
+        hipLaunchKernelGGL(blend_scalar_kernel, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>(cdiv64(numel, 256), 16384))),
+                           dim3(256), 0, s, a, wa, b, wb, out, numel);
+        FS_HIP(hipGetLastError());
+        return 0;
+    }
     const int64_t n4 = numel / 4;
     hipLaunchKernelGGL(blend_kernel, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>(cdiv64(n4, 256), 16384))), dim3(256), 0, s,
                        a, wa, b, wb, out, n4, numel);

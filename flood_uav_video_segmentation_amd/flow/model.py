@@ -1,0 +1,189 @@
+"""FlowModel on the HIP path -- drop-in for the reference's flow/model.py (same constructor,
+attributes, forward / predict / warp / warp_batch signatures and return dicts).
+
+What differs is only HOW the work is done:
+  * both key frames go through the encoder / decoder as ONE batch of two;
+  * the tail of predict_segmentation (upsample, warp chains at grid resolution, linear fusion)
+    is one fused HIP launch sequence (fs_seg_tail) instead of ~25 torch ops;
+  * every warp / resize / blend is a HIP kernel (ops.py); nothing falls back to torch arithmetic.
+`self.model` may be any object exposing `.encoder` / `.decoder` callables (as in the reference);
+the HIP network mirrors (model/pspnet.py, model/deeplabv3.py) are the intended ones.
+"""
+import contextlib
+
+import numpy as np
+import torch
+from torch import nn
+
+from .. import ops
+
+
+def get_default_grid():
+    """Identity block-motion grid of a 1920x1072 frame cut in 16x16 blocks: float64 [67,120,2],
+    last dim (x, y) in [-1,1] = block centres (reference flow/model.py:10-21)."""
+    width, height, block = 1920, 1072, 16
+    nby, nbx = height // block, width // block
+    cx = (np.arange(nbx, dtype=np.float64) * block + block // 2) / width * 2 - 1
+    cy = (np.arange(nby, dtype=np.float64) * block + block // 2) / height * 2 - 1
+    grid = np.empty((nby, nbx, 2), dtype=np.float64)
+    grid[..., 0] = cx[None, :]
+    grid[..., 1] = cy[:, None]
+    return grid
+
+
+def _region(profiler, name):
+    """The reference passes Lightning's profiler; any object with .profile(name) works, None is allowed."""
+    if profiler is None:
+        return contextlib.nullcontext()
+    return profiler.profile(name)
+
+
+class FlowModel(nn.Module):
+    def __init__(self, model, feature_based=True, no_warp=False, no_interpolation_percentage=0.0):
+        super().__init__()
+        self.model = model
+        self.feature_based = feature_based
+        self.no_warp = no_warp
+        self.no_interpolation_percentage = no_interpolation_percentage
+        # plain attribute (not a buffer), moved to the device lazily -- as the reference does (:32, :155-156)
+        self.default_motion_vector = torch.from_numpy(get_default_grid()).float().unsqueeze(0)
+
+    # ------------------------------------------------------------------------------------ helpers
+    def _encode(self, *frames):
+        """Encoder over the key frames as ONE batch -> [sum(B_i), C, fh, fw] (slice it, do not re-cat)."""
+        x = frames[0] if len(frames) == 1 else torch.cat(frames, 0)
+        return self.model.encoder(x)
+
+    @staticmethod
+    def _fit(t, h, w):
+        if t.shape[2] != h or t.shape[3] != w:
+            t = ops.resize_bilinear(t, (h, w), align_corners=True)
+        return t
+
+    def warp(self, frame, motion_vectors):
+        """grid_sample(bilinear, border, align_corners=False); identity when no_warp (reference :244-249)."""
+        if self.no_warp:
+            return frame
+        return ops.grid_sample(frame, motion_vectors, align_corners=False)
+
+    # ------------------------------------------------------------------------------------ eval forward
+    def forward(self, frame_current, frame_prev, frame_next, mvs_left, mvs_right, left_index, right_index):
+        """One interpolated frame per sample from two key frames (reference :35-88, eval path)."""
+        if self.training:
+            raise NotImplementedError("FlowModel(HIP) is an inference path; call .eval() (training branch: flow/model.py:37-43)")
+        left = [int(i) for i in left_index]
+        right = [int(i) for i in right_index]
+        total = [a + b for a, b in zip(left, right)]
+        h, w = frame_prev.shape[2], frame_prev.shape[3]
+        nb = frame_prev.shape[0]
+        feats = self._encode(frame_prev, frame_next)
+        f_prev, f_next = feats[:nb], feats[nb:]
+        if self.feature_based:
+            mixed = ops.blend(self.warp_batch(f_prev, mvs_left, left, total), 1.0,
+                              self.warp_batch(f_next, mvs_right, right, total), 1.0)
+            out = self.model.decoder(mixed)
+        else:
+            lows = self.model.decoder(feats)
+            o_prev, o_next = lows[:nb], lows[nb:]
+            out = ops.blend(self.warp_batch(o_prev, mvs_left, left, total), 1.0,
+                            self.warp_batch(o_next, mvs_right, right, total), 1.0)
+        return {"pred": self._fit(out, h, w)}
+
+    def warp_batch(self, input, mvs, index_list, n_list):
+        """Per-sample chains of `index` warps, resized back and weighted by (n-index)/n (reference :92-106).
+        The reference's size test compares shape[1]/shape[2] with (i_h, i_w) (:102), i.e. channels vs
+        height: it is almost always true, so the resize runs whenever warping is enabled -- kept."""
+        i_h, i_w = input.shape[2], input.shape[3]
+        rows = []
+        for i, index in enumerate(index_list):
+            cur = input[i:i + 1]
+            if not self.no_warp:
+                for j in range(index):
+                    cur = self.warp(cur, mvs[j][i:i + 1])
+                if cur.shape[1] != i_h or cur.shape[2] != i_w:
+                    cur = ops.resize_bilinear(cur, (i_h, i_w), align_corners=True)
+            rows.append(ops.blend(cur, (n_list[i] - index) / n_list[i]))
+        if ops.is_channels_last_dense(rows[0]) and rows[0].shape[1] > 1:
+            out = ops.empty_nhwc(len(rows), rows[0].shape[1], i_h, i_w, input.device)
+            for i, r in enumerate(rows):
+                out[i:i + 1].copy_(r)
+            return out
+        return torch.cat(rows, 0)
+
+    # ------------------------------------------------------------------------------------ inference
+    def predict(self, *args, **kwargs):
+        if self.feature_based:
+            return self.predict_feature(*args, **kwargs)
+        return self.predict_segmentation(*args, **kwargs)
+
+    def predict_segmentation(self, frame_prev, frame_next, mvs_left, mvs_right, n, profiler=None):
+        """Segment the key frames, propagate the LOGITS (reference :184-241).
+        Returns {"pred": [n,K,h,w]} ([1,K,h,w] when frame_next is None)."""
+        h, w = frame_prev.shape[2], frame_prev.shape[3]
+        frames = (frame_prev,) if frame_next is None else (frame_prev, frame_next)
+        with _region(profiler, "predict_encoder"):
+            feats = self._encode(*frames)
+        with _region(profiler, "predict_decoder"):
+            lows = self.model.decoder(feats)
+        lo_prev = lows[0:1]
+        lo_next = lows[1:2] if frame_next is not None else None
+        with _region(profiler, "predict_warp"), _region(profiler, "predict_fusion"):
+            logits, _ = ops.seg_tail(lo_prev, lo_next, mvs_left, mvs_right, n, (h, w), self.no_warp, want_logits=True)
+        return {"pred": logits}
+
+    def predict_masks(self, frame_prev, frame_next, mvs_left, mvs_right, n, profiler=None):
+        """Same pipeline, but the fused tail emits the per-frame argmax directly: uint8 [n,h,w].
+        (Extension for the native-resolution timed region of bench.py; not a reference method.)"""
+        h, w = frame_prev.shape[2], frame_prev.shape[3]
+        frames = (frame_prev,) if frame_next is None else (frame_prev, frame_next)
+        with _region(profiler, "predict_encoder"):
+            feats = self._encode(*frames)
+        with _region(profiler, "predict_decoder"):
+            lows = self.model.decoder(feats)
+        with _region(profiler, "predict_fusion"):
+            _, mask = ops.seg_tail(lows[0:1], lows[1:2] if frame_next is not None else None, mvs_left, mvs_right, n, (h, w),
+                                   self.no_warp, want_logits=False, want_mask=True)
+        return mask
+
+    def predict_feature(self, frame_prev, frame_next, mvs_left, mvs_right, n, profiler=None):
+        """Propagate encoder FEATURES, decode all n maps in one batch (reference :116-181)."""
+        h, w = frame_prev.shape[2], frame_prev.shape[3]
+        frames = (frame_prev,) if frame_next is None else (frame_prev, frame_next)
+        with _region(profiler, "predict_encoder"):
+            feats = self._encode(*frames)
+        f = feats[0:1]
+        f_next = feats[1:2] if frame_next is not None else None
+        f_h, f_w = f.shape[2], f.shape[3]
+        fwd, bwd = [], []
+        if f_next is not None and not self.no_warp:
+            with _region(profiler, "predict_warp"):
+                cur = f
+                for m in mvs_left:
+                    cur = self.warp(cur, m)
+                    fwd.append(self._fit(cur, f_h, f_w))
+                cur = f_next
+                for m in mvs_right:
+                    cur = self.warp(cur, m)
+                    bwd.append(self._fit(cur, f_h, f_w))
+        if not self.no_warp:
+            # the key-frame feature goes through the 67x120 identity grid, align_corners=True (:154-159)
+            if self.default_motion_vector.device != f.device:
+                self.default_motion_vector = self.default_motion_vector.to(device=f.device)
+            f = self._fit(ops.grid_sample(f, self.default_motion_vector, align_corners=True), f_h, f_w)
+        maps = [f]
+        if f_next is not None:
+            with _region(profiler, "predict_fusion"):
+                for p in range(1, n):
+                    if self.no_warp:
+                        maps.append(ops.blend(f, (n - p) / n, f_next, p / n))
+                    else:
+                        maps.append(ops.blend(fwd[p - 1], (n - p) / n, bwd[n - p - 1], p / n))
+        with _region(profiler, "predict_decoder"):
+            if ops.is_channels_last_dense(maps[0]) and maps[0].shape[1] > 1:
+                stack = ops.empty_nhwc(len(maps), maps[0].shape[1], f_h, f_w, f.device)
+                for i, m in enumerate(maps):
+                    stack[i:i + 1].copy_(m)
+            else:
+                stack = torch.cat(maps, 0)
+            out = self._fit(self.model.decoder(stack), h, w)
+        return {"pred": out}

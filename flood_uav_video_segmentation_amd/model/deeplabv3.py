@@ -1,0 +1,30 @@
+"""FlowDeepLabv3 on the HIP path -- mirrors the reference's model/deeplabv3.py:47-54 interface.
+
+encoder = torchvision ResNet backbone ["out"] (output stride 8), decoder = DeepLabHead(2048, K).
+PARITY UNPINNED: torchvision is not vendored by the reference and absent offline, so the architecture
+is restated from its public definition and checked only against oracle/deeplab_oracle.py.
+"""
+from .. import _lib
+from .hipnet import HipSegNet
+
+
+class FlowDeepLabv3(HipSegNet):
+    ARCH = _lib.ARCH_DEEPLABV3
+
+    def __init__(self, hparams, *args, **kwargs):
+        super().__init__(hparams)
+        if getattr(hparams, "pretrained", False):
+            # the reference fetches pytorch/vision:v0.10.0 through torch.hub here (model/deeplabv3.py:15)
+            raise RuntimeError("FlowDeepLabv3(HIP): pretrained=True is not supported, load a state_dict instead")
+
+    @staticmethod
+    def canonical_name(key):
+        if key.endswith("num_batches_tracked"):
+            return None
+        if key.startswith("encoder.model."):
+            return "backbone." + key[len("encoder.model."):]
+        if key.startswith("decoder."):
+            return "classifier." + key[len("decoder."):]
+        if key.startswith(("backbone.", "classifier.")):
+            return key
+        return None

@@ -1,0 +1,174 @@
+"""Host handle around one fs_net (libfloodseg.so): weight upload, encoder / decoder launches.
+
+Shared by the FlowPSPNet / FlowDeepLabv3 mirrors.  All compute happens in the HIP library; this file
+only validates shapes, allocates outputs through torch and passes raw pointers + the current stream.
+"""
+import ctypes
+
+import torch
+from torch import nn
+
+from .. import _lib, ops
+from .._lib import check, ptr, stream_ptr
+
+
+class HipNet:
+    def __init__(self, arch, layers, classes):
+        self.arch, self.layers, self.classes = arch, int(layers), int(classes)
+        self._h = None
+        self.ready = False
+        self._lib = None
+
+    # -- lifecycle ---------------------------------------------------------------------------
+    def _create(self):
+        lib = self._lib = _lib.load()
+        cfg = _lib.FsConfig(self.arch, self.layers, self.classes)
+        h = ctypes.c_void_p()
+        check(lib.fs_create(ctypes.byref(cfg), ctypes.byref(h)))
+        self._h = h
+
+    def load(self, canonical_state):
+        """canonical_state: {canonical name -> tensor (any device)}; replaces any previous weights."""
+        if not torch.cuda.is_available():
+            raise RuntimeError("floodseg: a HIP device is required (there is no CPU fallback for this path)")
+        self.close()
+        self._create()
+        lib = self._lib
+        for name, t in canonical_state.items():
+            t = t.detach()
+            if t.dtype != torch.float32:
+                t = t.float()
+            t = t.contiguous()
+            shape = (ctypes.c_int64 * max(t.dim(), 1))(*t.shape)
+            check(lib.fs_load_weight(self._h, name.encode(), ptr(t), shape, t.dim(), int(t.is_cuda), stream_ptr()))
+        torch.cuda.current_stream().synchronize()
+        check(lib.fs_finalize(self._h, stream_ptr()))
+        self.ready = True
+
+    def close(self):
+        if self._h is not None and self._lib is not None:
+            self._lib.fs_destroy(self._h)
+        self._h = None
+        self.ready = False
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001  interpreter shutdown
+            pass
+
+    # -- forward -----------------------------------------------------------------------------
+    def _need_ready(self):
+        if not self.ready:
+            raise RuntimeError("floodseg: weights not loaded -- call load_state_dict() on the network first")
+
+    def feature_shape(self, h, w):
+        self._need_ready()
+        c, fh, fw = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        check(self._lib.fs_feature_shape(self._h, h, w, ctypes.byref(c), ctypes.byref(fh), ctypes.byref(fw)))
+        return c.value, fh.value, fw.value
+
+    def encode(self, x):
+        """[B,3,H,W] NCHW -> [B,C,fh,fw] logical NCHW stored channels_last (model.encoder(x))."""
+        self._need_ready()
+        if x.dim() != 4 or x.shape[1] != 3:
+            raise RuntimeError(f"floodseg encoder: expected [B,3,H,W], got {tuple(x.shape)}")
+        if not x.is_cuda:
+            raise RuntimeError("floodseg encoder: input must be on the GPU")
+        x = x.float().contiguous()
+        b, _, h, w = x.shape
+        c, fh, fw = self.feature_shape(h, w)
+        out = ops.empty_nhwc(b, c, fh, fw, x.device)
+        check(self._lib.fs_encoder_forward(self._h, ptr(x), b, h, w, ptr(out), stream_ptr()))
+        return out
+
+    def decode(self, f):
+        """[B,C,fh,fw] -> [B,K,fh,fw] NCHW logits (model.decoder(f))."""
+        self._need_ready()
+        c_expected = 4096 if self.arch == _lib.ARCH_PSPNET else 2048
+        if f.dim() != 4 or f.shape[1] != c_expected:
+            raise RuntimeError(f"floodseg decoder: expected [B,{c_expected},h,w], got {tuple(f.shape)}")
+        f = ops.as_nhwc(f)
+        b, _, fh, fw = f.shape
+        out = torch.empty((b, self.classes, fh, fw), dtype=torch.float32, device=f.device)
+        check(self._lib.fs_decoder_forward(self._h, ptr(f), b, fh, fw, ptr(out), stream_ptr()))
+        return out
+
+    # -- profiling ---------------------------------------------------------------------------
+    def profile(self, on):
+        self._need_ready()
+        check(self._lib.fs_profile_enable(self._h, int(on)))
+
+    def profile_dump(self):
+        """[(name, kernel, flops, bytes, ms)] for every launch recorded since profile(True)."""
+        buf = ctypes.create_string_buffer(1 << 20)
+        check(self._lib.fs_profile_dump(self._h, buf, len(buf)))
+        rows = []
+        for line in buf.value.decode().splitlines():
+            name, kernel, flops, nbytes, ms = line.rsplit(" ", 4)
+            rows.append((name, kernel, float(flops), float(nbytes), float(ms)))
+        return rows
+
+
+class HipStage(nn.Module):
+    """Parameter-less nn.Module standing where the reference has a torch sub-network
+    (`model.encoder`, `model.decoder`, `model.layers`, `model.ppm`: flow/base.py:96-101 only calls
+    .parameters() on them)."""
+
+    def __init__(self, fn=None, what=""):
+        super().__init__()
+        self._fn = fn
+        self._what = what
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        return  # the owning HipSegNet consumes every key under its prefix, aliases included
+
+    def forward(self, x):
+        if self._fn is None:
+            raise RuntimeError(f"floodseg: '{self._what}' has no standalone forward on the HIP path")
+        return self._fn(x)
+
+
+class HipSegNet(nn.Module):
+    """Common base of the network mirrors: swallows the reference's state_dict keys (with their
+    aliases) in load_state_dict and forwards them to the HIP library."""
+
+    ARCH = None
+
+    def __init__(self, hparams):
+        super().__init__()
+        self._hip_net = HipNet(self.ARCH, hparams.layers, hparams.classes)
+        self.encoder = HipStage(self._hip_net.encode, "encoder")
+        self.decoder = HipStage(self._hip_net.decode, "decoder")
+        self._host_state = {}
+
+    @staticmethod
+    def canonical_name(key):
+        raise NotImplementedError
+
+    def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
+        canon = {}
+        for key, t in state_dict.items():
+            if not key.startswith(prefix):
+                continue
+            name = self.canonical_name(key[len(prefix):])
+            if name is None:
+                continue
+            if name in canon:
+                continue  # an alias of a tensor already taken (FlowPSPNet registers modules under several names)
+            canon[name] = t
+        if not canon:
+            if strict:
+                missing_keys.append(prefix + "<all weights>")
+            return
+        try:
+            self._hip_net.load(canon)
+        except RuntimeError as e:
+            error_msgs.append(str(e))
+
+    def load_state_dict(self, state_dict, strict=True, assign=False):  # noqa: ARG002
+        missing, unexpected, errors = [], [], []
+        self._load_from_state_dict(dict(state_dict), "", {}, strict, missing, unexpected, errors)
+        if errors or (strict and missing):
+            raise RuntimeError("Error(s) in loading state_dict for {}:\n\t{}".format(type(self).__name__, "\n\t".join(errors + missing)))
+        return torch.nn.modules.module._IncompatibleKeys(missing, unexpected)

@@ -1,0 +1,48 @@
+"""FlowPSPNet on the HIP path -- mirrors the reference's model/pspnet.py:113-141 interface.
+
+    net = FlowPSPNet(hparams)            # hparams.layers / .pretrained / .classes
+    net.load_state_dict(ckpt)            # reference keys, any of their aliases
+    f = net.encoder(x); o = net.decoder(f)
+
+`encoder` = dilated ResNet (model/resnet.py:99-147 with the dilation patch of model/pspnet.py:55-64)
++ pyramid pooling (model/pspnet.py:16-34); `decoder` = cls head (model/pspnet.py:70-76).  Inference only:
+the aux head, PSPNetSemi and the training-mode branches are out of scope.
+"""
+import re
+
+from .. import _lib
+from .hipnet import HipSegNet, HipStage
+
+
+class FlowPSPNet(HipSegNet):
+    ARCH = _lib.ARCH_PSPNET
+
+    def __init__(self, hparams, *args, **kwargs):
+        super().__init__(hparams)
+        if getattr(hparams, "pretrained", False):
+            # the reference reads ./initmodel/resnet*_v2.pth here (model/resnet.py:201); weights for the
+            # HIP path always arrive through load_state_dict
+            raise RuntimeError("FlowPSPNet(HIP): pretrained=True is not supported, load a state_dict instead")
+        # attribute names the reference exposes (flow/base.py:96-98 builds optimiser groups from them)
+        self.layers = HipStage(None, "layers")
+        self.ppm = HipStage(None, "ppm")
+
+    _ALIAS = (
+        (re.compile(r"^layers\.(\d)\.(.*)$"), r"layer\1.\2"),
+        (re.compile(r"^encoder\.0\.(\d)\.(.*)$"), r"layer\1.\2"),
+        (re.compile(r"^encoder\.1\.(.*)$"), r"ppm.\1"),
+    )
+
+    @staticmethod
+    def canonical_name(key):
+        """Map any alias FlowPSPNet's state_dict holds (1046 keys, 362 tensors) to
+        its canonical name; None for keys the inference path does not need."""
+        if key.endswith("num_batches_tracked"):
+            return None
+        for rx, rep in FlowPSPNet._ALIAS:
+            if rx.match(key):
+                key = rx.sub(rep, key)
+                break
+        if re.match(r"^(layer[0-4]|ppm|decoder)\.", key):
+            return key
+        return None

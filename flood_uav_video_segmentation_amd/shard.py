@@ -1,0 +1,68 @@
+"""Multi-GPU layout of the path: one process per GPU, clips sharded statically, weights replicated.
+
+The reference has no multi-GPU inference (Lightning DDP is only used for training), and
+the path shards into independent units -- clips (and, inside a clip, windows) -- so there is NO
+data-path collective.  The only exchange is the end-of-run reduction of the metric histograms
+(int64[3,K] + frame count, SUM) and of the elapsed time (MAX): ~130 bytes over RCCL (backend "nccl"
+on ROCm) or gloo on CPU.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def world():
+    """(rank, local_rank, world_size) from the torchrun environment (1 process when absent)."""
+    return int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+
+
+def init(backend=None):
+    """Initialise torch.distributed when launched with WORLD_SIZE > 1; returns (rank, local_rank, world_size)."""
+    rank, local_rank, size = world()
+    if size > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend=backend, rank=rank, world_size=size)
+    return rank, local_rank, size
+
+
+def clips_for_rank(num_clips, rank, world_size):
+    """Static round-robin: rank r takes clips r, r+W, ... (all clips cost the same: 21 frames each)."""
+    if not 0 <= rank < world_size:
+        raise ValueError(f"rank {rank} outside world of {world_size}")
+    return list(range(rank, num_clips, world_size))
+
+
+def windows_of_clip(num_frames, frame_delta):
+    """Key-frame windows of one clip as FlowData(split='predict') enumerates them
+    (flow/dataset.py:64,113-114): window i spans frames [i*d, (i+1)*d], num_frames // d windows."""
+    return [(i * frame_delta, (i + 1) * frame_delta) for i in range(num_frames // frame_delta)]
+
+
+def barrier():
+    if dist.is_available() and dist.is_initialized():
+        dist.barrier()
+
+
+def reduce_run(hist, frames, seconds, device="cpu"):
+    """Combine per-rank results: (sum of int64[3,K] histograms, total frames, max seconds)."""
+    hist = torch.as_tensor(hist, dtype=torch.int64, device=device).clone()
+    cnt = torch.tensor([int(frames)], dtype=torch.int64, device=device)
+    sec = torch.tensor([float(seconds)], dtype=torch.float64, device=device)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(hist, op=dist.ReduceOp.SUM)
+        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+        dist.all_reduce(sec, op=dist.ReduceOp.MAX)
+    return hist.cpu(), int(cnt.item()), float(sec.item())
+
+
+def miou_from_hist(hist):
+    """mIoU with the reference's epsilon (flow/base.py:332-336); hist = (intersection, |pred|, |target|)."""
+    h = hist.double()
+    union = h[1] + h[2] - h[0]
+    return float((h[0] / (union + 1e-10)).mean())

@@ -67,7 +67,17 @@ def make_pspnet_state(layers=50, classes=5, seed=0):
     _bn(rng, s, "decoder.1", 512)
     s["decoder.4.weight"] = torch.from_numpy((rng.standard_normal((classes, 512, 1, 1)) * 0.05).astype(np.float32))
     s["decoder.4.bias"] = torch.from_numpy((rng.standard_normal(classes) * 0.01).astype(np.float32))
+    if (layers, classes, seed) in _LOGIT_CENTRES:
+        s["decoder.4.bias"] = -torch.tensor(_LOGIT_CENTRES[(layers, classes, seed)], dtype=torch.float32)
     return s
+
+
+# Random deep nets emit logits with a large spatially-constant per-class offset, which makes every
+# synthetic mask a single class.  These constants (per-class mean logit of the un-biased net on clip
+# seed 1000, frame 0) centre the logits so that all classes appear in the synthetic masks.
+_LOGIT_CENTRES = {
+    (50, 5, 0): [5.79, 14.89, -5.38, 23.80, -22.28],
+}
 
 
 def make_deeplab_state(layers=101, classes=5, seed=0):
@@ -93,24 +103,32 @@ def make_deeplab_state(layers=101, classes=5, seed=0):
     return s
 
 
-def make_clip(frames, size, seed, shift=(2, 1)):
-    """[T,3,S,S] float32 normalised frames: a smooth random field translated by `shift` px/frame + noise."""
+def make_clip(frames, size, seed, shift=(2, 1), only=None):
+    """[T,3,S,S] float32 normalised frames: a smooth random field translated by `shift` px/frame + noise.
+    only: optional list of frame indices to materialise (same values as in the full clip)."""
     h = w = size
     if isinstance(size, (tuple, list)):
         h, w = size
     rng = _rng(seed)
-    pad = max(abs(shift[0]), abs(shift[1])) * frames + 2
-    yy, xx = np.mgrid[0:h + 2 * pad, 0:w + 2 * pad].astype(np.float64)
-    base = np.zeros((3, h + 2 * pad, w + 2 * pad))
+    comps = []
     for c in range(3):
         for _ in range(6):
             fx, fy = rng.uniform(0.004, 0.05, 2)
             ph = rng.uniform(0, 2 * np.pi, 2)
-            base[c] += rng.uniform(0.3, 1.0) * np.sin(2 * np.pi * fx * xx + ph[0]) * np.cos(2 * np.pi * fy * yy + ph[1])
-    out = np.empty((frames, 3, h, w), dtype=np.float32)
+            comps.append((c, fx, fy, ph[0], ph[1], rng.uniform(0.3, 1.0)))
+    keep = list(range(frames)) if only is None else list(only)
+    out = np.empty((len(keep), 3, h, w), dtype=np.float32)
     for t in range(frames):
-        oy, ox = pad + shift[1] * t, pad + shift[0] * t
-        out[t] = base[:, oy:oy + h, ox:ox + w] + rng.standard_normal((3, h, w)) * 0.1
+        noise = rng.standard_normal((3, h, w)) * 0.1  # drawn for every frame: frame t depends on (seed, t) only
+        if t not in keep:
+            continue
+        # the field lives in absolute scene coordinates; frame t looks at the window shifted by t*shift
+        yy = (np.arange(h, dtype=np.float64) + shift[1] * t)[:, None]
+        xx = (np.arange(w, dtype=np.float64) + shift[0] * t)[None, :]
+        img = np.zeros((3, h, w))
+        for (c, fx, fy, p0, p1, amp) in comps:
+            img[c] += amp * np.sin(2 * np.pi * fx * xx + p0) * np.cos(2 * np.pi * fy * yy + p1)
+        out[keep.index(t)] = img + noise
     return torch.from_numpy(out)
 
 

@@ -1,0 +1,63 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def pytest_collection_modifyitems(config, items):
+    if torch.cuda.is_available():
+        return
+    skip = pytest.mark.skip(reason="no GPU in this container")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
+def load_golden(name):
+    with np.load(os.path.join(GOLDEN, name), allow_pickle=False) as z:
+        return {k: z[k] for k in z.files}
+
+
+@pytest.fixture(scope="session")
+def golden():
+    return load_golden
+
+
+class NullProfiler:
+    """Stands in for Lightning's profiler: records the region names FlowModel.predict opens."""
+
+    def __init__(self):
+        self.names = []
+
+    def profile(self, name):
+        import contextlib
+
+        self.names.append(name)
+        return contextlib.nullcontext()
+
+
+@pytest.fixture()
+def profiler():
+    return NullProfiler()
+
+
+def toy_weights():
+    z = load_golden("toy_predict.npz")
+    return {k: torch.from_numpy(z[k]) for k in ("enc_w", "enc_b", "dec_w", "dec_b")}
+
+
+def rel_err(got, ref):
+    got = torch.as_tensor(got).double()
+    ref = torch.as_tensor(ref).double()
+    return ((got - ref).abs().max() / ref.abs().max().clamp_min(1e-12)).item()

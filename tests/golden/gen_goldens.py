@@ -1,0 +1,185 @@
+#!/usr/bin/env python3
+"""Generates the golden fixtures under tests/golden/ by running THE REFERENCE ITSELF on CPU.
+
+Runs only in the build container (needs /root/reference, which never travels to the GPU box):
+
+    cd /tmp && PYTHONDONTWRITEBYTECODE=1 PYTHONPATH=/root/reference:/root/repo python3 /root/repo/tests/golden/gen_goldens.py
+
+Inputs/weights come from flood_uav_video_segmentation_amd.synth (seeded numpy PCG64), so tests regenerate
+them bit-identically and only the reference's OUTPUTS are stored.  Nothing from the reference's source
+is copied: the fixtures are arrays.
+"""
+import contextlib
+import hashlib
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+import flow.model as ref_flow  # reference
+import model.pspnet as ref_psp  # reference
+import util.util as ref_util  # reference
+
+from flood_uav_video_segmentation_amd import synth
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+torch.manual_seed(0)
+torch.set_grad_enabled(False)
+
+
+class Prof:
+    @contextlib.contextmanager
+    def profile(self, name):
+        yield
+
+
+class HP:
+    layers = 50
+    pretrained = False
+    classes = 5
+
+
+def save(name, **arrays):
+    path = os.path.join(OUT, name)
+    np.savez_compressed(path, **{k: (v.numpy() if isinstance(v, torch.Tensor) else np.asarray(v)) for k, v in arrays.items()})
+    print(f"{name}: {os.path.getsize(path) / 1024:.1f} KiB")
+
+
+def toy_model(seed=3):
+    g = torch.Generator().manual_seed(seed)
+    m = nn.Module()
+    enc = nn.Conv2d(3, 8, 3, stride=4, padding=1)
+    dec = nn.Conv2d(8, 5, 1)
+    for p in list(enc.parameters()) + list(dec.parameters()):
+        p.data = torch.randn(p.shape, generator=g) * 0.5
+    m.encoder = nn.Sequential(enc, nn.ReLU())
+    m.decoder = dec
+    return m.eval(), {"enc_w": enc.weight.data, "enc_b": enc.bias.data, "dec_w": dec.weight.data, "dec_b": dec.bias.data}
+
+
+def gen_default_grid():
+    g = ref_flow.get_default_grid()
+    save("default_grid.npz", grid=g, sha256=np.frombuffer(hashlib.sha256(g.tobytes()).digest(), dtype=np.uint8))
+
+
+def gen_ops_small():
+    g = torch.Generator().manual_seed(21)
+    fm = ref_flow.FlowModel(nn.Module(), feature_based=False, no_warp=False)
+    x = torch.randn(1, 3, 7, 9, generator=g)
+    grid = torch.rand(1, 4, 5, 2, generator=g) * 2.8 - 1.4  # out-of-range values exercise the border clamp
+    grid64 = grid.double()  # the reference casts non-float grids (flow/model.py:246-247)
+    save("ops_small.npz", x=x, grid=grid, warp=fm.warp(x, grid), warp_from_f64=fm.warp(x, grid64),
+         up_ac=F.interpolate(x, size=(15, 20), mode="bilinear", align_corners=True),
+         down_ac=F.interpolate(x, size=(4, 5), mode="bilinear", align_corners=True),
+         ident_ac=F.grid_sample(x, torch.from_numpy(ref_flow.get_default_grid()).float()[None], padding_mode="border",
+                                align_corners=True)[:, :, ::8, ::12])
+
+
+def gen_toy_predict():
+    toy, w = toy_model()
+    arrays = dict(w)
+    h, wd = 33, 41
+    clip = synth.make_clip(2, (h, wd), seed=5)
+    prev, nxt = clip[0:1], clip[1:2]
+    arrays["prev"], arrays["next"] = prev, nxt
+    for n in (3, 5):
+        mvl, mvr = synth.make_grids(n, 4, 5, seed=40 + n, frame=(h, wd), jitter=0.05)
+        for fb in (False, True):
+            for nw in (False, True):
+                fm = ref_flow.FlowModel(toy, feature_based=fb, no_warp=nw).eval()
+                ml, mr = (synth.dummy_grids(n) if nw else (mvl, mvr))
+                out = fm.predict(prev, nxt, ml, mr, n, Prof())["pred"]
+                arrays[f"predict_n{n}_fb{int(fb)}_nw{int(nw)}"] = out
+        fm = ref_flow.FlowModel(toy, feature_based=False, no_warp=False).eval()
+        arrays[f"single_n{n}"] = fm.predict(prev, None, mvl, mvr, n, Prof())["pred"]
+    # eval forward(): batch 3, mixed distances, grids [n-1][B,Hg,Wg,2]
+    clip3 = synth.make_clip(6, (h, wd), seed=6)
+    fp, fn_ = clip3[0:3], clip3[3:6]
+    n = 5
+    per = [synth.make_grids(n, 4, 5, seed=60 + b, frame=(h, wd), jitter=0.05) for b in range(3)]
+    mvl = [torch.cat([per[b][0][j] for b in range(3)], 0) for j in range(n - 1)]
+    mvr = [torch.cat([per[b][1][j] for b in range(3)], 0) for j in range(n - 1)]
+    left, right = [1, 2, 4], [4, 3, 1]
+    arrays["fwd_prev"], arrays["fwd_next"] = fp, fn_
+    for fb in (False, True):
+        for nw in (False, True):
+            fm = ref_flow.FlowModel(toy, feature_based=fb, no_warp=nw).eval()
+            out = fm(None, fp, fn_, mvl, mvr, torch.tensor(left), torch.tensor(right))["pred"]
+            arrays[f"forward_fb{int(fb)}_nw{int(nw)}"] = out
+    save("toy_predict.npz", **arrays)
+
+
+def build_ref_pspnet(state):
+    net = ref_psp.FlowPSPNet(hparams=HP()).eval()
+    res = net.load_state_dict(state, strict=False)
+    assert not res.unexpected_keys, res.unexpected_keys
+    bad = [k for k in res.missing_keys if not (k.startswith(("layers.", "encoder.")) or k.endswith("num_batches_tracked"))]
+    assert not bad, bad
+    return net
+
+
+def stage_stats(net, x):
+    stats = {}
+    y = x
+    for i, layer in enumerate([net.layer0, net.layer1, net.layer2, net.layer3, net.layer4]):
+        y = layer(y)
+        stats[f"layer{i}"] = np.array([y.double().mean().item(), y.double().abs().mean().item(), y.abs().max().item()])
+    return stats, y
+
+
+def gen_pspnet():
+    state = synth.make_pspnet_state(50, 5, seed=0)
+    net = build_ref_pspnet(state)
+    # small: 65x65, batch 2 -> full tensors
+    clip = synth.make_clip(2, 65, seed=100)
+    feat = net.encoder(clip)
+    logits = net.decoder(feat)
+    stats, _ = stage_stats(net, clip)
+    save("pspnet_small.npz", logits=logits, feat_slice=feat[:, ::128], feat_absmean=feat.double().abs().mean().item(),
+         **{"stat_" + k: v for k, v in stats.items()})
+    # 713: config-1 single frame + config-2 / config-3-style windows
+    clip = synth.make_clip(6, 713, seed=1000)
+    prev, nxt = clip[0:1], clip[5:6]
+    feat = net.encoder(prev)
+    lo = net.decoder(feat)
+    stats, _ = stage_stats(net, prev)
+    full = F.interpolate(lo, size=(713, 713), mode="bilinear", align_corners=True)
+    mask = full.max(1)[1].to(torch.uint8)
+    print("713 single-frame class histogram:", np.bincount(mask.numpy().ravel(), minlength=5),
+          "logit range", lo.min().item(), lo.max().item())
+    save("pspnet_713.npz", logits_lo=lo, mask=mask, feat_absmean=feat.double().abs().mean().item(),
+         feat_slice=feat[:, ::256, ::6, ::6], **{"stat_" + k: v for k, v in stats.items()})
+    n = 5
+    fm = ref_flow.FlowModel(net, feature_based=False, no_warp=True).eval()
+    dl, dr = synth.dummy_grids(n)
+    out2 = fm.predict(prev, nxt, dl, dr, n, Prof())["pred"]
+    mvl, mvr = synth.make_grids(n, 44, 44, seed=2000)
+    fm = ref_flow.FlowModel(net, feature_based=False, no_warp=False).eval()
+    out3 = fm.predict(prev, nxt, mvl, mvr, n, Prof())["pred"]
+    m2 = out2.max(1)[1].to(torch.uint8)
+    m3 = out3.max(1)[1].to(torch.uint8)
+    post2 = F.interpolate(out2, (1072, 1920), mode="bilinear", align_corners=True).max(1)[1].to(torch.uint8)
+    for f in range(n):
+        print(f"frame {f}: cfg2 hist {np.bincount(m2[f].numpy().ravel(), minlength=5)} cfg3 hist {np.bincount(m3[f].numpy().ravel(), minlength=5)}")
+    save("predict_713.npz", cfg2_mask=m2, cfg3_mask=m3, cfg2_logits_sub=out2[:, :, ::16, ::16], cfg3_logits_sub=out3[:, :, ::16, ::16],
+         cfg2_post_mask_sub=post2[:, ::4, ::4])
+    # metric fixture on real masks (util/util.py:36-47)
+    tgt = m3[1].numpy().copy()
+    tgt[:40] = 255
+    ai, au, at = ref_util.intersectionAndUnion(m2[1].numpy(), tgt, 5, 255)
+    save("metrics.npz", inter=ai, union=au, target=at)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["grid", "ops", "toy", "pspnet"]
+    if "grid" in which:
+        gen_default_grid()
+    if "ops" in which:
+        gen_ops_small()
+    if "toy" in which:
+        gen_toy_predict()
+    if "pspnet" in which:
+        gen_pspnet()

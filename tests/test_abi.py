@@ -1,0 +1,61 @@
+"""CPU checks of the drop-in boundary: the C-ABI library loads and exports every symbol that
+include/floodseg.h declares (no compute calls here -- there is no GPU in the build container)."""
+import ctypes
+import os
+import re
+import subprocess
+
+from flood_uav_video_segmentation_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "floodseg.h")
+
+
+def header_symbols():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(fs_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_declares_the_bound_symbols():
+    assert header_symbols() == _lib.exported_symbols()
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.load()
+    for name in header_symbols():
+        assert hasattr(lib, name), name
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = set(re.findall(r" T (fs_[a-z0-9_]+)", out))
+    assert set(header_symbols()) <= exported
+    # nothing but the C ABI leaks out of the shared object
+    leaked = [l for l in out.splitlines() if " T " in l and " T fs_" not in l and " T _init" not in l and " T _fini" not in l]
+    assert not leaked, leaked
+
+
+def test_version_and_error_string_are_callable_without_a_gpu():
+    lib = _lib.load()
+    assert lib.fs_version() >= 100
+    assert isinstance(lib.fs_last_error(), bytes)
+
+
+def test_bad_config_is_rejected_with_a_message():
+    lib = _lib.load()
+    cfg = _lib.FsConfig(7, 50, 5)
+    h = ctypes.c_void_p()
+    assert lib.fs_create(ctypes.byref(cfg), ctypes.byref(h)) != 0
+    assert b"arch" in lib.fs_last_error()
+    cfg = _lib.FsConfig(_lib.ARCH_PSPNET, 34, 5)
+    assert lib.fs_create(ctypes.byref(cfg), ctypes.byref(h)) != 0
+    assert b"layers" in lib.fs_last_error()
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "libfloodseg.so"))
+    try:
+        _lib.load()
+    except RuntimeError as e:
+        assert "no CPU fallback" in str(e)
+    else:
+        raise AssertionError("loading a missing library must raise")

@@ -1,0 +1,138 @@
+"""GPU parity of FlowModel (HIP path) against the reference-generated goldens and the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+from conftest import load_golden, rel_err, toy_weights
+from flood_uav_video_segmentation_amd import ops, synth
+from flood_uav_video_segmentation_amd.flow.model import FlowModel, get_default_grid
+from flood_uav_video_segmentation_amd.model.pspnet import FlowPSPNet
+from oracle import flow_oracle, pspnet_oracle
+
+pytestmark = pytest.mark.gpu
+torch.set_grad_enabled(False)
+TOL = 2e-5       # toy model: tiny torch convs on the GPU + HIP interpolation kernels
+NET_TOL = 2e-4   # full PSPNet in fp32 (see test_gpu_net.py)
+
+
+def toy_model():
+    w = toy_weights()
+    m = nn.Module()
+    enc, dec = nn.Conv2d(3, 8, 3, stride=4, padding=1), nn.Conv2d(8, 5, 1)
+    enc.weight.data, enc.bias.data, dec.weight.data, dec.bias.data = w["enc_w"], w["enc_b"], w["dec_w"], w["dec_b"]
+    m.encoder, m.decoder = nn.Sequential(enc, nn.ReLU()), dec
+    return m.cuda().eval()
+
+
+def cu(ts):
+    return [t.cuda() for t in ts]
+
+
+def test_default_grid_is_the_reference_array():
+    g = get_default_grid()
+    assert g.dtype == np.float64 and np.array_equal(g, load_golden("default_grid.npz")["grid"])
+
+
+@pytest.mark.parametrize("n", [3, 5])
+@pytest.mark.parametrize("fb", [False, True])
+@pytest.mark.parametrize("nw", [False, True])
+def test_predict_toy_model_matches_reference(n, fb, nw, profiler):
+    z = load_golden("toy_predict.npz")
+    prev, nxt = torch.from_numpy(z["prev"]).cuda(), torch.from_numpy(z["next"]).cuda()
+    h, w = prev.shape[2:]
+    mvl, mvr = synth.dummy_grids(n) if nw else synth.make_grids(n, 4, 5, seed=40 + n, frame=(h, w), jitter=0.05)
+    fm = FlowModel(toy_model(), feature_based=fb, no_warp=nw).eval()
+    keep = prev.clone()
+    out = fm.predict(prev, nxt, cu(mvl), cu(mvr), n, profiler)["pred"]
+    assert out.shape == (n, 5, h, w) and out.dtype == torch.float32
+    assert rel_err(out.cpu(), z[f"predict_n{n}_fb{int(fb)}_nw{int(nw)}"]) < TOL
+    assert torch.equal(prev, keep)  # inputs are never mutated
+    assert {"predict_encoder", "predict_decoder"} <= set(profiler.names)
+
+
+def test_predict_single_frame_and_f64_grids(profiler):
+    z = load_golden("toy_predict.npz")
+    prev, nxt = torch.from_numpy(z["prev"]).cuda(), torch.from_numpy(z["next"]).cuda()
+    fm = FlowModel(toy_model(), feature_based=False, no_warp=False).eval()
+    out = fm.predict(prev, None, [], [], 5, profiler)["pred"]
+    assert out.shape[0] == 1 and rel_err(out.cpu(), z["single_n5"]) < TOL
+    mvl, mvr = synth.make_grids(5, 4, 5, seed=45, frame=tuple(prev.shape[2:]), jitter=0.05)
+    out64 = fm.predict(prev, nxt, [m.double().cuda() for m in mvl], [m.double().cuda() for m in mvr], 5, profiler)["pred"]
+    assert rel_err(out64.cpu(), z["predict_n5_fb0_nw0"]) < TOL
+
+
+@pytest.mark.parametrize("fb", [False, True])
+@pytest.mark.parametrize("nw", [False, True])
+def test_eval_forward_mixed_distances_matches_reference(fb, nw):
+    z = load_golden("toy_predict.npz")
+    fp, fn_ = torch.from_numpy(z["fwd_prev"]).cuda(), torch.from_numpy(z["fwd_next"]).cuda()
+    h, w = fp.shape[2:]
+    n = 5
+    per = [synth.make_grids(n, 4, 5, seed=60 + b, frame=(h, w), jitter=0.05) for b in range(3)]
+    mvl = [torch.cat([per[b][0][j] for b in range(3)], 0).cuda() for j in range(n - 1)]
+    mvr = [torch.cat([per[b][1][j] for b in range(3)], 0).cuda() for j in range(n - 1)]
+    fm = FlowModel(toy_model(), feature_based=fb, no_warp=nw).eval()
+    out = fm(None, fp, fn_, mvl, mvr, torch.tensor([1, 2, 4]), torch.tensor([4, 3, 1]))["pred"]
+    assert rel_err(out.cpu(), z[f"forward_fb{int(fb)}_nw{int(nw)}"]) < TOL
+
+
+def test_training_mode_is_refused():
+    fm = FlowModel(toy_model()).train()
+    with pytest.raises(NotImplementedError):
+        fm(None, None, None, [], [], [1], [1])
+
+
+class HP:
+    layers, classes, pretrained = 50, 5, False
+
+
+@pytest.fixture(scope="module")
+def psp_flow():
+    net = FlowPSPNet(HP()).eval()
+    state = synth.make_pspnet_state(50, 5, seed=0)
+    net.load_state_dict(state)
+    return net, state
+
+
+def test_pspnet_713_config2_and_config3_match_reference_masks(psp_flow, profiler):
+    """BASELINE configs[1] (key-frame + linear interp) and configs[2]-style (logit warp) at full size."""
+    net, _ = psp_flow
+    z = load_golden("predict_713.npz")
+    clip = synth.make_clip(6, 713, seed=1000)
+    prev, nxt = clip[0:1].cuda(), clip[5:6].cuda()
+    n = 5
+    dl, dr = synth.dummy_grids(n)
+    fm = FlowModel(net, feature_based=False, no_warp=True).eval()
+    out2 = fm.predict(prev, nxt, cu(dl), cu(dr), n, profiler)["pred"]
+    assert out2.shape == (5, 5, 713, 713)
+    assert rel_err(out2[:, :, ::16, ::16].cpu(), z["cfg2_logits_sub"]) < NET_TOL
+    assert (ops.argmax_u8(out2).cpu().numpy() == z["cfg2_mask"]).mean() > 0.999
+    assert torch.equal(fm.predict_masks(prev, nxt, cu(dl), cu(dr), n), ops.argmax_u8(out2))
+    post = ops.resize_argmax_u8(out2, (1072, 1920))  # flow/base.py:275-277 without the 206 MB intermediate
+    assert (post[:, ::4, ::4].cpu().numpy() == z["cfg2_post_mask_sub"]).mean() > 0.999
+    mvl, mvr = synth.make_grids(n, 44, 44, seed=2000)
+    fm = FlowModel(net, feature_based=False, no_warp=False).eval()
+    out3 = fm.predict(prev, nxt, cu(mvl), cu(mvr), n, profiler)["pred"]
+    assert rel_err(out3[:, :, ::16, ::16].cpu(), z["cfg3_logits_sub"]) < NET_TOL
+    assert (ops.argmax_u8(out3).cpu().numpy() == z["cfg3_mask"]).mean() > 0.999
+    # mIoU of the HIP masks against the reference masks (util/util.py semantics): within 0.1 pp of 100 %
+    hist = ops.iou_hist(ops.argmax_u8(out3), torch.from_numpy(z["cfg3_mask"]).cuda(), 5).cpu().numpy().astype(np.float64)
+    miou = np.mean(hist[0] / (hist[1] + hist[2] - hist[0] + 1e-10))
+    assert miou > 0.999
+
+
+@pytest.mark.parametrize("nw", [False, True])
+def test_pspnet_feature_based_against_oracle(psp_flow, nw, profiler):
+    """Feature propagation (predict_feature) on the real network at a small frame: C=4096 NHWC warps."""
+    net, state = psp_flow
+    n = 3
+    clip = synth.make_clip(2, 129, seed=21)
+    mvl, mvr = synth.dummy_grids(n) if nw else synth.make_grids(n, 8, 8, seed=77, frame=(129, 129), jitter=0.05)
+    fm = FlowModel(net, feature_based=True, no_warp=nw).eval()
+    out = fm.predict(clip[0:1].cuda(), clip[1:2].cuda(), cu(mvl), cu(mvr), n, profiler)["pred"]
+    enc = lambda x: pspnet_oracle.encoder(x, state, 50)  # noqa: E731
+    dec = lambda f: pspnet_oracle.decoder(f, state)  # noqa: E731
+    ref = flow_oracle.predict_feature(enc, dec, clip[0:1], clip[1:2], mvl, mvr, n, nw)["pred"]
+    assert out.shape == ref.shape == (3, 5, 129, 129)
+    assert rel_err(out.cpu(), ref) < NET_TOL

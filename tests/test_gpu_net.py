@@ -1,0 +1,132 @@
+"""GPU parity of the network path (FlowPSPNet / FlowDeepLabv3 mirrors over the C ABI) against the CPU
+oracle and the reference-generated golden fixtures.  fp32 end to end.
+
+Tolerance: decoder logits max-abs error <= 1e-3 x max|logit|; masks >= 99.9 % equal.
+Measured errors are ~1e-5, the asserts use 2e-4 to leave room for summation-order differences."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, rel_err
+from flood_uav_video_segmentation_amd import synth
+from flood_uav_video_segmentation_amd.model.deeplabv3 import FlowDeepLabv3
+from flood_uav_video_segmentation_amd.model.pspnet import FlowPSPNet
+from oracle import deeplab_oracle, pspnet_oracle
+
+pytestmark = pytest.mark.gpu
+torch.set_grad_enabled(False)
+LOGIT_TOL = 2e-4
+
+
+class HP:
+    def __init__(self, layers=50, classes=5):
+        self.layers, self.classes, self.pretrained = layers, classes, False
+
+
+@pytest.fixture(scope="module")
+def psp():
+    state = synth.make_pspnet_state(50, 5, seed=0)
+    net = FlowPSPNet(HP(50, 5)).eval()
+    net.load_state_dict(state)
+    return net, state
+
+
+def test_weights_required_before_forward():
+    net = FlowPSPNet(HP())
+    with pytest.raises(RuntimeError, match="weights not loaded"):
+        net.encoder(torch.zeros(1, 3, 65, 65, device="cuda"))
+
+
+def test_state_dict_aliases_are_accepted(psp):
+    _, state = psp
+    aliased = {}
+    for k, v in state.items():
+        if k.startswith("layer"):
+            aliased["model_G.model.encoder.0." + k[5] + k[6:]] = v     # encoder.0.<N>.*
+            aliased["model_G.model.layers." + k[5] + k[6:]] = v        # layers.<N>.*
+        elif k.startswith("ppm."):
+            aliased["model_G.model.encoder.1." + k[4:]] = v
+        else:
+            aliased["model_G.model." + k] = v
+    aliased["model_G.model.layer0.1.num_batches_tracked"] = torch.tensor(0)
+    net = FlowPSPNet(HP()).eval()
+    missing, unexpected, errors = [], [], []
+    net._load_from_state_dict(aliased, "model_G.model.", {}, True, missing, unexpected, errors)
+    assert not missing and not unexpected and not errors
+    x = synth.make_clip(1, 65, seed=100).cuda()
+    ref, _ = psp
+    assert torch.equal(net.decoder(net.encoder(x)), ref.decoder(ref.encoder(x)))
+
+
+def test_pspnet_small_against_oracle_and_reference_golden(psp):
+    net, state = psp
+    z = load_golden("pspnet_small.npz")
+    clip = synth.make_clip(2, 65, seed=100)
+    feat = net.encoder(clip.cuda())
+    assert feat.shape == (2, 4096, 9, 9)
+    assert feat.stride() == (9 * 9 * 4096, 1, 9 * 4096, 4096)  # channels_last: zero-copy hand-off to the decoder
+    logits = net.decoder(feat)
+    assert logits.shape == (2, 5, 9, 9) and logits.is_contiguous()
+    ofeat = pspnet_oracle.encoder(clip, state, 50)
+    assert rel_err(feat.cpu(), ofeat) < LOGIT_TOL
+    assert rel_err(logits.cpu(), pspnet_oracle.decoder(ofeat, state)) < LOGIT_TOL
+    assert rel_err(feat.cpu()[:, ::128], z["feat_slice"]) < LOGIT_TOL       # reference itself
+    assert rel_err(logits.cpu(), z["logits"]) < LOGIT_TOL                   # reference itself
+
+
+def test_pspnet_713_single_frame_against_reference_golden(psp):
+    net, _ = psp
+    z = load_golden("pspnet_713.npz")
+    prev = synth.make_clip(6, 713, seed=1000)[0:1].cuda()
+    feat = net.encoder(prev)
+    assert feat.shape == (1, 4096, 90, 90)
+    assert rel_err(feat.cpu()[:, ::256, ::6, ::6], z["feat_slice"]) < LOGIT_TOL
+    assert abs(feat.double().abs().mean().item() / float(z["feat_absmean"]) - 1) < 1e-5
+    lo = net.decoder(feat)
+    assert rel_err(lo.cpu(), z["logits_lo"]) < LOGIT_TOL
+    from flood_uav_video_segmentation_amd import ops
+    _, mask = ops.seg_tail(lo, None, [], [], 1, (713, 713), True, want_logits=False, want_mask=True)
+    assert (mask[0].cpu().numpy() == z["mask"]).mean() > 0.999
+
+
+def test_batch_of_two_equals_two_single_frames(psp):
+    net, _ = psp
+    clip = synth.make_clip(2, 129, seed=7).cuda()
+    both = net.decoder(net.encoder(clip))
+    one = torch.cat([net.decoder(net.encoder(clip[i:i + 1])) for i in range(2)], 0)
+    assert torch.equal(both, one)  # same kernels, same per-image reduction order
+
+
+def test_decoder_accepts_nchw_contiguous_features(psp):
+    net, _ = psp
+    x = synth.make_clip(1, 65, seed=3).cuda()
+    f = net.encoder(x)
+    assert torch.equal(net.decoder(f.contiguous()), net.decoder(f))
+
+
+def test_pspnet101_small_against_oracle():
+    state = synth.make_pspnet_state(101, 5, seed=1)
+    net = FlowPSPNet(HP(101, 5)).eval()
+    net.load_state_dict(state)
+    x = synth.make_clip(1, 65, seed=8)
+    got = net.decoder(net.encoder(x.cuda())).cpu()
+    assert rel_err(got, pspnet_oracle.decoder(pspnet_oracle.encoder(x, state, 101), state)) < LOGIT_TOL
+
+
+def test_deeplabv3_r101_against_oracle_parity_unpinned():
+    """DeepLabv3's arithmetic lives in un-vendored torchvision: no reference output exists offline, so this
+    only checks HIP path == our own restatement of the public architecture (PARITY UNPINNED)."""
+    state = synth.make_deeplab_state(101, 5, seed=0)
+    net = FlowDeepLabv3(HP(101, 5)).eval()
+    net.load_state_dict(state)
+    x = synth.make_clip(2, 97, seed=9)
+    feat = net.encoder(x.cuda())
+    assert feat.shape == (2, 2048, 13, 13)
+    ofeat = deeplab_oracle.encoder(x, state, 101)
+    assert rel_err(feat.cpu(), ofeat) < LOGIT_TOL
+    assert rel_err(net.decoder(feat).cpu(), deeplab_oracle.decoder(ofeat, state)) < LOGIT_TOL
+    # keys as FlowDeepLabv3's state_dict spells them (encoder.model.* / decoder.*)
+    ref_keys = {("encoder.model." + k[9:] if k.startswith("backbone.") else "decoder." + k[11:]): v for k, v in state.items()}
+    net2 = FlowDeepLabv3(HP(101, 5)).eval()
+    net2.load_state_dict(ref_keys)
+    assert torch.equal(net2.decoder(net2.encoder(x.cuda())), net.decoder(feat))

@@ -1,0 +1,54 @@
+"""N > 1 path on CPU: two gloo ranks shard 7 clips and reduce histograms / frame counts / time."""
+import os
+import socket
+
+import torch
+import torch.multiprocessing as mp
+
+from flood_uav_video_segmentation_amd import shard
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world_size, port, out_dir):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world_size), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    r, _, w = shard.init("gloo")
+    assert (r, w) == (rank, world_size)
+    clips = shard.clips_for_rank(7, r, w)
+    hist = torch.zeros(3, 5, dtype=torch.int64)
+    frames = 0
+    for c in clips:  # stand-in for the per-clip window loop: deterministic per-clip contributions
+        for (_k0, _k1) in shard.windows_of_clip(21, 5):
+            hist += torch.arange(15).view(3, 5) * (c + 1)
+            frames += 5
+    shard.barrier()
+    total, nframes, sec = shard.reduce_run(hist, frames, 1.0 + rank)
+    torch.save({"clips": clips, "hist": total, "frames": nframes, "sec": sec}, os.path.join(out_dir, f"r{rank}.pt"))
+    torch.distributed.destroy_process_group()
+
+
+def test_two_ranks_shard_and_reduce(tmp_path):
+    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    r0 = torch.load(tmp_path / "r0.pt")
+    r1 = torch.load(tmp_path / "r1.pt")
+    assert r0["clips"] == [0, 2, 4, 6] and r1["clips"] == [1, 3, 5]
+    assert sorted(r0["clips"] + r1["clips"]) == list(range(7))
+    expect = torch.arange(15).view(3, 5) * sum(range(1, 8)) * 4  # 4 windows per 21-frame clip
+    for r in (r0, r1):
+        assert torch.equal(r["hist"], expect)
+        assert r["frames"] == 7 * 4 * 5
+        assert r["sec"] == 2.0  # MAX over ranks
+
+
+def test_single_process_is_a_no_op():
+    hist, frames, sec = shard.reduce_run(torch.ones(3, 5, dtype=torch.int64), 20, 0.5)
+    assert frames == 20 and sec == 0.5 and int(hist.sum()) == 15
+    assert shard.clips_for_rank(64, 3, 8) == list(range(3, 64, 8))
+    assert shard.windows_of_clip(21, 5) == [(0, 5), (5, 10), (10, 15), (15, 20)]
+    perfect = torch.tensor([[4, 4, 4, 4, 4], [4, 4, 4, 4, 4], [4, 4, 4, 4, 4]])
+    assert abs(shard.miou_from_hist(perfect) - 1.0) < 1e-9
