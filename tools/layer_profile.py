@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""Per-launch table (HIP events inside the library) of one key-frame batch: PSPNet-R50, B=2, 713x713."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from flood_uav_video_segmentation_amd import synth  # noqa: E402
+from flood_uav_video_segmentation_amd.model.pspnet import FlowPSPNet  # noqa: E402
+
+
+class HP:
+    layers, classes, pretrained = 50, 5, False
+
+
+def main():
+    b = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+    torch.set_grad_enabled(False)
+    net = FlowPSPNet(HP()).eval()
+    net.load_state_dict(synth.make_pspnet_state(50, 5, 0))
+    x = synth.make_clip(b, 713, seed=1000).cuda()
+    for _ in range(2):
+        net.decoder(net.encoder(x))
+    torch.cuda.synchronize()
+    reps = 5
+    net._hip_net.profile(True)
+    for _ in range(reps):
+        net.decoder(net.encoder(x))
+    rows = net._hip_net.profile_dump()
+    nops = len(rows) // reps
+    tot = 0.0
+    print(f"{'op':42s} {'kernel':18s} {'ms':>8s} {'GFLOP':>9s} {'TFLOP/s':>8s}")
+    for i in range(nops):
+        ms = sum(rows[i + r * nops][4] for r in range(reps)) / reps
+        name, kernel, flops = rows[i][0], rows[i][1], rows[i][2]
+        tot += ms
+        print(f"{name:42s} {kernel:18s} {ms:8.4f} {flops / 1e9:9.3f} {flops / ms / 1e9 if ms > 0 else 0:8.1f}")
+    print(f"total {tot:.3f} ms for B={b}")
+
+
+if __name__ == "__main__":
+    main()
