@@ -20,11 +20,13 @@ c_f32 = ctypes.c_float
 
 
 class FsConfig(ctypes.Structure):
-    _fields_ = [("arch", c_int), ("layers", c_int), ("classes", c_int)]
+    _fields_ = [("arch", c_int), ("layers", c_int), ("classes", c_int), ("patch", c_int), ("d_model", c_int),
+                ("n_layers", c_int), ("dec_layers", c_int), ("image_size", c_int)]
 
 
 ARCH_PSPNET = 0
 ARCH_DEEPLABV3 = 1
+ARCH_SEGMENTER = 2
 
 # name -> (restype, argtypes); must list every symbol of include/floodseg.h
 _SIGNATURES = {

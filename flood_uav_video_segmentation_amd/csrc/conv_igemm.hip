@@ -190,7 +190,8 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(ConvParams p, int tiles_m,
             for (int e = 0; e < 16; ++e) {
                 const int m = mb + (e & 3) + 8 * (e >> 2);
                 float v = acc[i][j][e] * sc_n + sh_n + rv[e];
-                if (p.relu) v = fmaxf(v, 0.f);
+                if (p.relu == 1) v = fmaxf(v, 0.f);
+                else if (p.relu == 2) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752f));  // nn.GELU (erf form)
                 if (nok && m < M) p.out[(size_t)m * p.ld_out + n] = v;
             }
         }

@@ -24,7 +24,7 @@ struct ConvParams {
     int B, H, W, Cin;
     int Ho, Wo, Cout;
     int KH, KW, stride, pad, dil;
-    int relu;
+    int relu;  // epilogue activation: 0 none, 1 ReLU, 2 GELU (erf)
 };
 // tile: 0 = heuristic, 1 = 128x128, 2 = 128x64, 3 = 64x64, 4 = 64x128
 int launch_conv_igemm(const ConvParams& p, hipStream_t s, int tile = 0);
@@ -117,5 +117,27 @@ int launch_resize_argmax_u8(const float* in, int B, int K, int Hi, int Wi, uint8
 // intersection / union / target histograms (util/util.py:52-63), int64[3][K] accumulated.
 int launch_iou_hist(const uint8_t* pred, const uint8_t* target, int64_t numel, int K, int ignore_index,
                     long long* hist3K, hipStream_t s);
+
+
+// ---------------------------------------------------------------------------------
+// Segmenter / ViT pieces (segm/model/vit.py, blocks.py, decoder.py); token matrices are row-major
+// [rows][D] -- i.e. the same "NHWC with ld" layout, so every nn.Linear runs on conv_igemm_f32.
+// ---------------------------------------------------------------------------------
+// Zero-padded (right/bottom) im2col of non-overlapping PxP patches: NCHW frame -> [B*gh*gw][3*P*P],
+// column order (c, py, px) = Conv2d(k=s=P) weight flattening (segm/model/vit.py:28-35, utils.py:65-76).
+int launch_patchify(const float* in, float* out, int B, int H, int W, int P, int gh, int gw, hipStream_t s);
+// X[b][0] = cls + pos[0];  X[b][1+i] = emb[b*N+i] + pos[1+i]   (segm/model/vit.py:112-131)
+int launch_vit_assemble(const float* emb, const float* cls, const float* pos, float* X, int B, int N, int D, hipStream_t s);
+// Z[b][i<N] = Y[b*N+i];  Z[b][N+k] = cls_emb[k]                (segm/model/decoder.py:84-86)
+int launch_dec_assemble(const float* Y, const float* cls_emb, float* Z, int B, int N, int K, int D, hipStream_t s);
+// nn.LayerNorm(D) per row; drop_first > 0: input rows are [B][rows_per_batch] and row 0 of every batch
+// (the cls token) is skipped in the output (segm/model/segmenter.py:41-42).
+int launch_layernorm(const float* in, const float* gamma, const float* beta, float* out, int rows, int D, int rows_per_batch,
+                     int drop_first, hipStream_t s);
+// softmax(q k^T * scale) v for all heads, fp32 MFMA flash-style; qkv rows are [3][heads][64] (blocks.py:56-77).
+int launch_attention_f32(const float* qkv, float* out, int B, int N, int heads, float scale, hipStream_t s);
+// masks[b][k][i] = LayerNorm_K( <pp[b][i]/|pp|, cc[b][N+k]/|cc|> )  (segm/model/decoder.py:90-100), NCHW out
+int launch_mask_head(const float* pp, const float* cc, const float* gamma, const float* beta, float* out, int B, int N, int K,
+                     int D, hipStream_t s);
 
 }  // namespace fs

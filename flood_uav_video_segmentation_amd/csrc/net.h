@@ -36,6 +36,23 @@ struct Bottleneck {
     bool has_ds = false;
 };
 
+// nn.Linear / nn.LayerNorm of the Segmenter (weights kept [out][in] exactly as torch stores them)
+struct Linear {
+    std::string name;
+    float* w = nullptr;
+    float* b = nullptr;
+    int in = 0, out = 0;
+};
+struct LNorm {
+    float* g = nullptr;
+    float* b = nullptr;
+    int D = 0;
+};
+struct VitBlock {
+    LNorm n1, n2;
+    Linear qkv, proj, fc1, fc2;
+};
+
 struct ProfRec {
     std::string name, kernel;
     double flops = 0, bytes = 0;
@@ -67,6 +84,20 @@ struct fs_net {
     fs::ConvBN project, head_conv;
     int cls_cin = 512;
 
+    // Segmenter (ViT encoder + mask transformer): segm/model/{vit,blocks,decoder}.py
+    fs::Linear patch_embed;          // Conv2d(3, D, k=s=P) flattened to [D][3*P*P]
+    float* cls_token = nullptr;      // [D]
+    float* pos_embed = nullptr;      // [1 + g0*g0][D] as constructed
+    int pos_g0 = 0;
+    float* pos_cur = nullptr;        // [1 + gh*gw][D] resized for the current geometry
+    int pos_gh = 0, pos_gw = 0;
+    std::vector<fs::VitBlock> enc_blocks, dec_blocks;
+    fs::LNorm enc_norm, dec_norm, mask_norm;
+    fs::Linear proj_dec, proj_patch, proj_classes;  // proj_patch/_classes stored transposed ([out][in])
+    float* cls_emb = nullptr;        // [K][D]
+    float* vit_ws = nullptr;
+    size_t vit_ws_elems = 0;
+
     // workspace
     float* buf[4] = {nullptr, nullptr, nullptr, nullptr};
     size_t buf_elems = 0;
@@ -77,7 +108,10 @@ struct fs_net {
     bool profiling = false;
     std::vector<fs::ProfRec> prof;
 
-    int feat_channels() const { return cfg.arch == FS_ARCH_PSPNET ? 4096 : 2048; }
+    int feat_channels() const {
+        if (cfg.arch == FS_ARCH_SEGMENTER) return cfg.d_model;
+        return cfg.arch == FS_ARCH_PSPNET ? 4096 : 2048;
+    }
 };
 
 namespace fs {
@@ -91,4 +125,14 @@ size_t net_workspace_bytes(fs_handle h, int B, int H, int W);
 int net_encoder(fs_handle h, const float* in_nchw, int B, int H, int W, float* out_nhwc, hipStream_t s);
 int net_decoder(fs_handle h, const float* feat, int B, int fh, int fw, float* out_nchw, hipStream_t s);
 int net_profile_dump(fs_handle h, char* buf, size_t n);
+
+// shared with vit_net.hip
+int dev_alloc(fs_net* h, float** p, size_t elems);
+int fetch(fs_net* h, const std::string& name, const RawTensor** out);
+int prof_begin(fs_net* h, const std::string& name, const char* kernel, double flops, double bytes, hipStream_t s);
+int prof_end(fs_net* h, hipStream_t s);
+int vit_finalize(fs_handle h, hipStream_t s);
+int vit_feature_shape(fs_handle h, int H, int W, int* C, int* fh, int* fw);
+int vit_encoder(fs_handle h, const float* in_nchw, int B, int H, int W, float* out_tokens, hipStream_t s);
+int vit_decoder(fs_handle h, const float* tokens, int B, int gh, int gw, float* out_nchw, hipStream_t s);
 }  // namespace fs

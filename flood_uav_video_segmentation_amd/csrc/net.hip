@@ -22,8 +22,6 @@ int fail(const char* fmt, ...) {
     return 1;
 }
 
-namespace {
-
 int dev_alloc(fs_net* h, float** p, size_t elems) {
     FS_HIP(hipMalloc(reinterpret_cast<void**>(p), std::max<size_t>(elems, 4) * sizeof(float)));
     h->owned.push_back(*p);
@@ -42,6 +40,8 @@ int to_host(const RawTensor& t, std::vector<float>& v) {
     FS_HIP(hipMemcpy(v.data(), t.d, v.size() * sizeof(float), hipMemcpyDeviceToHost));
     return 0;
 }
+
+namespace {
 
 // conv weight + BatchNorm prefix (or bias name, or neither)
 int make_conv(fs_net* h, ConvBN& c, const std::string& wname, const std::string& bn, const std::string& bias, int stride,
@@ -96,6 +96,8 @@ int make_conv(fs_net* h, ConvBN& c, const std::string& wname, const std::string&
     return 0;
 }
 
+}  // namespace
+
 int prof_begin(fs_net* h, const std::string& name, const char* kernel, double flops, double bytes, hipStream_t s) {
     if (!h->profiling) return 0;
     ProfRec r;
@@ -114,6 +116,8 @@ int prof_end(fs_net* h, hipStream_t s) {
     FS_HIP(hipEventRecord(h->prof.back().e1, s));
     return 0;
 }
+
+namespace {
 
 int run_conv(fs_net* h, const ConvBN& c, const float* in, int ld_in, int B, int H, int W, float* out, int ld_out,
              const float* res, int ld_res, hipStream_t s) {
@@ -198,8 +202,10 @@ size_t small_elems_for(int B) { return (size_t)B * 50 * (2048 + 512) + 1024; }
 // ---------------------------------------------------------------------------------------------
 int net_create(const fs_config* cfg, fs_handle* out) {
     FS_REQUIRE(cfg && out, "fs_create: null argument");
-    FS_REQUIRE(cfg->arch == FS_ARCH_PSPNET || cfg->arch == FS_ARCH_DEEPLABV3, "fs_create: unknown arch %d", cfg->arch);
-    FS_REQUIRE(cfg->layers == 50 || cfg->layers == 101 || cfg->layers == 152, "fs_create: layers must be 50, 101 or 152");
+    FS_REQUIRE(cfg->arch == FS_ARCH_PSPNET || cfg->arch == FS_ARCH_DEEPLABV3 || cfg->arch == FS_ARCH_SEGMENTER,
+               "fs_create: unknown arch %d", cfg->arch);
+    FS_REQUIRE(cfg->arch == FS_ARCH_SEGMENTER || cfg->layers == 50 || cfg->layers == 101 || cfg->layers == 152,
+               "fs_create: layers must be 50, 101 or 152");
     FS_REQUIRE(cfg->classes >= 1 && cfg->classes <= 255, "fs_create: classes out of range");
     fs_net* h = new fs_net();
     h->cfg = *cfg;
@@ -217,6 +223,8 @@ int net_destroy(fs_handle h) {
     for (int i = 0; i < 4; ++i)
         if (h->buf[i]) (void)hipFree(h->buf[i]);
     if (h->small) (void)hipFree(h->small);
+    if (h->vit_ws) (void)hipFree(h->vit_ws);
+    if (h->pos_cur) (void)hipFree(h->pos_cur);
     for (auto& r : h->prof) {
         (void)hipEventDestroy(r.e0);
         (void)hipEventDestroy(r.e1);
@@ -248,6 +256,17 @@ int net_finalize(fs_handle h, hipStream_t s) {
     FS_REQUIRE(h, "fs_finalize: null handle");
     FS_REQUIRE(!h->finalized, "fs_finalize: already finalized");
     FS_HIP(hipStreamSynchronize(s));
+    if (h->cfg.arch == FS_ARCH_SEGMENTER) {
+        FS_TRY(vit_finalize(h, s));
+        FS_HIP(hipDeviceSynchronize());
+        for (auto& kv : h->raw) {
+            (void)hipFree(kv.second.d);
+            kv.second.d = nullptr;
+        }
+        h->raw.clear();
+        h->finalized = true;
+        return 0;
+    }
     const bool psp = h->cfg.arch == FS_ARCH_PSPNET;
     const std::string bb = psp ? "" : "backbone.";
     // ---- stem
@@ -342,6 +361,7 @@ int net_finalize(fs_handle h, hipStream_t s) {
 
 int net_feature_shape(fs_handle h, int H, int W, int* C, int* fh, int* fw) {
     FS_REQUIRE(h && h->finalized, "fs_feature_shape: network not finalized");
+    if (h->cfg.arch == FS_ARCH_SEGMENTER) return vit_feature_shape(h, H, W, C, fh, fw);
     const Geometry g = geometry(h, H, W);
     if (C) *C = h->feat_channels();
     if (fh) *fh = g.H3;
@@ -351,12 +371,18 @@ int net_feature_shape(fs_handle h, int H, int W, int* C, int* fh, int* fw) {
 
 size_t net_workspace_bytes(fs_handle h, int B, int H, int W) {
     if (!h || !h->finalized) return 0;
+    if (h->cfg.arch == FS_ARCH_SEGMENTER) {
+        const int P = h->cfg.patch, D = h->cfg.d_model;
+        const size_t T = (size_t)B * (((H + P - 1) / P) * ((W + P - 1) / P) + 1 + h->cfg.classes);
+        return (T * D * 11 + T * 3 * P * P + 64) * sizeof(float);
+    }
     return (4 * encoder_buf_elems(h, B, H, W) + small_elems_for(B)) * sizeof(float);
 }
 
 // ---------------------------------------------------------------------------------------------
 int net_encoder(fs_handle h, const float* in_nchw, int B, int H, int W, float* out, hipStream_t s) {
     FS_REQUIRE(h && h->finalized, "fs_encoder_forward: network not finalized");
+    if (h->cfg.arch == FS_ARCH_SEGMENTER) return vit_encoder(h, in_nchw, B, H, W, out, s);
     FS_REQUIRE(in_nchw && out && B >= 1 && H >= 33 && W >= 33, "fs_encoder_forward: bad arguments (B=%d H=%d W=%d)", B, H, W);
     const Geometry g = geometry(h, H, W);
     FS_TRY(ensure_workspace(h, encoder_buf_elems(h, B, H, W), small_elems_for(B)));
@@ -457,6 +483,7 @@ int net_encoder(fs_handle h, const float* in_nchw, int B, int H, int W, float* o
 // ---------------------------------------------------------------------------------------------
 int net_decoder(fs_handle h, const float* feat, int B, int fh, int fw, float* out_nchw, hipStream_t s) {
     FS_REQUIRE(h && h->finalized, "fs_decoder_forward: network not finalized");
+    if (h->cfg.arch == FS_ARCH_SEGMENTER) return vit_decoder(h, feat, B, fh, fw, out_nchw, s);
     FS_REQUIRE(feat && out_nchw && B >= 1 && fh >= 1 && fw >= 1, "fs_decoder_forward: bad arguments");
     const int K = h->cfg.classes;
     const size_t px = (size_t)B * fh * fw;

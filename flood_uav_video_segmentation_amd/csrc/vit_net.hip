@@ -1,0 +1,216 @@
+// Segmenter executor: ViT encoder + mask-transformer decoder as a fixed launch sequence.
+// Restates model/vit.py:13-56 -> segm/model/segmenter.py:32-48, vit.py:108-137, blocks.py:16-95,
+// decoder.py:80-102, utils.py:22-40,65-76.  Every nn.Linear runs on conv_igemm_f32 (1x1 "conv" over
+// the token matrix), attention on attention_f32_kernel.
+#include "net.h"
+
+namespace fs {
+namespace {
+
+int copy_param(fs_net* h, const std::string& name, int64_t expect, float** dst) {
+    const RawTensor* t;
+    FS_TRY(fetch(h, name, &t));
+    FS_REQUIRE(expect < 0 || t->numel() == expect, "'%s' has %lld elements, expected %lld", name.c_str(), (long long)t->numel(),
+               (long long)expect);
+    FS_TRY(dev_alloc(h, dst, (size_t)t->numel()));
+    FS_HIP(hipMemcpy(*dst, t->d, (size_t)t->numel() * sizeof(float), hipMemcpyDeviceToDevice));
+    return 0;
+}
+
+int make_linear(fs_net* h, Linear& l, const std::string& prefix, int in, int out, bool bias) {
+    l.name = prefix;
+    l.in = in;
+    l.out = out;
+    FS_TRY(copy_param(h, prefix + ".weight", (int64_t)in * out, &l.w));
+    if (bias) FS_TRY(copy_param(h, prefix + ".bias", out, &l.b));
+    return 0;
+}
+
+int make_norm(fs_net* h, LNorm& n, const std::string& prefix, int D) {
+    n.D = D;
+    FS_TRY(copy_param(h, prefix + ".weight", D, &n.g));
+    FS_TRY(copy_param(h, prefix + ".bias", D, &n.b));
+    return 0;
+}
+
+int make_block(fs_net* h, VitBlock& b, const std::string& p, int D) {
+    FS_TRY(make_norm(h, b.n1, p + "norm1", D));
+    FS_TRY(make_norm(h, b.n2, p + "norm2", D));
+    FS_TRY(make_linear(h, b.qkv, p + "attn.qkv", D, 3 * D, true));
+    FS_TRY(make_linear(h, b.proj, p + "attn.proj", D, D, true));
+    FS_TRY(make_linear(h, b.fc1, p + "mlp.fc1", D, 4 * D, true));
+    FS_TRY(make_linear(h, b.fc2, p + "mlp.fc2", 4 * D, D, true));
+    return 0;
+}
+
+// out[rows][l.out] = act(in[rows][l.in] @ W^T + b (+ res))
+int run_linear(fs_net* h, const Linear& l, const float* in, int rows, float* out, const float* res, int act, hipStream_t s) {
+    ConvParams p{};
+    p.in = in;
+    p.ld_in = l.in;
+    p.wgt = l.w;
+    p.scale = nullptr;
+    p.shift = l.b;
+    p.res = res;
+    p.ld_res = l.out;
+    p.out = out;
+    p.ld_out = l.out;
+    p.B = 1;
+    p.H = rows;
+    p.W = 1;
+    p.Cin = l.in;
+    p.Ho = rows;
+    p.Wo = 1;
+    p.Cout = l.out;
+    p.KH = p.KW = 1;
+    p.stride = 1;
+    p.pad = 0;
+    p.dil = 1;
+    p.relu = act;
+    const double flops = 2.0 * rows * (double)l.in * l.out;
+    FS_TRY(prof_begin(h, l.name, conv_igemm_tile_name(p), flops, 4.0 * ((double)rows * (l.in + l.out) + (double)l.in * l.out), s));
+    FS_TRY(launch_conv_igemm(p, s));
+    return prof_end(h, s);
+}
+
+int run_norm(fs_net* h, const LNorm& n, const float* in, float* out, int rows, int rows_per_batch, int drop_first, hipStream_t s) {
+    FS_TRY(prof_begin(h, "layernorm", "layernorm", 0, 8.0 * rows * n.D, s));
+    FS_TRY(launch_layernorm(in, n.g, n.b, out, rows, n.D, rows_per_batch, drop_first, s));
+    return prof_end(h, s);
+}
+
+struct VitWs {
+    float *X, *Xn, *QKV, *A, *Hd, *patches, *emb;
+};
+
+int vit_workspace(fs_net* h, int B, int tokens, VitWs* ws) {
+    const size_t D = (size_t)h->cfg.d_model, T = (size_t)B * tokens;
+    const size_t P2 = (size_t)3 * h->cfg.patch * h->cfg.patch;
+    const size_t need = T * D * 3 + T * 3 * D + T * 4 * D + T * P2 + T * D + 64;
+    if (need > h->vit_ws_elems) {
+        FS_HIP(hipDeviceSynchronize());
+        if (h->vit_ws) FS_HIP(hipFree(h->vit_ws));
+        h->vit_ws = nullptr;
+        FS_HIP(hipMalloc(reinterpret_cast<void**>(&h->vit_ws), need * sizeof(float)));
+        h->vit_ws_elems = need;
+    }
+    float* p = h->vit_ws;
+    ws->X = p; p += T * D;
+    ws->Xn = p; p += T * D;
+    ws->A = p; p += T * D;
+    ws->QKV = p; p += T * 3 * D;
+    ws->Hd = p; p += T * 4 * D;
+    ws->patches = p; p += T * P2;
+    ws->emb = p;
+    return 0;
+}
+
+// pre-LN transformer block, in place on X (blocks.py:89-95)
+int run_block(fs_net* h, const VitBlock& blk, const VitWs& ws, int B, int tokens, hipStream_t s) {
+    const int D = h->cfg.d_model, heads = D / 64, rows = B * tokens;
+    FS_TRY(run_norm(h, blk.n1, ws.X, ws.Xn, rows, tokens, 0, s));
+    FS_TRY(run_linear(h, blk.qkv, ws.Xn, rows, ws.QKV, nullptr, 0, s));
+    const double aflops = 4.0 * B * heads * (double)tokens * tokens * 64;
+    FS_TRY(prof_begin(h, blk.qkv.name + ".attention", "attention_f32", aflops, 4.0 * rows * 4.0 * D, s));
+    FS_TRY(launch_attention_f32(ws.QKV, ws.A, B, tokens, heads, 0.125f, s));
+    FS_TRY(prof_end(h, s));
+    FS_TRY(run_linear(h, blk.proj, ws.A, rows, ws.X, ws.X, 0, s));          // x = x + proj(attn)
+    FS_TRY(run_norm(h, blk.n2, ws.X, ws.Xn, rows, tokens, 0, s));
+    FS_TRY(run_linear(h, blk.fc1, ws.Xn, rows, ws.Hd, nullptr, 2, s));       // GELU
+    FS_TRY(run_linear(h, blk.fc2, ws.Hd, rows, ws.X, ws.X, 0, s));           // x = x + mlp(x)
+    return 0;
+}
+
+}  // namespace
+
+int vit_finalize(fs_handle h, hipStream_t s) {
+    const fs_config& c = h->cfg;
+    const int D = c.d_model, P = c.patch, K = c.classes;
+    FS_REQUIRE(D % 64 == 0 && D >= 64 && D <= 1024, "segmenter: d_model=%d must be a multiple of 64 (head_dim 64), <= 1024", D);
+    FS_REQUIRE(P >= 4 && P % 4 == 0 && (3 * P * P) % 32 == 0, "segmenter: unsupported patch size %d", P);
+    FS_REQUIRE(c.image_size % P == 0 && c.image_size >= P, "segmenter: image_size %d not divisible by patch %d", c.image_size, P);
+    FS_REQUIRE(c.n_layers >= 1 && c.dec_layers >= 1, "segmenter: layer counts must be positive");
+    h->pos_g0 = c.image_size / P;
+    FS_TRY(make_linear(h, h->patch_embed, "encoder.patch_embed.proj", 3 * P * P, D, true));
+    FS_TRY(copy_param(h, "encoder.cls_token", D, &h->cls_token));
+    FS_TRY(copy_param(h, "encoder.pos_embed", (int64_t)(1 + h->pos_g0 * h->pos_g0) * D, &h->pos_embed));
+    h->enc_blocks.resize((size_t)c.n_layers);
+    for (int i = 0; i < c.n_layers; ++i) FS_TRY(make_block(h, h->enc_blocks[(size_t)i], "encoder.blocks." + std::to_string(i) + ".", D));
+    FS_TRY(make_norm(h, h->enc_norm, "encoder.norm", D));
+    h->dec_blocks.resize((size_t)c.dec_layers);
+    for (int i = 0; i < c.dec_layers; ++i) FS_TRY(make_block(h, h->dec_blocks[(size_t)i], "decoder.blocks." + std::to_string(i) + ".", D));
+    FS_TRY(make_linear(h, h->proj_dec, "decoder.proj_dec", D, D, true));
+    FS_TRY(make_norm(h, h->dec_norm, "decoder.decoder_norm", D));
+    FS_TRY(make_norm(h, h->mask_norm, "decoder.mask_norm", K));
+    FS_TRY(copy_param(h, "decoder.cls_emb", (int64_t)K * D, &h->cls_emb));
+    // `patches @ proj_patch` uses the parameter as [in][out]: store the transpose so it is a Linear weight
+    for (int which = 0; which < 2; ++which) {
+        Linear& l = which ? h->proj_classes : h->proj_patch;
+        const std::string name = which ? "decoder.proj_classes" : "decoder.proj_patch";
+        const RawTensor* t;
+        FS_TRY(fetch(h, name, &t));
+        FS_REQUIRE(t->numel() == (int64_t)D * D, "'%s' must be [%d,%d]", name.c_str(), D, D);
+        l.name = name;
+        l.in = l.out = D;
+        FS_TRY(dev_alloc(h, &l.w, (size_t)D * D));
+        FS_TRY(launch_nchw_to_nhwc(t->d, l.w, D, 1, D, D, s));  // [in][out] -> [out][in]
+    }
+    FS_HIP(hipStreamSynchronize(s));
+    return 0;
+}
+
+int vit_feature_shape(fs_handle h, int H, int W, int* C, int* fh, int* fw) {
+    const int P = h->cfg.patch;
+    if (C) *C = h->cfg.d_model;
+    if (fh) *fh = (H + P - 1) / P;
+    if (fw) *fw = (W + P - 1) / P;
+    return 0;
+}
+
+int vit_encoder(fs_handle h, const float* in_nchw, int B, int H, int W, float* out_tokens, hipStream_t s) {
+    FS_REQUIRE(in_nchw && out_tokens && B >= 1 && H >= 1 && W >= 1, "fs_encoder_forward(segmenter): bad arguments");
+    const int P = h->cfg.patch, D = h->cfg.d_model;
+    const int gh = (H + P - 1) / P, gw = (W + P - 1) / P, N = gh * gw;
+    VitWs ws;
+    FS_TRY(vit_workspace(h, B, N + 1 + h->cfg.classes, &ws));
+    // position embedding for this grid (segm/model/vit.py:122-130, utils.py:22-40: bilinear, align_corners=False)
+    const float* pos = h->pos_embed;
+    if (gh != h->pos_g0 || gw != h->pos_g0) {
+        if (gh != h->pos_gh || gw != h->pos_gw) {
+            FS_HIP(hipDeviceSynchronize());
+            if (h->pos_cur) FS_HIP(hipFree(h->pos_cur));
+            h->pos_cur = nullptr;
+            FS_HIP(hipMalloc(reinterpret_cast<void**>(&h->pos_cur), (size_t)(1 + N) * D * sizeof(float)));
+            FS_HIP(hipMemcpyAsync(h->pos_cur, h->pos_embed, (size_t)D * sizeof(float), hipMemcpyDeviceToDevice, s));
+            FS_TRY(launch_resize_bilinear_nhwc(h->pos_embed + D, D, 1, D, h->pos_g0, h->pos_g0, h->pos_cur + D, D, gh, gw, 0, s));
+            h->pos_gh = gh;
+            h->pos_gw = gw;
+        }
+        pos = h->pos_cur;
+    }
+    FS_TRY(prof_begin(h, "patchify", "patchify", 0, 8.0 * B * N * 3.0 * P * P, s));
+    FS_TRY(launch_patchify(in_nchw, ws.patches, B, H, W, P, gh, gw, s));
+    FS_TRY(prof_end(h, s));
+    FS_TRY(run_linear(h, h->patch_embed, ws.patches, B * N, ws.emb, nullptr, 0, s));
+    FS_TRY(launch_vit_assemble(ws.emb, h->cls_token, pos, ws.X, B, N, D, s));
+    for (const VitBlock& blk : h->enc_blocks) FS_TRY(run_block(h, blk, ws, B, N + 1, s));
+    return run_norm(h, h->enc_norm, ws.X, out_tokens, B * (N + 1), N + 1, 1, s);  // final norm, cls token dropped
+}
+
+int vit_decoder(fs_handle h, const float* tokens, int B, int gh, int gw, float* out_nchw, hipStream_t s) {
+    FS_REQUIRE(tokens && out_nchw && B >= 1 && gh >= 1 && gw >= 1, "fs_decoder_forward(segmenter): bad arguments");
+    const int D = h->cfg.d_model, K = h->cfg.classes, N = gh * gw, T = N + K;
+    VitWs ws;
+    FS_TRY(vit_workspace(h, B, N + 1 + K, &ws));
+    FS_TRY(run_linear(h, h->proj_dec, tokens, B * N, ws.emb, nullptr, 0, s));
+    FS_TRY(launch_dec_assemble(ws.emb, h->cls_emb, ws.X, B, N, K, D, s));
+    for (const VitBlock& blk : h->dec_blocks) FS_TRY(run_block(h, blk, ws, B, T, s));
+    FS_TRY(run_norm(h, h->dec_norm, ws.X, ws.Xn, B * T, T, 0, s));
+    FS_TRY(run_linear(h, h->proj_patch, ws.Xn, B * T, ws.A, nullptr, 0, s));     // all rows; only the patch rows are read
+    FS_TRY(run_linear(h, h->proj_classes, ws.Xn, B * T, ws.QKV, nullptr, 0, s)); // all rows; only the class rows are read
+    FS_TRY(prof_begin(h, "mask_head", "mask_head", 2.0 * B * N * (double)K * D, 4.0 * B * N * (double)D, s));
+    FS_TRY(launch_mask_head(ws.A, ws.QKV, h->mask_norm.g, h->mask_norm.b, out_nchw, B, N, K, D, s));
+    return prof_end(h, s);
+}
+
+}  // namespace fs

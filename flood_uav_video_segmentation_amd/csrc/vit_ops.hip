@@ -1,0 +1,339 @@
+// Segmenter (ViT encoder + mask-transformer decoder) kernels that are not plain nn.Linear:
+// patchify, token assembly, LayerNorm, fp32-MFMA attention, mask head.
+// Reference arithmetic: segm/model/vit.py:17-137, blocks.py:39-95, decoder.py:80-102, utils.py:65-76.
+#include "kernels.h"
+
+namespace fs {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ------------------------------------------------------------------ patchify (zero padded right/bottom)
+__global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int H, int W,
+                                                       int P, int gh, int gw) {
+    const int Kc = 3 * P * P;
+    const int64_t total = (int64_t)B * gh * gw * Kc;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int col = (int)(i % Kc);
+        const int64_t row = i / Kc;
+        const int px = col % P, py = (col / P) % P, c = col / (P * P);
+        const int gx = (int)(row % gw), gy = (int)((row / gw) % gh), b = (int)(row / ((int64_t)gw * gh));
+        const int y = gy * P + py, x = gx * P + px;
+        out[i] = (y < H && x < W) ? in[((size_t)(b * 3 + c) * H + y) * W + x] : 0.f;
+    }
+}
+
+int launch_patchify(const float* in, float* out, int B, int H, int W, int P, int gh, int gw, hipStream_t s) {
+    const int64_t total = (int64_t)B * gh * gw * 3 * P * P;
+    hipLaunchKernelGGL(patchify_kernel, dim3((unsigned)std::min<int64_t>(cdiv64(total, 256), 16384)), dim3(256), 0, s, in, out, B, H, W,
+                       P, gh, gw);
+    FS_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------ token assembly
+__global__ __launch_bounds__(256) void vit_assemble_kernel(const float* __restrict__ emb, const float* __restrict__ cls,
+                                                           const float* __restrict__ pos, float* __restrict__ X, int B, int N, int D4) {
+    const int64_t total = (int64_t)B * (N + 1) * D4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int d4 = (int)(i % D4);
+        const int t = (int)((i / D4) % (N + 1));
+        const int b = (int)(i / ((int64_t)D4 * (N + 1)));
+        const f32x4 pe = reinterpret_cast<const f32x4*>(pos)[(size_t)t * D4 + d4];
+        const f32x4 v = t == 0 ? reinterpret_cast<const f32x4*>(cls)[d4]
+                               : reinterpret_cast<const f32x4*>(emb)[((size_t)b * N + t - 1) * D4 + d4];
+        reinterpret_cast<f32x4*>(X)[i] = v + pe;
+    }
+}
+
+int launch_vit_assemble(const float* emb, const float* cls, const float* pos, float* X, int B, int N, int D, hipStream_t s) {
+    FS_REQUIRE(D % 4 == 0, "vit_assemble: D must be a multiple of 4");
+    const int64_t total = (int64_t)B * (N + 1) * (D / 4);
+    hipLaunchKernelGGL(vit_assemble_kernel, dim3((unsigned)std::min<int64_t>(cdiv64(total, 256), 8192)), dim3(256), 0, s, emb, cls, pos,
+                       X, B, N, D / 4);
+    FS_HIP(hipGetLastError());
+    return 0;
+}
+
+__global__ __launch_bounds__(256) void dec_assemble_kernel(const float* __restrict__ Y, const float* __restrict__ cls_emb,
+                                                           float* __restrict__ Z, int B, int N, int K, int D4) {
+    const int64_t total = (int64_t)B * (N + K) * D4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int d4 = (int)(i % D4);
+        const int t = (int)((i / D4) % (N + K));
+        const int b = (int)(i / ((int64_t)D4 * (N + K)));
+        reinterpret_cast<f32x4*>(Z)[i] = t < N ? reinterpret_cast<const f32x4*>(Y)[((size_t)b * N + t) * D4 + d4]
+                                               : reinterpret_cast<const f32x4*>(cls_emb)[(size_t)(t - N) * D4 + d4];
+    }
+}
+
+int launch_dec_assemble(const float* Y, const float* cls_emb, float* Z, int B, int N, int K, int D, hipStream_t s) {
+    FS_REQUIRE(D % 4 == 0, "dec_assemble: D must be a multiple of 4");
+    const int64_t total = (int64_t)B * (N + K) * (D / 4);
+    hipLaunchKernelGGL(dec_assemble_kernel, dim3((unsigned)std::min<int64_t>(cdiv64(total, 256), 8192)), dim3(256), 0, s, Y, cls_emb, Z,
+                       B, N, K, D / 4);
+    FS_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------ LayerNorm: one wave per row, D <= 1024
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ in, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, float* __restrict__ out, int rows, int D4,
+                                                        int rows_per_batch, int drop_first) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    int orow = row;
+    if (drop_first) {
+        const int b = row / rows_per_batch, t = row - b * rows_per_batch;
+        if (t == 0) return;  // wave-uniform
+        orow = b * (rows_per_batch - 1) + t - 1;
+    }
+    const f32x4* x = reinterpret_cast<const f32x4*>(in) + (size_t)row * D4;
+    f32x4 v[4];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = lane + 64 * i;
+        v[i] = c < D4 ? x[c] : f32x4{0.f, 0.f, 0.f, 0.f};
+        sum += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
+    const float mean = sum / (float)(D4 * 4);
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (lane + 64 * i < D4) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float d = v[i][e] - mean;
+                sq += d * d;
+            }
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) sq += __shfl_xor(sq, off, 64);
+    const float rstd = 1.f / sqrtf(sq / (float)(D4 * 4) + 1e-5f);
+    f32x4* y = reinterpret_cast<f32x4*>(out) + (size_t)orow * D4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = lane + 64 * i;
+        if (c < D4) {
+            const f32x4 g = reinterpret_cast<const f32x4*>(gamma)[c], bt = reinterpret_cast<const f32x4*>(beta)[c];
+            f32x4 r;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) r[e] = (v[i][e] - mean) * rstd * g[e] + bt[e];
+            y[c] = r;
+        }
+    }
+}
+
+int launch_layernorm(const float* in, const float* gamma, const float* beta, float* out, int rows, int D, int rows_per_batch,
+                     int drop_first, hipStream_t s) {
+    FS_REQUIRE(D % 4 == 0 && D <= 1024, "layernorm: D=%d must be a multiple of 4 and <= 1024", D);
+    hipLaunchKernelGGL(layernorm_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, s, in, gamma, beta, out, rows, D / 4, rows_per_batch,
+                       drop_first);
+    FS_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------ attention, fp32 MFMA, head_dim 64
+// Workgroup = 128 queries of one (batch, head); wave w owns queries 32w..32w+31, one per lane (lane&31).
+// Per 32-key block:   S^T = K * Q^T          A = K rows (lane i = key),  B = Q^T (lane j = query)   32 MFMAs
+//                     online softmax          every lane owns ONE query: max/sum are in-register + 1 shuffle
+//                     O^T += V^T * P^T        B operand = the S^T accumulator registers as they stand   32 MFMAs
+// (the 32x32 accumulator has its column on the lane and rows (r&3)+8(r>>2)+4h in registers: fed back as
+//  the B operand, step r consumes key (r&3)+8(r>>2) from lane-half 0 and that key + 4 from lane-half 1,
+//  and the A operand reads V at exactly those two keys.)
+// K tile rows are padded to 68 floats: ds_read_b128 of a 16-lane group then hits 16 distinct 4-bank slots.
+constexpr int ATT_DH = 64;
+constexpr int ATT_KT = 64;   // keys per LDS tile
+constexpr int ATT_LDK = 68;
+
+__global__ __launch_bounds__(256) void attention_f32_kernel(const float* __restrict__ qkv, float* __restrict__ out, int N, int heads,
+                                                            float scale) {
+    __shared__ __attribute__((aligned(16))) float Ks[ATT_KT * ATT_LDK];
+    __shared__ __attribute__((aligned(16))) float Vs[ATT_KT * ATT_DH];
+    const int D = heads * ATT_DH, ld = 3 * D;
+    const int b = blockIdx.z, head = blockIdx.y;
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int l31 = lane & 31, hh = lane >> 5;
+    const int q = blockIdx.x * 128 + wv * 32 + l31;
+    const int qc = min(q, N - 1);
+    const float* base = qkv + (size_t)b * N * ld + head * ATT_DH;
+
+    // this lane's query row, dims 32*hh .. 32*hh+31, pre-scaled (scale is a power of two for dh = 64)
+    float qreg[32];
+    {
+        const f32x4* qp = reinterpret_cast<const f32x4*>(base + (size_t)qc * ld + 32 * hh);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const f32x4 v = qp[u];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) qreg[4 * u + e] = v[e] * scale;
+        }
+    }
+    f32x16 acc_o[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc_o[i][e] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+
+    const int ntiles = (N + ATT_KT - 1) / ATT_KT;
+    for (int kt = 0; kt < ntiles; ++kt) {
+        __syncthreads();
+        // stage 64 keys x 64 dims of K and V (zero rows beyond N)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int idx = t + 256 * j;       // 0..1023
+            const int row = idx >> 4, c4 = idx & 15;
+            const int key = kt * ATT_KT + row;
+            f32x4 kv = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
+            if (key < N) {
+                const float* rp = base + (size_t)key * ld + c4 * 4;
+                kv = *reinterpret_cast<const f32x4*>(rp + D);
+                vv = *reinterpret_cast<const f32x4*>(rp + 2 * D);
+            }
+            *reinterpret_cast<f32x4*>(&Ks[row * ATT_LDK + c4 * 4]) = kv;
+            *reinterpret_cast<f32x4*>(&Vs[row * ATT_DH + c4 * 4]) = vv;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            const int key0 = kt * ATT_KT + kb * 32;
+            if (key0 >= N) break;  // block-uniform
+            f32x16 sT;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) sT[e] = 0.f;
+            const float* krow = &Ks[(kb * 32 + l31) * ATT_LDK + 32 * hh];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const f32x4 kf = *reinterpret_cast<const f32x4*>(krow + 4 * u);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) sT = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[e], qreg[4 * u + e], sT, 0, 0, 0);
+            }
+            // mask keys beyond N, running max over this lane's 16 keys and the other half's 16
+            float mloc = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = key0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                if (key >= N) sT[r] = -INFINITY;
+                mloc = fmaxf(mloc, sT[r]);
+            }
+            mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+            const float m_new = fmaxf(m_run, mloc);           // finite: key0 < N guarantees one valid key
+            const float alpha = expf(m_run - m_new);        // exp(-inf) = 0 on the first block
+            float lsum = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                sT[r] = expf(sT[r] - m_new);
+                lsum += sT[r];
+            }
+            l_run = l_run * alpha + lsum;
+            m_run = m_new;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc_o[i][e] *= alpha;
+            // O^T += V^T P^T
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int krow_r = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                const float v0 = Vs[krow_r * ATT_DH + l31];
+                const float v1 = Vs[krow_r * ATT_DH + 32 + l31];
+                acc_o[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(v0, sT[r], acc_o[0], 0, 0, 0);
+                acc_o[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(v1, sT[r], acc_o[1], 0, 0, 0);
+            }
+        }
+    }
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.f / l_tot;
+    if (q < N) {
+        float* op = out + ((size_t)b * N + q) * D + head * ATT_DH;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc_o[i][4 * g + e] * inv;
+                *reinterpret_cast<f32x4*>(op + i * 32 + 8 * g + 4 * hh) = v;
+            }
+    }
+}
+
+int launch_attention_f32(const float* qkv, float* out, int B, int N, int heads, float scale, hipStream_t s) {
+    FS_REQUIRE(B >= 1 && N >= 1 && heads >= 1, "attention: bad shape");
+    hipLaunchKernelGGL(attention_f32_kernel, dim3(cdiv(N, 128), heads, B), dim3(256), 0, s, qkv, out, N, heads, scale);
+    FS_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------ mask head: one wave per patch token
+__global__ __launch_bounds__(256) void mask_head_kernel(const float* __restrict__ pp, const float* __restrict__ cc,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        float* __restrict__ out, int B, int N, int K, int D4) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);  // b*N + i
+    if (row >= B * N) return;
+    const int b = row / N, i = row - b * N;
+    const int T = N + K;
+    const f32x4* p = reinterpret_cast<const f32x4*>(pp) + ((size_t)b * T + i) * D4;
+    float pn = 0.f;
+    f32x4 pv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int c = lane + 64 * u;
+        pv[u] = c < D4 ? p[c] : f32x4{0.f, 0.f, 0.f, 0.f};
+        pn += pv[u][0] * pv[u][0] + pv[u][1] * pv[u][1] + pv[u][2] * pv[u][2] + pv[u][3] * pv[u][3];
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) pn += __shfl_xor(pn, off, 64);
+    const float pinv = 1.f / sqrtf(pn);
+    float mval = 0.f;   // lane k keeps the mask value of class k (K <= 64)
+    float msum = 0.f;
+    for (int k = 0; k < K; ++k) {
+        const f32x4* c = reinterpret_cast<const f32x4*>(cc) + ((size_t)b * T + N + k) * D4;
+        float dot = 0.f, cn = 0.f;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int ci = lane + 64 * u;
+            if (ci < D4) {
+                const f32x4 cv = c[ci];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    dot += pv[u][e] * cv[e];
+                    cn += cv[e] * cv[e];
+                }
+            }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            dot += __shfl_xor(dot, off, 64);
+            cn += __shfl_xor(cn, off, 64);
+        }
+        const float mk = dot * pinv / sqrtf(cn);
+        if (lane == k) mval = mk;
+        msum += mk;
+    }
+    // LayerNorm over the K class scores (decoder.mask_norm)
+    const float mean = msum / (float)K;
+    float d = lane < K ? mval - mean : 0.f;
+    float var = d * d;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) var += __shfl_xor(var, off, 64);
+    const float rstd = 1.f / sqrtf(var / (float)K + 1e-5f);
+    if (lane < K) out[((size_t)b * K + lane) * N + i] = d * rstd * gamma[lane] + beta[lane];
+}
+
+int launch_mask_head(const float* pp, const float* cc, const float* gamma, const float* beta, float* out, int B, int N, int K,
+                     int D, hipStream_t s) {
+    FS_REQUIRE(D % 4 == 0 && D <= 1024 && K >= 1 && K <= 64, "mask_head: unsupported D=%d / K=%d", D, K);
+    hipLaunchKernelGGL(mask_head_kernel, dim3(cdiv(B * N, 4)), dim3(256), 0, s, pp, cc, gamma, beta, out, B, N, K, D / 4);
+    FS_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace fs

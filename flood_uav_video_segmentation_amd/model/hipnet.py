@@ -13,8 +13,9 @@ from .._lib import check, ptr, stream_ptr
 
 
 class HipNet:
-    def __init__(self, arch, layers, classes):
+    def __init__(self, arch, layers, classes, patch=0, d_model=0, n_layers=0, dec_layers=0, image_size=0):
         self.arch, self.layers, self.classes = arch, int(layers), int(classes)
+        self.vit = (int(patch), int(d_model), int(n_layers), int(dec_layers), int(image_size))
         self._h = None
         self.ready = False
         self._lib = None
@@ -22,7 +23,7 @@ class HipNet:
     # -- lifecycle ---------------------------------------------------------------------------
     def _create(self):
         lib = self._lib = _lib.load()
-        cfg = _lib.FsConfig(self.arch, self.layers, self.classes)
+        cfg = _lib.FsConfig(self.arch, self.layers, self.classes, *self.vit)
         h = ctypes.c_void_p()
         check(lib.fs_create(ctypes.byref(cfg), ctypes.byref(h)))
         self._h = h
@@ -85,7 +86,7 @@ class HipNet:
     def decode(self, f):
         """[B,C,fh,fw] -> [B,K,fh,fw] NCHW logits (model.decoder(f))."""
         self._need_ready()
-        c_expected = 4096 if self.arch == _lib.ARCH_PSPNET else 2048
+        c_expected = {_lib.ARCH_PSPNET: 4096, _lib.ARCH_DEEPLABV3: 2048}.get(self.arch, self.vit[1])
         if f.dim() != 4 or f.shape[1] != c_expected:
             raise RuntimeError(f"floodseg decoder: expected [B,{c_expected},h,w], got {tuple(f.shape)}")
         f = ops.as_nhwc(f)

@@ -1,0 +1,67 @@
+"""VITSegmentModel (Segmenter) on the HIP path -- mirrors the reference's model/vit.py:13-56.
+
+    net = VITSegmentModel(num_classes, image_size)      # ViT-B/32 as the reference hard-codes it
+    net.load_state_dict(ckpt); net(x) -> {"pred": [B,K,H,W]}
+
+forward = segm/model/segmenter.py:32-48: zero-pad to a multiple of the patch size, ViT encoder
+(patch-embed GEMM, pre-LN blocks with fp32-MFMA attention, final LayerNorm), drop the cls token,
+MaskTransformer decoder, bilinear (align_corners=False) to the padded size, crop.
+
+`patch_size`, `d_model`, `n_layers` are parameters here (the reference fixes 32 / 768 / 12, model/vit.py:17-38;
+BASELINE's "ViT-S/16" is patch 16, d_model 384).  `.encoder` / `.decoder` expose the token map as a
+[B,D,gh,gw] feature map so that FlowModel's feature propagation can run on it -- an EXTENSION: the reference
+never wires ViT into the flow path (flow/base.py:94-103), so that combination is parity-unpinned.
+"""
+import torch
+from torch import nn
+
+from .. import _lib, ops
+from .hipnet import HipNet, HipSegNet, HipStage
+
+
+class VITSegmentModel(HipSegNet):
+    ARCH = _lib.ARCH_SEGMENTER
+
+    def __init__(self, num_classes, image_size, dropout=0.1, patch_size=32, d_model=768, n_layers=12, dec_layers=2, *args, **kwargs):
+        nn.Module.__init__(self)
+        self.patch_size = patch_size
+        self.image_size = image_size
+        self.num_classes = num_classes
+        self.dropout = dropout  # identity in eval
+        self.d_model = d_model
+        self._hip_net = HipNet(self.ARCH, 0, num_classes, patch_size, d_model, n_layers, dec_layers, image_size)
+        self.encoder = HipStage(self._encode_map, "encoder")
+        self.decoder = HipStage(self._decode_map, "decoder")
+        self._frame_hw = None
+
+    @staticmethod
+    def canonical_name(key):
+        if key.startswith("model."):
+            key = key[len("model."):]
+        if key.startswith("encoder.head.") or key.startswith("encoder.pre_logits"):
+            return None  # classification head, unused by Segmenter.forward
+        if key.startswith(("encoder.", "decoder.")):
+            return key
+        return None
+
+    # -- FlowModel-facing callables (feature map view of the tokens)
+    def _encode_map(self, x):
+        self._frame_hw = (x.shape[2], x.shape[3])
+        return self._hip_net.encode(x)  # [B, D, gh, gw], stored as [B, gh*gw, D]
+
+    def _decode_map(self, f):
+        masks = self._hip_net.decode(f)  # [B, K, gh, gw]
+        gh, gw = masks.shape[2], masks.shape[3]
+        full = ops.resize_bilinear(masks, (gh * self.patch_size, gw * self.patch_size), align_corners=False)
+        if self._frame_hw is not None:
+            full = full[:, :, : self._frame_hw[0], : self._frame_hw[1]]
+        return full
+
+    def forward(self, x):
+        if self.training:
+            raise NotImplementedError("VITSegmentModel(HIP) is an inference path; call .eval()")
+        h, w = x.shape[2], x.shape[3]
+        masks = self._hip_net.decode(self._hip_net.encode(x))
+        gh, gw = masks.shape[2], masks.shape[3]
+        full = ops.resize_bilinear(masks, (gh * self.patch_size, gw * self.patch_size), align_corners=False)
+        return {"pred": full[:, :, :h, :w]}

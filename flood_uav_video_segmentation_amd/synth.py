@@ -103,6 +103,48 @@ def make_deeplab_state(layers=101, classes=5, seed=0):
     return s
 
 
+def make_vit_state(classes=5, image_size=704, patch=32, d_model=768, n_layers=12, dec_layers=2, seed=0):
+    """State dict of VITSegmentModel's Segmenter (keys encoder.* / decoder.*; segm/model/{vit,decoder}.py).
+    Larger-than-init scales (0.02 trunc-normal in the reference) so that attention is not near-uniform."""
+    rng = _rng(seed + 104729)
+    s = {}
+    f32 = lambda a: torch.from_numpy(np.asarray(a, dtype=np.float32))  # noqa: E731
+    d, g0 = d_model, image_size // patch
+
+    def lin(prefix, out_f, in_f, std):
+        s[prefix + ".weight"] = f32(rng.standard_normal((out_f, in_f)) * std)
+        s[prefix + ".bias"] = f32(rng.standard_normal(out_f) * 0.02)
+
+    def norm(prefix, n):
+        s[prefix + ".weight"] = f32(rng.uniform(0.8, 1.2, n))
+        s[prefix + ".bias"] = f32(rng.standard_normal(n) * 0.05)
+
+    def block(prefix):
+        norm(prefix + "norm1", d)
+        norm(prefix + "norm2", d)
+        lin(prefix + "attn.qkv", 3 * d, d, 2.0 / math.sqrt(d))
+        lin(prefix + "attn.proj", d, d, 0.5 / math.sqrt(d))
+        lin(prefix + "mlp.fc1", 4 * d, d, 1.0 / math.sqrt(d))
+        lin(prefix + "mlp.fc2", d, 4 * d, 0.5 / math.sqrt(4 * d))
+
+    s["encoder.patch_embed.proj.weight"] = f32(rng.standard_normal((d, 3, patch, patch)) / math.sqrt(3 * patch * patch))
+    s["encoder.patch_embed.proj.bias"] = f32(rng.standard_normal(d) * 0.02)
+    s["encoder.cls_token"] = f32(rng.standard_normal((1, 1, d)) * 0.5)
+    s["encoder.pos_embed"] = f32(rng.standard_normal((1, g0 * g0 + 1, d)) * 0.5)
+    for i in range(n_layers):
+        block(f"encoder.blocks.{i}.")
+    norm("encoder.norm", d)
+    for i in range(dec_layers):
+        block(f"decoder.blocks.{i}.")
+    s["decoder.cls_emb"] = f32(rng.standard_normal((1, classes, d)) * 0.5)
+    lin("decoder.proj_dec", d, d, 1.0 / math.sqrt(d))
+    s["decoder.proj_patch"] = f32(rng.standard_normal((d, d)) / math.sqrt(d))
+    s["decoder.proj_classes"] = f32(rng.standard_normal((d, d)) / math.sqrt(d))
+    norm("decoder.decoder_norm", d)
+    norm("decoder.mask_norm", classes)
+    return s
+
+
 def make_clip(frames, size, seed, shift=(2, 1), only=None):
     """[T,3,S,S] float32 normalised frames: a smooth random field translated by `shift` px/frame + noise.
     only: optional list of frame indices to materialise (same values as in the full clip)."""

@@ -36,12 +36,18 @@ extern "C" {
 typedef struct fs_net* fs_handle;
 typedef void* fs_stream;
 
-enum { FS_ARCH_PSPNET = 0, FS_ARCH_DEEPLABV3 = 1 };
+enum { FS_ARCH_PSPNET = 0, FS_ARCH_DEEPLABV3 = 1, FS_ARCH_SEGMENTER = 2 };
 
 typedef struct fs_config {
-    int arch;     /* FS_ARCH_*                                  flow/base.py:94-103            */
-    int layers;   /* 50 | 101 | 152                             model/pspnet.py:45-50          */
-    int classes;  /* K                                          dataset/flow/config.yaml:2     */
+    int arch;        /* FS_ARCH_*                               flow/base.py:94-103            */
+    int layers;      /* ResNet depth 50 | 101 | 152             model/pspnet.py:45-50          */
+    int classes;     /* K                                       dataset/flow/config.yaml:2     */
+    /* FS_ARCH_SEGMENTER only (ignored otherwise)               model/vit.py:13-56             */
+    int patch;       /* patch size P (32 as shipped, 16 for ViT-S/16)                          */
+    int d_model;     /* 768 | 384 ...; head_dim is fixed to 64 => heads = d_model / 64         */
+    int n_layers;    /* encoder blocks (12)                                                    */
+    int dec_layers;  /* mask-transformer blocks (2)                                            */
+    int image_size;  /* construction size: pos_embed holds (image_size/P)^2 + 1 rows           */
 } fs_config;
 
 int fs_version(void);
@@ -61,7 +67,9 @@ int fs_feature_shape(fs_handle h, int H, int W, int* C, int* fh, int* fw);
 /* Bytes of library-owned workspace a forward at this geometry needs (allocated lazily). */
 size_t fs_workspace_bytes(fs_handle h, int B, int H, int W);
 
-/* model.encoder(x):  in NCHW [B,3,H,W]  ->  out NHWC [B,fh,fw,C] (ld = C; a channels_last torch tensor) */
+/* model.encoder(x):  in NCHW [B,3,H,W]  ->  out NHWC [B,fh,fw,C] (ld = C; a channels_last torch tensor)
+ * FS_ARCH_SEGMENTER: out = the ViT tokens after the final LayerNorm, cls token dropped, [B, gh*gw, D]
+ * (segm/model/segmenter.py:37-42); decoder = MaskTransformer -> [B,K,gh,gw] (before the bilinear resize). */
 int fs_encoder_forward(fs_handle h, const float* in_nchw, int B, int H, int W, float* out_nhwc, fs_stream stream);
 /* model.decoder(f):  in NHWC [B,fh,fw,C]  ->  out NCHW [B,K,fh,fw] */
 int fs_decoder_forward(fs_handle h, const float* feat_nhwc, int B, int fh, int fw, float* out_nchw, fs_stream stream);

@@ -173,8 +173,43 @@ def gen_pspnet():
     save("metrics.npz", inter=ai, union=au, target=at)
 
 
+def gen_vit():
+    """VITSegmentModel (ViT-B/32 as model/vit.py hard-codes it).  timm is absent offline; the reference imports
+    three timm symbols that do not take part in the eval forward (DropPath(0) == Identity, trunc_normal_ and
+    _load_weights are initialisers/loaders), so stand-ins for exactly those names are registered first."""
+    import types
+
+    timm = types.ModuleType("timm")
+    timm.models = types.ModuleType("timm.models")
+    timm.models.layers = types.ModuleType("timm.models.layers")
+    timm.models.vision_transformer = types.ModuleType("timm.models.vision_transformer")
+    timm.models.layers.DropPath = lambda p=0.0: nn.Identity()
+    timm.models.layers.trunc_normal_ = nn.init.trunc_normal_
+    timm.models.vision_transformer._load_weights = lambda *a, **k: None
+    for name, mod in (("timm", timm), ("timm.models", timm.models), ("timm.models.layers", timm.models.layers),
+                      ("timm.models.vision_transformer", timm.models.vision_transformer)):
+        sys.modules[name] = mod
+    import model.vit as ref_vit  # reference
+
+    state = synth.make_vit_state(5, 704, seed=0)
+    net = ref_vit.VITSegmentModel(5, 704).eval()
+    res = net.load_state_dict({"model." + k: v for k, v in state.items()}, strict=False)
+    assert not res.unexpected_keys, res.unexpected_keys
+    assert all(k.startswith("model.encoder.head") for k in res.missing_keys), res.missing_keys
+    x704 = synth.make_clip(2, 704, seed=300)
+    x713 = synth.make_clip(1, 713, seed=301)
+    o704 = net(x704)["pred"]
+    o713 = net(x713)["pred"]
+    print("vit 704 hist", np.bincount(o704.max(1)[1].numpy().ravel(), minlength=5), "713 hist",
+          np.bincount(o713.max(1)[1].numpy().ravel(), minlength=5))
+    save("vit_b32.npz", pred704_sub=o704[:, :, ::8, ::8], mask704=o704.max(1)[1].to(torch.uint8)[:, ::2, ::2],
+         pred713_sub=o713[:, :, ::8, ::8], mask713=o713.max(1)[1].to(torch.uint8)[:, ::2, ::2])
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["grid", "ops", "toy", "pspnet"]
+    which = sys.argv[1:] or ["grid", "ops", "toy", "pspnet", "vit"]
+    if "vit" in which:
+        gen_vit()
     if "grid" in which:
         gen_default_grid()
     if "ops" in which:

@@ -145,3 +145,21 @@ def test_intersection_and_union_matches_reference():
     tgt[:40] = 255
     ai, au, at = flow_oracle.intersection_and_union(p["cfg2_mask"][1], tgt, 5, 255)
     assert np.array_equal(ai, z["inter"]) and np.array_equal(au, z["union"]) and np.array_equal(at, z["target"])
+
+
+def test_vit_b32_matches_reference():
+    """Segmenter ViT-B/32 exactly as model/vit.py builds it; 704 (native grid) and 713 (zero padding to 736 +
+    position-embedding resize).  Golden produced by the reference's own segm/model code (timm stand-in for
+    three non-arithmetic symbols, see tests/golden/gen_goldens.py::gen_vit)."""
+    from oracle import vit_oracle
+
+    z = load_golden("vit_b32.npz")
+    s = synth.make_vit_state(5, 704, seed=0)
+    o704 = vit_oracle.forward(synth.make_clip(2, 704, seed=300), s)["pred"]
+    assert o704.shape == (2, 5, 704, 704)
+    assert rel_err(o704[:, :, ::8, ::8], z["pred704_sub"]) < 2e-5
+    assert (o704.max(1)[1].to(torch.uint8)[:, ::2, ::2].numpy() == z["mask704"]).mean() > 0.9999
+    o713 = vit_oracle.forward(synth.make_clip(1, 713, seed=301), s)["pred"]
+    assert o713.shape == (1, 5, 713, 713)
+    assert rel_err(o713[:, :, ::8, ::8], z["pred713_sub"]) < 2e-5
+    assert (o713.max(1)[1].to(torch.uint8)[:, ::2, ::2].numpy() == z["mask713"]).mean() > 0.9999
