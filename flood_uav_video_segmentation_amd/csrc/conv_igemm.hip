@@ -22,7 +22,12 @@ namespace fs {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-template <int BM, int BN>
+// PIPE = 0: one LDS buffer, two barriers per chunk (bring-up structure, kept for A/B).
+// PIPE = 1: two LDS buffers, ONE barrier per chunk, the next chunk is written to the other buffer at the head
+//           of the compute phase, and MFMA fragments are double-buffered in registers so that the LDS read
+//           latency of sub-step s+1 hides under the 16 MFMAs of sub-step s.
+// (Tried and measured null, removed: start-time stagger of co-resident blocks; s_setprio around the MFMAs.)
+template <int BM, int BN, int PIPE>
 __global__ __launch_bounds__(256) void conv_igemm_f32(ConvParams p, int tiles_m, int tiles_n) {
     constexpr int BK = 32;
     constexpr int WM = BM / 2, WN = BN / 2;
@@ -30,7 +35,8 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(ConvParams p, int tiles_m,
     constexpr int RA = BM / 32, RB = BN / 32;  // staged rows per thread
     constexpr int PM = 8;                      // m-tiles per raster panel
 
-    __shared__ __attribute__((aligned(16))) float lds[(BM + BN) * BK];
+    constexpr int STAGE = (BM + BN) * BK;  // floats per LDS stage
+    __shared__ __attribute__((aligned(1024))) float lds[STAGE * (PIPE ? 2 : 1)];
     float* As = lds;
     float* Bs = lds + BM * BK;
 
@@ -107,9 +113,16 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(ConvParams p, int tiles_m,
 #pragma unroll
         for (int j = 0; j < RB; ++j) rb[j] = *reinterpret_cast<const f32x4*>(b_src[j] + (size_t)kc * 32);
         // advance (cc, tap_s, tap_r) to the next chunk
-        if (++cc == cpt) {
-            cc = 0;
-            if (++tap_s == p.KW) { tap_s = 0; ++tap_r; }
+        if (p.korder == 0) {  // k = (r, s, c): channel chunks innermost
+            if (++cc == cpt) {
+                cc = 0;
+                if (++tap_s == p.KW) { tap_s = 0; ++tap_r; }
+            }
+        } else {  // k = (c/32, r, s, c%32): the 9 taps of one 32-channel slab are consecutive -> L2 reuse of the pixel lines
+            if (++tap_s == p.KW) {
+                tap_s = 0;
+                if (++tap_r == p.KH) { tap_r = 0; ++cc; }
+            }
         }
     };
 
@@ -124,41 +137,83 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(ConvParams p, int tiles_m,
     const int sw = (l31 >> 1) & 7;  // read-side swizzle key (row base is a multiple of 32)
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
-    load_chunk(0);
-    for (int kc = 0; kc < nchunks; ++kc) {
-        __syncthreads();  // everyone finished reading the previous chunk
+    auto store_stage = [&](float* a_dst, float* b_dst) {
 #pragma unroll
         for (int j = 0; j < RA; ++j) {
             const int row = r0 + 32 * j;
             const f32x4 v = ((ra_ok >> j) & 1u) ? ra[j] : zero4;
-            *reinterpret_cast<f32x4*>(&As[row * BK + 4 * (sc ^ ((row >> 1) & 7))]) = v;
+            *reinterpret_cast<f32x4*>(&a_dst[row * BK + 4 * (sc ^ ((row >> 1) & 7))]) = v;
         }
 #pragma unroll
         for (int j = 0; j < RB; ++j) {
             const int row = r0 + 32 * j;
             const f32x4 v = ((b_valid >> j) & 1u) ? rb[j] : zero4;
-            *reinterpret_cast<f32x4*>(&Bs[row * BK + 4 * (sc ^ ((row >> 1) & 7))]) = v;
+            *reinterpret_cast<f32x4*>(&b_dst[row * BK + 4 * (sc ^ ((row >> 1) & 7))]) = v;
         }
-        __syncthreads();
-        if (kc + 1 < nchunks) load_chunk(kc + 1);  // in flight under the MFMAs below
-
+    };
+    auto load_frags = [&](const float* a_src, const float* b_src_, int s_, f32x4 (&a)[TM], f32x4 (&b)[TN]) {
+        const int cidx = (2 * s_ + hh) ^ sw;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const int cidx = (2 * s + hh) ^ sw;
-            f32x4 a[TM], b[TN];
+        for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const f32x4*>(&a_src[(wm * WM + i * 32 + l31) * BK + 4 * cidx]);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const f32x4*>(&b_src_[(wn * WN + j * 32 + l31) * BK + 4 * cidx]);
+    };
+    auto mma = [&](const f32x4 (&a)[TM], const f32x4 (&b)[TN]) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
 #pragma unroll
             for (int i = 0; i < TM; ++i)
-                a[i] = *reinterpret_cast<const f32x4*>(&As[(wm * WM + i * 32 + l31) * BK + 4 * cidx]);
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
-                b[j] = *reinterpret_cast<const f32x4*>(&Bs[(wn * WN + j * 32 + l31) * BK + 4 * cidx]);
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
+    };
+
+    if (PIPE == 0) {
+        load_chunk(0);
+        for (int kc = 0; kc < nchunks; ++kc) {
+            __syncthreads();  // everyone finished reading the previous chunk
+            store_stage(As, Bs);
+            __syncthreads();
+            if (kc + 1 < nchunks) load_chunk(kc + 1);  // in flight under the MFMAs below
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
+            for (int s = 0; s < 4; ++s) {
+                f32x4 a[TM], b[TN];
+                load_frags(As, Bs, s, a, b);
+                mma(a, b);
+            }
+        }
+    } else {
+        load_chunk(0);
+        store_stage(As, Bs);
+        if (nchunks > 1) load_chunk(1);
+        __syncthreads();
+        int cur = 0;
+        for (int kc = 0; kc < nchunks; ++kc) {
+            const float* a_cur = As + cur * STAGE;
+            const float* b_cur = Bs + cur * STAGE;
+            f32x4 a0[TM], b0[TN], a1[TM], b1[TN];
+            load_frags(a_cur, b_cur, 0, a0, b0);
+            if (kc + 1 < nchunks) {
+                if (!(p.dbg & 8)) store_stage(As + (cur ^ 1) * STAGE, Bs + (cur ^ 1) * STAGE);  // chunk kc+1 (registers loaded one chunk ago)
+                if (kc + 2 < nchunks && !(p.dbg & 4)) load_chunk(kc + 2);
+            }
+            // sched_barrier(0) pins "reads of sub-step s+1, then the 16 MFMAs of sub-step s": left alone, hipcc
+            // sinks each read group to just before its consumers and the MFMA pipe drains on every sub-step.
+            if (!(p.dbg & 1)) load_frags(a_cur, b_cur, 1, a1, b1); else { for (int i = 0; i < TM; ++i) a1[i] = a0[i]; for (int j = 0; j < TN; ++j) b1[j] = b0[j]; }
+            __builtin_amdgcn_sched_barrier(0);
+            mma(a0, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (!(p.dbg & 1)) load_frags(a_cur, b_cur, 2, a0, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(a1, b1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (!(p.dbg & 1)) load_frags(a_cur, b_cur, 3, a1, b1);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(a0, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(a1, b1);
+            __syncthreads();  // stage cur^1 complete and stage cur no longer read
+            cur ^= 1;
         }
     }
 
@@ -198,6 +253,195 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(ConvParams p, int tiles_m,
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// conv_igemm_dma_f32: same tiling / fragments / epilogue as above, but the tiles go global -> LDS DIRECTLY
+// (global_load_lds_dwordx4: no VGPR staging, no ds_write pass, no vmcnt ladder), two LDS stages, one barrier
+// per 32-deep chunk, fragment reads double-buffered in registers.  One wave-instruction of the DMA writes a
+// lane-linear 1 KiB (8 rows x 128 B), so the XOR swizzle is applied to the per-lane SOURCE address; padding
+// taps / rows beyond M / channels beyond Cout read a zero page (an integer OFFSET select from the operand base:
+// a select between two kernarg pointers makes hipcc load the chosen pointer from memory and wait for it).
+// Elimination runs on the decoder conv (profiles/): VGPR-staged loads cost ~9 %, the ds_write pass ~5 %.
+// ---------------------------------------------------------------------------------------------------------
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void conv_igemm_dma_f32(ConvParams p, int tiles_m, int tiles_n) {
+    constexpr int BK = 32;
+    constexpr int WM = BM / 2, WN = BN / 2;
+    constexpr int TM = WM / 32, TN = WN / 32;
+    constexpr int RA = BM / 32, RB = BN / 32;
+    constexpr int PM = 8;
+    constexpr int STAGE = (BM + BN) * BK;
+    __shared__ __attribute__((aligned(1024))) float lds[2 * STAGE];
+
+    const int nblk = gridDim.x, bid = blockIdx.x;
+    const int q = nblk >> 3, rr = nblk & 7, xcd = bid & 7;
+    const int lid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (bid >> 3);
+    const int panel = lid / (PM * tiles_n);
+    const int within = lid - panel * (PM * tiles_n);
+    const int prow = min(PM, tiles_m - panel * PM);
+    const int m0 = (panel * PM + within % prow) * BM, n0 = (within / prow) * BN;
+
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int wm = wv >> 1, wn = wv & 1, l31 = lane & 31, hh = lane >> 5;
+    const int wv_u = __builtin_amdgcn_readfirstlane(wv);
+    const int M = p.B * p.Ho * p.Wo;
+    const int K = p.KH * p.KW * p.Cin;
+    const int cpt = p.Cin >> 5;
+    const int nchunks = p.KH * p.KW * cpt;
+
+    const int sc = t & 7, r0 = t >> 3;
+    const int swz = sc ^ ((r0 >> 1) & 7);  // logical chunk this lane fetches into LDS slot sc (same key for rows r0+32j)
+    const long long zoff_a = (p.zero - p.in) + sc * 4;
+    const long long zoff_b = (p.zero - p.wgt) + sc * 4;
+    int a_iy0[RA], a_ix0[RA], a_pix[RA];
+#pragma unroll
+    for (int j = 0; j < RA; ++j) {
+        const int m = m0 + r0 + 32 * j;
+        const bool v = m < M;
+        const int mm = v ? m : 0;
+        const int hw = p.Ho * p.Wo;
+        const int b = mm / hw;
+        const int rem = mm - b * hw;
+        const int oy = rem / p.Wo;
+        const int ox = rem - oy * p.Wo;
+        a_iy0[j] = v ? oy * p.stride - p.pad : -(1 << 28);  // rows beyond M never pass the bounds test
+        a_ix0[j] = ox * p.stride - p.pad;
+        a_pix[j] = b * p.H * p.W;
+    }
+    long long b_off[RB];
+#pragma unroll
+    for (int j = 0; j < RB; ++j) {
+        const int n = n0 + r0 + 32 * j;
+        b_off[j] = n < p.Cout ? (long long)n * K + swz * 4 : zoff_b;
+    }
+    const long long b_step = 32;  // floats per chunk along k
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    const int sw = (l31 >> 1) & 7;
+
+    int tap_r = 0, tap_s = 0, cc = 0;  // chunk being fetched
+
+    // One DMA row (A rows first, then B rows): ROW_ in [0, RA+RB).  The address math is interleaved with the MFMAs
+    // of the region it is placed in; the advance of (cc, tap) happens once per chunk in FS_DMA_ADVANCE.
+#define FS_DMA_ROW(STG, ROW_)                                                                                     \
+    if ((ROW_) < RA) {                                                                                            \
+        const int j = (ROW_) < RA ? (ROW_) : 0;                                                                   \
+        const int iy = a_iy0[j] + tap_r * p.dil, ix = a_ix0[j] + tap_s * p.dil;                                   \
+        const bool ok = ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);                          \
+        const long long off = (long long)(a_pix[j] + iy * p.W + ix) * p.ld_in + (cc * 32 + swz * 4);              \
+        const float* src = p.in + (ok ? off : zoff_a);                                                            \
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,                      \
+                                         (__attribute__((address_space(3))) void*)(lds + (STG) * STAGE + (8 * wv_u + 32 * j) * BK), 16, 0, 0); \
+    } else {                                                                                                      \
+        const int j = (ROW_) >= RA ? (ROW_) - RA : 0;                                                             \
+        const float* src = p.wgt + b_off[j];                                                                      \
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,                      \
+                                         (__attribute__((address_space(3))) void*)(lds + (STG) * STAGE + BM * BK + (8 * wv_u + 32 * j) * BK), 16, 0, 0); \
+        b_off[j] += (n0 + r0 + 32 * j < p.Cout) ? b_step : 0;                                                     \
+    }
+#define FS_DMA_ADVANCE()                                                                                          \
+    {                                                                                                             \
+        if (p.korder == 0) {                                                                                      \
+            if (++cc == cpt) { cc = 0; if (++tap_s == p.KW) { tap_s = 0; ++tap_r; } }                             \
+        } else {                                                                                                  \
+            if (++tap_s == p.KW) { tap_s = 0; if (++tap_r == p.KH) { tap_r = 0; ++cc; } }                         \
+        }                                                                                                         \
+    }
+#define FS_DMA_ALL(STG)                                                                                           \
+    _Pragma("unroll") for (int rw = 0; rw < RA + RB; ++rw) { FS_DMA_ROW(STG, rw) }
+
+#define FS_FRAGS(STG, S_, A_, B_)                                                                                 \
+    {                                                                                                             \
+        const float* a_src = lds + (STG) * STAGE;                                                                 \
+        const float* b_src = a_src + BM * BK;                                                                     \
+        const int cidx = (2 * (S_) + hh) ^ sw;                                                                    \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                            \
+            A_[i] = *reinterpret_cast<const f32x4*>(&a_src[(wm * WM + i * 32 + l31) * BK + 4 * cidx]);            \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                            \
+            B_[j] = *reinterpret_cast<const f32x4*>(&b_src[(wn * WN + j * 32 + l31) * BK + 4 * cidx]);            \
+    }
+
+#define FS_MMA(A_, B_)                                                                                            \
+    _Pragma("unroll") for (int e = 0; e < 4; ++e)                                                                 \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                            \
+            _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                        \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(A_[i][e], B_[j][e], acc[i][j], 0, 0, 0);
+
+    FS_DMA_ALL(0)
+    FS_DMA_ADVANCE()
+    __syncthreads();  // s_waitcnt vmcnt(0) + s_barrier: stage 0 has landed for every wave
+    int cur = 0;
+    for (int kc = 0; kc < nchunks; ++kc) {
+        // The whole DMA of chunk kc+1 is issued up front and lands under the 64 MFMAs below.  (Spreading the eight
+        // DMA instructions over the four MFMA groups was measured 5 % SLOWER on the decoder conv: 121.7 vs 128.7.)
+        if (kc + 1 < nchunks) {
+            FS_DMA_ALL(cur ^ 1)
+            FS_DMA_ADVANCE()
+        }
+        f32x4 a0[TM], b0[TN], a1[TM], b1[TN];
+        FS_FRAGS(cur, 0, a0, b0)
+        FS_FRAGS(cur, 1, a1, b1)
+        __builtin_amdgcn_sched_barrier(0);
+        FS_MMA(a0, b0)
+        __builtin_amdgcn_sched_barrier(0);
+        FS_FRAGS(cur, 2, a0, b0)
+        __builtin_amdgcn_sched_barrier(0);
+        FS_MMA(a1, b1)
+        __builtin_amdgcn_sched_barrier(0);
+        FS_FRAGS(cur, 3, a1, b1)
+        __builtin_amdgcn_sched_barrier(0);
+        FS_MMA(a0, b0)
+        __builtin_amdgcn_sched_barrier(0);
+        FS_MMA(a1, b1)
+        __syncthreads();  // own DMA landed (vmcnt(0)), then everyone's; stage `cur` is free for the next DMA
+        cur ^= 1;
+    }
+#undef FS_DMA_ROW
+#undef FS_DMA_ADVANCE
+#undef FS_DMA_ALL
+#undef FS_FRAGS
+#undef FS_MMA
+
+    // ---- epilogue (identical to conv_igemm_f32)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * WN + j * 32 + l31;
+        const bool nok = n < p.Cout;
+        const float sc_n = (nok && p.scale) ? p.scale[n] : 1.f;
+        const float sh_n = (nok && p.shift) ? p.shift[n] : 0.f;
+        const int nc = nok ? n : 0;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int mb = m0 + wm * WM + i * 32 + 4 * hh;
+            float rv[16];
+            if (p.res) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int m = min(mb + (e & 3) + 8 * (e >> 2), M - 1);
+                    rv[e] = p.res[(size_t)m * p.ld_res + nc];
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) rv[e] = 0.f;
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = mb + (e & 3) + 8 * (e >> 2);
+                float v = acc[i][j][e] * sc_n + sh_n + rv[e];
+                if (p.relu == 1) v = fmaxf(v, 0.f);
+                else if (p.relu == 2) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752f));
+                if (nok && m < M) p.out[(size_t)m * p.ld_out + n] = v;
+            }
+        }
+    }
+}
+
 namespace {
 struct TileCfg { int bm, bn; const char* name; };
 const TileCfg kTiles[5] = {{0, 0, "auto"}, {128, 128, "igemm128x128"}, {128, 64, "igemm128x64"},
@@ -222,11 +466,31 @@ int pick_tile(const ConvParams& p) {
 }  // namespace
 
 const char* conv_igemm_tile_name(const ConvParams& p, int tile) {
+    tile &= 0xff;
     if (tile <= 0 || tile > 4) tile = pick_tile(p);
     return kTiles[tile].name;
 }
 
-int launch_conv_igemm(const ConvParams& p, hipStream_t s, int tile) {
+namespace {
+// 256 B of zeros per device: the source of padding / out-of-range lanes of the direct-to-LDS loads
+const float* zero_page() {
+    static const float* pages[64] = {nullptr};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    if (!pages[dev]) {
+        void* z = nullptr;
+        if (hipMalloc(&z, 256) != hipSuccess) return nullptr;
+        if (hipMemset(z, 0, 256) != hipSuccess) return nullptr;
+        pages[dev] = static_cast<const float*>(z);
+    }
+    return pages[dev];
+}
+}  // namespace
+
+int launch_conv_igemm(const ConvParams& p_in, hipStream_t s, int tile) {
+    ConvParams p = p_in;
+    p.zero = zero_page();
+    FS_REQUIRE(p.zero, "conv_igemm: cannot allocate the zero page");
     FS_REQUIRE(p.Cin % 32 == 0, "conv_igemm: Cin=%d must be a multiple of 32", p.Cin);
     FS_REQUIRE(p.ld_in % 4 == 0 && p.ld_in >= p.Cin, "conv_igemm: bad ld_in=%d (Cin=%d)", p.ld_in, p.Cin);
     FS_REQUIRE(p.ld_out >= p.Cout, "conv_igemm: bad ld_out=%d (Cout=%d)", p.ld_out, p.Cout);
@@ -236,17 +500,28 @@ int launch_conv_igemm(const ConvParams& p, hipStream_t s, int tile) {
                "conv_igemm: output geometry %dx%d inconsistent with input %dx%d", p.Ho, p.Wo, p.H, p.W);
     FS_REQUIRE((int64_t)p.B * p.H * p.W * p.ld_in < (int64_t)1 << 31, "conv_igemm: input too large for 32-bit pixel index");
     if (!(p.res == nullptr || p.ld_res >= p.Cout)) return fail("conv_igemm: bad ld_res");
+    const int var = (tile >> 8) & 1 ? 0 : ((tile >> 9) & 1 ? 1 : 2);  // default PIPE 2; tile bit 8 -> PIPE 0, bit 9 -> PIPE 1
+    tile &= 0xff;
     if (tile <= 0 || tile > 4) tile = pick_tile(p);
     const int M = p.B * p.Ho * p.Wo;
     const int bm = kTiles[tile].bm, bn = kTiles[tile].bn;
     const int tm = cdiv(M, bm), tn = cdiv(p.Cout, bn);
     const dim3 grid(tm * tn), block(256);
+    const size_t dyn = (p.dbg & 2) ? 56 * 1024 : 0;  // timing experiment: push occupancy to one block per CU
+#define FS_CONV_LAUNCH(BM_, BN_)                                                                        \
+    if (var == 2)                                                                                       \
+        hipLaunchKernelGGL((conv_igemm_dma_f32<BM_, BN_>), grid, block, dyn, s, p, tm, tn);             \
+    else if (var == 1)                                                                                  \
+        hipLaunchKernelGGL((conv_igemm_f32<BM_, BN_, 1>), grid, block, dyn, s, p, tm, tn);              \
+    else                                                                                                \
+        hipLaunchKernelGGL((conv_igemm_f32<BM_, BN_, 0>), grid, block, dyn, s, p, tm, tn);
     switch (tile) {
-        case 1: hipLaunchKernelGGL((conv_igemm_f32<128, 128>), grid, block, 0, s, p, tm, tn); break;
-        case 2: hipLaunchKernelGGL((conv_igemm_f32<128, 64>), grid, block, 0, s, p, tm, tn); break;
-        case 3: hipLaunchKernelGGL((conv_igemm_f32<64, 64>), grid, block, 0, s, p, tm, tn); break;
-        default: hipLaunchKernelGGL((conv_igemm_f32<64, 128>), grid, block, 0, s, p, tm, tn); break;
+        case 1: FS_CONV_LAUNCH(128, 128) break;
+        case 2: FS_CONV_LAUNCH(128, 64) break;
+        case 3: FS_CONV_LAUNCH(64, 64) break;
+        default: FS_CONV_LAUNCH(64, 128) break;
     }
+#undef FS_CONV_LAUNCH
     FS_HIP(hipGetLastError());
     return 0;
 }

@@ -25,6 +25,9 @@ struct ConvParams {
     int Ho, Wo, Cout;
     int KH, KW, stride, pad, dil;
     int relu;  // epilogue activation: 0 none, 1 ReLU, 2 GELU (erf)
+    int korder;  // weight k order: 0 = (r, s, c) ; 1 = (c/32, r, s, c%32)
+    const float* zero;  // set by the launcher: >= 128 B of zeros (padding source of the direct-to-LDS loads)
+    int dbg;     // timing experiments only (results are wrong when != 0): 1 = no fragment reloads, 2 = one block per CU
 };
 // tile: 0 = heuristic, 1 = 128x128, 2 = 128x64, 3 = 64x64, 4 = 64x128
 int launch_conv_igemm(const ConvParams& p, hipStream_t s, int tile = 0);
@@ -70,6 +73,9 @@ int launch_classifier_nchw(const float* in, int ld_in, const float* wgt /*[K][C]
 // ---------------------------------------------------------------------------------
 int launch_pack_oihw_to_ohwi(const float* w, float* out, int O, int I, int KH, int KW, hipStream_t s);
 int launch_pack_oihw_to_hwio(const float* w, float* out, int O, int I, int KH, int KW, hipStream_t s);
+// [O][I/32][KH][KW][32]: the taps of one 32-channel slab are consecutive along k (ConvParams::korder == 1), so the
+// pixel lines a 3x3 conv re-reads for its 9 taps are touched back to back and hit in L2.
+int launch_pack_oihw_chunk_major(const float* w, float* out, int O, int I, int KH, int KW, hipStream_t s);
 int launch_nchw_to_nhwc(const float* in, float* out, int ld_out, int B, int C, int HW, hipStream_t s);
 int launch_nhwc_to_nchw(const float* in, int ld_in, float* out, int B, int C, int HW, hipStream_t s);
 

@@ -28,6 +28,7 @@ struct ConvBN {
     float* scale = nullptr;
     float* shift = nullptr;
     int Cin = 0, Cout = 0, KH = 1, KW = 1, stride = 1, pad = 0, dil = 1, relu = 0;
+    int korder = 0;  // 1: filters packed chunk-major (3x3 convs)
     int out_size(int in) const { return (in + 2 * pad - dil * (KH - 1) - 1) / stride + 1; }
 };
 

@@ -59,10 +59,14 @@ int make_conv(fs_net* h, ConvBN& c, const std::string& wname, const std::string&
     c.dil = dil;
     c.relu = relu;
     FS_TRY(dev_alloc(h, &c.w, (size_t)w->numel()));
-    if (hwio)
+    if (hwio) {
         FS_TRY(launch_pack_oihw_to_hwio(w->d, c.w, c.Cout, c.Cin, c.KH, c.KW, s));
-    else
+    } else if (c.KH * c.KW > 1 && c.Cin % 32 == 0) {
+        c.korder = 1;
+        FS_TRY(launch_pack_oihw_chunk_major(w->d, c.w, c.Cout, c.Cin, c.KH, c.KW, s));
+    } else {
         FS_TRY(launch_pack_oihw_to_ohwi(w->d, c.w, c.Cout, c.Cin, c.KH, c.KW, s));
+    }
     if (!bn.empty()) {
         const RawTensor *g, *b, *m, *v;
         FS_TRY(fetch(h, bn + ".weight", &g));
@@ -144,6 +148,7 @@ int run_conv(fs_net* h, const ConvBN& c, const float* in, int ld_in, int B, int 
     p.pad = c.pad;
     p.dil = c.dil;
     p.relu = c.relu;
+    p.korder = c.korder;
     const double M = (double)B * p.Ho * p.Wo;
     const double flops = 2.0 * M * c.Cout * c.KH * c.KW * c.Cin;
     const double bytes = 4.0 * ((double)B * H * W * c.Cin + (double)c.Cout * c.KH * c.KW * c.Cin + M * c.Cout * (res ? 2 : 1));

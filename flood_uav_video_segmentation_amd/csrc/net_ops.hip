@@ -312,7 +312,13 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restri
         const int r = (int)((i / KW) % KH);
         const int ci = (int)((i / ((int64_t)KW * KH)) % I);
         const int o = (int)(i / ((int64_t)KW * KH * I));
-        const size_t dst = hwio ? ((size_t)((r * KW + s) * I + ci)) * O + o : ((size_t)((o * KH + r) * KW + s)) * I + ci;
+        size_t dst;
+        if (hwio == 1)
+            dst = ((size_t)((r * KW + s) * I + ci)) * O + o;
+        else if (hwio == 2)  // chunk-major k: [O][I/32][KH][KW][32] (ConvParams::korder == 1)
+            dst = (((size_t)o * (I / 32) + ci / 32) * KH * KW + r * KW + s) * 32 + (ci & 31);
+        else
+            dst = ((size_t)((o * KH + r) * KW + s)) * I + ci;
         out[dst] = w[i];
     }
 }
@@ -321,6 +327,14 @@ int launch_pack_oihw_to_ohwi(const float* w, float* out, int O, int I, int KH, i
     const int64_t total = (int64_t)O * I * KH * KW;
     hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)std::min<int64_t>(cdiv64(total, 256), 65535)), dim3(256), 0, s, w, out,
                        O, I, KH, KW, 0);
+    FS_HIP(hipGetLastError());
+    return 0;
+}
+int launch_pack_oihw_chunk_major(const float* w, float* out, int O, int I, int KH, int KW, hipStream_t s) {
+    FS_REQUIRE(I % 32 == 0, "pack(chunk-major): Cin must be a multiple of 32");
+    const int64_t total = (int64_t)O * I * KH * KW;
+    hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)std::min<int64_t>(cdiv64(total, 256), 65535)), dim3(256), 0, s, w, out,
+                       O, I, KH, KW, 2);
     FS_HIP(hipGetLastError());
     return 0;
 }
