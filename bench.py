@@ -174,7 +174,7 @@ def main():
         all_ms = sum(v["ms"] for v in conv.values())
         all_fl = sum(v["flops"] for v in conv.values())
         result["roofline"] = {
-            "bound": "mfma", "kernel": f"conv_igemm_f32<{dom_name[5:].replace('x', ',')}>", "achieved": round(ach, 2),
+            "bound": "mfma", "kernel": f"conv_igemm_dma_f32<{dom_name[5:].replace('x', ', ')}>", "achieved": round(ach, 2),
             "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
             "avg_launch_ms": round(dom["ms"] / dom["launches"], 5), "launches_per_step": dom["launches"] // prof_steps,
             "gflop_per_launch": round(dom["flops"] / dom["launches"] / 1e9, 3),

@@ -256,15 +256,18 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(ConvParams p, int tiles_m,
 
 // ---------------------------------------------------------------------------------------------------------
 // conv_igemm_dma_f32: same tiling / fragments / epilogue as above, but the tiles go global -> LDS DIRECTLY
-// (global_load_lds_dwordx4: no VGPR staging, no ds_write pass, no vmcnt ladder), two LDS stages, one barrier
-// per 32-deep chunk, fragment reads double-buffered in registers.  One wave-instruction of the DMA writes a
-// lane-linear 1 KiB (8 rows x 128 B), so the XOR swizzle is applied to the per-lane SOURCE address; padding
-// taps / rows beyond M / channels beyond Cout read a zero page (an integer OFFSET select from the operand base:
-// a select between two kernarg pointers makes hipcc load the chosen pointer from memory and wait for it).
+// (buffer_load_dwordx4 ... offen lds: no VGPR staging, no ds_write pass, no vmcnt ladder), two LDS stages, one
+// barrier per 32-deep chunk, fragment reads double-buffered in registers.  One wave-instruction of the DMA writes
+// a lane-linear 1 KiB (8 rows x 128 B), so the XOR swizzle is applied to the per-lane SOURCE offset.
+// Padding is done by the buffer descriptor's RANGE CHECK: an out-of-range lane makes the DMA write zeros into LDS
+// (probed on MI355X, tools/probe_buffer_lds.hip), so a padding tap / a row beyond M / a channel beyond Cout is just
+// the sentinel voffset 0x80000000.  Per chunk the issue is 8 DMAs + ~12 VALU: the per-lane offsets are loop
+// invariants, the chunk position is the scalar soffset, tap validity is one bit of a per-row mask.
 // Elimination runs on the decoder conv (profiles/): VGPR-staged loads cost ~9 %, the ds_write pass ~5 %.
 // ---------------------------------------------------------------------------------------------------------
 template <int BM, int BN>
 __global__ __launch_bounds__(256) void conv_igemm_dma_f32(ConvParams p, int tiles_m, int tiles_n) {
+#if defined(__HIP_DEVICE_COMPILE__)  // the buffer-resource builtins do not exist in the host pass, which only needs the launch stub
     constexpr int BK = 32;
     constexpr int WM = BM / 2, WN = BN / 2;
     constexpr int TM = WM / 32, TN = WN / 32;
@@ -291,9 +294,14 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_f32(ConvParams p, int tile
 
     const int sc = t & 7, r0 = t >> 3;
     const int swz = sc ^ ((r0 >> 1) & 7);  // logical chunk this lane fetches into LDS slot sc (same key for rows r0+32j)
-    const long long zoff_a = (p.zero - p.in) + sc * 4;
-    const long long zoff_b = (p.zero - p.wgt) + sc * 4;
-    int a_iy0[RA], a_ix0[RA], a_pix[RA];
+    constexpr unsigned SENT = 0x80000000u;  // >= num_records of both descriptors (tensors < 2 GiB, checked by the launcher)
+    // A descriptor starts `pad` rows and `pad` pixels BEFORE the tensor so that every tap offset (soffset) is >= 0;
+    // lanes that are valid by the tap mask always land inside the tensor.
+    const long long pad_off = ((long long)p.pad * p.W + p.pad) * p.ld_in;
+    const unsigned a_bytes = (unsigned)(((long long)p.B * p.H * p.W * p.ld_in + pad_off) * 4);
+    const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(p.in - pad_off), 0, a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.wgt, 0, (unsigned)((long long)p.Cout * K * 4), 0x00020000);
+    unsigned a_voff[RA], a_mask[RA];
 #pragma unroll
     for (int j = 0; j < RA; ++j) {
         const int m = m0 + r0 + 32 * j;
@@ -304,17 +312,21 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_f32(ConvParams p, int tile
         const int rem = mm - b * hw;
         const int oy = rem / p.Wo;
         const int ox = rem - oy * p.Wo;
-        a_iy0[j] = v ? oy * p.stride - p.pad : -(1 << 28);  // rows beyond M never pass the bounds test
-        a_ix0[j] = ox * p.stride - p.pad;
-        a_pix[j] = b * p.H * p.W;
+        a_voff[j] = (unsigned)(((b * p.H * p.W + oy * p.stride * p.W + ox * p.stride) * p.ld_in + swz * 4) * 4);
+        unsigned mask = 0;
+        for (int r = 0; r < p.KH; ++r)
+            for (int q2 = 0; q2 < p.KW; ++q2) {
+                const int iy = oy * p.stride - p.pad + r * p.dil, ix = ox * p.stride - p.pad + q2 * p.dil;
+                if (v && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) mask |= 1u << (r * p.KW + q2);
+            }
+        a_mask[j] = mask;
     }
-    long long b_off[RB];
+    unsigned b_voff[RB];
 #pragma unroll
     for (int j = 0; j < RB; ++j) {
         const int n = n0 + r0 + 32 * j;
-        b_off[j] = n < p.Cout ? (long long)n * K + swz * 4 : zoff_b;
+        b_voff[j] = n < p.Cout ? (unsigned)((n * K + swz * 4) * 4) : SENT;
     }
-    const long long b_step = 32;  // floats per chunk along k
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -326,24 +338,19 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_f32(ConvParams p, int tile
     const int sw = (l31 >> 1) & 7;
 
     int tap_r = 0, tap_s = 0, cc = 0;  // chunk being fetched
+    unsigned b_soff = 0;               // its byte offset along k in the packed filters
 
-    // One DMA row (A rows first, then B rows): ROW_ in [0, RA+RB).  The address math is interleaved with the MFMAs
-    // of the region it is placed in; the advance of (cc, tap) happens once per chunk in FS_DMA_ADVANCE.
+    // One DMA row (A rows first, then B rows): ROW_ in [0, RA+RB).
 #define FS_DMA_ROW(STG, ROW_)                                                                                     \
     if ((ROW_) < RA) {                                                                                            \
         const int j = (ROW_) < RA ? (ROW_) : 0;                                                                   \
-        const int iy = a_iy0[j] + tap_r * p.dil, ix = a_ix0[j] + tap_s * p.dil;                                   \
-        const bool ok = ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);                          \
-        const long long off = (long long)(a_pix[j] + iy * p.W + ix) * p.ld_in + (cc * 32 + swz * 4);              \
-        const float* src = p.in + (ok ? off : zoff_a);                                                            \
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,                      \
-                                         (__attribute__((address_space(3))) void*)(lds + (STG) * STAGE + (8 * wv_u + 32 * j) * BK), 16, 0, 0); \
+        const unsigned vo = ((a_mask[j] >> tap_bit) & 1u) ? a_voff[j] : SENT;                                     \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (__attribute__((address_space(3))) void*)(lds + (STG) * STAGE + (8 * wv_u + 32 * j) * BK), \
+                                                 16, vo, a_soff, 0, 0);                                           \
     } else {                                                                                                      \
         const int j = (ROW_) >= RA ? (ROW_) - RA : 0;                                                             \
-        const float* src = p.wgt + b_off[j];                                                                      \
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,                      \
-                                         (__attribute__((address_space(3))) void*)(lds + (STG) * STAGE + BM * BK + (8 * wv_u + 32 * j) * BK), 16, 0, 0); \
-        b_off[j] += (n0 + r0 + 32 * j < p.Cout) ? b_step : 0;                                                     \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(b_rsrc, (__attribute__((address_space(3))) void*)(lds + (STG) * STAGE + BM * BK + (8 * wv_u + 32 * j) * BK), \
+                                                 16, b_voff[j], b_soff, 0, 0);                                    \
     }
 #define FS_DMA_ADVANCE()                                                                                          \
     {                                                                                                             \
@@ -354,7 +361,12 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_f32(ConvParams p, int tile
         }                                                                                                         \
     }
 #define FS_DMA_ALL(STG)                                                                                           \
-    _Pragma("unroll") for (int rw = 0; rw < RA + RB; ++rw) { FS_DMA_ROW(STG, rw) }
+    {                                                                                                             \
+        const int tap_bit = tap_r * p.KW + tap_s;                                                                 \
+        const unsigned a_soff = (unsigned)((((tap_r * p.W + tap_s) * p.dil) * p.ld_in + cc * 32) * 4);            \
+        _Pragma("unroll") for (int rw = 0; rw < RA + RB; ++rw) { FS_DMA_ROW(STG, rw) }                            \
+        b_soff += 128;                                                                                            \
+    }
 
 #define FS_FRAGS(STG, S_, A_, B_)                                                                                 \
     {                                                                                                             \
@@ -440,6 +452,7 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_f32(ConvParams p, int tile
             }
         }
     }
+#endif
 }
 
 namespace {
@@ -471,26 +484,7 @@ const char* conv_igemm_tile_name(const ConvParams& p, int tile) {
     return kTiles[tile].name;
 }
 
-namespace {
-// 256 B of zeros per device: the source of padding / out-of-range lanes of the direct-to-LDS loads
-const float* zero_page() {
-    static const float* pages[64] = {nullptr};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-    if (!pages[dev]) {
-        void* z = nullptr;
-        if (hipMalloc(&z, 256) != hipSuccess) return nullptr;
-        if (hipMemset(z, 0, 256) != hipSuccess) return nullptr;
-        pages[dev] = static_cast<const float*>(z);
-    }
-    return pages[dev];
-}
-}  // namespace
-
-int launch_conv_igemm(const ConvParams& p_in, hipStream_t s, int tile) {
-    ConvParams p = p_in;
-    p.zero = zero_page();
-    FS_REQUIRE(p.zero, "conv_igemm: cannot allocate the zero page");
+int launch_conv_igemm(const ConvParams& p, hipStream_t s, int tile) {
     FS_REQUIRE(p.Cin % 32 == 0, "conv_igemm: Cin=%d must be a multiple of 32", p.Cin);
     FS_REQUIRE(p.ld_in % 4 == 0 && p.ld_in >= p.Cin, "conv_igemm: bad ld_in=%d (Cin=%d)", p.ld_in, p.Cin);
     FS_REQUIRE(p.ld_out >= p.Cout, "conv_igemm: bad ld_out=%d (Cout=%d)", p.ld_out, p.Cout);
@@ -498,7 +492,11 @@ int launch_conv_igemm(const ConvParams& p_in, hipStream_t s, int tile) {
     FS_REQUIRE(p.Ho == (p.H + 2 * p.pad - p.dil * (p.KH - 1) - 1) / p.stride + 1 &&
                p.Wo == (p.W + 2 * p.pad - p.dil * (p.KW - 1) - 1) / p.stride + 1,
                "conv_igemm: output geometry %dx%d inconsistent with input %dx%d", p.Ho, p.Wo, p.H, p.W);
-    FS_REQUIRE((int64_t)p.B * p.H * p.W * p.ld_in < (int64_t)1 << 31, "conv_igemm: input too large for 32-bit pixel index");
+    // the DMA kernel addresses both operands with 32-bit byte offsets and uses 0x80000000 as the out-of-range sentinel
+    FS_REQUIRE(((int64_t)p.B * p.H * p.W * p.ld_in + ((int64_t)p.pad * p.W + p.pad) * p.ld_in) * 4 < (int64_t)1 << 31,
+               "conv_igemm: input tensor must be smaller than 2 GiB");
+    FS_REQUIRE((int64_t)p.Cout * p.KH * p.KW * p.Cin * 4 < (int64_t)1 << 31, "conv_igemm: filter bank must be smaller than 2 GiB");
+    FS_REQUIRE(p.KH * p.KW <= 32, "conv_igemm: at most 32 filter taps");
     if (!(p.res == nullptr || p.ld_res >= p.Cout)) return fail("conv_igemm: bad ld_res");
     const int var = (tile >> 8) & 1 ? 0 : ((tile >> 9) & 1 ? 1 : 2);  // default PIPE 2; tile bit 8 -> PIPE 0, bit 9 -> PIPE 1
     tile &= 0xff;

@@ -26,7 +26,6 @@ struct ConvParams {
     int KH, KW, stride, pad, dil;
     int relu;  // epilogue activation: 0 none, 1 ReLU, 2 GELU (erf)
     int korder;  // weight k order: 0 = (r, s, c) ; 1 = (c/32, r, s, c%32)
-    const float* zero;  // set by the launcher: >= 128 B of zeros (padding source of the direct-to-LDS loads)
     int dbg;     // timing experiments only (results are wrong when != 0): 1 = no fragment reloads, 2 = one block per CU
 };
 // tile: 0 = heuristic, 1 = 128x128, 2 = 128x64, 3 = 64x64, 4 = 64x128
