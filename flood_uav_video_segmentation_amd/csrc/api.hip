@@ -131,7 +131,7 @@ FS_API int fs_conv2d_nhwc(const float* in, int ld_in, const float* wgt_ohwi, con
     p.Wo = (W + 2 * pad - dil * (KW - 1) - 1) / stride + 1;
     if (p.Ho < 1 || p.Wo < 1) return fs::fail("fs_conv2d_nhwc: empty output");
     p.korder = (tile >> 10) & 1;  // bring-up knob: weights packed chunk-major (see kernels.h)
-    p.dbg = (tile >> 11) & 15;     // timing experiments (kernels.h)
+    p.dbg = (tile >> 11) & 31;     // timing experiments (kernels.h)
     return fs::launch_conv_igemm(p, S(stream), tile & 0x3ff);
 }
 FS_API int fs_stem_conv_nchw(const float* in_nchw, const float* wgt_hwio, const float* scale, const float* shift,

@@ -265,13 +265,16 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(ConvParams p, int tiles_m,
 // invariants, the chunk position is the scalar soffset, tap validity is one bit of a per-row mask.
 // Elimination runs on the decoder conv (profiles/): VGPR-staged loads cost ~9 %, the ds_write pass ~5 %.
 // ---------------------------------------------------------------------------------------------------------
-template <int BM, int BN>
-__global__ __launch_bounds__(256) void conv_igemm_dma_f32(ConvParams p, int tiles_m, int tiles_n) {
+// WGM x WGN waves per workgroup (2x2 = 256 threads, two workgroups per CU; 4x2 = 512 threads, one per CU).
+template <int BM, int BN, int WGM = 2, int WGN = 2>
+__global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_dma_f32(ConvParams p, int tiles_m, int tiles_n) {
 #if defined(__HIP_DEVICE_COMPILE__)  // the buffer-resource builtins do not exist in the host pass, which only needs the launch stub
     constexpr int BK = 32;
-    constexpr int WM = BM / 2, WN = BN / 2;
+    constexpr int NT = 64 * WGM * WGN;   // threads
+    constexpr int RSTEP = NT / 8;        // tile rows staged per DMA pass (8 lanes per 128-B row)
+    constexpr int WM = BM / WGM, WN = BN / WGN;
     constexpr int TM = WM / 32, TN = WN / 32;
-    constexpr int RA = BM / 32, RB = BN / 32;
+    constexpr int RA = BM / RSTEP, RB = BN / RSTEP;
     constexpr int PM = 8;
     constexpr int STAGE = (BM + BN) * BK;
     __shared__ __attribute__((aligned(1024))) float lds[2 * STAGE];
@@ -285,7 +288,7 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_f32(ConvParams p, int tile
     const int m0 = (panel * PM + within % prow) * BM, n0 = (within / prow) * BN;
 
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-    const int wm = wv >> 1, wn = wv & 1, l31 = lane & 31, hh = lane >> 5;
+    const int wm = wv / WGN, wn = wv % WGN, l31 = lane & 31, hh = lane >> 5;
     const int wv_u = __builtin_amdgcn_readfirstlane(wv);
     const int M = p.B * p.Ho * p.Wo;
     const int K = p.KH * p.KW * p.Cin;
@@ -304,7 +307,7 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_f32(ConvParams p, int tile
     unsigned a_voff[RA], a_mask[RA];
 #pragma unroll
     for (int j = 0; j < RA; ++j) {
-        const int m = m0 + r0 + 32 * j;
+        const int m = m0 + r0 + RSTEP * j;
         const bool v = m < M;
         const int mm = v ? m : 0;
         const int hw = p.Ho * p.Wo;
@@ -324,7 +327,7 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_f32(ConvParams p, int tile
     unsigned b_voff[RB];
 #pragma unroll
     for (int j = 0; j < RB; ++j) {
-        const int n = n0 + r0 + 32 * j;
+        const int n = n0 + r0 + RSTEP * j;
         b_voff[j] = n < p.Cout ? (unsigned)((n * K + swz * 4) * 4) : SENT;
     }
 
@@ -345,11 +348,11 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_f32(ConvParams p, int tile
     if ((ROW_) < RA) {                                                                                            \
         const int j = (ROW_) < RA ? (ROW_) : 0;                                                                   \
         const unsigned vo = ((a_mask[j] >> tap_bit) & 1u) ? a_voff[j] : SENT;                                     \
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (__attribute__((address_space(3))) void*)(lds + (STG) * STAGE + (8 * wv_u + 32 * j) * BK), \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (__attribute__((address_space(3))) void*)(lds + (STG) * STAGE + (8 * wv_u + RSTEP * j) * BK), \
                                                  16, vo, a_soff, 0, 0);                                           \
     } else {                                                                                                      \
         const int j = (ROW_) >= RA ? (ROW_) - RA : 0;                                                             \
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(b_rsrc, (__attribute__((address_space(3))) void*)(lds + (STG) * STAGE + BM * BK + (8 * wv_u + 32 * j) * BK), \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(b_rsrc, (__attribute__((address_space(3))) void*)(lds + (STG) * STAGE + BM * BK + (8 * wv_u + RSTEP * j) * BK), \
                                                  16, b_voff[j], b_soff, 0, 0);                                    \
     }
 #define FS_DMA_ADVANCE()                                                                                          \
@@ -421,6 +424,7 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_f32(ConvParams p, int tile
 #undef FS_MMA
 
     // ---- epilogue (identical to conv_igemm_f32)
+    if ((p.dbg & 16) && p.ld_out >= 0) return;  // timing experiment: skip the epilogue (the test keeps the main loop alive)
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int n = n0 + wn * WN + j * 32 + l31;
@@ -457,8 +461,8 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_f32(ConvParams p, int tile
 
 namespace {
 struct TileCfg { int bm, bn; const char* name; };
-const TileCfg kTiles[5] = {{0, 0, "auto"}, {128, 128, "igemm128x128"}, {128, 64, "igemm128x64"},
-                           {64, 64, "igemm64x64"}, {64, 128, "igemm64x128"}};
+const TileCfg kTiles[6] = {{0, 0, "auto"}, {128, 128, "igemm128x128"}, {128, 64, "igemm128x64"},
+                           {64, 64, "igemm64x64"}, {64, 128, "igemm64x128"}, {256, 128, "igemm256x128"}};
 
 int pick_tile(const ConvParams& p) {
     const int M = p.B * p.Ho * p.Wo;
@@ -480,7 +484,7 @@ int pick_tile(const ConvParams& p) {
 
 const char* conv_igemm_tile_name(const ConvParams& p, int tile) {
     tile &= 0xff;
-    if (tile <= 0 || tile > 4) tile = pick_tile(p);
+    if (tile <= 0 || tile > 5) tile = pick_tile(p);
     return kTiles[tile].name;
 }
 
@@ -500,11 +504,16 @@ int launch_conv_igemm(const ConvParams& p, hipStream_t s, int tile) {
     if (!(p.res == nullptr || p.ld_res >= p.Cout)) return fail("conv_igemm: bad ld_res");
     const int var = (tile >> 8) & 1 ? 0 : ((tile >> 9) & 1 ? 1 : 2);  // default PIPE 2; tile bit 8 -> PIPE 0, bit 9 -> PIPE 1
     tile &= 0xff;
-    if (tile <= 0 || tile > 4) tile = pick_tile(p);
+    if (tile <= 0 || tile > 5) tile = pick_tile(p);
     const int M = p.B * p.Ho * p.Wo;
     const int bm = kTiles[tile].bm, bn = kTiles[tile].bn;
     const int tm = cdiv(M, bm), tn = cdiv(p.Cout, bn);
     const dim3 grid(tm * tn), block(256);
+    if (tile == 5) {  // 8-wave workgroup, one per CU
+        hipLaunchKernelGGL((conv_igemm_dma_f32<256, 128, 4, 2>), grid, dim3(512), 0, s, p, tm, tn);
+        FS_HIP(hipGetLastError());
+        return 0;
+    }
     const size_t dyn = (p.dbg & 2) ? 56 * 1024 : 0;  // timing experiment: push occupancy to one block per CU
 #define FS_CONV_LAUNCH(BM_, BN_)                                                                        \
     if (var == 2)                                                                                       \

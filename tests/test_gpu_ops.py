@@ -33,7 +33,7 @@ CONV_CASES = [
 ]
 
 
-@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5])
 @pytest.mark.parametrize("case", CONV_CASES)
 def test_conv_igemm(case, tile):
     b, h, w, cin, cout, k, stride, pad, dil, relu, res = case
