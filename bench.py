@@ -171,11 +171,23 @@ def main():
         conv = {k: v for k, v in per.items() if k.startswith("igemm")}
         dom_name, dom = max(conv.items(), key=lambda kv: kv[1]["ms"])
         ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
+        alg_bytes = sum(r[3] for r in rows if r[1] == dom_name) / max(1, dom["launches"])
+        traffic, traffic_note = None, "no PMC summary committed"
+        try:  # HBM bytes per launch from the committed rocprofv3 --pmc passes of this same command (tools/gpu_pmc_bench.sh);
+            # PMC counters cannot be read from inside the process, so this field is filled from profiles/
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+                pmc = json.load(f)
+            key = [k for k in pmc if f"<{dom_name[5:].replace('x', ', ')}," in k][0]
+            traffic = round(pmc[key]["hbm_bytes_per_launch"])
+            traffic_note = "(2*FETCH_SIZE + WRITE_SIZE)*1024 B averaged over the kernel's launches, profiles/r01_pmc_traffic.json"
+        except Exception:  # noqa: BLE001
+            pass
         all_ms = sum(v["ms"] for v in conv.values())
         all_fl = sum(v["flops"] for v in conv.values())
         result["roofline"] = {
             "bound": "mfma", "kernel": f"conv_igemm_dma_f32<{dom_name[5:].replace('x', ', ')}>", "achieved": round(ach, 2),
-            "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+            "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
+            "traffic_unit": "B per launch", "traffic_source": traffic_note, "algorithmic_bytes_per_launch": round(alg_bytes),
             "avg_launch_ms": round(dom["ms"] / dom["launches"], 5), "launches_per_step": dom["launches"] // prof_steps,
             "gflop_per_launch": round(dom["flops"] / dom["launches"] / 1e9, 3),
             "all_conv_kernels": {"achieved": round(all_fl / (all_ms * 1e-3) / 1e12, 2), "ms_per_step": round(all_ms / prof_steps, 4),
