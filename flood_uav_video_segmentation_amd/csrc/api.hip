@@ -97,6 +97,16 @@ FS_API int fs_iou_hist(const uint8_t* pred, const uint8_t* target, int64_t numel
     return fs::launch_iou_hist(pred, target, numel, K, ignore_index, hist3K, S(stream));
 }
 
+FS_API int fs_softmax_accumulate(const float* logits, int n, int K, int h, int w, double* canvas, double* count, int H, int W,
+                                 int y0, int x0, fs_stream stream) {
+    if (!logits || !canvas || !count || n < 1 || K < 1 || h < 1 || w < 1) return fs::fail("fs_softmax_accumulate: bad arguments");
+    return fs::launch_softmax_accumulate(logits, n, K, h, w, canvas, count, H, W, y0, x0, S(stream));
+}
+FS_API int fs_canvas_finish(double* canvas, const double* count, int n, int K, int64_t HW, uint8_t* mask, fs_stream stream) {
+    if (!canvas || !count || n < 1 || K < 1 || HW < 1) return fs::fail("fs_canvas_finish: bad arguments");
+    return fs::launch_canvas_finish(canvas, count, n, K, HW, mask, S(stream));
+}
+
 FS_API int fs_pack_conv_weight(const float* oihw, float* ohwi, int O, int I, int KH, int KW, fs_stream stream) {
     if (!oihw || !ohwi || O < 1 || I < 1 || KH < 1 || KW < 1) return fs::fail("fs_pack_conv_weight: bad arguments");
     return fs::launch_pack_oihw_to_ohwi(oihw, ohwi, O, I, KH, KW, S(stream));

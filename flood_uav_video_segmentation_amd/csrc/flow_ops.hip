@@ -383,6 +383,62 @@ int launch_resize_argmax_u8(const float* in, int B, int K, int Hi, int Wi, uint8
     return 0;
 }
 
+// ------------------------------------------------------------------ sliding-crop accumulation (flow/base.py:182-234)
+// canvas[f][k][y0+y][x0+x] += softmax_k(logits[f][:, y, x]);  count[y0+y][x0+x] += 1   (float64 canvas, :190-191)
+__global__ __launch_bounds__(256) void softmax_accumulate_kernel(const float* __restrict__ logits, int n, int K, int h, int w,
+                                                                 double* __restrict__ canvas, double* __restrict__ count, int H, int W,
+                                                                 int y0, int x0) {
+    const int64_t total = (int64_t)n * h * w;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int x = (int)(i % w), y = (int)((i / w) % h), f = (int)(i / ((int64_t)w * h));
+        const float* p = logits + ((size_t)f * K) * h * w + (size_t)y * w + x;
+        float mx = p[0];
+        for (int k = 1; k < K; ++k) mx = fmaxf(mx, p[(size_t)k * h * w]);
+        float sum = 0.f;
+        for (int k = 0; k < K; ++k) sum += expf(p[(size_t)k * h * w] - mx);
+        const size_t pix = (size_t)(y0 + y) * W + (x0 + x);
+        for (int k = 0; k < K; ++k) canvas[((size_t)f * K + k) * H * W + pix] += (double)(expf(p[(size_t)k * h * w] - mx) / sum);
+        if (f == 0) count[pix] += 1.0;
+    }
+}
+
+int launch_softmax_accumulate(const float* logits, int n, int K, int h, int w, double* canvas, double* count, int H, int W, int y0,
+                              int x0, hipStream_t s) {
+    FS_REQUIRE(y0 >= 0 && x0 >= 0 && y0 + h <= H && x0 + w <= W, "softmax_accumulate: crop outside the canvas");
+    const int64_t total = (int64_t)n * h * w;
+    hipLaunchKernelGGL(softmax_accumulate_kernel, dim3((unsigned)std::min<int64_t>(cdiv64(total, 256), 16384)), dim3(256), 0, s, logits, n,
+                       K, h, w, canvas, count, H, W, y0, x0);
+    FS_HIP(hipGetLastError());
+    return 0;
+}
+
+// canvas /= count (flow/base.py:208), optionally the per-frame argmax of the result
+__global__ __launch_bounds__(256) void canvas_finish_kernel(double* __restrict__ canvas, const double* __restrict__ count, int n, int K,
+                                                            int64_t HW, uint8_t* __restrict__ mask) {
+    const int64_t total = (int64_t)n * HW;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t pix = i % HW, f = i / HW;
+        const double c = count[pix];
+        double best = -1.0;
+        int arg = 0;
+        for (int k = 0; k < K; ++k) {
+            double* q = canvas + ((size_t)f * K + k) * HW + pix;
+            const double v = *q / c;
+            *q = v;
+            if (v > best) { best = v; arg = k; }
+        }
+        if (mask) mask[i] = (uint8_t)arg;
+    }
+}
+
+int launch_canvas_finish(double* canvas, const double* count, int n, int K, int64_t HW, uint8_t* mask, hipStream_t s) {
+    const int64_t total = (int64_t)n * HW;
+    hipLaunchKernelGGL(canvas_finish_kernel, dim3((unsigned)std::min<int64_t>(cdiv64(total, 256), 16384)), dim3(256), 0, s, canvas, count, n,
+                       K, HW, mask);
+    FS_HIP(hipGetLastError());
+    return 0;
+}
+
 // ------------------------------------------------------------------ IoU histograms (util/util.py:52-63)
 // hist[0][k] = |pred==target==k|, hist[1][k] = |pred==k| (after ignore masking), hist[2][k] = |target==k|;
 // union = hist[1] + hist[2] - hist[0] is formed by the caller.

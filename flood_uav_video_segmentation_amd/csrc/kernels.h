@@ -119,6 +119,11 @@ int launch_argmax_u8(const float* in, int B, int K, int64_t HW, uint8_t* out, hi
 // (flow/base.py:275-276: F.interpolate(output,(1072,1920)) then max(1)[1]).
 int launch_resize_argmax_u8(const float* in, int B, int K, int Hi, int Wi, uint8_t* out, int Ho, int Wo,
                             hipStream_t s);
+// Sliding-crop accumulation of compute_output / compute_predict_crop (flow/base.py:182-234): softmax over K of one
+// crop's logits added into a float64 canvas + per-pixel crop count; finish = divide by the count (+ argmax).
+int launch_softmax_accumulate(const float* logits, int n, int K, int h, int w, double* canvas, double* count, int H, int W, int y0,
+                              int x0, hipStream_t s);
+int launch_canvas_finish(double* canvas, const double* count, int n, int K, int64_t HW, uint8_t* mask, hipStream_t s);
 // intersection / union / target histograms (util/util.py:52-63), int64[3][K] accumulated.
 int launch_iou_hist(const uint8_t* pred, const uint8_t* target, int64_t numel, int K, int ignore_index,
                     long long* hist3K, hipStream_t s);

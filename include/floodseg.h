@@ -105,6 +105,13 @@ int fs_resize_argmax_u8(const float* in, int B, int K, int Hi, int Wi, uint8_t* 
 int fs_iou_hist(const uint8_t* pred, const uint8_t* target, int64_t numel, int K, int ignore_index, long long* hist3K,
                 fs_stream stream);
 
+/* Sliding-crop inference (flow/base.py:182-234): canvas[n,K,H,W] (float64, zeroed by the caller) += softmax_K(logits[n,K,h,w])
+ * at (y0, x0); count[H,W] += 1 over the crop.  fs_canvas_finish divides by the count (flow/base.py:208) and, if mask != NULL,
+ * writes the per-frame argmax. */
+int fs_softmax_accumulate(const float* logits, int n, int K, int h, int w, double* canvas, double* count, int H, int W, int y0,
+                          int x0, fs_stream stream);
+int fs_canvas_finish(double* canvas, const double* count, int n, int K, int64_t HW, uint8_t* mask, fs_stream stream);
+
 /* ---- building blocks (exposed for op-level parity tests and for other host code) ---------------- */
 int fs_pack_conv_weight(const float* oihw, float* ohwi, int O, int I, int KH, int KW, fs_stream stream);
 int fs_conv2d_nhwc(const float* in, int ld_in, const float* wgt_ohwi, const float* scale, const float* shift,

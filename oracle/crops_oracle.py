@@ -1,0 +1,61 @@
+"""Oracle for the sliding-crop route: flow/transform.py:215-261 (`crop_motion_vector`) and
+flow/base.py:182-234 (`compute_output` + `compute_predict_crop`).
+
+PARITY UNPINNED for the grid resize: the reference calls cv2.resize(INTER_LINEAR) and cv2 is absent offline
+(flow/transform.py cannot even be imported: cv2, skimage and `collections.Iterable`); the restatement uses
+F.interpolate(bilinear, align_corners=False), the same half-pixel-centre formula cv2 documents for float data.
+Everything else (block rounding with Python's banker's round, renormalisation, float64 accumulation, crop
+order) is restated literally.  TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+
+def crop_motion_vector(mvs_left, mvs_right, height, width, crop_height, crop_width, height_offset, width_offset):
+    mv_h, mv_w = mvs_left[0].shape[-3], mvs_left[0].shape[-2]
+    ppb_h, ppb_w = height / mv_h, width / mv_w
+    final_h, final_w = crop_height // 16, crop_width // 16
+    bho = round(height_offset / ppb_h)
+    bwo = round(width_offset / ppb_w)
+    bh = round((height_offset + crop_height) / ppb_h) - bho
+    bw = round((width_offset + crop_width) / ppb_w) - bwo
+
+    def one(m):
+        m = m.float().numpy()[0].copy()  # copy: the GPU branch of the reference never mutates its input
+        m = m[bho:bho + bh, bwo:bwo + bw]
+        m[:, :, 0] = ((((m[:, :, 0] + 1) / 2) * width - width_offset) / (bw * ppb_w)) * 2 - 1
+        m[:, :, 1] = ((((m[:, :, 1] + 1) / 2) * height - height_offset) / (bh * ppb_h)) * 2 - 1
+        t = torch.from_numpy(np.ascontiguousarray(m)).permute(2, 0, 1)[None]
+        if (bh, bw) != (final_h, final_w):
+            t = F.interpolate(t, size=(final_h, final_w), mode="bilinear", align_corners=False)
+        return t.permute(0, 2, 3, 1).contiguous()
+
+    return [one(m) for m in mvs_left], [one(m) for m in mvs_right]
+
+
+def compute_output(predict, n, frame_prev, frame_next, mvs_left, mvs_right, crop_h, crop_w, classes):
+    """predict(prev_crop, next_crop, mvs_left_crop, mvs_right_crop) -> [n,K,h,w] logits."""
+    stride_rate = 2 / 3
+    _, _, new_h, new_w = frame_prev.shape
+    stride_h = int(np.ceil(crop_h * stride_rate))
+    stride_w = int(np.ceil(crop_w * stride_rate))
+    grid_h = int(np.ceil(float(new_h - crop_h) / stride_h) + 1)
+    grid_w = int(np.ceil(float(new_w - crop_w) / stride_w) + 1)
+    pred = torch.zeros((n, classes, new_h, new_w), dtype=torch.float64)
+    count = torch.zeros((new_h, new_w), dtype=torch.float64)
+    for ih in range(grid_h):
+        for iw in range(grid_w):
+            s_h = ih * stride_h
+            e_h = min(s_h + crop_h, new_h)
+            s_h = e_h - crop_h
+            s_w = iw * stride_w
+            e_w = min(s_w + crop_w, new_w)
+            s_w = e_w - crop_w
+            ml, mr = crop_motion_vector(mvs_left, mvs_right, new_h, new_w, e_h - s_h, e_w - s_w, s_h, s_w)
+            out = predict(frame_prev[:, :, s_h:e_h, s_w:e_w].clone(), frame_next[:, :, s_h:e_h, s_w:e_w].clone(), ml, mr)
+            if out.shape[2:] != (crop_h, crop_w):
+                out = F.interpolate(out, (crop_h, crop_w), mode="bilinear", align_corners=True)
+            count[s_h:e_h, s_w:e_w] += 1
+            pred[:, :, s_h:e_h, s_w:e_w] += F.softmax(out, dim=1)
+    return pred / count[None, None]

@@ -136,3 +136,28 @@ def test_pspnet_feature_based_against_oracle(psp_flow, nw, profiler):
     ref = flow_oracle.predict_feature(enc, dec, clip[0:1], clip[1:2], mvl, mvr, n, nw)["pred"]
     assert out.shape == ref.shape == (3, 5, 129, 129)
     assert rel_err(out.cpu(), ref) < NET_TOL
+
+
+def test_sliding_crop_inference_against_oracle_parity_unpinned():
+    """compute_output + crop_motion_vector on a frame larger than the crop (toy network so the
+    CPU side stays cheap).  cv2 is absent offline -> the grid resize is restated (half-pixel bilinear): unpinned."""
+    from flood_uav_video_segmentation_amd.flow import crops
+    from oracle import crops_oracle
+
+    n, H, W, ch, cw, K = 3, 160, 272, 97, 97, 5
+    clip = synth.make_clip(2, (H, W), seed=41)
+    # full-frame block grids (H/16 x W/16), identity + motion + jitter
+    mvl, mvr = synth.make_grids(n, H // 16, W // 16, seed=42, frame=(H, W), jitter=0.03)
+    toy = toy_model()
+    fm = FlowModel(toy, feature_based=False, no_warp=False).eval()
+    got, mask = crops.compute_output(fm, n, clip[0:1].cuda(), clip[1:2].cuda(), cu(mvl), cu(mvr), ch, cw, K, want_mask=True)
+    w = toy_weights()
+    enc = lambda x: torch.relu(torch.nn.functional.conv2d(x, w["enc_w"], w["enc_b"], 4, 1))  # noqa: E731
+    dec = lambda f: torch.nn.functional.conv2d(f, w["dec_w"], w["dec_b"])  # noqa: E731
+    pred = lambda p, q, ml, mr: flow_oracle.predict_segmentation(enc, dec, p, q, ml, mr, n, False)["pred"]  # noqa: E731
+    ref = crops_oracle.compute_output(pred, n, clip[0:1], clip[1:2], mvl, mvr, ch, cw, K)
+    assert got.dtype == torch.float64 and got.shape == ref.shape == (n, K, H, W)
+    assert (got.cpu() - ref).abs().max().item() < 1e-5  # probabilities in [0,1]
+    assert (mask.cpu() == ref.max(1)[1].to(torch.uint8)).float().mean().item() > 0.999
+    assert crops.crop_windows(1072, 1920, 713, 713) == [(0, 713, 0, 713), (0, 713, 476, 1189), (0, 713, 952, 1665), (0, 713, 1207, 1920),
+                                                         (359, 1072, 0, 713), (359, 1072, 476, 1189), (359, 1072, 952, 1665), (359, 1072, 1207, 1920)]
