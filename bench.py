@@ -95,10 +95,14 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary variants (1072x1920 post-processing, key-frame cache)")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="multi-rank rehearsal on a 1-GPU box: every rank uses cuda:0 and the reduction runs over gloo")
     args = ap.parse_args()
 
-    rank, local_rank, world = shard.init()
+    rank, local_rank, world = shard.init("gloo" if args.rehearse_on_one_gpu else None)
     assert world == args.gpus, f"launched with WORLD_SIZE={world} but --gpus {args.gpus}"
+    if args.rehearse_on_one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     torch.set_grad_enabled(False)
@@ -124,7 +128,8 @@ def main():
         torch.cuda.current_stream().synchronize()  # masks are on the host when the step ends
 
     elapsed = timed(step_native, args.steps, args.warmup)
-    _, frames_total, elapsed_max = shard.reduce_run(torch.zeros(3, CLASSES, dtype=torch.int64), args.steps * N_DELTA, elapsed, dev)
+    rdev = "cpu" if args.rehearse_on_one_gpu else dev
+    _, frames_total, elapsed_max = shard.reduce_run(torch.zeros(3, CLASSES, dtype=torch.int64), args.steps * N_DELTA, elapsed, rdev)
     fps = frames_total / elapsed_max
 
     result = {
@@ -219,8 +224,8 @@ def main():
 
         e_post = timed(step_post, args.steps, 1)
         e_cache = timed(step_cached, args.steps, 1)
-        _, f_post, e_post = shard.reduce_run(torch.zeros(1, dtype=torch.int64), args.steps * N_DELTA, e_post, dev)
-        _, f_cache, e_cache = shard.reduce_run(torch.zeros(1, dtype=torch.int64), args.steps * N_DELTA, e_cache, dev)
+        _, f_post, e_post = shard.reduce_run(torch.zeros(1, dtype=torch.int64), args.steps * N_DELTA, e_post, rdev)
+        _, f_cache, e_cache = shard.reduce_run(torch.zeros(1, dtype=torch.int64), args.steps * N_DELTA, e_cache, rdev)
         result["variants"] = {
             "fps_post1072x1920_reference_exact_timed_region": round(f_post / e_post, 3),
             "fps_keyframe_cache_one_new_keyframe_per_window": round(f_cache / e_cache, 3),
