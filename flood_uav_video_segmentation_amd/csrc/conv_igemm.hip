@@ -282,10 +282,16 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_dma_f32(ConvParams 
     const int nblk = gridDim.x, bid = blockIdx.x;
     const int q = nblk >> 3, rr = nblk & 7, xcd = bid & 7;
     const int lid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (bid >> 3);
-    const int panel = lid / (PM * tiles_n);
-    const int within = lid - panel * (PM * tiles_n);
+    const int per_group = tiles_m * tiles_n;
+    const int grp = lid / per_group;           // grouped GEMM: consecutive logical ids walk one group's tiles
+    const int lig = lid - grp * per_group;
+    const int panel = lig / (PM * tiles_n);
+    const int within = lig - panel * (PM * tiles_n);
     const int prow = min(PM, tiles_m - panel * PM);
     const int m0 = (panel * PM + within % prow) * BM, n0 = (within / prow) * BN;
+    p.in += (long long)grp * p.g_in;
+    p.wgt += (long long)grp * p.g_wgt;
+    p.out += (long long)grp * p.g_out;
 
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     const int wm = wv / WGN, wn = wv % WGN, l31 = lane & 31, hh = lane >> 5;
@@ -473,7 +479,7 @@ int pick_tile(const ConvParams& p) {
     for (int c = 1; c <= 4; ++c) {
         const int bm = kTiles[c].bm, bn = kTiles[c].bn;
         if (p.Cout < bn && bn > 64) continue;
-        const long tiles = (long)cdiv(M, bm) * cdiv(p.Cout, bn);
+        const long tiles = (long)cdiv(M, bm) * cdiv(p.Cout, bn) * (p.groups > 1 ? p.groups : 1);
         const long rounds = (tiles + 255) / 256;
         const double t = (double)rounds * bm * bn / eff[c];
         if (t < best_t) { best_t = t; best = c; }
@@ -508,7 +514,10 @@ int launch_conv_igemm(const ConvParams& p, hipStream_t s, int tile) {
     const int M = p.B * p.Ho * p.Wo;
     const int bm = kTiles[tile].bm, bn = kTiles[tile].bn;
     const int tm = cdiv(M, bm), tn = cdiv(p.Cout, bn);
-    const dim3 grid(tm * tn), block(256);
+    const int groups = p.groups > 1 ? p.groups : 1;
+    FS_REQUIRE(groups == 1 || var == 2, "conv_igemm: grouped GEMM needs the DMA kernel");
+    FS_REQUIRE(groups == 1 || p.res == nullptr, "conv_igemm: grouped GEMM has no residual input");
+    const dim3 grid(tm * tn * groups), block(256);
     if (tile == 5) {  // 8-wave workgroup, one per CU
         hipLaunchKernelGGL((conv_igemm_dma_f32<256, 128, 4, 2>), grid, dim3(512), 0, s, p, tm, tn);
         FS_HIP(hipGetLastError());

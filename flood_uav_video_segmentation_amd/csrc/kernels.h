@@ -26,6 +26,9 @@ struct ConvParams {
     int KH, KW, stride, pad, dil;
     int relu;  // epilogue activation: 0 none, 1 ReLU, 2 GELU (erf)
     int korder;  // weight k order: 0 = (r, s, c) ; 1 = (c/32, r, s, c%32)
+    // grouped GEMM (Winograd: one GEMM per transform position): group g uses in + g*g_in, wgt + g*g_wgt, out + g*g_out
+    int groups;  // 0 or 1 = plain
+    long long g_in, g_wgt, g_out;  // strides in floats
     int dbg;     // timing experiments only (results are wrong when != 0): 1 = no fragment reloads, 2 = one block per CU
 };
 // tile: 0 = heuristic, 1 = 128x128, 2 = 128x64, 3 = 64x64, 4 = 64x128
@@ -149,5 +152,20 @@ int launch_attention_f32(const float* qkv, float* out, int B, int N, int heads, 
 // masks[b][k][i] = LayerNorm_K( <pp[b][i]/|pp|, cc[b][N+k]/|cc|> )  (segm/model/decoder.py:90-100), NCHW out
 int launch_mask_head(const float* pp, const float* cc, const float* gamma, const float* beta, float* out, int B, int N, int K,
                      int D, hipStream_t s);
+
+
+// ---------------------------------------------------------------------------------
+// Winograd F(4x4, 3x3) for stride-1, undilated, pad-1 3x3 convolutions with many input channels (the PSPNet
+// decoder conv 4096 -> 512: 42 % of the network FLOPs).  36 GEMMs [tiles x Cin] x [Cin x Cout] on the fp32 MFMA
+// kernel replace the direct conv: 4x fewer multiplies (2.25x after tile-edge waste), fp32 error ~7e-6 relative.
+//   V[xi][t][c]  = (B^T d B)[xi]      input transform,  xi in 0..35, t = (b, ty, tx) 4x4-output tiles
+//   M[xi][t][o]  = sum_c V[xi][t][c] * U[xi][o][c]      (grouped conv_igemm_dma_f32)
+//   out          = act(scale * (A^T M A) + shift)       output transform
+// ---------------------------------------------------------------------------------
+int launch_winograd_filter(const float* w_oihw, float* U /*[36][O][I]*/, int O, int I, hipStream_t s);
+int launch_winograd_input(const float* in, int ld_in, float* V /*[36][T][C]*/, int B, int H, int W, int C, hipStream_t s);
+int launch_winograd_output(const float* M /*[36][T][N]*/, const float* scale, const float* shift, float* out, int ld_out, int B,
+                           int H, int W, int N, int relu, hipStream_t s);
+static inline int winograd_tiles(int B, int H, int W) { return B * ((H + 3) / 4) * ((W + 3) / 4); }
 
 }  // namespace fs

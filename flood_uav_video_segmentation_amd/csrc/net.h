@@ -29,6 +29,7 @@ struct ConvBN {
     float* shift = nullptr;
     int Cin = 0, Cout = 0, KH = 1, KW = 1, stride = 1, pad = 0, dil = 1, relu = 0;
     int korder = 0;  // 1: filters packed chunk-major (3x3 convs)
+    float* wino_U = nullptr;  // [36][Cout][Cin] Winograd F(4,3) filters (3x3 s1 d1 p1 convs with Cin >= 1024)
     int out_size(int in) const { return (in + 2 * pad - dil * (KH - 1) - 1) / stride + 1; }
 };
 
@@ -98,6 +99,9 @@ struct fs_net {
     float* cls_emb = nullptr;        // [K][D]
     float* vit_ws = nullptr;
     size_t vit_ws_elems = 0;
+    float* wino_ws = nullptr;  // V [36][T][Cin] followed by M [36][T][Cout]
+    size_t wino_ws_elems = 0;
+    bool use_winograd = true;  // FS_NO_WINOGRAD=1 in the environment selects the direct conv everywhere
 
     // workspace
     float* buf[4] = {nullptr, nullptr, nullptr, nullptr};

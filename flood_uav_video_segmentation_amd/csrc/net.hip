@@ -67,6 +67,10 @@ int make_conv(fs_net* h, ConvBN& c, const std::string& wname, const std::string&
     } else {
         FS_TRY(launch_pack_oihw_to_ohwi(w->d, c.w, c.Cout, c.Cin, c.KH, c.KW, s));
     }
+    if (!hwio && c.KH == 3 && c.KW == 3 && stride == 1 && dil == 1 && pad == 1 && c.Cin >= 1024 && c.Cin % 32 == 0 && c.Cout % 4 == 0) {
+        FS_TRY(dev_alloc(h, &c.wino_U, (size_t)36 * c.Cout * c.Cin));
+        FS_TRY(launch_winograd_filter(w->d, c.wino_U, c.Cout, c.Cin, s));
+    }
     if (!bn.empty()) {
         const RawTensor *g, *b, *m, *v;
         FS_TRY(fetch(h, bn + ".weight", &g));
@@ -123,8 +127,55 @@ int prof_end(fs_net* h, hipStream_t s) {
 
 namespace {
 
+// 3x3 s1 p1 conv as Winograd F(4x4,3x3): input transform -> 36 grouped GEMMs -> output transform (+BN, ReLU)
+int run_conv_winograd(fs_net* h, const ConvBN& c, const float* in, int ld_in, int B, int H, int W, float* out, int ld_out,
+                      hipStream_t s) {
+    const int T = winograd_tiles(B, H, W);
+    const size_t v_elems = (size_t)36 * T * c.Cin, m_elems = (size_t)36 * T * c.Cout;
+    if (v_elems + m_elems > h->wino_ws_elems) {
+        FS_HIP(hipDeviceSynchronize());
+        if (h->wino_ws) FS_HIP(hipFree(h->wino_ws));
+        h->wino_ws = nullptr;
+        FS_HIP(hipMalloc(reinterpret_cast<void**>(&h->wino_ws), (v_elems + m_elems) * sizeof(float)));
+        h->wino_ws_elems = v_elems + m_elems;
+    }
+    float* V = h->wino_ws;
+    float* Mb = h->wino_ws + v_elems;
+    FS_TRY(prof_begin(h, c.name + ".wino_in", "winograd_input", 0, 4.0 * ((double)B * H * W * c.Cin + (double)v_elems), s));
+    FS_TRY(launch_winograd_input(in, ld_in, V, B, H, W, c.Cin, s));
+    FS_TRY(prof_end(h, s));
+    ConvParams p{};
+    p.in = V;
+    p.ld_in = c.Cin;
+    p.wgt = c.wino_U;
+    p.out = Mb;
+    p.ld_out = c.Cout;
+    p.B = 1;
+    p.H = T;
+    p.W = 1;
+    p.Cin = c.Cin;
+    p.Ho = T;
+    p.Wo = 1;
+    p.Cout = c.Cout;
+    p.KH = p.KW = 1;
+    p.stride = 1;
+    p.dil = 1;
+    p.groups = 36;
+    p.g_in = (long long)T * c.Cin;
+    p.g_wgt = (long long)c.Cout * c.Cin;
+    p.g_out = (long long)T * c.Cout;
+    const double flops = 2.0 * 36 * (double)T * c.Cin * c.Cout;
+    FS_TRY(prof_begin(h, c.name + ".wino_gemm", conv_igemm_tile_name(p), flops, 4.0 * ((double)v_elems + 36.0 * c.Cout * c.Cin + (double)m_elems), s));
+    FS_TRY(launch_conv_igemm(p, s));
+    FS_TRY(prof_end(h, s));
+    FS_TRY(prof_begin(h, c.name + ".wino_out", "winograd_output", 0, 4.0 * ((double)m_elems + (double)B * H * W * c.Cout), s));
+    FS_TRY(launch_winograd_output(Mb, c.scale, c.shift, out, ld_out, B, H, W, c.Cout, c.relu, s));
+    return prof_end(h, s);
+}
+
 int run_conv(fs_net* h, const ConvBN& c, const float* in, int ld_in, int B, int H, int W, float* out, int ld_out,
              const float* res, int ld_res, hipStream_t s) {
+    if (c.wino_U && h->use_winograd && !res) return run_conv_winograd(h, c, in, ld_in, B, H, W, out, ld_out, s);
     ConvParams p{};
     p.in = in;
     p.ld_in = ld_in;
@@ -214,6 +265,8 @@ int net_create(const fs_config* cfg, fs_handle* out) {
     FS_REQUIRE(cfg->classes >= 1 && cfg->classes <= 255, "fs_create: classes out of range");
     fs_net* h = new fs_net();
     h->cfg = *cfg;
+    const char* nw = getenv("FS_NO_WINOGRAD");
+    h->use_winograd = !(nw && nw[0] == '1');
     h->deep_stem = cfg->arch == FS_ARCH_PSPNET;
     *out = h;
     return 0;
@@ -229,6 +282,7 @@ int net_destroy(fs_handle h) {
         if (h->buf[i]) (void)hipFree(h->buf[i]);
     if (h->small) (void)hipFree(h->small);
     if (h->vit_ws) (void)hipFree(h->vit_ws);
+    if (h->wino_ws) (void)hipFree(h->wino_ws);
     if (h->pos_cur) (void)hipFree(h->pos_cur);
     for (auto& r : h->prof) {
         (void)hipEventDestroy(r.e0);
