@@ -163,9 +163,13 @@ int launch_mask_head(const float* pp, const float* cc, const float* gamma, const
 //   out          = act(scale * (A^T M A) + shift)       output transform
 // ---------------------------------------------------------------------------------
 int launch_winograd_filter(const float* w_oihw, float* U /*[36][O][I]*/, int O, int I, hipStream_t s);
-int launch_winograd_input(const float* in, int ld_in, float* V /*[36][T][C]*/, int B, int H, int W, int C, hipStream_t s);
+// dil > 1 (pad == dil): the conv is d*d independent undilated convs on the pixel lattices (py + d*i, px + d*j);
+// tiles are enumerated (b, py, px, ty, tx).
+int launch_winograd_input(const float* in, int ld_in, float* V /*[36][T][C]*/, int B, int H, int W, int C, int dil, hipStream_t s);
 int launch_winograd_output(const float* M /*[36][T][N]*/, const float* scale, const float* shift, float* out, int ld_out, int B,
-                           int H, int W, int N, int relu, hipStream_t s);
-static inline int winograd_tiles(int B, int H, int W) { return B * ((H + 3) / 4) * ((W + 3) / 4); }
+                           int H, int W, int N, int relu, int dil, hipStream_t s);
+static inline int winograd_tiles(int B, int H, int W, int dil) {
+    return B * dil * dil * ((cdiv(H, dil) + 3) / 4) * ((cdiv(W, dil) + 3) / 4);
+}
 
 }  // namespace fs

@@ -67,7 +67,7 @@ int make_conv(fs_net* h, ConvBN& c, const std::string& wname, const std::string&
     } else {
         FS_TRY(launch_pack_oihw_to_ohwi(w->d, c.w, c.Cout, c.Cin, c.KH, c.KW, s));
     }
-    if (!hwio && c.KH == 3 && c.KW == 3 && stride == 1 && dil == 1 && pad == 1 && c.Cin >= 1024 && c.Cin % 32 == 0 && c.Cout % 4 == 0) {
+    if (!hwio && c.KH == 3 && c.KW == 3 && stride == 1 && pad == dil && dil <= 4 && c.Cin >= 256 && c.Cin % 32 == 0 && c.Cout % 4 == 0) {
         FS_TRY(dev_alloc(h, &c.wino_U, (size_t)36 * c.Cout * c.Cin));
         FS_TRY(launch_winograd_filter(w->d, c.wino_U, c.Cout, c.Cin, s));
     }
@@ -130,7 +130,7 @@ namespace {
 // 3x3 s1 p1 conv as Winograd F(4x4,3x3): input transform -> 36 grouped GEMMs -> output transform (+BN, ReLU)
 int run_conv_winograd(fs_net* h, const ConvBN& c, const float* in, int ld_in, int B, int H, int W, float* out, int ld_out,
                       hipStream_t s) {
-    const int T = winograd_tiles(B, H, W);
+    const int T = winograd_tiles(B, H, W, c.dil);
     const size_t v_elems = (size_t)36 * T * c.Cin, m_elems = (size_t)36 * T * c.Cout;
     if (v_elems + m_elems > h->wino_ws_elems) {
         FS_HIP(hipDeviceSynchronize());
@@ -142,7 +142,7 @@ int run_conv_winograd(fs_net* h, const ConvBN& c, const float* in, int ld_in, in
     float* V = h->wino_ws;
     float* Mb = h->wino_ws + v_elems;
     FS_TRY(prof_begin(h, c.name + ".wino_in", "winograd_input", 0, 4.0 * ((double)B * H * W * c.Cin + (double)v_elems), s));
-    FS_TRY(launch_winograd_input(in, ld_in, V, B, H, W, c.Cin, s));
+    FS_TRY(launch_winograd_input(in, ld_in, V, B, H, W, c.Cin, c.dil, s));
     FS_TRY(prof_end(h, s));
     ConvParams p{};
     p.in = V;
@@ -169,7 +169,7 @@ int run_conv_winograd(fs_net* h, const ConvBN& c, const float* in, int ld_in, in
     FS_TRY(launch_conv_igemm(p, s));
     FS_TRY(prof_end(h, s));
     FS_TRY(prof_begin(h, c.name + ".wino_out", "winograd_output", 0, 4.0 * ((double)m_elems + (double)B * H * W * c.Cout), s));
-    FS_TRY(launch_winograd_output(Mb, c.scale, c.shift, out, ld_out, B, H, W, c.Cout, c.relu, s));
+    FS_TRY(launch_winograd_output(Mb, c.scale, c.shift, out, ld_out, B, H, W, c.Cout, c.relu, c.dil, s));
     return prof_end(h, s);
 }
 

@@ -72,23 +72,27 @@ int launch_winograd_filter(const float* w_oihw, float* U, int O, int I, hipStrea
 
 // ---- input transform: thread per (tile, float2 channel pair); 36 coalesced loads (zero outside the image)
 __global__ __launch_bounds__(256) void winograd_input_kernel(const float* __restrict__ in, int ld_in, float* __restrict__ V, int B, int H,
-                                                             int W, int CV, int th, int tw) {
-    const int64_t T = (int64_t)B * th * tw;
+                                                             int W, int CV, int th, int tw, int dil) {
+    // dilation d: the conv splits into d*d independent undilated convs on the pixel lattices (py + d*i, px + d*j);
+    // tile t = (b, py, px, ty, tx) covers lattice rows 4*ty-1 .. 4*ty+4 of phase (py, px)
+    const int64_t T = (int64_t)B * dil * dil * th * tw;
     const int64_t total = T * CV;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int cv = (int)(i % CV);
         const int64_t t = i / CV;
-        const int tx = (int)(t % tw), ty = (int)((t / tw) % th), b = (int)(t / ((int64_t)tw * th));
-        const int y0 = ty * 4 - 1, x0 = tx * 4 - 1;  // pad 1
+        const int tx = (int)(t % tw), ty = (int)((t / tw) % th);
+        const int ph = (int)((t / ((int64_t)tw * th)) % (dil * dil)), b = (int)(t / ((int64_t)tw * th * dil * dil));
+        const int py = ph / dil, px = ph - py * dil;
+        const int y0 = py + dil * (ty * 4 - 1), x0 = px + dil * (tx * 4 - 1);  // pad = dil <=> lattice pad 1
         const float* base = in + (size_t)b * H * W * ld_in + cv * WV;
         wv_t tmp[6][6];  // rows transformed: tmp[r][x] = (B^T d)[r][x]
 #pragma unroll
         for (int x = 0; x < 6; ++x) {
             wv_t col[6];
-            const int ix = x0 + x;
+            const int ix = x0 + dil * x;
 #pragma unroll
             for (int y = 0; y < 6; ++y) {
-                const int iy = y0 + y;
+                const int iy = y0 + dil * y;
                 const bool ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
                 const size_t off = ok ? ((size_t)iy * W + ix) * ld_in : 0;
                 const wv_t v = *reinterpret_cast<const wv_t*>(base + off);
@@ -110,12 +114,12 @@ __global__ __launch_bounds__(256) void winograd_input_kernel(const float* __rest
     }
 }
 
-int launch_winograd_input(const float* in, int ld_in, float* V, int B, int H, int W, int C, hipStream_t s) {
-    FS_REQUIRE(C % 4 == 0 && ld_in % 4 == 0, "winograd_input: C must be a multiple of 4");
-    const int th = (H + 3) / 4, tw = (W + 3) / 4;
-    const int64_t total = (int64_t)B * th * tw * (C / WV);
+int launch_winograd_input(const float* in, int ld_in, float* V, int B, int H, int W, int C, int dil, hipStream_t s) {
+    FS_REQUIRE(C % 4 == 0 && ld_in % 4 == 0 && dil >= 1, "winograd_input: C must be a multiple of 4");
+    const int th = (cdiv(H, dil) + 3) / 4, tw = (cdiv(W, dil) + 3) / 4;
+    const int64_t total = (int64_t)B * dil * dil * th * tw * (C / WV);
     hipLaunchKernelGGL(winograd_input_kernel, dim3((unsigned)std::min<int64_t>(cdiv64(total, 256), 1 << 20)), dim3(256), 0, s, in, ld_in, V,
-                       B, H, W, C / WV, th, tw);
+                       B, H, W, C / WV, th, tw, dil);
     FS_HIP(hipGetLastError());
     return 0;
 }
@@ -123,13 +127,15 @@ int launch_winograd_input(const float* in, int ld_in, float* V, int B, int H, in
 // ---- output transform + scale/shift + activation: thread per (tile, float2 output-channel pair)
 __global__ __launch_bounds__(256) void winograd_output_kernel(const float* __restrict__ M, const float* __restrict__ scale,
                                                               const float* __restrict__ shift, float* __restrict__ out, int ld_out, int B,
-                                                              int H, int W, int NV, int th, int tw, int relu) {
-    const int64_t T = (int64_t)B * th * tw;
+                                                              int H, int W, int NV, int th, int tw, int relu, int dil) {
+    const int64_t T = (int64_t)B * dil * dil * th * tw;
     const int64_t total = T * NV;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int nv = (int)(i % NV);
         const int64_t t = i / NV;
-        const int tx = (int)(t % tw), ty = (int)((t / tw) % th), b = (int)(t / ((int64_t)tw * th));
+        const int tx = (int)(t % tw), ty = (int)((t / tw) % th);
+        const int ph = (int)((t / ((int64_t)tw * th)) % (dil * dil)), b = (int)(t / ((int64_t)tw * th * dil * dil));
+        const int py = ph / dil, px = ph - py * dil;
         wv_t tmp[4][6];  // tmp[a][q] = (A^T m)[a][q]
 #pragma unroll
         for (int q = 0; q < 6; ++q) {
@@ -147,11 +153,11 @@ __global__ __launch_bounds__(256) void winograd_output_kernel(const float* __res
         for (int a = 0; a < 4; ++a) {
             wv_t y[4];
             wino_at(tmp[a], y);
-            const int oy = ty * 4 + a;
+            const int oy = py + dil * (ty * 4 + a);
             if (oy >= H) continue;
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                const int ox = tx * 4 + c;
+                const int ox = px + dil * (tx * 4 + c);
                 if (ox >= W) continue;
                 wv_t v = y[c] * sc + sh;
                 if (relu) {
@@ -165,12 +171,12 @@ __global__ __launch_bounds__(256) void winograd_output_kernel(const float* __res
 }
 
 int launch_winograd_output(const float* M, const float* scale, const float* shift, float* out, int ld_out, int B, int H, int W, int N,
-                           int relu, hipStream_t s) {
-    FS_REQUIRE(N % 4 == 0 && ld_out % 4 == 0, "winograd_output: N must be a multiple of 4");
-    const int th = (H + 3) / 4, tw = (W + 3) / 4;
-    const int64_t total = (int64_t)B * th * tw * (N / WV);
+                           int relu, int dil, hipStream_t s) {
+    FS_REQUIRE(N % 4 == 0 && ld_out % 4 == 0 && dil >= 1, "winograd_output: N must be a multiple of 4");
+    const int th = (cdiv(H, dil) + 3) / 4, tw = (cdiv(W, dil) + 3) / 4;
+    const int64_t total = (int64_t)B * dil * dil * th * tw * (N / WV);
     hipLaunchKernelGGL(winograd_output_kernel, dim3((unsigned)std::min<int64_t>(cdiv64(total, 256), 1 << 20)), dim3(256), 0, s, M, scale,
-                       shift, out, ld_out, B, H, W, N / WV, th, tw, relu);
+                       shift, out, ld_out, B, H, W, N / WV, th, tw, relu, dil);
     FS_HIP(hipGetLastError());
     return 0;
 }
