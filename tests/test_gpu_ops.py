@@ -176,3 +176,36 @@ def test_argmax_resize_argmax_and_iou_hist():
         assert hist[0, k] == ((pm == k) & (t == k)).sum()
         assert hist[1, k] == (pm == k).sum()
         assert hist[2, k] == (t == k).sum()
+
+
+WINO_TOL = 5e-5  # F(4x4,3x3) in fp32: ~7e-6 relative on unit-scale data; the tolerance leaves room for K = 1024
+
+
+@pytest.mark.parametrize("case", [
+    # b, h, w, cin, cout, dil, relu
+    (1, 16, 16, 256, 64, 1, True),
+    (2, 23, 29, 256, 96, 1, False),     # ragged: not a multiple of the 4x4 output tile
+    (1, 45, 45, 256, 128, 2, True),     # dilation 2 -> 4 lattice phases of 23/22 rows
+    (1, 31, 27, 512, 64, 4, True),      # dilation 4 -> 16 phases, some with a single tile row
+    (1, 9, 9, 1024, 32, 1, False),
+    (1, 3, 5, 256, 32, 4, False),       # image smaller than the dilation lattice step
+])
+def test_winograd_conv3x3(case):
+    lib = _lib.load()
+    b, h, w, cin, cout, dil, relu = case
+    g = torch.Generator().manual_seed(h * 100 + cin + dil)
+    x = torch.randn(b, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (cin * 9)) ** 0.5
+    sc, sh = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.1
+    ref = F.conv2d(x, wt, None, 1, dil, dil) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)
+    if relu:
+        ref = ref.relu()
+    xd = ops.as_nhwc(x.to(DEV))
+    out = torch.full((b, h, w, cout + 32), -7.0, device=DEV)  # written as a channel slice of a wider buffer
+    ws = torch.empty(lib.fs_winograd_workspace_floats(b, h, w, cin, cout, dil), device=DEV)
+    wd, scd, shd = wt.to(DEV), sc.to(DEV), sh.to(DEV)
+    view = out[..., 16:]
+    check(lib.fs_conv3x3_winograd_nhwc(ptr(xd), cin, ptr(wd), ptr(scd), ptr(shd), ptr(view), cout + 32, b, h, w, cin, cout, dil, int(relu),
+                                       ptr(ws), stream_ptr()))
+    assert rel(out[..., 16:16 + cout].permute(0, 3, 1, 2), ref) < WINO_TOL
+    assert (out[..., :16] == -7.0).all() and (out[..., 16 + cout:] == -7.0).all()
