@@ -232,7 +232,9 @@ def main():
         }
 
     if rank == 0:
-        result["tflops_keyframes_end_to_end"] = round(2 * KEYFRAME_GFLOP * 1e-3 * (fps / world) / N_DELTA, 2)
+        # direct-convolution-equivalent rate (727.44 GFLOP per key frame); the 3x3 convs run as Winograd
+        # F(4x4,3x3), which executes ~2x fewer FLOPs, so this "effective" figure may exceed the fp32 MFMA peak
+        result["effective_tflops_direct_conv_equivalent_per_gpu"] = round(2 * KEYFRAME_GFLOP * 1e-3 * (fps / world) / N_DELTA, 2)
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(state, windows_cpu)
         print(json.dumps(result), flush=True)
