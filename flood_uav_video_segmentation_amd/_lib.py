@@ -52,6 +52,8 @@ _SIGNATURES = {
     "fs_argmax_u8": (c_int, [c_void, c_int, c_int, c_i64, c_void, c_void]),
     "fs_resize_argmax_u8": (c_int, [c_void, c_int, c_int, c_int, c_int, c_void, c_int, c_int, c_void]),
     "fs_iou_hist": (c_int, [c_void, c_void, c_i64, c_int, c_int, c_void, c_void]),
+    "fs_colorize": (c_int, [c_void, c_void, c_int, c_void, c_i64, c_void]),
+    "fs_mv_to_grids": (c_int, [c_void, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void, c_void, c_void, c_void]),
     "fs_softmax_accumulate": (c_int, [c_void, c_int, c_int, c_int, c_int, c_void, c_void, c_int, c_int, c_int, c_int, c_void]),
     "fs_canvas_finish": (c_int, [c_void, c_void, c_int, c_int, c_i64, c_void, c_void]),
     "fs_pack_conv_weight": (c_int, [c_void, c_void, c_int, c_int, c_int, c_int, c_void]),

@@ -97,6 +97,16 @@ FS_API int fs_iou_hist(const uint8_t* pred, const uint8_t* target, int64_t numel
     return fs::launch_iou_hist(pred, target, numel, K, ignore_index, hist3K, S(stream));
 }
 
+FS_API int fs_colorize(const uint8_t* mask, const uint8_t* palette, int K, uint8_t* rgb, int64_t numel, fs_stream stream) {
+    if (!mask || !palette || !rgb || K < 1 || numel < 0) return fs::fail("fs_colorize: bad arguments");
+    if (numel == 0) return 0;
+    return fs::launch_colorize(mask, palette, K, rgb, numel, S(stream));
+}
+FS_API int fs_mv_to_grids(const int* mv, int n, int stride, int hb, int wb, int block, int H, int W, int* owners, double* grid,
+                          double* inv_grid, fs_stream stream) {
+    if ((n > 0 && !mv) || !owners || !grid || !inv_grid || n < 0) return fs::fail("fs_mv_to_grids: bad arguments");
+    return fs::launch_mv_to_grids(mv, n, stride, hb, wb, block, H, W, owners, grid, inv_grid, S(stream));
+}
 FS_API int fs_softmax_accumulate(const float* logits, int n, int K, int h, int w, double* canvas, double* count, int H, int W,
                                  int y0, int x0, fs_stream stream) {
     if (!logits || !canvas || !count || n < 1 || K < 1 || h < 1 || w < 1) return fs::fail("fs_softmax_accumulate: bad arguments");

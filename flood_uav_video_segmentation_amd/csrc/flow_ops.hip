@@ -439,6 +439,85 @@ int launch_canvas_finish(double* canvas, const double* count, int n, int K, int6
     return 0;
 }
 
+// ------------------------------------------------------------------ palette colourise (flow/base.py:308-312: colors[output])
+__global__ __launch_bounds__(256) void colorize_kernel(const uint8_t* __restrict__ mask, const uint8_t* __restrict__ palette, int K,
+                                                       uint8_t* __restrict__ rgb, int64_t numel) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < numel; i += (int64_t)gridDim.x * 256) {
+        const int c = mask[i] < K ? mask[i] : 0;
+        rgb[i * 3 + 0] = palette[c * 3 + 0];
+        rgb[i * 3 + 1] = palette[c * 3 + 1];
+        rgb[i * 3 + 2] = palette[c * 3 + 2];
+    }
+}
+
+int launch_colorize(const uint8_t* mask, const uint8_t* palette, int K, uint8_t* rgb, int64_t numel, hipStream_t s) {
+    hipLaunchKernelGGL(colorize_kernel, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>(cdiv64(numel, 256), 16384))), dim3(256), 0, s,
+                       mask, palette, K, rgb, numel);
+    FS_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------ block motion vectors -> sampling grids
+// dataset/flow/extract_motion_vectors.py:21-43.  mv rows: (source, w, h, src_x, src_y, dst_x, dst_y, ...) int32.
+// The reference loops over the vectors in order, so for a block hit twice the LAST vector wins: pass 1 records the
+// highest vector index per cell (atomicMax), pass 2 fills the cells from their owners; cells nobody hits keep the
+// identity grid of flow/model.py:10-21.
+__global__ __launch_bounds__(256) void mv_owner_kernel(const int* __restrict__ mv, int n, int stride, int hb, int wb, int bs,
+                                                       int* __restrict__ own_fwd, int* __restrict__ own_inv) {
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const int* m = mv + (size_t)i * stride;
+        // Python floor division for possibly negative coordinates
+        const int sx = (m[3] >= 0 ? m[3] / bs : -((-m[3] + bs - 1) / bs)), sy = (m[4] >= 0 ? m[4] / bs : -((-m[4] + bs - 1) / bs));
+        const int dx = (m[5] >= 0 ? m[5] / bs : -((-m[5] + bs - 1) / bs)), dy = (m[6] >= 0 ? m[6] / bs : -((-m[6] + bs - 1) / bs));
+        if (dx >= 0 && dx < wb && dy >= 0 && dy < hb) atomicMax(&own_fwd[dy * wb + dx], i);
+        if (sx >= 0 && sx < wb && sy >= 0 && sy < hb) atomicMax(&own_inv[sy * wb + sx], i);
+    }
+}
+
+__global__ __launch_bounds__(256) void mv_fill_kernel(const int* __restrict__ mv, int stride, int hb, int wb, int bs, int H, int W,
+                                                      const int* __restrict__ own_fwd, const int* __restrict__ own_inv,
+                                                      double* __restrict__ grid, double* __restrict__ inv_grid) {
+    const int cells = hb * wb;
+    for (int c = blockIdx.x * 256 + threadIdx.x; c < cells; c += gridDim.x * 256) {
+        const int by = c / wb, bx = c - by * wb;
+        // identity (flow/model.py:19-20 with the grid's own 1920x1072 geometry = wb*bs x hb*bs)
+        double gx = (double)(bx * bs + bs / 2) / (double)(wb * bs) * 2 - 1, gy = (double)(by * bs + bs / 2) / (double)(hb * bs) * 2 - 1;
+        double ix = gx, iy = gy;
+        const int of = own_fwd[c], oi = own_inv[c];
+        if (of >= 0) {
+            const int* m = mv + (size_t)of * stride;
+            const int sx = (m[3] >= 0 ? m[3] / bs : -((-m[3] + bs - 1) / bs)), sy = (m[4] >= 0 ? m[4] / bs : -((-m[4] + bs - 1) / bs));
+            gx = (double)(sx * bs + bs / 2) / (double)W * 2 - 1;
+            gy = (double)(sy * bs + bs / 2) / (double)H * 2 - 1;
+        }
+        if (oi >= 0) {
+            const int* m = mv + (size_t)oi * stride;
+            const int dx = (m[5] >= 0 ? m[5] / bs : -((-m[5] + bs - 1) / bs)), dy = (m[6] >= 0 ? m[6] / bs : -((-m[6] + bs - 1) / bs));
+            ix = (double)(dx * bs + bs / 2) / (double)W * 2 - 1;
+            iy = (double)(dy * bs + bs / 2) / (double)H * 2 - 1;
+        }
+        grid[c * 2 + 0] = gx;
+        grid[c * 2 + 1] = gy;
+        inv_grid[c * 2 + 0] = ix;
+        inv_grid[c * 2 + 1] = iy;
+    }
+}
+
+int launch_mv_to_grids(const int* mv, int n, int stride, int hb, int wb, int bs, int H, int W, int* owners /*2*hb*wb*/, double* grid,
+                       double* inv_grid, hipStream_t s) {
+    FS_REQUIRE(stride >= 7 && hb > 0 && wb > 0 && bs > 0, "mv_to_grids: bad geometry");
+    FS_HIP(hipMemsetAsync(owners, 0xFF, (size_t)2 * hb * wb * sizeof(int), s));  // -1
+    if (n > 0) {
+        hipLaunchKernelGGL(mv_owner_kernel, dim3(std::min(cdiv(n, 256), 1024)), dim3(256), 0, s, mv, n, stride, hb, wb, bs, owners,
+                           owners + hb * wb);
+        FS_HIP(hipGetLastError());
+    }
+    hipLaunchKernelGGL(mv_fill_kernel, dim3(cdiv(hb * wb, 256)), dim3(256), 0, s, mv, stride, hb, wb, bs, H, W, owners, owners + hb * wb,
+                       grid, inv_grid);
+    FS_HIP(hipGetLastError());
+    return 0;
+}
+
 // ------------------------------------------------------------------ IoU histograms (util/util.py:52-63)
 // hist[0][k] = |pred==target==k|, hist[1][k] = |pred==k| (after ignore masking), hist[2][k] = |target==k|;
 // union = hist[1] + hist[2] - hist[0] is formed by the caller.

@@ -127,6 +127,11 @@ int launch_resize_argmax_u8(const float* in, int B, int K, int Hi, int Wi, uint8
 int launch_softmax_accumulate(const float* logits, int n, int K, int h, int w, double* canvas, double* count, int H, int W, int y0,
                               int x0, hipStream_t s);
 int launch_canvas_finish(double* canvas, const double* count, int n, int K, int64_t HW, uint8_t* mask, hipStream_t s);
+// rgb[i] = palette[mask[i]] (flow/base.py:308-312)
+int launch_colorize(const uint8_t* mask, const uint8_t* palette, int K, uint8_t* rgb, int64_t numel, hipStream_t s);
+// H.264 block motion vectors -> forward / inverse sampling grids (dataset/flow/extract_motion_vectors.py:21-43), float64
+int launch_mv_to_grids(const int* mv, int n, int stride, int hb, int wb, int bs, int H, int W, int* owners, double* grid,
+                       double* inv_grid, hipStream_t s);
 // intersection / union / target histograms (util/util.py:52-63), int64[3][K] accumulated.
 int launch_iou_hist(const uint8_t* pred, const uint8_t* target, int64_t numel, int K, int ignore_index,
                     long long* hist3K, hipStream_t s);

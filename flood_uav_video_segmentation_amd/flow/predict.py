@@ -1,0 +1,66 @@
+"""predict_step on the HIP path -- mirrors the timed unit and the post-processing of the reference's
+FlowBaseModel.predict_step / on_predict_end (flow/base.py:236-343) without Lightning:
+
+    p = FlowPredictor(flow_model, classes=5, out_size=(1072, 1920), crop=None)
+    masks = p.predict_window(frame_prev, frame_next, mvs_left, mvs_right)   # uint8 numpy [n, 1072, 1920]
+    p.temporal_consistency()                                               # mIoU / mAcc / accuracy between consecutive frames
+"""
+import numpy as np
+import torch
+
+from .. import _lib, ops
+from .._lib import check, ptr, stream_ptr
+from . import crops
+
+PALETTE = np.array([[0, 0, 0], [30, 95, 170], [65, 117, 5], [212, 98, 1], [255, 244, 116]], dtype=np.uint8)  # dataset/flow/list/colors.txt
+
+
+class FlowPredictor:
+    def __init__(self, flow_model, classes=5, out_size=(1072, 1920), crop=None, compute_metrics=True, ignore_index=255):
+        self.model = flow_model
+        self.classes = classes
+        self.out_size = tuple(out_size)
+        self.crop = crop  # (crop_h, crop_w) -> sliding crops (no_cropping=False); None -> whole frame (no_cropping=True)
+        self.compute_metrics = compute_metrics
+        self.ignore_index = ignore_index
+        self.last_output = None  # flow/base.py:247, :295
+        self.hist = None         # int64[3,K]: intersection, |pred|, |target| accumulated over the run
+
+    def predict_window(self, frame_prev, frame_next, mvs_left, mvs_right, profiler=None, to_host=True):
+        assert frame_prev.shape[0] == 1                      # flow/base.py:263
+        assert len(mvs_left) == len(mvs_right)               # :264
+        n = len(mvs_left) + 1                                # :266 -- the list length encodes n, also for no_warp dummies
+        if self.crop is None:
+            logits = self.model.predict(frame_prev, frame_next, mvs_left, mvs_right, n, profiler)["pred"]
+            masks = ops.resize_argmax_u8(logits, self.out_size)       # :275-276 without the fp32 intermediate
+        else:
+            canvas = crops.compute_output(self.model, n, frame_prev, frame_next, mvs_left, mvs_right, self.crop[0], self.crop[1],
+                                          self.classes, profiler)
+            if tuple(canvas.shape[2:]) != self.out_size:
+                canvas = torch.nn.functional.interpolate(canvas, self.out_size, mode="bilinear", align_corners=True)  # float64: rare path
+            masks = canvas.max(1)[1].to(torch.uint8)
+        if self.compute_metrics:                                      # :280-295 temporal consistency between consecutive frames
+            for p in range(n):
+                prev = masks[p - 1] if p > 0 else self.last_output
+                if prev is not None:
+                    self.hist = ops.iou_hist(masks[p], prev, self.classes, self.ignore_index, self.hist)
+            self.last_output = masks[n - 1].clone()
+        return masks.cpu().numpy() if to_host else masks                # :277
+
+    def temporal_consistency(self):
+        """on_predict_end's summary (flow/base.py:330-343): (mIoU, mAcc, accuracy) with the reference's 1e-10 epsilon."""
+        if self.hist is None:
+            return None
+        h = self.hist.cpu().numpy().astype(np.float64)
+        inter, union, target = h[0], h[1] + h[2] - h[0], h[2]
+        return float(np.mean(inter / (union + 1e-10))), float(np.mean(inter / (target + 1e-10))), float(inter.sum() / (target.sum() + 1e-10))
+
+
+def colorize(masks_u8, palette=PALETTE):
+    """colors[output] (flow/base.py:308-312): uint8 [..., 3] RGB frames for the video writer / PNG dump."""
+    lib = _lib.load()
+    m = masks_u8.contiguous()
+    pal = torch.as_tensor(palette, dtype=torch.uint8, device=m.device).contiguous()
+    out = torch.empty(tuple(m.shape) + (3,), dtype=torch.uint8, device=m.device)
+    check(lib.fs_colorize(ptr(m), ptr(pal), pal.shape[0], ptr(out), m.numel(), stream_ptr()))
+    return out

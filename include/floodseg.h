@@ -105,6 +105,14 @@ int fs_resize_argmax_u8(const float* in, int B, int K, int Hi, int Wi, uint8_t* 
 int fs_iou_hist(const uint8_t* pred, const uint8_t* target, int64_t numel, int K, int ignore_index, long long* hist3K,
                 fs_stream stream);
 
+/* rgb[numel,3] = palette[K,3][mask[numel]]  (flow/base.py:308-312) */
+int fs_colorize(const uint8_t* mask, const uint8_t* palette, int K, uint8_t* rgb, int64_t numel, fs_stream stream);
+/* H.264 block motion vectors -> forward / inverse sampling grids (dataset/flow/extract_motion_vectors.py:21-43).
+ * mv: int32 [n, stride>=7] rows (source, w, h, src_x, src_y, dst_x, dst_y, ...) on the device; grids: float64 [hb, wb, 2];
+ * owners: 2*hb*wb ints of scratch.  A block hit by several vectors takes the LAST one, as the reference's loop does. */
+int fs_mv_to_grids(const int* mv, int n, int stride, int hb, int wb, int block, int H, int W, int* owners, double* grid,
+                   double* inv_grid, fs_stream stream);
+
 /* Sliding-crop inference (flow/base.py:182-234): canvas[n,K,H,W] (float64, zeroed by the caller) += softmax_K(logits[n,K,h,w])
  * at (y0, x0); count[H,W] += 1 over the crop.  fs_canvas_finish divides by the count (flow/base.py:208) and, if mask != NULL,
  * writes the per-frame argmax. */

@@ -59,3 +59,19 @@ def compute_output(predict, n, frame_prev, frame_next, mvs_left, mvs_right, crop
             count[s_h:e_h, s_w:e_w] += 1
             pred[:, :, s_h:e_h, s_w:e_w] += F.softmax(out, dim=1)
     return pred / count[None, None]
+
+
+def motion_vectors_to_grids(motion_vectors, H, W, default_grid):
+    """dataset/flow/extract_motion_vectors.py:21-43, literally (a block hit twice keeps the LAST vector)."""
+    bs, hb, wb = 16, 1072 // 16, 1920 // 16
+    grid, inv_grid = np.copy(default_grid), np.copy(default_grid)
+    for m in motion_vectors:
+        assert m[0] == -1
+        sx, sy, dx, dy = m[3] // bs, m[4] // bs, m[5] // bs, m[6] // bs
+        if 0 <= dx < wb and 0 <= dy < hb:
+            grid[dy][dx][0] = (sx * bs + bs // 2) / W * 2 - 1
+            grid[dy][dx][1] = (sy * bs + bs // 2) / H * 2 - 1
+        if 0 <= sx < wb and 0 <= sy < hb:
+            inv_grid[sy][sx][0] = (dx * bs + bs // 2) / W * 2 - 1
+            inv_grid[sy][sx][1] = (dy * bs + bs // 2) / H * 2 - 1
+    return grid, inv_grid

@@ -161,3 +161,56 @@ def test_sliding_crop_inference_against_oracle_parity_unpinned():
     assert (mask.cpu() == ref.max(1)[1].to(torch.uint8)).float().mean().item() > 0.999
     assert crops.crop_windows(1072, 1920, 713, 713) == [(0, 713, 0, 713), (0, 713, 476, 1189), (0, 713, 952, 1665), (0, 713, 1207, 1920),
                                                          (359, 1072, 0, 713), (359, 1072, 476, 1189), (359, 1072, 952, 1665), (359, 1072, 1207, 1920)]
+
+
+def test_motion_vectors_to_grids_last_writer_wins_and_npy_round_trip(tmp_path):
+    """the grid producer (the reference script needs cv2 + mvextractor at import: restated, unpinned)."""
+    from flood_uav_video_segmentation_amd.flow import grids
+    from oracle import crops_oracle
+
+    rng = np.random.default_rng(7)
+    n = 9000  # more vectors than blocks: many cells are hit several times
+    src = np.stack([rng.integers(-40, 1960, n), rng.integers(-40, 1100, n)], 1)
+    dst = src + rng.integers(-48, 49, (n, 2))
+    mv = np.concatenate([np.full((n, 1), -1), np.full((n, 2), 16), src, dst, np.zeros((n, 3), int)], 1).astype(np.int64)
+    grid, inv = grids.motion_vectors_to_grids(mv, 1080, 1920)
+    rgrid, rinv = crops_oracle.motion_vectors_to_grids(mv, 1080, 1920, get_default_grid())
+    assert grid.dtype == torch.float64 and grid.shape == (67, 120, 2)
+    assert np.array_equal(grid.cpu().numpy(), rgrid) and np.array_equal(inv.cpu().numpy(), rinv)  # float64, bit-exact
+    g0, i0 = grids.motion_vectors_to_grids(np.zeros((0, 10), np.int64), 1072, 1920)
+    assert np.array_equal(g0.cpu().numpy(), get_default_grid()) and np.array_equal(i0.cpu().numpy(), get_default_grid())
+    grids.save_grid(tmp_path / "0.npy", grid)
+    back = grids.load_grid(tmp_path / "0.npy")
+    assert back.dtype == torch.float32 and torch.equal(back, grid.float().cpu())
+    with pytest.raises(AssertionError):
+        bad = mv.copy()
+        bad[3, 0] = 1
+        grids.motion_vectors_to_grids(bad, 1080, 1920)
+
+
+def test_predict_step_mirror_masks_metric_and_palette(psp_flow):
+    """flow/base.py:259-343 on the HIP path: 1072x1920 masks, temporal-consistency mIoU over two windows, palette."""
+    from flood_uav_video_segmentation_amd.flow.predict import PALETTE, FlowPredictor, colorize
+
+    net, _ = psp_flow
+    n = 5
+    keys = synth.make_clip(11, 713, seed=1000, only=[0, 5, 10]).cuda()
+    dl, dr = synth.dummy_grids(n)
+    fm = FlowModel(net, feature_based=False, no_warp=True).eval()
+    p = FlowPredictor(fm, classes=5, out_size=(1072, 1920))
+    m0 = p.predict_window(keys[0:1], keys[1:2], cu(dl), cu(dr))
+    m1 = p.predict_window(keys[1:2], keys[2:3], cu(dl), cu(dr))
+    assert m0.shape == m1.shape == (5, 1072, 1920) and m0.dtype == np.uint8
+    z = load_golden("predict_713.npz")
+    assert (m0[:, ::4, ::4] == z["cfg2_post_mask_sub"]).mean() > 0.999  # the reference's own post-processed masks
+    # temporal consistency against the oracle's metric on the same 10 masks (9 consecutive pairs)
+    allm = np.concatenate([m0, m1])
+    inter = union = target = 0
+    for i in range(1, 10):
+        a, u, t = flow_oracle.intersection_and_union(allm[i], allm[i - 1], 5, 255)
+        inter, union, target = inter + a, union + u, target + t
+    miou, macc, acc = p.temporal_consistency()
+    assert abs(miou - np.mean(inter / (union + 1e-10))) < 1e-12
+    assert abs(macc - np.mean(inter / (target + 1e-10))) < 1e-12 and abs(acc - inter.sum() / (target.sum() + 1e-10)) < 1e-12
+    rgb = colorize(torch.from_numpy(m0[0]).cuda()).cpu().numpy()
+    assert rgb.shape == (1072, 1920, 3) and np.array_equal(rgb, PALETTE[m0[0]])
