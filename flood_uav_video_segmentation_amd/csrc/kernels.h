@@ -56,6 +56,9 @@ int launch_maxpool3x3s2(const float* in, int ld_in, float* out, int ld_out, int 
 int launch_adaptive_avgpool(const float* in, int ld_in, float* out, int B, int H, int W, int C, int bin,
                             hipStream_t s);
 
+// bins 1, 2, 3 from the 6x6 cell means (all windows equal-sized: H, W multiples of 6)
+int launch_ppm_pool_combine(const float* cell_mean, float* out1, float* out2, float* out3, int B, int C, hipStream_t s);
+
 // Small-M 1x1 convolution (+scale/shift+ReLU): out[m][n] = act(scale[n]*dot(in[m], w[n]) + shift[n]).
 // Used for the pooled PPM / ASPP-pooling branches (M = B*bin*bin <= ~100).
 int launch_rowdot_1x1(const float* in, int ld_in, const float* wgt, const float* scale, const float* shift,

@@ -29,7 +29,7 @@ struct ConvBN {
     float* shift = nullptr;
     int Cin = 0, Cout = 0, KH = 1, KW = 1, stride = 1, pad = 0, dil = 1, relu = 0;
     int korder = 0;  // 1: filters packed chunk-major (3x3 convs)
-    float* wino_U = nullptr;  // [36][Cout][Cin] Winograd F(4,3) filters (3x3 stride-1 convs with pad == dil <= 4 and Cin >= 256)
+    float* wino_U = nullptr;  // [36][Cout][Cin] Winograd F(4,3) filters (3x3 stride-1 convs with pad == dil and Cin >= 256)
     int out_size(int in) const { return (in + 2 * pad - dil * (KH - 1) - 1) / stride + 1; }
 };
 

@@ -175,7 +175,13 @@ int run_conv_winograd(fs_net* h, const ConvBN& c, const float* in, int ld_in, in
 
 int run_conv(fs_net* h, const ConvBN& c, const float* in, int ld_in, int B, int H, int W, float* out, int ld_out,
              const float* res, int ld_res, hipStream_t s) {
-    if (c.wino_U && h->use_winograd && !res) return run_conv_winograd(h, c, in, ld_in, B, H, W, out, ld_out, s);
+    // Winograd pays when its 36 GEMM rows per 4x4 tile undercut the 9 taps per pixel of the direct conv even after the
+    // tile-edge / lattice-phase waste (large dilations on a small map leave mostly-empty tiles): 36*T < 0.8 * 9*M
+    // (measured: the ASPP convs with dilation 12/24/36 on a 90x90 map are FASTER direct -- 358 vs 335 FPS for configs[2] --
+    //  so the lattice decomposition is limited to dilation <= 4)
+    if (c.wino_U && h->use_winograd && !res && c.dil <= 4 &&
+        36.0 * winograd_tiles(B, H, W, c.dil) < 0.8 * 9.0 * (double)B * c.out_size(H) * c.out_size(W))
+        return run_conv_winograd(h, c, in, ld_in, B, H, W, out, ld_out, s);
     ConvParams p{};
     p.in = in;
     p.ld_in = ld_in;
@@ -519,22 +525,39 @@ int net_encoder(fs_handle h, const float* in_nchw, int B, int H, int W, float* o
     // ---- pyramid pooling: pooled -> 1x1 conv + BN + ReLU -> bilinear(ac=True) into channels 2048+512*i
     float* pooled = h->small;
     float* reduced = h->small + (size_t)B * 50 * 2048;
-    size_t poff = 0, roff = 0;
+    // pooled layout: bins in order (1, 2, 3, 6): offsets 0, B*1*2048, B*5*2048, B*14*2048
+    size_t pool_off[4], red_off[4];
+    {
+        size_t po = 0, ro = 0;
+        for (int i = 0; i < 4; ++i) {
+            pool_off[i] = po;
+            red_off[i] = ro;
+            po += (size_t)B * h->bins[i] * h->bins[i] * 2048;
+            ro += (size_t)B * h->bins[i] * h->bins[i] * 512;
+        }
+    }
+    const bool even = curH % 6 == 0 && curW % 6 == 0 && h->bins[0] == 1 && h->bins[1] == 2 && h->bins[2] == 3 && h->bins[3] == 6;
+    if (even) {  // one pass over the 2048-channel map instead of four
+        FS_TRY(prof_begin(h, "ppm.pool6+combine", "adaptive_avgpool", 0, 4.0 * B * curH * curW * 2048.0, s));
+        FS_TRY(launch_adaptive_avgpool(out, 4096, pooled + pool_off[3], B, curH, curW, 2048, 6, s));
+        FS_TRY(launch_ppm_pool_combine(pooled + pool_off[3], pooled + pool_off[0], pooled + pool_off[1], pooled + pool_off[2], B, 2048, s));
+        FS_TRY(prof_end(h, s));
+    }
     for (int i = 0; i < 4; ++i) {
         const int bin = h->bins[i];
         const int cells = bin * bin;
-        FS_TRY(prof_begin(h, "ppm.pool" + std::to_string(bin), "adaptive_avgpool", 0, 4.0 * B * curH * curW * 2048.0, s));
-        FS_TRY(launch_adaptive_avgpool(out, 4096, pooled + poff, B, curH, curW, 2048, bin, s));
-        FS_TRY(prof_end(h, s));
+        if (!even) {
+            FS_TRY(prof_begin(h, "ppm.pool" + std::to_string(bin), "adaptive_avgpool", 0, 4.0 * B * curH * curW * 2048.0, s));
+            FS_TRY(launch_adaptive_avgpool(out, 4096, pooled + pool_off[i], B, curH, curW, 2048, bin, s));
+            FS_TRY(prof_end(h, s));
+        }
         const ConvBN& c = h->ppm[i];
         FS_TRY(prof_begin(h, c.name, "rowdot_1x1", 2.0 * B * cells * 2048.0 * 512.0, 4.0 * 2048.0 * 512.0, s));
-        FS_TRY(launch_rowdot_1x1(pooled + poff, 2048, c.w, c.scale, c.shift, reduced + roff, 512, B * cells, 2048, 512, 1, s));
+        FS_TRY(launch_rowdot_1x1(pooled + pool_off[i], 2048, c.w, c.scale, c.shift, reduced + red_off[i], 512, B * cells, 2048, 512, 1, s));
         FS_TRY(prof_end(h, s));
         FS_TRY(prof_begin(h, "ppm.up" + std::to_string(bin), "upsample_into", 0, 4.0 * B * curH * curW * 512.0, s));
-        FS_TRY(launch_upsample_into(reduced + roff, bin, bin, out + 2048 + 512 * i, 4096, B, curH, curW, 512, 1, s));
+        FS_TRY(launch_upsample_into(reduced + red_off[i], bin, bin, out + 2048 + 512 * i, 4096, B, curH, curW, 512, 1, s));
         FS_TRY(prof_end(h, s));
-        poff += (size_t)B * cells * 2048;
-        roff += (size_t)B * cells * 512;
     }
     return 0;
 }

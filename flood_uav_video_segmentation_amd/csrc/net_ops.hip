@@ -163,6 +163,44 @@ int launch_adaptive_avgpool(const float* in, int ld_in, float* out, int B, int H
 }
 
 // -------------------------------------------------------------------------------------------
+// PPM fast path: all four AdaptiveAvgPool2d bins (1,2,3,6) of model/pspnet.py:42 in ONE pass over the map when
+// H and W are multiples of 6 (90x90 at 713^2): stage 1 sums the 6x6 cells, stage 2 combines cells into the 3/2/1 bins.
+// (Window sums are combined hierarchically, so the last bits differ from a flat sum; covered by the 5e-6 test tolerance.)
+// -------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ppm_pool_combine_kernel(const float* __restrict__ cell_mean /*[B][36][C]*/, float* __restrict__ out1,
+                                                               float* __restrict__ out2, float* __restrict__ out3, int B, int C) {
+    const int64_t total = (int64_t)B * C;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i % C), b = (int)(i / C);
+        const float* m = cell_mean + (size_t)b * 36 * C + c;
+        float s3[9], s2[4] = {0.f, 0.f, 0.f, 0.f}, s1 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) s3[k] = 0.f;
+#pragma unroll
+        for (int y = 0; y < 6; ++y)
+#pragma unroll
+            for (int x = 0; x < 6; ++x) {
+                const float v = m[(size_t)(y * 6 + x) * C];
+                s3[(y / 2) * 3 + x / 2] += v;
+                s2[(y / 3) * 2 + x / 3] += v;
+                s1 += v;
+            }
+#pragma unroll
+        for (int k = 0; k < 9; ++k) out3[((size_t)b * 9 + k) * C + c] = s3[k] * 0.25f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) out2[((size_t)b * 4 + k) * C + c] = s2[k] * (1.f / 9.f);
+        out1[(size_t)b * C + c] = s1 * (1.f / 36.f);
+    }
+}
+
+int launch_ppm_pool_combine(const float* cell_mean, float* out1, float* out2, float* out3, int B, int C, hipStream_t s) {
+    const int64_t total = (int64_t)B * C;
+    hipLaunchKernelGGL(ppm_pool_combine_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, s, cell_mean, out1, out2, out3, B, C);
+    FS_HIP(hipGetLastError());
+    return 0;
+}
+
+// -------------------------------------------------------------------------------------------
 // Small-M 1x1 conv: one wave per output channel n, weight row held in registers, loop over m.
 // -------------------------------------------------------------------------------------------
 template <int KV /* float4 per lane = K/256 */>
