@@ -150,16 +150,20 @@ int launch_layernorm(const float* in, const float* gamma, const float* beta, flo
 constexpr int ATT_DH = 64;
 constexpr int ATT_KT = 64;   // keys per LDS tile
 constexpr int ATT_LDK = 68;
+constexpr int ATT_NW = 4;    // waves per workgroup = 128 queries per staged K/V tile.  Measured on ViT-S/16 (N = 1937): 2 waves
+                             // (64 queries, 4 workgroups/CU) 36 TFLOP/s -- the K/V staging per query doubles; 4 waves 52+
 
-__global__ __launch_bounds__(256) void attention_f32_kernel(const float* __restrict__ qkv, float* __restrict__ out, int N, int heads,
-                                                            float scale) {
+__global__ __launch_bounds__(64 * ATT_NW) void attention_f32_kernel(const float* __restrict__ qkv, float* __restrict__ out, int N,
+                                                                     int heads, float scale) {
     __shared__ __attribute__((aligned(16))) float Ks[ATT_KT * ATT_LDK];
     __shared__ __attribute__((aligned(16))) float Vs[ATT_KT * ATT_DH];
+    constexpr int NT = 64 * ATT_NW;
+    constexpr int LPT = ATT_KT * 16 / NT;  // float4 of K (and of V) staged per thread
     const int D = heads * ATT_DH, ld = 3 * D;
     const int b = blockIdx.z, head = blockIdx.y;
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     const int l31 = lane & 31, hh = lane >> 5;
-    const int q = blockIdx.x * 128 + wv * 32 + l31;
+    const int q = blockIdx.x * (32 * ATT_NW) + wv * 32 + l31;
     const int qc = min(q, N - 1);
     const float* base = qkv + (size_t)b * N * ld + head * ATT_DH;
 
@@ -182,24 +186,32 @@ __global__ __launch_bounds__(256) void attention_f32_kernel(const float* __restr
     float m_run = -INFINITY, l_run = 0.f;
 
     const int ntiles = (N + ATT_KT - 1) / ATT_KT;
-    for (int kt = 0; kt < ntiles; ++kt) {
-        __syncthreads();
-        // stage 64 keys x 64 dims of K and V (zero rows beyond N)
+    f32x4 kreg[LPT], vreg[LPT];  // next K/V tile, in flight while the current one is multiplied
+    auto fetch = [&](int kt) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int idx = t + 256 * j;       // 0..1023
+        for (int j = 0; j < LPT; ++j) {
+            const int idx = t + NT * j;
             const int row = idx >> 4, c4 = idx & 15;
-            const int key = kt * ATT_KT + row;
-            f32x4 kv = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
-            if (key < N) {
-                const float* rp = base + (size_t)key * ld + c4 * 4;
-                kv = *reinterpret_cast<const f32x4*>(rp + D);
-                vv = *reinterpret_cast<const f32x4*>(rp + 2 * D);
-            }
-            *reinterpret_cast<f32x4*>(&Ks[row * ATT_LDK + c4 * 4]) = kv;
-            *reinterpret_cast<f32x4*>(&Vs[row * ATT_DH + c4 * 4]) = vv;
+            const int key = min(kt * ATT_KT + row, N - 1);  // clamped; rows beyond N are zeroed when stored
+            const float* rp = base + (size_t)key * ld + c4 * 4;
+            kreg[j] = *reinterpret_cast<const f32x4*>(rp + D);
+            vreg[j] = *reinterpret_cast<const f32x4*>(rp + 2 * D);
+        }
+    };
+    fetch(0);
+    for (int kt = 0; kt < ntiles; ++kt) {
+        __syncthreads();  // previous tile fully consumed
+#pragma unroll
+        for (int j = 0; j < LPT; ++j) {
+            const int idx = t + NT * j;
+            const int row = idx >> 4, c4 = idx & 15;
+            const bool ok = kt * ATT_KT + row < N;
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            *reinterpret_cast<f32x4*>(&Ks[row * ATT_LDK + c4 * 4]) = ok ? kreg[j] : z;
+            *reinterpret_cast<f32x4*>(&Vs[row * ATT_DH + c4 * 4]) = ok ? vreg[j] : z;
         }
         __syncthreads();
+        if (kt + 1 < ntiles) fetch(kt + 1);
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
             const int key0 = kt * ATT_KT + kb * 32;
@@ -224,7 +236,7 @@ __global__ __launch_bounds__(256) void attention_f32_kernel(const float* __restr
             }
             mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
             const float m_new = fmaxf(m_run, mloc);           // finite: key0 < N guarantees one valid key
-            const float alpha = expf(m_run - m_new);        // exp(-inf) = 0 on the first block
+            const float alpha = expf(m_run - m_new);          // exp(-inf) = 0 on the first block
             float lsum = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -266,7 +278,7 @@ __global__ __launch_bounds__(256) void attention_f32_kernel(const float* __restr
 
 int launch_attention_f32(const float* qkv, float* out, int B, int N, int heads, float scale, hipStream_t s) {
     FS_REQUIRE(B >= 1 && N >= 1 && heads >= 1, "attention: bad shape");
-    hipLaunchKernelGGL(attention_f32_kernel, dim3(cdiv(N, 128), heads, B), dim3(256), 0, s, qkv, out, N, heads, scale);
+    hipLaunchKernelGGL(attention_f32_kernel, dim3(cdiv(N, 32 * ATT_NW), heads, B), dim3(64 * ATT_NW), 0, s, qkv, out, N, heads, scale);
     FS_HIP(hipGetLastError());
     return 0;
 }
