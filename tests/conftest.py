@@ -13,6 +13,12 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the C-ABI library is built in-tree and is git-ignored: (re)build it when it is missing (hipcc cross-compiles on CPU)
+    lib = os.path.join(ROOT, "flood_uav_video_segmentation_amd", "libfloodseg.so")
+    if not os.path.exists(lib):
+        import __graft_entry__
+
+        __graft_entry__.build()
 
 
 def pytest_collection_modifyitems(config, items):

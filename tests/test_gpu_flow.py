@@ -214,3 +214,60 @@ def test_predict_step_mirror_masks_metric_and_palette(psp_flow):
     assert abs(macc - np.mean(inter / (target + 1e-10))) < 1e-12 and abs(acc - inter.sum() / (target.sum() + 1e-10)) < 1e-12
     rgb = colorize(torch.from_numpy(m0[0]).cuda()).cpu().numpy()
     assert rgb.shape == (1072, 1920, 3) and np.array_equal(rgb, PALETTE[m0[0]])
+
+
+def test_end_to_end_fake_video_through_dataset_predictor_and_grid_producer(tmp_path, psp_flow):
+    """A tiny 'video' on disk -> PredictWindows (flow/dataset.py mirror) -> FlowPredictor (predict_step mirror):
+    the host pieces either side of the hot path hand tensors of the contract shapes to each other."""
+    import os
+
+    from PIL import Image
+
+    from flood_uav_video_segmentation_amd.flow import grids
+    from flood_uav_video_segmentation_amd.flow.dataset import MEAN, STD, PredictWindows
+    from flood_uav_video_segmentation_amd.flow.predict import FlowPredictor
+
+    base = os.path.join(tmp_path, "frames", "vid")
+    for d in ("images", "grids", "inv_grids"):
+        os.makedirs(os.path.join(base, d))
+    rng = np.random.default_rng(3)
+    mv = np.concatenate([np.full((400, 1), -1), np.full((400, 2), 16), rng.integers(0, 1900, (400, 4)), np.zeros((400, 3), int)], 1)
+    for i in range(11):
+        img = (rng.random((161, 225, 3)) * 255).astype(np.uint8)
+        Image.fromarray(img).save(os.path.join(base, "images", f"{i}.jpg"), quality=95)
+        g, gi = grids.motion_vectors_to_grids(mv, 1072, 1920)
+        grids.save_grid(os.path.join(base, "grids", f"{i}.npy"), g)
+        grids.save_grid(os.path.join(base, "inv_grids", f"{i}.npy"), gi)
+    ds = PredictWindows(str(tmp_path), "vid", frame_delta=5, no_warp=False)
+    assert len(ds) == 2
+    item = ds[0]
+    assert item["frame_prev"].shape == (1, 3, 161, 225) and item["frame_prev"].dtype == torch.float32 and item["frame_id"] == 0
+    assert len(item["mvs_left"]) == len(item["mvs_right"]) == 4 and item["mvs_left"][0].shape == (1, 67, 120, 2)
+    ref = (torch.from_numpy(np.asarray(Image.open(os.path.join(base, "images", "0.jpg")))).permute(2, 0, 1).float()
+           - torch.tensor(MEAN).view(3, 1, 1)) / torch.tensor(STD).view(3, 1, 1)
+    assert torch.allclose(item["frame_prev"][0].cpu(), ref, atol=1e-5)   # Normalize with mean/std * 255 (base/foundation.py:27-31)
+    net, _ = psp_flow
+    fm = FlowModel(net, feature_based=False, no_warp=False).eval()
+    pred = FlowPredictor(fm, classes=5, out_size=(161, 225))
+    for i in range(len(ds)):
+        it = ds[i]
+        masks = pred.predict_window(it["frame_prev"], it["frame_next"], it["mvs_left"], it["mvs_right"])
+        assert masks.shape == (5, 161, 225) and masks.dtype == np.uint8 and masks.max() < 5
+    miou, macc, acc = pred.temporal_consistency()
+    assert 0.0 <= miou <= 1.0 and 0.0 <= acc <= 1.0
+
+
+def test_pspnet_non_square_frame_with_full_frame_grids_against_oracle(psp_flow, profiler):
+    """no_cropping=True route: non-square frame, non-divisible PPM windows (feature map 13x21), 67x120-style full-frame
+    grids of a different size than the logits."""
+    net, state = psp_flow
+    n, H, W = 3, 97, 161
+    clip = synth.make_clip(2, (H, W), seed=51)
+    mvl, mvr = synth.make_grids(n, H // 16, W // 16, seed=52, frame=(H, W), jitter=0.04)
+    fm = FlowModel(net, feature_based=False, no_warp=False).eval()
+    out = fm.predict(clip[0:1].cuda(), clip[1:2].cuda(), cu(mvl), cu(mvr), n, profiler)["pred"]
+    enc = lambda x: pspnet_oracle.encoder(x, state, 50)  # noqa: E731
+    dec = lambda f: pspnet_oracle.decoder(f, state)  # noqa: E731
+    ref = flow_oracle.predict_segmentation(enc, dec, clip[0:1], clip[1:2], mvl, mvr, n, False)["pred"]
+    assert out.shape == ref.shape == (n, 5, H, W)
+    assert rel_err(out.cpu(), ref) < NET_TOL

@@ -97,3 +97,34 @@ def test_synthetic_generators_are_deterministic_and_shaped():
     s1, s2 = synth.make_pspnet_state(50, 5, 0), synth.make_pspnet_state(50, 5, 0)
     assert all(torch.equal(s1[k], s2[k]) for k in s1)
     assert s1["decoder.0.weight"].shape == (512, 4096, 3, 3) and s1["layer3.5.conv2.weight"].shape == (256, 256, 3, 3)
+
+
+def _fake_video(root, n_frames, missing=()):
+    import os
+
+    from PIL import Image
+
+    base = os.path.join(root, "frames", "vid")
+    for d in ("images", "grids", "inv_grids"):
+        os.makedirs(os.path.join(base, d))
+    for i in range(n_frames):
+        Image.fromarray(np.full((8, 12, 3), i, np.uint8)).save(os.path.join(base, "images", f"{i}.jpg"))
+        if i not in missing:
+            np.save(os.path.join(base, "grids", f"{i}.npy"), np.full((67, 120, 2), i, np.float64))
+            np.save(os.path.join(base, "inv_grids", f"{i}.npy"), np.full((67, 120, 2), -i, np.float64))
+
+
+def test_predict_window_indexing_and_missing_frame_fallback(tmp_path):
+    """flow/dataset.py:64, 112-146: windows = frames // delta; a key frame without grids slides forward (prev) / back (next);
+    inverse grids come reversed."""
+    from flood_uav_video_segmentation_amd.flow.dataset import PredictWindows
+
+    _fake_video(str(tmp_path), 23, missing=(5, 10))
+    w = PredictWindows(str(tmp_path), "vid", frame_delta=5, no_warp=False, device="cpu")
+    assert len(w) == 23 // 5
+    assert w.indices(0) == (0, 0, 4)       # next key 5 has no grids -> 4
+    assert w.indices(1) == (5, 6, 9)       # prev key 5 -> 6 ; next key 10 -> 9
+    assert w.indices(2) == (10, 11, 15)
+    assert w.grid_ids(1) == ([6, 7, 8, 9], [9, 8, 7, 6])
+    nw = PredictWindows(str(tmp_path), "vid", frame_delta=5, no_warp=True, device="cpu")
+    assert nw.grid_ids(3) == ([16, 17, 18, 19], [19, 18, 17, 16])
