@@ -27,7 +27,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 //           of the compute phase, and MFMA fragments are double-buffered in registers so that the LDS read
 //           latency of sub-step s+1 hides under the 16 MFMAs of sub-step s.
 // (Tried and measured null, removed: start-time stagger of co-resident blocks; s_setprio around the MFMAs; an
-//  LDS-transposed epilogue with 16-B residual loads / stores -- 4x fewer global instructions, same time.)
+//  LDS-transposed epilogue with 16-B residual loads / stores -- 4x fewer global instructions, same time; persistent
+//  tiles with the next tile's first DMA issued before the epilogue -- same time as one tile per workgroup.)
 template <int BM, int BN, int PIPE>
 __global__ __launch_bounds__(256) void conv_igemm_f32(ConvParams p, int tiles_m, int tiles_n) {
     constexpr int BK = 32;
