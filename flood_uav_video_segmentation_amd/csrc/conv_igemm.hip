@@ -473,8 +473,10 @@ const TileCfg kTiles[6] = {{0, 0, "auto"}, {128, 128, "igemm128x128"}, {128, 64,
                            {64, 64, "igemm64x64"}, {64, 128, "igemm64x128"}, {256, 128, "igemm256x128"}};
 
 int pick_tile(const ConvParams& p) {
+    // Cost model fitted to the MI355X tile sweeps (profiles/r01_conv_tile_sweep*.txt): per-tile MFMA efficiency by tile
+    // shape; a CU that hosts a single workgroup runs at ~0.8 of the rate it reaches with two or more co-resident ones;
+    // the launch takes as long as its most loaded CU (ceil(tiles / 256) workgroups).
     const int M = p.B * p.Ho * p.Wo;
-    // relative per-tile MFMA efficiency guesses; refined from rocprof later
     const double eff[5] = {0, 1.00, 0.92, 0.80, 0.92};
     int best = 1;
     double best_t = 1e300;
@@ -482,8 +484,8 @@ int pick_tile(const ConvParams& p) {
         const int bm = kTiles[c].bm, bn = kTiles[c].bn;
         if (p.Cout < bn && bn > 64) continue;
         const long tiles = (long)cdiv(M, bm) * cdiv(p.Cout, bn) * (p.groups > 1 ? p.groups : 1);
-        const long rounds = (tiles + 255) / 256;
-        const double t = (double)rounds * bm * bn / eff[c];
+        const long per_cu = (tiles + 255) / 256;
+        const double t = (double)per_cu * bm * bn / (eff[c] * (per_cu >= 2 ? 1.0 : 0.8));
         if (t < best_t) { best_t = t; best = c; }
     }
     return best;

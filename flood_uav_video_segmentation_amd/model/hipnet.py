@@ -35,14 +35,17 @@ class HipNet:
         self.close()
         self._create()
         lib = self._lib
+        keep = []  # the copies are asynchronous: every source tensor must outlive the synchronize below
         for name, t in canonical_state.items():
             t = t.detach()
             if t.dtype != torch.float32:
                 t = t.float()
             t = t.contiguous()
+            keep.append(t)
             shape = (ctypes.c_int64 * max(t.dim(), 1))(*t.shape)
             check(lib.fs_load_weight(self._h, name.encode(), ptr(t), shape, t.dim(), int(t.is_cuda), stream_ptr()))
         torch.cuda.current_stream().synchronize()
+        del keep
         check(lib.fs_finalize(self._h, stream_ptr()))
         self.ready = True
 

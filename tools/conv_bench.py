@@ -25,6 +25,9 @@ SHAPES = {  # b, h, w, cin, cout, k, stride, pad, dil
 
 
 def main():
+    if os.environ.get("CONV_BENCH_B"):
+        for k, v in list(SHAPES.items()):
+            SHAPES[k] = (int(os.environ["CONV_BENCH_B"]),) + v[1:]
     name = sys.argv[1] if len(sys.argv) > 1 else "dec"
     tile = int(sys.argv[2], 0) if len(sys.argv) > 2 else 0
     iters = int(sys.argv[3]) if len(sys.argv) > 3 else 20
