@@ -70,9 +70,11 @@ def crop_windows(new_h, new_w, crop_h, crop_w, stride_rate=2 / 3):
 
 
 def compute_output(flow_model, n, frame_prev, frame_next, mvs_left, mvs_right, crop_h, crop_w, classes, profiler=None,
-                   want_mask=False):
-    """flow/base.py:182-209 with `function = compute_predict_crop` (:226-234): returns the float64
-    [n,K,H,W] crop-averaged softmax (and, optionally, its per-frame argmax as uint8 [n,H,W])."""
+                   want_mask=False, function=None):
+    """flow/base.py:182-209: returns the float64 [n,K,H,W] crop-averaged softmax (and, optionally, its per-frame
+    argmax as uint8 [n,H,W]).  `function(prev_crop, next_crop, mvs_left_crop, mvs_right_crop) -> logits [n,K,h,w]`
+    is the per-crop network call: default `compute_predict_crop` (:226-234, FlowModel.predict); test_step passes
+    `compute_test_crop` (:212-222, FlowModel.forward with left/right indices)."""
     lib = _lib.load()
     _, _, new_h, new_w = frame_prev.shape
     dev = frame_prev.device
@@ -82,7 +84,10 @@ def compute_output(flow_model, n, frame_prev, frame_next, mvs_left, mvs_right, c
         prev_c = frame_prev[:, :, s_h:e_h, s_w:e_w].contiguous()
         next_c = frame_next[:, :, s_h:e_h, s_w:e_w].contiguous()
         ml, mr = crop_motion_vector(mvs_left, mvs_right, new_h, new_w, e_h - s_h, e_w - s_w, s_h, s_w)
-        logits = flow_model.predict(prev_c, next_c, ml, mr, n, profiler)["pred"]
+        if function is None:
+            logits = flow_model.predict(prev_c, next_c, ml, mr, n, profiler)["pred"]
+        else:
+            logits = function(prev_c, next_c, ml, mr)
         if logits.shape[2] != crop_h or logits.shape[3] != crop_w:
             logits = ops.resize_bilinear(logits, (crop_h, crop_w), align_corners=True)
         logits = logits.contiguous()

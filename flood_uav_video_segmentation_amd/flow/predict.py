@@ -56,6 +56,60 @@ class FlowPredictor:
         return float(np.mean(inter / (union + 1e-10))), float(np.mean(inter / (target + 1e-10))), float(inter.sum() / (target.sum() + 1e-10))
 
 
+class FlowEvaluator:
+    """validation_step / test_step on the HIP path (flow/base.py:143-176, summary of on_test_epoch_end in
+    base/foundation.py): one interpolated frame per item from FlowModel.forward, argmax, intersection / union / target
+    histograms against the label, one meter set per test list (Florida = 0, Texas = 1, flow/base.py:170-175).
+
+        ev = FlowEvaluator(flow_model, classes=5, crop=(713, 713))       # crop=None <=> no_cropping=True
+        for item in EvalWindows(...): ev.test_step(item, test_idx=0)
+        miou, macc, acc, iou_class, acc_class = ev.summary(0)
+    """
+
+    def __init__(self, flow_model, classes=5, crop=None, ignore_index=255):
+        self.model = flow_model
+        self.classes, self.crop, self.ignore_index = classes, crop, ignore_index
+        self.hist = {}  # meter id -> int64[3,K] (intersection, |pred|, |target|)
+
+    def forward(self, frame_prev, frame_next, mvs_left, mvs_right, left_index, right_index):
+        return self.model(None, frame_prev, frame_next, mvs_left, mvs_right, left_index, right_index)   # flow/base.py:134-135
+
+    def _update(self, meter, pred, label):
+        pred, label = pred.to(torch.uint8).contiguous(), label.to(torch.uint8).contiguous()   # ids 0..K-1 and 255 fit
+        self.hist[meter] = ops.iou_hist(pred, label, self.classes, self.ignore_index, self.hist.get(meter))
+
+    def validation_step(self, batch):
+        out = self.forward(batch["frame_prev"], batch["frame_next"], batch["mvs_left"], batch["mvs_right"], batch["left_index"],
+                           batch["right_index"])["pred"]
+        pred = ops.argmax_u8(out)
+        self._update("val", pred, batch["label"])
+        return pred
+
+    def test_step(self, batch, test_idx=0):
+        frame_prev, frame_next, label = batch["frame_prev"], batch["frame_next"], batch["label"]
+        assert frame_prev.shape[0] == 1 and label.shape[0] == 1                                    # flow/base.py:160
+        li, ri = batch["left_index"], batch["right_index"]
+        if self.crop is None:
+            out = self.forward(frame_prev, frame_next, batch["mvs_left"], batch["mvs_right"], li, ri)["pred"]
+            pred = ops.argmax_u8(out)
+        else:
+            fn = lambda p, q, ml, mr: self.forward(p, q, ml, mr, li, ri)["pred"]                # compute_test_crop (:212-222)
+            _, pred = crops.compute_output(self.model, frame_prev.shape[0], frame_prev, frame_next, batch["mvs_left"],
+                                           batch["mvs_right"], self.crop[0], self.crop[1], self.classes, want_mask=True,
+                                           function=fn)
+        self._update(1 if test_idx > 0 else 0, pred, label)
+        return pred
+
+    def summary(self, meter=0):
+        """(mIoU, mAcc, accuracy, iou_class, accuracy_class) with the reference's 1e-10 epsilon (flow/base.py:332-336)."""
+        if meter not in self.hist:
+            return None
+        h = self.hist[meter].cpu().numpy().astype(np.float64)
+        inter, union, target = h[0], h[1] + h[2] - h[0], h[2]
+        iou_class, acc_class = inter / (union + 1e-10), inter / (target + 1e-10)
+        return float(np.mean(iou_class)), float(np.mean(acc_class)), float(inter.sum() / (target.sum() + 1e-10)), iou_class, acc_class
+
+
 def colorize(masks_u8, palette=PALETTE):
     """colors[output] (flow/base.py:308-312): uint8 [..., 3] RGB frames for the video writer / PNG dump."""
     lib = _lib.load()

@@ -13,6 +13,8 @@ import torch.nn.functional as F
 
 
 def crop_motion_vector(mvs_left, mvs_right, height, width, crop_height, crop_width, height_offset, width_offset):
+    if not (mvs_left is not None and isinstance(mvs_left, list) and len(mvs_left) > 0 and len(mvs_left[0].shape) >= 3):
+        return mvs_left, mvs_right  # no_warp placeholders pass through untouched (flow/transform.py:216-221)
     mv_h, mv_w = mvs_left[0].shape[-3], mvs_left[0].shape[-2]
     ppb_h, ppb_w = height / mv_h, width / mv_w
     final_h, final_w = crop_height // 16, crop_width // 16

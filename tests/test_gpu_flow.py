@@ -271,3 +271,89 @@ def test_pspnet_non_square_frame_with_full_frame_grids_against_oracle(psp_flow, 
     ref = flow_oracle.predict_segmentation(enc, dec, clip[0:1], clip[1:2], mvl, mvr, n, False)["pred"]
     assert out.shape == ref.shape == (n, 5, H, W)
     assert rel_err(out.cpu(), ref) < NET_TOL
+
+
+@pytest.mark.parametrize("crop", [None, (97, 97)])
+@pytest.mark.parametrize("nw", [False, True])
+def test_test_step_mirror_against_oracle_parity_unpinned(tmp_path, crop, nw):
+    """labelled `test` split -> EvalWindows (flow/dataset.py:89-181) -> FlowEvaluator.test_step
+    (flow/base.py:156-176; whole frame or compute_output + compute_test_crop) -> intersection / union / target meters.
+    The CPU side restates the same chain with oracle/ (dataset indexing and cv2 resizes are unpinned: cv2 / skimage absent)."""
+    import os
+
+    from PIL import Image
+
+    from flood_uav_video_segmentation_amd.flow.dataset import MEAN, STD, EvalWindows
+    from flood_uav_video_segmentation_amd.flow.predict import FlowEvaluator
+    from oracle import crops_oracle, dataset_oracle
+
+    H, W, delta, K = 160, 272, 5, 5
+    base = os.path.join(tmp_path, "frames", "florida")
+    for d in ("images", "grids", "inv_grids"):
+        os.makedirs(os.path.join(base, d))
+    os.makedirs(os.path.join(tmp_path, "masks"))
+    missing = (7, 16)   # key frames of items 1, 2 and 3 (a missing IN-BETWEEN grid raises in the reference as well)
+    clip = synth.make_clip(24, (H, W), seed=51)
+    for i in range(24):
+        img = ((clip[i].permute(1, 2, 0) * 40 + 128).clamp(0, 255)).to(torch.uint8).numpy()
+        Image.fromarray(img).save(os.path.join(base, "images", f"{i}.jpg"), quality=95)
+        if i in missing:
+            continue
+        ml, mr = synth.make_grids(2, 67, 120, seed=60 + i, frame=(H, W), jitter=0.01)
+        np.save(os.path.join(base, "grids", f"{i}.npy"), ml[0][0].double().numpy())
+        np.save(os.path.join(base, "inv_grids", f"{i}.npy"), mr[0][0].double().numpy())
+    rng = np.random.default_rng(7)
+    labelled = [4, 9, 12, 18]
+    with open(os.path.join(tmp_path, "test.txt"), "w") as fh:
+        for j, f in enumerate(labelled):
+            lab = rng.integers(0, 6, (H + 8, W)).astype(np.uint8)     # 5 -> IgnoreClasses; taller than the frame -> nearest resize
+            lab[:3] = 255                                             # ignore_index rows
+            Image.fromarray(lab).save(os.path.join(tmp_path, "masks", f"{j}.png"))
+            fh.write(f"masks/{j}.png florida {f}\n")
+    ds = EvalWindows(str(tmp_path), os.path.join(tmp_path, "test.txt"), split="test", frame_delta=delta, no_warp=nw, size=(H, W),
+                     classes_ignore=(5,))
+    fm = FlowModel(toy_model(), feature_based=False, no_warp=nw).eval()
+    ev = FlowEvaluator(fm, classes=K, crop=crop)
+
+    w = toy_weights()
+    enc = lambda x: torch.relu(torch.nn.functional.conv2d(x, w["enc_w"], w["enc_b"], 4, 1))  # noqa: E731
+    dec = lambda f: torch.nn.functional.conv2d(f, w["dec_w"], w["dec_b"])  # noqa: E731
+    have = lambda f: f not in missing and 0 <= f < 24  # noqa: E731
+    default = torch.from_numpy(flow_oracle.get_default_grid()).float()[None]
+    hist = np.zeros((3, K), np.int64)
+    agree = []
+    for i in range(len(ds)):
+        item = ds[i]
+        assert item["label"].shape == (1, H, W) and item["label"].dtype == torch.int64
+        pred = ev.test_step(item, test_idx=0)
+        # ---- CPU restatement of the same item
+        l, r, prev_real, next_real, left, right = dataset_oracle.eval_item(have, i, labelled[i], delta, "test")
+        assert int(item["left_index"][0]) == l and int(item["right_index"][0]) == r
+
+        def frame(f):
+            x = torch.from_numpy(np.asarray(Image.open(os.path.join(base, "images", f"{f}.jpg")))).permute(2, 0, 1).float()
+            return ((x - torch.tensor(MEAN).view(3, 1, 1)) / torch.tensor(STD).view(3, 1, 1))[None]
+
+        def grid(g, name):
+            return default if g is None else torch.from_numpy(np.load(os.path.join(base, name, f"{g}.npy"))).float()[None]
+
+        mvl = [torch.zeros(1, 1)] * (delta - 1) if nw else [grid(g, "grids") for g in left]
+        mvr = [torch.zeros(1, 1)] * (delta - 1) if nw else [grid(g, "inv_grids") for g in right]
+        fwd = lambda p, q, a, b: flow_oracle.forward(enc, dec, p, q, a, b, [l], [r], False, nw)["pred"]  # noqa: E731
+        if crop is None:
+            ref = fwd(frame(prev_real), frame(next_real), mvl, mvr).max(1)[1]
+        else:
+            ref = crops_oracle.compute_output(fwd, 1, frame(prev_real), frame(next_real), mvl, mvr, crop[0], crop[1], K).max(1)[1]
+        raw = np.array(Image.open(os.path.join(tmp_path, "masks", f"{i}.png")))
+        lab = dataset_oracle.ignore_classes(dataset_oracle.resize_label_nearest(raw, (H, W)), (5,))
+        assert np.array_equal(item["label"][0].cpu().numpy(), lab)
+        agree.append((pred.cpu() == ref.to(torch.uint8)).float().mean().item())
+        # meters from the HIP masks with the oracle's histogram: isolates the metric path from fp-level mask flips
+        a, u, t = flow_oracle.intersection_and_union(pred.cpu().long().numpy(), lab[None].astype(np.int64), K, 255)
+        hist += np.stack([a, u, t]).astype(np.int64)
+    assert min(agree) > 0.999
+    h = ev.hist[0].cpu().numpy()
+    inter, union, target = h[0], h[1] + h[2] - h[0], h[2]
+    assert np.array_equal(inter, hist[0]) and np.array_equal(union, hist[1]) and np.array_equal(target, hist[2])
+    miou, macc, acc, iou_c, acc_c = ev.summary(0)
+    assert abs(miou - float(np.mean(hist[0] / (hist[1] + 1e-10)))) < 1e-12 and ev.summary(1) is None

@@ -128,3 +128,79 @@ def test_predict_window_indexing_and_missing_frame_fallback(tmp_path):
     assert w.grid_ids(1) == ([6, 7, 8, 9], [9, 8, 7, 6])
     nw = PredictWindows(str(tmp_path), "vid", frame_delta=5, no_warp=True, device="cpu")
     assert nw.grid_ids(3) == ([16, 17, 18, 19], [19, 18, 17, 16])
+
+
+def _fake_labelled_video(root, n_frames, labelled, missing=()):
+    import os
+
+    from PIL import Image
+
+    _fake_video(root, n_frames, missing)
+    os.rename(os.path.join(root, "frames", "vid"), os.path.join(root, "frames", "florida"))
+    os.makedirs(os.path.join(root, "masks", "florida-01"))
+    os.makedirs(os.path.join(root, "list"))
+    rng = np.random.default_rng(5)
+    lines = []
+    for j, f in enumerate(labelled):
+        lab = rng.integers(0, 7, (9, 14)).astype(np.uint8)   # ids 5, 6 exercise IgnoreClasses
+        Image.fromarray(lab).save(os.path.join(root, "masks", "florida-01", f"{j}.png"))
+        lines.append(f"masks/florida-01/{j}.png florida {f}")
+    with open(os.path.join(root, "list", "test.txt"), "w") as fh:
+        fh.write("\n".join(lines) + "\n")
+    return os.path.join(root, "list", "test.txt")
+
+
+def test_eval_window_plan_matches_the_restated_flowdata_indexing(tmp_path):
+    """flow/dataset.py:16-43, 89-92, 115-171 (val / test split): seeded l/r split, missing key frames slide inward,
+    grids at or before the real previous key / after the real next key become the identity grid, inverse grids reversed,
+    both lists padded to frame_delta - 1.  PARITY UNPINNED (skimage / cv2 absent): checked against oracle/dataset_oracle."""
+    import os
+
+    from flood_uav_video_segmentation_amd.flow.dataset import EvalWindows, read_label_list
+    from oracle import dataset_oracle
+
+    labelled = [1, 12, 20, 33, 41, 57]
+    missing = (9, 10, 22, 23, 24, 35, 43, 44)
+    lst = _fake_labelled_video(str(tmp_path), 70, labelled, missing)
+    have = lambda f: f not in missing and 0 <= f < 70  # noqa: E731
+    for delta in (5, 8):
+        ds = EvalWindows(str(tmp_path), lst, split="test", frame_delta=delta, device="cpu")
+        ref_list = dataset_oracle.make_dataset(open(lst).read().splitlines(), delta)
+        assert ds.label_list == ref_list == read_label_list(lst, delta)
+        assert len(ds) == len(labelled) - 1   # frame 1 < delta // 2 is dropped
+        for i, (_, _, f) in enumerate(ref_list):
+            l, r, prev_real, next_real, left, right = dataset_oracle.eval_item(have, i, f, delta, "test")
+            p = ds.plan(i)
+            assert (p["l"], p["r"], p["prev_real"], p["next_real"]) == (l, r, prev_real, next_real)
+            assert p["left_ids"] == left and p["right_ids"] == right
+            assert len(left) == len(right) == delta - 1 and l + r == delta
+    with open(os.path.join(tmp_path, "bad.txt"), "w") as fh:
+        fh.write("masks/x.png florida\n")
+    with pytest.raises(RuntimeError, match="Image list file read line error"):
+        read_label_list(os.path.join(tmp_path, "bad.txt"), 5)
+    with pytest.raises(ValueError):
+        EvalWindows(str(tmp_path), lst, split="train")
+
+
+def test_eval_window_label_transform_and_item_layout(tmp_path):
+    """Resize(INTER_NEAREST) + IgnoreClasses on the label (flow/transform.py:104-105, 361-371); default-grid slots hold
+    get_default_grid(); left_index / right_index arrive as 1-element tensors like the collated batch."""
+    from flood_uav_video_segmentation_amd.flow.dataset import EvalWindows, resize_label_nearest
+    from flood_uav_video_segmentation_amd.flow.model import get_default_grid
+    from oracle import dataset_oracle
+
+    rng = np.random.default_rng(6)
+    lab = rng.integers(0, 5, (1080, 1920)).astype(np.uint8)
+    for size in ((1072, 1920), (536, 960), (1080, 1920), (713, 713)):
+        assert np.array_equal(resize_label_nearest(lab, size), dataset_oracle.resize_label_nearest(lab, size))
+    lst = _fake_labelled_video(str(tmp_path), 30, [12], missing=(13,))
+    ds = EvalWindows(str(tmp_path), lst, split="test", frame_delta=5, size=(8, 12), classes_ignore=(5, 6), device="cpu")
+    p = ds.plan(0)
+    # pure host path: labels and grids only (frames need the HIP resize -> covered by the GPU test)
+    label = ds._label(ds.label_list[0][0])
+    from PIL import Image
+    raw = np.array(Image.open(tmp_path / "masks" / "florida-01" / "0.png"))
+    want = dataset_oracle.ignore_classes(dataset_oracle.resize_label_nearest(raw, (8, 12)), (5, 6))
+    assert label.dtype == torch.int64 and np.array_equal(label.numpy(), want) and label.max() <= 4
+    assert None in p["left_ids"] + p["right_ids"]
+    assert ds.default_grid.dtype == torch.float32 and np.array_equal(ds.default_grid.numpy(), get_default_grid().astype(np.float32))
