@@ -17,6 +17,9 @@
 // multiplied out of LDS (64 MFMAs = 4096 cycles per wave per chunk at 128x128).
 #include "kernels.h"
 
+#include <algorithm>
+#include <cstdlib>
+
 namespace fs {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -266,7 +269,27 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(ConvParams p, int tiles_m,
 // the sentinel voffset 0x80000000.  Per chunk the issue is 8 DMAs + ~12 VALU: the per-lane offsets are loop
 // invariants, the chunk position is the scalar soffset, tap validity is one bit of a per-row mask.
 // Elimination runs on the decoder conv (profiles/): VGPR-staged loads cost ~9 %, the ds_write pass ~5 %.
+// Workgroup timelines (tools/probe_conv_trace.hip, profiles/r01_conv_wg_timeline.txt): with two workgroups per CU the
+// main loop keeps the MFMA pipe busy 93 % of its cycles and only 1.6 % of them are spent in the per-chunk wait+barrier;
+// a lone workgroup reaches 83 %.  What short-K layers lose is outside the loop: ~6 k cycles of prologue (index math +
+// first DMA) and ~11-17 k cycles of epilogue per tile, during which the co-resident workgroup is in the same phase
+// (both were dispatched together), i.e. 4 % of a K=2048 tile, 17 % at K=512, 27 % at K=256.  In that lock-step all
+// 512 resident workgroups store their 64 KB tiles at once (33 MB in ~4.7 us = HBM write peak), so the epilogue is
+// bandwidth-bound, which is why vector stores did not shorten it.  De-phasing the two workgroups of a CU (delaying
+// bid+256) was measured too: the epilogue then competes with the other workgroup's MFMAs for issue slots and grows
+// 2-4x; net -3 % (K=512) to -4 % (K=256).
 // ---------------------------------------------------------------------------------------------------------
+#ifdef FS_TRACE
+// tools/probe_conv_trace.hip only (never in libfloodseg.so): per-workgroup timeline, 8 x u64 per workgroup:
+// [0] start, [1] first stage landed, [2] main loop done, [3] epilogue done (shader clock, s_memtime),
+// [4] cycles spent in the per-chunk wait+barrier, [5] HW_ID | XCC_ID << 32, [6] start (100 MHz wall clock), [7] end (wall)
+__device__ unsigned long long fs_trace_buf[8 * 65536];
+#define FS_TRACE_DECL unsigned long long tr_start = __builtin_readcyclecounter(), tr_wall = wall_clock64(), tr_ready = 0, tr_loop = 0, tr_wait = 0;
+#define FS_TRACE_SYNC() { const unsigned long long tw = __builtin_readcyclecounter(); __syncthreads(); tr_wait += __builtin_readcyclecounter() - tw; }
+#else
+#define FS_TRACE_DECL
+#define FS_TRACE_SYNC() __syncthreads();
+#endif
 // WGM x WGN waves per workgroup (2x2 = 256 threads, two workgroups per CU; 4x2 = 512 threads, one per CU).
 template <int BM, int BN, int WGM = 2, int WGN = 2>
 __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_dma_f32(ConvParams p, int tiles_m, int tiles_n) {
@@ -277,11 +300,17 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_dma_f32(ConvParams 
     constexpr int WM = BM / WGM, WN = BN / WGN;
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int RA = BM / RSTEP, RB = BN / RSTEP;
-    constexpr int PM = 8;
+    constexpr int PM = 8;  // m-tiles per raster panel (panels sized to the ~64 tiles co-resident on an XCD: same time, +3 % L2 misses)
     constexpr int STAGE = (BM + BN) * BK;
     __shared__ __attribute__((aligned(1024))) float lds[2 * STAGE];
+    FS_TRACE_DECL
 
     const int nblk = gridDim.x, bid = blockIdx.x;
+#ifdef FS_TRACE
+    // experiment: de-phase the workgroups that share a CU (dispatch order puts bid and bid + 256 on the same CU)
+    if ((p.dbg & 32) && ((bid >> 8) & 1))
+        for (int i = 0; i < (p.dbg >> 8); ++i) __builtin_amdgcn_s_sleep(16);  // 1024 cycles each
+#endif
     const int q = nblk >> 3, rr = nblk & 7, xcd = bid & 7;
     const int lid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (bid >> 3);
     const int per_group = tiles_m * tiles_n;
@@ -399,6 +428,9 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_dma_f32(ConvParams 
     FS_DMA_ALL(0)
     FS_DMA_ADVANCE()
     __syncthreads();  // s_waitcnt vmcnt(0) + s_barrier: stage 0 has landed for every wave
+#ifdef FS_TRACE
+    tr_ready = __builtin_readcyclecounter();
+#endif
     int cur = 0;
     for (int kc = 0; kc < nchunks; ++kc) {
         // The whole DMA of chunk kc+1 is issued up front and lands under the 64 MFMAs below.  (Spreading the eight
@@ -422,9 +454,12 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_dma_f32(ConvParams 
         FS_MMA(a0, b0)
         __builtin_amdgcn_sched_barrier(0);
         FS_MMA(a1, b1)
-        __syncthreads();  // own DMA landed (vmcnt(0)), then everyone's; stage `cur` is free for the next DMA
+        FS_TRACE_SYNC()  // __syncthreads: own DMA landed (vmcnt(0)), then everyone's; stage `cur` is free for the next DMA
         cur ^= 1;
     }
+#ifdef FS_TRACE
+    tr_loop = __builtin_readcyclecounter();
+#endif
 #undef FS_DMA_ROW
 #undef FS_DMA_ADVANCE
 #undef FS_DMA_ALL
@@ -464,6 +499,14 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_dma_f32(ConvParams 
             }
         }
     }
+#ifdef FS_TRACE
+    if (t == 0) {
+        unsigned long long* o = fs_trace_buf + 8 * (size_t)(bid & 65535);
+        o[0] = tr_start; o[1] = tr_ready; o[2] = tr_loop; o[3] = __builtin_readcyclecounter(); o[4] = tr_wait;
+        o[5] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
+        o[6] = tr_wall; o[7] = wall_clock64();
+    }
+#endif
 #endif
 }
 
