@@ -116,5 +116,7 @@ def colorize(masks_u8, palette=PALETTE):
     m = masks_u8.contiguous()
     pal = torch.as_tensor(palette, dtype=torch.uint8, device=m.device).contiguous()
     out = torch.empty(tuple(m.shape) + (3,), dtype=torch.uint8, device=m.device)
+    if m.numel() == 0:
+        return out
     check(lib.fs_colorize(ptr(m), ptr(pal), pal.shape[0], ptr(out), m.numel(), stream_ptr()))
     return out

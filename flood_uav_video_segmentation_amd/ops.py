@@ -48,6 +48,8 @@ def grid_sample(inp, grid, align_corners=False):
     if two != 2 or gb != b:
         raise RuntimeError(f"floodseg.grid_sample: grid shape {tuple(grid.shape)} does not match input batch {b}")
     grid = _f32c(grid, "grid")
+    if b == 0:  # empty batch: nothing to launch (torch returns an empty tensor too)
+        return torch.empty((0, c, hg, wg), dtype=torch.float32, device=inp.device)
     if inp.dim() == 4 and c % 4 == 0 and c >= 64 and is_channels_last_dense(inp):
         src = inp if inp.dtype == torch.float32 else inp.float()
         out = empty_nhwc(b, c, hg, wg, inp.device)
@@ -64,6 +66,9 @@ def resize_bilinear(inp, size, align_corners=True):
     lib = _lib.load()
     b, c, hi, wi = inp.shape
     ho, wo = int(size[0]), int(size[1])
+    if b == 0:
+        _f32c(inp, "input")
+        return torch.empty((0, c, ho, wo), dtype=torch.float32, device=inp.device)
     if c % 4 == 0 and c >= 64 and is_channels_last_dense(inp):
         src = inp if inp.dtype == torch.float32 else inp.float()
         out = empty_nhwc(b, c, ho, wo, inp.device)
@@ -87,6 +92,8 @@ def blend(a, wa, b=None, wb=0.0):
         a = a.contiguous()
     a = a if a.dtype == torch.float32 else a.float()
     out = torch.empty_like(a)
+    if a.numel() == 0:
+        return out
     check(lib.fs_blend(ptr(a), float(wa), ptr(b), float(wb), ptr(out), a.numel(), stream_ptr()))
     return out
 
@@ -140,6 +147,8 @@ def argmax_u8(logits):
     x = _f32c(logits)
     b, k, h, w = x.shape
     out = torch.empty((b, h, w), dtype=torch.uint8, device=x.device)
+    if b == 0:
+        return out
     check(lib.fs_argmax_u8(ptr(x), b, k, h * w, ptr(out), stream_ptr()))
     return out
 
@@ -150,6 +159,8 @@ def resize_argmax_u8(logits, size):
     x = _f32c(logits)
     b, k, h, w = x.shape
     out = torch.empty((b, int(size[0]), int(size[1])), dtype=torch.uint8, device=x.device)
+    if b == 0:
+        return out
     check(lib.fs_resize_argmax_u8(ptr(x), b, k, h, w, ptr(out), int(size[0]), int(size[1]), stream_ptr()))
     return out
 
@@ -163,6 +174,8 @@ def iou_hist(pred_u8, target_u8, classes, ignore_index=255, hist=None):
         raise RuntimeError("floodseg.iou_hist: uint8 tensors of equal shape required")
     if hist is None:
         hist = torch.zeros((3, classes), dtype=torch.int64, device=p.device)
+    if p.numel() == 0:
+        return hist
     check(lib.fs_iou_hist(ptr(p), ptr(t), p.numel(), classes, ignore_index, ptr(hist), stream_ptr()))
     return hist
 
