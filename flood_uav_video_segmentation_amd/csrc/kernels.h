@@ -156,7 +156,9 @@ int launch_dec_assemble(const float* Y, const float* cls_emb, float* Z, int B, i
 int launch_layernorm(const float* in, const float* gamma, const float* beta, float* out, int rows, int D, int rows_per_batch,
                      int drop_first, hipStream_t s);
 // softmax(q k^T * scale) v for all heads, fp32 MFMA flash-style; qkv rows are [3][heads][64] (blocks.py:56-77).
-int launch_attention_f32(const float* qkv, float* out, int B, int N, int heads, float scale, hipStream_t s);
+// scratch: attention_scratch_floats(B, N, heads) floats for the key-split partials (nullptr = single pass)
+size_t attention_scratch_floats(int B, int N, int heads);
+int launch_attention_f32(const float* qkv, float* out, int B, int N, int heads, float scale, float* scratch, hipStream_t s);
 // masks[b][k][i] = LayerNorm_K( <pp[b][i]/|pp|, cc[b][N+k]/|cc|> )  (segm/model/decoder.py:90-100), NCHW out
 int launch_mask_head(const float* pp, const float* cc, const float* gamma, const float* beta, float* out, int B, int N, int K,
                      int D, hipStream_t s);

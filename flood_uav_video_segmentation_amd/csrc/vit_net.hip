@@ -80,13 +80,14 @@ int run_norm(fs_net* h, const LNorm& n, const float* in, float* out, int rows, i
 }
 
 struct VitWs {
-    float *X, *Xn, *QKV, *A, *Hd, *patches, *emb;
+    float *X, *Xn, *QKV, *A, *Hd, *patches, *emb, *att;
 };
 
 int vit_workspace(fs_net* h, int B, int tokens, VitWs* ws) {
     const size_t D = (size_t)h->cfg.d_model, T = (size_t)B * tokens;
     const size_t P2 = (size_t)3 * h->cfg.patch * h->cfg.patch;
-    const size_t need = T * D * 3 + T * 3 * D + T * 4 * D + T * P2 + T * D + 64;
+    const size_t att = attention_scratch_floats(B, tokens, (int)(D / 64));
+    const size_t need = T * D * 3 + T * 3 * D + T * 4 * D + T * P2 + T * D + att + 64;
     if (need > h->vit_ws_elems) {
         FS_HIP(hipDeviceSynchronize());
         if (h->vit_ws) FS_HIP(hipFree(h->vit_ws));
@@ -101,7 +102,8 @@ int vit_workspace(fs_net* h, int B, int tokens, VitWs* ws) {
     ws->QKV = p; p += T * 3 * D;
     ws->Hd = p; p += T * 4 * D;
     ws->patches = p; p += T * P2;
-    ws->emb = p;
+    ws->emb = p; p += T * D;
+    ws->att = att ? p : nullptr;
     return 0;
 }
 
@@ -112,7 +114,7 @@ int run_block(fs_net* h, const VitBlock& blk, const VitWs& ws, int B, int tokens
     FS_TRY(run_linear(h, blk.qkv, ws.Xn, rows, ws.QKV, nullptr, 0, s));
     const double aflops = 4.0 * B * heads * (double)tokens * tokens * 64;
     FS_TRY(prof_begin(h, blk.qkv.name + ".attention", "attention_f32", aflops, 4.0 * rows * 4.0 * D, s));
-    FS_TRY(launch_attention_f32(ws.QKV, ws.A, B, tokens, heads, 0.125f, s));
+    FS_TRY(launch_attention_f32(ws.QKV, ws.A, B, tokens, heads, 0.125f, ws.att, s));
     FS_TRY(prof_end(h, s));
     FS_TRY(run_linear(h, blk.proj, ws.A, rows, ws.X, ws.X, 0, s));          // x = x + proj(attn)
     FS_TRY(run_norm(h, blk.n2, ws.X, ws.Xn, rows, tokens, 0, s));

@@ -153,8 +153,14 @@ constexpr int ATT_LDK = 68;
 constexpr int ATT_NW = 4;    // waves per workgroup = 128 queries per staged K/V tile.  Measured on ViT-S/16 (N = 1937): 2 waves
                              // (64 queries, 4 workgroups/CU) 36 TFLOP/s -- the K/V staging per query doubles; 4 waves 52+
 
-__global__ __launch_bounds__(64 * ATT_NW) void attention_f32_kernel(const float* __restrict__ qkv, float* __restrict__ out, int N,
-                                                                     int heads, float scale) {
+// Key split (flash-decoding style): ViT-S/16 at 713x713 has 16 query tiles x 6 heads x 2 frames = 192 workgroups for 256
+// CUs, one wave per SIMD, so the softmax VALU work of a wave is never hidden behind another wave's MFMAs.  With
+// nsplit > 1 workgroup (query tile, split) walks only its share of the key tiles and stores the UNNORMALISED O^T plus
+// (running max, running sum) per query; attention_combine_kernel merges the splits.  nsplit == 1 writes `out` directly.
+template <bool SPLIT>
+__global__ __launch_bounds__(64 * ATT_NW) void attention_f32_kernel(const float* __restrict__ qkv, float* __restrict__ out,
+                                                                     float* __restrict__ part_o, float* __restrict__ part_ml, int N,
+                                                                     int heads, float scale, int nsplit) {
     __shared__ __attribute__((aligned(16))) float Ks[ATT_KT * ATT_LDK];
     __shared__ __attribute__((aligned(16))) float Vs[ATT_KT * ATT_DH];
     constexpr int NT = 64 * ATT_NW;
@@ -163,11 +169,15 @@ __global__ __launch_bounds__(64 * ATT_NW) void attention_f32_kernel(const float*
     const int b = blockIdx.z, head = blockIdx.y;
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     const int l31 = lane & 31, hh = lane >> 5;
-    const int q = blockIdx.x * (32 * ATT_NW) + wv * 32 + l31;
+    const int qtiles = SPLIT ? gridDim.x / nsplit : gridDim.x;
+    const int qt = SPLIT ? blockIdx.x % qtiles : blockIdx.x, split = SPLIT ? blockIdx.x / qtiles : 0;
+    const int q = qt * (32 * ATT_NW) + wv * 32 + l31;
     const int qc = min(q, N - 1);
     const float* base = qkv + (size_t)b * N * ld + head * ATT_DH;
 
-    // this lane's query row, dims 32*hh .. 32*hh+31, pre-scaled (scale is a power of two for dh = 64)
+    // this lane's query row, dims 32*hh .. 32*hh+31, pre-scaled by scale * log2(e): the softmax then runs on v_exp_f32
+    // (2^x, 1 ulp) directly -- exp(s - m) == 2^(s' - m') with s' = s * log2(e)
+    const float scale2 = scale * 1.44269504088896340736f;
     float qreg[32];
     {
         const f32x4* qp = reinterpret_cast<const f32x4*>(base + (size_t)qc * ld + 32 * hh);
@@ -175,7 +185,7 @@ __global__ __launch_bounds__(64 * ATT_NW) void attention_f32_kernel(const float*
         for (int u = 0; u < 8; ++u) {
             const f32x4 v = qp[u];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) qreg[4 * u + e] = v[e] * scale;
+            for (int e = 0; e < 4; ++e) qreg[4 * u + e] = v[e] * scale2;
         }
     }
     f32x16 acc_o[2];
@@ -185,7 +195,9 @@ __global__ __launch_bounds__(64 * ATT_NW) void attention_f32_kernel(const float*
         for (int e = 0; e < 16; ++e) acc_o[i][e] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;
 
-    const int ntiles = (N + ATT_KT - 1) / ATT_KT;
+    const int ntiles_all = (N + ATT_KT - 1) / ATT_KT;
+    const int kt0 = SPLIT ? (ntiles_all * split) / nsplit : 0;             // launcher: nsplit <= ntiles_all, so never empty
+    const int ntiles = SPLIT ? (ntiles_all * (split + 1)) / nsplit : ntiles_all;
     f32x4 kreg[LPT], vreg[LPT];  // next K/V tile, in flight while the current one is multiplied
     auto fetch = [&](int kt) {
 #pragma unroll
@@ -198,8 +210,8 @@ __global__ __launch_bounds__(64 * ATT_NW) void attention_f32_kernel(const float*
             vreg[j] = *reinterpret_cast<const f32x4*>(rp + 2 * D);
         }
     };
-    fetch(0);
-    for (int kt = 0; kt < ntiles; ++kt) {
+    fetch(kt0);
+    for (int kt = kt0; kt < ntiles; ++kt) {
         __syncthreads();  // previous tile fully consumed
 #pragma unroll
         for (int j = 0; j < LPT; ++j) {
@@ -227,28 +239,31 @@ __global__ __launch_bounds__(64 * ATT_NW) void attention_f32_kernel(const float*
                 for (int e = 0; e < 4; ++e) sT = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[e], qreg[4 * u + e], sT, 0, 0, 0);
             }
             // mask keys beyond N, running max over this lane's 16 keys and the other half's 16
-            float mloc = -INFINITY;
+            if (key0 + 32 > N) {  // block-uniform: only the last block has keys to mask
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = key0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-                if (key >= N) sT[r] = -INFINITY;
-                mloc = fmaxf(mloc, sT[r]);
+                for (int r = 0; r < 16; ++r)
+                    if (key0 + (r & 3) + 8 * (r >> 2) + 4 * hh >= N) sT[r] = -INFINITY;
             }
+            float mloc = sT[0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) mloc = fmaxf(mloc, sT[r]);
             mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
-            const float m_new = fmaxf(m_run, mloc);           // finite: key0 < N guarantees one valid key
-            const float alpha = expf(m_run - m_new);          // exp(-inf) = 0 on the first block
+            const float m_new = fmaxf(m_run, mloc);                        // finite: key0 < N guarantees one valid key
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);     // 2^(-inf) = 0 on the first block
             float lsum = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                sT[r] = expf(sT[r] - m_new);
+                sT[r] = __builtin_amdgcn_exp2f(sT[r] - m_new);
                 lsum += sT[r];
             }
             l_run = l_run * alpha + lsum;
             m_run = m_new;
+            if (__any(alpha != 1.f)) {  // the running max settles after a few blocks: skip the 32 rescaling multiplies then
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) acc_o[i][e] *= alpha;
+                    for (int e = 0; e < 16; ++e) acc_o[i][e] *= alpha;
+            }
             // O^T += V^T P^T
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -261,6 +276,26 @@ __global__ __launch_bounds__(64 * ATT_NW) void attention_f32_kernel(const float*
         }
     }
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    if (SPLIT) {
+        if (q < N) {
+            const size_t row = ((size_t)(b * heads + head) * nsplit + split) * N + q;
+            float* op = part_o + row * ATT_DH;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = acc_o[i][4 * g + e];
+                    *reinterpret_cast<f32x4*>(op + i * 32 + 8 * g + 4 * hh) = v;
+                }
+            if (hh == 0) {
+                part_ml[2 * row] = m_run;
+                part_ml[2 * row + 1] = l_tot;
+            }
+        }
+        return;
+    }
     const float inv = 1.f / l_tot;
     if (q < N) {
         float* op = out + ((size_t)b * N + q) * D + head * ATT_DH;
@@ -276,9 +311,66 @@ __global__ __launch_bounds__(64 * ATT_NW) void attention_f32_kernel(const float*
     }
 }
 
-int launch_attention_f32(const float* qkv, float* out, int B, int N, int heads, float scale, hipStream_t s) {
+// merge the key splits of one query: O = sum_s e^(m_s - M) O_s / sum_s e^(m_s - M) l_s ; thread = (query row, float4 of dh)
+__global__ __launch_bounds__(256) void attention_combine_kernel(const float* __restrict__ part_o, const float* __restrict__ part_ml,
+                                                                float* __restrict__ out, int B, int N, int heads, int nsplit) {
+    const int64_t total = (int64_t)B * heads * N * 16;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int c4 = (int)(i & 15);
+    const int64_t r = i >> 4;
+    const int q = (int)(r % N);
+    const int bh = (int)(r / N);
+    float M = -INFINITY;
+    for (int sp = 0; sp < nsplit; ++sp) M = fmaxf(M, part_ml[2 * (((size_t)bh * nsplit + sp) * N + q)]);
+    float L = 0.f;
+    f32x4 o = {0.f, 0.f, 0.f, 0.f};
+    for (int sp = 0; sp < nsplit; ++sp) {
+        const size_t row = ((size_t)bh * nsplit + sp) * N + q;
+        const float w = __builtin_amdgcn_exp2f(part_ml[2 * row] - M);   // the partial maxima are in log2 units (see the kernel)
+        L += w * part_ml[2 * row + 1];
+        const f32x4 v = *reinterpret_cast<const f32x4*>(part_o + row * ATT_DH + c4 * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] += w * v[e];
+    }
+    const float inv = 1.f / L;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] *= inv;
+    const int b = bh / heads, head = bh - b * heads;
+    *reinterpret_cast<f32x4*>(out + ((size_t)b * N + q) * (heads * ATT_DH) + head * ATT_DH + c4 * 4) = o;
+}
+
+int attention_splits(int B, int N, int heads) {
+    // aim at ~3 workgroups per CU (256 CUs): their waves share a SIMD, so one's softmax overlaps another's MFMAs
+    const int units = cdiv(N, 32 * ATT_NW) * heads * B;
+    const int ntiles = cdiv(N, ATT_KT);
+    int ns = (768 + units / 2) / units;
+    ns = std::min(ns, std::min(4, ntiles / 2));
+    return std::max(ns, 1);
+}
+
+size_t attention_scratch_floats(int B, int N, int heads) {
+    const int ns = attention_splits(B, N, heads);
+    return ns > 1 ? (size_t)B * heads * ns * N * (ATT_DH + 2) : 0;
+}
+
+int launch_attention_f32(const float* qkv, float* out, int B, int N, int heads, float scale, float* scratch, hipStream_t s) {
     FS_REQUIRE(B >= 1 && N >= 1 && heads >= 1, "attention: bad shape");
-    hipLaunchKernelGGL(attention_f32_kernel, dim3(cdiv(N, 32 * ATT_NW), heads, B), dim3(64 * ATT_NW), 0, s, qkv, out, N, heads, scale);
+    const int qtiles = cdiv(N, 32 * ATT_NW);
+    const int ns = scratch ? attention_splits(B, N, heads) : 1;
+    if (ns == 1) {
+        hipLaunchKernelGGL(attention_f32_kernel<false>, dim3(qtiles, heads, B), dim3(64 * ATT_NW), 0, s, qkv, out, nullptr, nullptr, N, heads,
+                           scale, 1);
+        FS_HIP(hipGetLastError());
+        return 0;
+    }
+    float* part_o = scratch;
+    float* part_ml = scratch + (size_t)B * heads * ns * N * ATT_DH;
+    hipLaunchKernelGGL(attention_f32_kernel<true>, dim3(qtiles * ns, heads, B), dim3(64 * ATT_NW), 0, s, qkv, out, part_o, part_ml, N, heads,
+                       scale, ns);
+    FS_HIP(hipGetLastError());
+    const int64_t total = (int64_t)B * heads * N * 16;
+    hipLaunchKernelGGL(attention_combine_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, s, part_o, part_ml, out, B, N, heads, ns);
     FS_HIP(hipGetLastError());
     return 0;
 }
