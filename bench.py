@@ -215,8 +215,8 @@ def main():
             prev, nxt = windows[i % 4]
             lo_prev = cache.get("lo")
             if lo_prev is None or i % 4 == 0:
-                lo_prev = net.decoder(net.encoder(prev))
-            lo_next = net.decoder(net.encoder(nxt))
+                lo_prev = net.segment(prev)
+            lo_next = net.segment(nxt)
             _, mask = ops.seg_tail(lo_prev, lo_next, dl, dr, N_DELTA, (SIZE, SIZE), True, want_logits=False, want_mask=True)
             cache["lo"] = lo_next
             host_masks.copy_(mask, non_blocking=True)

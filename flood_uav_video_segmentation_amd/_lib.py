@@ -40,6 +40,7 @@ _SIGNATURES = {
     "fs_workspace_bytes": (ctypes.c_size_t, [c_void, c_int, c_int, c_int]),
     "fs_encoder_forward": (c_int, [c_void, c_void, c_int, c_int, c_int, c_void, c_void]),
     "fs_decoder_forward": (c_int, [c_void, c_void, c_int, c_int, c_int, c_void, c_void]),
+    "fs_segment_forward": (c_int, [c_void, c_void, c_int, c_int, c_int, c_void, c_void]),
     "fs_profile_enable": (c_int, [c_void, c_int]),
     "fs_profile_dump": (c_int, [c_void, ctypes.c_char_p, ctypes.c_size_t]),
     "fs_grid_sample_nchw": (c_int, [c_void, c_int, c_int, c_int, c_int, c_void, c_int, c_int, c_void, c_int, c_void]),

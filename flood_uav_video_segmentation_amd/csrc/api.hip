@@ -25,6 +25,9 @@ FS_API int fs_encoder_forward(fs_handle h, const float* in_nchw, int B, int H, i
 FS_API int fs_decoder_forward(fs_handle h, const float* feat_nhwc, int B, int fh, int fw, float* out_nchw, fs_stream stream) {
     return fs::net_decoder(h, feat_nhwc, B, fh, fw, out_nchw, S(stream));
 }
+FS_API int fs_segment_forward(fs_handle h, const float* in_nchw, int B, int H, int W, float* out_nchw, fs_stream stream) {
+    return fs::net_segment(h, in_nchw, B, H, W, out_nchw, S(stream));
+}
 FS_API int fs_profile_enable(fs_handle h, int on) {
     if (!h) return fs::fail("fs_profile_enable: null handle");
     h->profiling = on != 0;

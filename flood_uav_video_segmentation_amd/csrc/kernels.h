@@ -81,6 +81,11 @@ int launch_pack_oihw_to_hwio(const float* w, float* out, int O, int I, int KH, i
 // [O][I/32][KH][KW][32]: the taps of one 32-channel slab are consecutive along k (ConvParams::korder == 1), so the
 // pixel lines a 3x3 conv re-reads for its 9 taps are touched back to back and hit in L2.
 int launch_pack_oihw_chunk_major(const float* w, float* out, int O, int I, int KH, int KW, hipStream_t s);
+// out[(tap*O + o)*nc + c] = w[o][c0 + c][tap]: input-channel slice of an OIHW bank as a [taps*O][nc] 1x1 filter matrix
+int launch_pack_slice_tap_major(const float* w, float* out, int O, int I, int c0, int nc, int taps, hipStream_t s);
+// T = act(scale * (T + sum_b conv-of-upsampled-pyramid term from Z_b) + shift), see net_ops.hip (PSPNet head)
+int launch_ppm_term_finish(float* T, int ld, const float* const Z[4], const int bins[4], const float* scale, const float* shift, int B,
+                           int H, int W, int C, int relu, hipStream_t s);
 int launch_nchw_to_nhwc(const float* in, float* out, int ld_out, int B, int C, int HW, hipStream_t s);
 int launch_nhwc_to_nchw(const float* in, int ld_in, float* out, int B, int C, int HW, hipStream_t s);
 

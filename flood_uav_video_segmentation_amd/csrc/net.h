@@ -78,6 +78,12 @@ struct fs_net {
     fs::ConvBN ppm[4];
     int bins[4] = {1, 2, 3, 6};
     fs::ConvBN cls_conv;  // 3x3 4096->512
+    // fused encoder+decoder route (fs_segment_forward): the head conv over the 2048 backbone channels only, and the
+    // [9*512][512] filter matrices that take the pooled pyramid maps straight to their share of the head conv (net_ops.hip)
+    fs::ConvBN cls_main;
+    fs::ConvBN ppm_z[4];
+    float* seg_feat = nullptr;  // internal feature map for fs_segment_forward on the heads without a fused route
+    size_t seg_feat_elems = 0;
     float* cls_w = nullptr;  // [K][512]
     float* cls_b = nullptr;
     // DeepLabv3 head
@@ -102,6 +108,7 @@ struct fs_net {
     float* wino_ws = nullptr;  // V [36][T][Cin] followed by M [36][T][Cout]
     size_t wino_ws_elems = 0;
     bool use_winograd = true;  // FS_NO_WINOGRAD=1 in the environment selects the direct conv everywhere
+    bool use_fused_head = true;  // FS_NO_FUSED_HEAD=1: fs_segment_forward runs encoder + decoder over the 4096-channel concat (A/B)
 
     // workspace
     float* buf[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -128,6 +135,7 @@ int net_finalize(fs_handle h, hipStream_t s);
 int net_feature_shape(fs_handle h, int H, int W, int* C, int* fh, int* fw);
 size_t net_workspace_bytes(fs_handle h, int B, int H, int W);
 int net_encoder(fs_handle h, const float* in_nchw, int B, int H, int W, float* out_nhwc, hipStream_t s);
+int net_segment(fs_handle h, const float* in_nchw, int B, int H, int W, float* out_nchw, hipStream_t s);
 int net_decoder(fs_handle h, const float* feat, int B, int fh, int fw, float* out_nchw, hipStream_t s);
 int net_profile_dump(fs_handle h, char* buf, size_t n);
 

@@ -257,7 +257,7 @@ size_t encoder_buf_elems(const fs_net* h, int B, int H, int W) {
     return std::max(a, std::max(b, c));
 }
 
-size_t small_elems_for(int B) { return (size_t)B * 50 * (2048 + 512) + 1024; }
+size_t small_elems_for(int B) { return (size_t)B * 50 * (2048 + 512 + 9 * 512) + 1024; }  // pooled, reduced, Z (fused head)
 
 }  // namespace
 
@@ -273,6 +273,8 @@ int net_create(const fs_config* cfg, fs_handle* out) {
     h->cfg = *cfg;
     const char* nw = getenv("FS_NO_WINOGRAD");
     h->use_winograd = !(nw && nw[0] == '1');
+    const char* nf = getenv("FS_NO_FUSED_HEAD");
+    h->use_fused_head = !(nf && nf[0] == '1');
     h->deep_stem = cfg->arch == FS_ARCH_PSPNET;
     *out = h;
     return 0;
@@ -288,6 +290,7 @@ int net_destroy(fs_handle h) {
         if (h->buf[i]) (void)hipFree(h->buf[i]);
     if (h->small) (void)hipFree(h->small);
     if (h->vit_ws) (void)hipFree(h->vit_ws);
+    if (h->seg_feat) (void)hipFree(h->seg_feat);
     if (h->wino_ws) (void)hipFree(h->wino_ws);
     if (h->pos_cur) (void)hipFree(h->pos_cur);
     for (auto& r : h->prof) {
@@ -385,6 +388,35 @@ int net_finalize(fs_handle h, hipStream_t s) {
         FS_TRY(make_conv(h, h->cls_conv, "decoder.0.weight", "decoder.1", "", 1, 1, 1, 1, false, s));
         FS_REQUIRE(h->cls_conv.Cin == 4096, "decoder.0 must take 4096 channels");
         h->cls_cin = h->cls_conv.Cout;
+        {   // fused route: backbone half of the head conv (own packed filters, BatchNorm shared) + pyramid filter matrices
+            const RawTensor* w;
+            FS_TRY(fetch(h, "decoder.0.weight", &w));
+            const int O = h->cls_conv.Cout;
+            ConvBN& m = h->cls_main;
+            m = h->cls_conv;
+            m.name = "decoder.0.weight[:, :2048]";
+            m.Cin = 2048;
+            m.w = m.wino_U = nullptr;
+            float* sl = nullptr;  // OIHW slice [O][2048][3][3]
+            FS_HIP(hipMalloc(reinterpret_cast<void**>(&sl), (size_t)O * 2048 * 9 * sizeof(float)));
+            FS_HIP(hipMemcpy2DAsync(sl, (size_t)2048 * 9 * sizeof(float), w->d, (size_t)4096 * 9 * sizeof(float),
+                                    (size_t)2048 * 9 * sizeof(float), (size_t)O, hipMemcpyDeviceToDevice, s));
+            FS_TRY(dev_alloc(h, &m.w, (size_t)O * 2048 * 9));
+            m.korder = 1;
+            FS_TRY(launch_pack_oihw_chunk_major(sl, m.w, O, 2048, 3, 3, s));
+            FS_TRY(dev_alloc(h, &m.wino_U, (size_t)36 * O * 2048));
+            FS_TRY(launch_winograd_filter(sl, m.wino_U, O, 2048, s));
+            FS_HIP(hipStreamSynchronize(s));
+            FS_HIP(hipFree(sl));
+            for (int i = 0; i < 4; ++i) {
+                ConvBN& z = h->ppm_z[i];
+                z.name = "decoder.0.weight[:, ppm" + std::to_string(h->bins[i]) + "]";
+                z.Cin = 512;
+                z.Cout = 9 * O;
+                FS_TRY(dev_alloc(h, &z.w, (size_t)9 * O * 512));
+                FS_TRY(launch_pack_slice_tap_major(w->d, z.w, O, 4096, 2048 + 512 * i, 512, 9, s));
+            }
+        }
         const RawTensor *w, *b;
         FS_TRY(fetch(h, "decoder.4.weight", &w));
         FS_TRY(fetch(h, "decoder.4.bias", &b));
@@ -445,10 +477,12 @@ size_t net_workspace_bytes(fs_handle h, int B, int H, int W) {
 }
 
 // ---------------------------------------------------------------------------------------------
-int net_encoder(fs_handle h, const float* in_nchw, int B, int H, int W, float* out, hipStream_t s) {
-    FS_REQUIRE(h && h->finalized, "fs_encoder_forward: network not finalized");
-    if (h->cfg.arch == FS_ARCH_SEGMENTER) return vit_encoder(h, in_nchw, B, H, W, out, s);
-    FS_REQUIRE(in_nchw && out && B >= 1 && H >= 33 && W >= 33, "fs_encoder_forward: bad arguments (B=%d H=%d W=%d)", B, H, W);
+namespace {
+// ResNet backbone (+ pyramid pooling for PSPNet).  out != nullptr: the reference's encoder output (PSPNet: 4096-channel
+// concat with the upsampled pyramid; ld_out = feat_channels()).  out == nullptr (fused PSPNet route): the 2048 backbone
+// channels stay in a workspace buffer (*feat2048, ld 2048) and the pyramid stops at the pooled+reduced maps in h->small.
+int encoder_core(fs_handle h, const float* in_nchw, int B, int H, int W, float* out, float** feat2048, hipStream_t s) {
+    const bool fused = out == nullptr;
     const Geometry g = geometry(h, H, W);
     FS_TRY(ensure_workspace(h, encoder_buf_elems(h, B, H, W), small_elems_for(B)));
     const bool psp = h->cfg.arch == FS_ARCH_PSPNET;
@@ -502,8 +536,8 @@ int net_encoder(fs_handle h, const float* in_nchw, int B, int H, int W, float* o
         FS_TRY(run_conv(h, blk.c1, X, C, B, curH, curW, F1, blk.c1.Cout, nullptr, 0, s));
         FS_TRY(run_conv(h, blk.c2, F1, blk.c1.Cout, B, curH, curW, F2, blk.c2.Cout, nullptr, 0, s));
         const int Cn = blk.c3.Cout;
-        float* dst = last ? out : nullptr;
-        const int ld_dst = last ? h->feat_channels() : Cn;
+        float* dst = last ? (fused ? F1 : out) : nullptr;  // F1 (conv1's output) is free again once conv2 has run
+        const int ld_dst = last && !fused ? h->feat_channels() : Cn;
         ConvBN c3 = blk.c3;
         c3.relu = 1;  // ReLU after the residual add (model/resnet.py:93-94)
         if (blk.has_ds) {
@@ -520,7 +554,12 @@ int net_encoder(fs_handle h, const float* in_nchw, int B, int H, int W, float* o
         curW = oW;
     }
     FS_REQUIRE(curH == g.H3 && curW == g.W3 && C == 2048, "encoder geometry mismatch");
+    if (fused) {
+        *feat2048 = F1;
+        out = F1;
+    }
     if (!psp) return 0;
+    const int ld_feat = fused ? 2048 : 4096;
 
     // ---- pyramid pooling: pooled -> 1x1 conv + BN + ReLU -> bilinear(ac=True) into channels 2048+512*i
     float* pooled = h->small;
@@ -539,7 +578,7 @@ int net_encoder(fs_handle h, const float* in_nchw, int B, int H, int W, float* o
     const bool even = curH % 6 == 0 && curW % 6 == 0 && h->bins[0] == 1 && h->bins[1] == 2 && h->bins[2] == 3 && h->bins[3] == 6;
     if (even) {  // one pass over the 2048-channel map instead of four
         FS_TRY(prof_begin(h, "ppm.pool6+combine", "adaptive_avgpool", 0, 4.0 * B * curH * curW * 2048.0, s));
-        FS_TRY(launch_adaptive_avgpool(out, 4096, pooled + pool_off[3], B, curH, curW, 2048, 6, s));
+        FS_TRY(launch_adaptive_avgpool(out, ld_feat, pooled + pool_off[3], B, curH, curW, 2048, 6, s));
         FS_TRY(launch_ppm_pool_combine(pooled + pool_off[3], pooled + pool_off[0], pooled + pool_off[1], pooled + pool_off[2], B, 2048, s));
         FS_TRY(prof_end(h, s));
     }
@@ -548,18 +587,86 @@ int net_encoder(fs_handle h, const float* in_nchw, int B, int H, int W, float* o
         const int cells = bin * bin;
         if (!even) {
             FS_TRY(prof_begin(h, "ppm.pool" + std::to_string(bin), "adaptive_avgpool", 0, 4.0 * B * curH * curW * 2048.0, s));
-            FS_TRY(launch_adaptive_avgpool(out, 4096, pooled + pool_off[i], B, curH, curW, 2048, bin, s));
+            FS_TRY(launch_adaptive_avgpool(out, ld_feat, pooled + pool_off[i], B, curH, curW, 2048, bin, s));
             FS_TRY(prof_end(h, s));
         }
         const ConvBN& c = h->ppm[i];
         FS_TRY(prof_begin(h, c.name, "rowdot_1x1", 2.0 * B * cells * 2048.0 * 512.0, 4.0 * 2048.0 * 512.0, s));
         FS_TRY(launch_rowdot_1x1(pooled + pool_off[i], 2048, c.w, c.scale, c.shift, reduced + red_off[i], 512, B * cells, 2048, 512, 1, s));
         FS_TRY(prof_end(h, s));
+        if (fused) continue;  // the head consumes the reduced maps directly (net_segment)
         FS_TRY(prof_begin(h, "ppm.up" + std::to_string(bin), "upsample_into", 0, 4.0 * B * curH * curW * 512.0, s));
         FS_TRY(launch_upsample_into(reduced + red_off[i], bin, bin, out + 2048 + 512 * i, 4096, B, curH, curW, 512, 1, s));
         FS_TRY(prof_end(h, s));
     }
     return 0;
+}
+}  // namespace
+
+int net_encoder(fs_handle h, const float* in_nchw, int B, int H, int W, float* out, hipStream_t s) {
+    FS_REQUIRE(h && h->finalized, "fs_encoder_forward: network not finalized");
+    if (h->cfg.arch == FS_ARCH_SEGMENTER) return vit_encoder(h, in_nchw, B, H, W, out, s);
+    FS_REQUIRE(in_nchw && out && B >= 1 && H >= 33 && W >= 33, "fs_encoder_forward: bad arguments (B=%d H=%d W=%d)", B, H, W);
+    return encoder_core(h, in_nchw, B, H, W, out, nullptr, s);
+}
+
+// decoder(encoder(x)) in one call (flow/model.py:39-40, 189-191, 202-204; single-frame inference).  PSPNet takes the
+// fused route (no 4096-channel concat, see net_ops.hip); the other heads run encoder + decoder over an internal feature map.
+int net_segment(fs_handle h, const float* in_nchw, int B, int H, int W, float* out_nchw, hipStream_t s) {
+    FS_REQUIRE(h && h->finalized, "fs_segment_forward: network not finalized");
+    FS_REQUIRE(in_nchw && out_nchw && B >= 1 && H >= 1 && W >= 1, "fs_segment_forward: bad arguments (B=%d H=%d W=%d)", B, H, W);
+    int C = 0, fh = 0, fw = 0;
+    if (h->cfg.arch != FS_ARCH_PSPNET || !h->use_fused_head) {
+        FS_TRY(net_feature_shape(h, H, W, &C, &fh, &fw));
+        const size_t need = h->cfg.arch == FS_ARCH_SEGMENTER ? (size_t)B * (fh * fw + 1) * C : (size_t)B * fh * fw * C;
+        if (need > h->seg_feat_elems) {
+            FS_HIP(hipDeviceSynchronize());
+            if (h->seg_feat) FS_HIP(hipFree(h->seg_feat));
+            h->seg_feat = nullptr;
+            FS_HIP(hipMalloc(reinterpret_cast<void**>(&h->seg_feat), need * sizeof(float)));
+            h->seg_feat_elems = need;
+        }
+        FS_TRY(net_encoder(h, in_nchw, B, H, W, h->seg_feat, s));
+        return net_decoder(h, h->seg_feat, B, fh, fw, out_nchw, s);
+    }
+    FS_REQUIRE(H >= 33 && W >= 33, "fs_segment_forward: bad arguments (B=%d H=%d W=%d)", B, H, W);
+    const Geometry g = geometry(h, H, W);
+    fh = g.H3;
+    fw = g.W3;
+    FS_TRY(ensure_workspace(h, encoder_buf_elems(h, B, H, W), small_elems_for(B)));
+    float* feat = nullptr;
+    FS_TRY(encoder_core(h, in_nchw, B, H, W, nullptr, &feat, s));
+    // free workspace buffers now: every h->buf[] except `feat`
+    float* T = nullptr;
+    for (int i = 0; i < 4; ++i)
+        if (h->buf[i] != feat) T = h->buf[i];
+    const int K = h->cfg.classes, O = h->cls_main.Cout;
+    const size_t px = (size_t)B * fh * fw;
+    // Z_b = reduced_b x W_b: [B*bin*bin] x [9*O]
+    float* reduced = h->small + (size_t)B * 50 * 2048;
+    float* zbuf = reduced + (size_t)B * 50 * 512;
+    const float* Z[4];
+    {
+        size_t ro = 0, zo = 0;
+        for (int i = 0; i < 4; ++i) {
+            const int rows = B * h->bins[i] * h->bins[i];
+            const ConvBN& z = h->ppm_z[i];
+            FS_TRY(run_conv(h, z, reduced + ro, 512, 1, rows, 1, zbuf + zo, z.Cout, nullptr, 0, s));
+            Z[i] = zbuf + zo;
+            ro += (size_t)rows * 512;
+            zo += (size_t)rows * z.Cout;
+        }
+    }
+    ConvBN raw = h->cls_main;  // raw sums: BatchNorm + ReLU are applied after the pyramid term has been added
+    raw.scale = raw.shift = nullptr;
+    raw.relu = 0;
+    FS_TRY(run_conv(h, raw, feat, 2048, B, fh, fw, T, O, nullptr, 0, s));
+    FS_TRY(prof_begin(h, "decoder.0.pyramid_term", "ppm_term_finish", 2.0 * px * O * 144.0, 4.0 * 2.0 * px * O, s));
+    FS_TRY(launch_ppm_term_finish(T, O, Z, h->bins, h->cls_main.scale, h->cls_main.shift, B, fh, fw, O, 1, s));
+    FS_TRY(prof_end(h, s));
+    FS_TRY(prof_begin(h, "decoder.4", "classifier_nchw", 2.0 * px * (double)O * K, 4.0 * px * O, s));
+    FS_TRY(launch_classifier_nchw(T, O, h->cls_w, h->cls_b, out_nchw, B, fh * fw, O, K, s));
+    return prof_end(h, s);
 }
 
 // ---------------------------------------------------------------------------------------------

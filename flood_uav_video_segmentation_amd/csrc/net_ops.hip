@@ -384,6 +384,129 @@ int launch_pack_oihw_to_hwio(const float* w, float* out, int O, int I, int KH, i
     return 0;
 }
 
+// Slice of the input channels of an OIHW filter bank, tap-major: out[(tap*O + o)*nc + c] = w[o][c0 + c][tap].
+__global__ __launch_bounds__(256) void pack_slice_tap_major_kernel(const float* __restrict__ w, float* __restrict__ out, int O, int I,
+                                                                   int c0, int nc, int taps) {
+    const int64_t total = (int64_t)taps * O * nc;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i % nc);
+        const int o = (int)((i / nc) % O);
+        const int tap = (int)(i / ((int64_t)nc * O));
+        out[i] = w[((size_t)o * I + c0 + c) * taps + tap];
+    }
+}
+int launch_pack_slice_tap_major(const float* w, float* out, int O, int I, int c0, int nc, int taps, hipStream_t s) {
+    FS_REQUIRE(c0 >= 0 && nc >= 1 && c0 + nc <= I, "pack(slice): channel range outside the filter bank");
+    const int64_t total = (int64_t)taps * O * nc;
+    hipLaunchKernelGGL(pack_slice_tap_major_kernel, dim3((unsigned)std::min<int64_t>(cdiv64(total, 256), 65535)), dim3(256), 0, s, w, out, O,
+                       I, c0, nc, taps);
+    FS_HIP(hipGetLastError());
+    return 0;
+}
+
+// -------------------------------------------------------------------------------------------
+// PSPNet head without the upsampled pyramid channels (model/pspnet.py:28-34, 70-73).
+// The head's 3x3 conv is linear and so is the bilinear upsample of the four pooled maps p_b (b x b cells):
+//   conv3x3(cat(f, up(p_1), up(p_2), up(p_3), up(p_6)))[y,x,o]
+//     = conv3x3_f(f)[y,x,o] + sum_b sum_tap [tap inside the map] sum_cell a_b(y + r - 1, x + s - 1; cell) * Z_b[cell][tap][o]
+//   with Z_b[cell][tap][o] = sum_c W[o][2048 + 512 i_b + c][tap] * p_b[c][cell]   (a [B b^2] x [9*512] x 512 GEMM)
+// and a_b the bilinear (align_corners=True) weights of F.interpolate.  This kernel adds the second term to the raw main
+// conv output and applies BatchNorm scale/shift + ReLU in place.  The 2048 pyramid channels of the reference's 4096-
+// channel concat never exist: half of the head's GEMM and of its Winograd input transform disappear.
+// One block = PPM_P consecutive pixels of a row x all C channels (a float4 per thread): every Z row is loaded once per
+// block and reused for the pixels that touch the same cell; the coordinate math is block-uniform (scalar unit).
+// -------------------------------------------------------------------------------------------
+constexpr int PPM_P = 6;
+struct PpmTermParams {
+    float* T; int ld;        // [B*H*W][ld]: raw conv output in, finished activations out
+    const float* Z[4];       // [B*bin*bin][9*C]
+    int bin[4];
+    float sy[4], sx[4];      // resize_scale(bin, H, 1), resize_scale(bin, W, 1)
+    const float* scale; const float* shift;
+    int B, H, W, C, relu;
+};
+
+__device__ __forceinline__ float lin_weight(const LinCoord& c, int i) { return (i == c.i0 ? c.w0 : 0.f) + (i == c.i1 ? c.w1 : 0.f); }
+
+__global__ __launch_bounds__(256) void ppm_term_finish_kernel(PpmTermParams p) {
+    const int xt = blockIdx.x, y = blockIdx.y, b = blockIdx.z;
+    const int x0 = xt * PPM_P;
+    const int c = threadIdx.x * 4;
+    if (c >= p.C) return;
+    f32x4 acc[PPM_P];
+#pragma unroll
+    for (int px = 0; px < PPM_P; ++px) acc[px] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int bi = 0; bi < 4; ++bi) {
+        const int bin = p.bin[bi];
+        const float* Zb = p.Z[bi] + (size_t)b * bin * bin * 9 * p.C + c;
+        for (int r = 0; r < 3; ++r) {
+            const int Y = y + r - 1;
+            if (Y < 0 || Y >= p.H) continue;  // zero padding of the conv
+            const LinCoord cy = lin_coord(Y, bin, p.sy[bi], 1);
+            for (int s = 0; s < 3; ++s) {
+                LinCoord cx[PPM_P];
+                bool ok[PPM_P];
+                int jmin = bin, jmax = -1;
+#pragma unroll
+                for (int px = 0; px < PPM_P; ++px) {
+                    const int X = x0 + px + s - 1;
+                    ok[px] = X >= 0 && X < p.W && x0 + px < p.W;
+                    cx[px] = lin_coord(ok[px] ? X : 0, bin, p.sx[bi], 1);
+                    if (ok[px]) {
+                        jmin = min(jmin, cx[px].i0);
+                        jmax = max(jmax, cx[px].i1);
+                    }
+                }
+                const int tap = r * 3 + s;
+                for (int i = cy.i0; i <= cy.i1; ++i) {
+                    const float wy = lin_weight(cy, i);
+                    for (int j = jmin; j <= jmax; ++j) {
+                        const f32x4 z = *reinterpret_cast<const f32x4*>(Zb + ((size_t)(i * bin + j) * 9 + tap) * p.C);
+#pragma unroll
+                        for (int px = 0; px < PPM_P; ++px) {
+                            const float w = ok[px] ? wy * lin_weight(cx[px], j) : 0.f;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) acc[px][e] = fmaf(w, z[e], acc[px][e]);
+                        }
+                    }
+                }
+            }
+        }
+    }
+    const f32x4 sc = p.scale ? *reinterpret_cast<const f32x4*>(p.scale + c) : f32x4{1.f, 1.f, 1.f, 1.f};
+    const f32x4 sh = p.shift ? *reinterpret_cast<const f32x4*>(p.shift + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int px = 0; px < PPM_P; ++px) {
+        if (x0 + px >= p.W) break;
+        float* t = p.T + ((size_t)(b * p.H + y) * p.W + x0 + px) * p.ld + c;
+        f32x4 v = *reinterpret_cast<const f32x4*>(t);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            v[e] = (v[e] + acc[px][e]) * sc[e] + sh[e];
+            if (p.relu) v[e] = fmaxf(v[e], 0.f);
+        }
+        *reinterpret_cast<f32x4*>(t) = v;
+    }
+}
+
+int launch_ppm_term_finish(float* T, int ld, const float* const Z[4], const int bins[4], const float* scale, const float* shift, int B,
+                           int H, int W, int C, int relu, hipStream_t s) {
+    FS_REQUIRE(C % 4 == 0 && C <= 1024 && ld % 4 == 0 && ((uintptr_t)T & 15) == 0, "ppm_term_finish: C must be a multiple of 4, <= 1024");
+    FS_REQUIRE(H <= 65535 && B <= 65535, "ppm_term_finish: map too large for the launch grid");
+    PpmTermParams p{};
+    p.T = T; p.ld = ld; p.scale = scale; p.shift = shift;
+    p.B = B; p.H = H; p.W = W; p.C = C; p.relu = relu;
+    for (int i = 0; i < 4; ++i) {
+        p.Z[i] = Z[i];
+        p.bin[i] = bins[i];
+        p.sy[i] = resize_scale(bins[i], H, 1);
+        p.sx[i] = resize_scale(bins[i], W, 1);
+    }
+    hipLaunchKernelGGL(ppm_term_finish_kernel, dim3(cdiv(W, PPM_P), H, B), dim3(((C / 4 + 63) / 64) * 64), 0, s, p);
+    FS_HIP(hipGetLastError());
+    return 0;
+}
+
 // 32x32 LDS-tiled transposes between [B][C][HW] and [B][HW][ld]
 __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ in, float* __restrict__ out, int ld_out, int C,
                                                            int HW) {

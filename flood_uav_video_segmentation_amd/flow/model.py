@@ -54,6 +54,15 @@ class FlowModel(nn.Module):
         x = frames[0] if len(frames) == 1 else torch.cat(frames, 0)
         return self.model.encoder(x)
 
+    def _segment(self, *frames):
+        """decoder(encoder(frames)) as ONE batch -> low-resolution logits [sum(B_i), K, fh, fw].  Networks that offer a
+        fused `segment` (the HIP mirrors) are called once; any other module goes through .encoder / .decoder."""
+        x = frames[0] if len(frames) == 1 else torch.cat(frames, 0)
+        seg = getattr(self.model, "segment", None)
+        if seg is not None:
+            return seg(x)
+        return self.model.decoder(self.model.encoder(x))
+
     @staticmethod
     def _fit(t, h, w):
         if t.shape[2] != h or t.shape[3] != w:
@@ -76,14 +85,14 @@ class FlowModel(nn.Module):
         total = [a + b for a, b in zip(left, right)]
         h, w = frame_prev.shape[2], frame_prev.shape[3]
         nb = frame_prev.shape[0]
-        feats = self._encode(frame_prev, frame_next)
-        f_prev, f_next = feats[:nb], feats[nb:]
         if self.feature_based:
+            feats = self._encode(frame_prev, frame_next)
+            f_prev, f_next = feats[:nb], feats[nb:]
             mixed = ops.blend(self.warp_batch(f_prev, mvs_left, left, total), 1.0,
                               self.warp_batch(f_next, mvs_right, right, total), 1.0)
             out = self.model.decoder(mixed)
         else:
-            lows = self.model.decoder(feats)
+            lows = self._segment(frame_prev, frame_next)
             o_prev, o_next = lows[:nb], lows[nb:]
             out = ops.blend(self.warp_batch(o_prev, mvs_left, left, total), 1.0,
                             self.warp_batch(o_next, mvs_right, right, total), 1.0)
@@ -121,10 +130,8 @@ class FlowModel(nn.Module):
         Returns {"pred": [n,K,h,w]} ([1,K,h,w] when frame_next is None)."""
         h, w = frame_prev.shape[2], frame_prev.shape[3]
         frames = (frame_prev,) if frame_next is None else (frame_prev, frame_next)
-        with _region(profiler, "predict_encoder"):
-            feats = self._encode(*frames)
-        with _region(profiler, "predict_decoder"):
-            lows = self.model.decoder(feats)
+        with _region(profiler, "predict_encoder"), _region(profiler, "predict_decoder"):
+            lows = self._segment(*frames)
         lo_prev = lows[0:1]
         lo_next = lows[1:2] if frame_next is not None else None
         with _region(profiler, "predict_warp"), _region(profiler, "predict_fusion"):
@@ -136,10 +143,8 @@ class FlowModel(nn.Module):
         (Extension for the native-resolution timed region of bench.py; not a reference method.)"""
         h, w = frame_prev.shape[2], frame_prev.shape[3]
         frames = (frame_prev,) if frame_next is None else (frame_prev, frame_next)
-        with _region(profiler, "predict_encoder"):
-            feats = self._encode(*frames)
-        with _region(profiler, "predict_decoder"):
-            lows = self.model.decoder(feats)
+        with _region(profiler, "predict_encoder"), _region(profiler, "predict_decoder"):
+            lows = self._segment(*frames)
         with _region(profiler, "predict_fusion"):
             _, mask = ops.seg_tail(lows[0:1], lows[1:2] if frame_next is not None else None, mvs_left, mvs_right, n, (h, w),
                                    self.no_warp, want_logits=False, want_mask=True)

@@ -17,6 +17,11 @@ class FlowDeepLabv3(HipSegNet):
             # the reference fetches pytorch/vision:v0.10.0 through torch.hub here (model/deeplabv3.py:15)
             raise RuntimeError("FlowDeepLabv3(HIP): pretrained=True is not supported, load a state_dict instead")
 
+    def segment(self, x):
+        """decoder(encoder(x)) in one library call (encoder + decoder over a library-owned feature map); FlowModel's segmentation-mode paths
+        (flow/model.py:39-40, 189-191, 202-204) use it when the wrapped network offers it."""
+        return self._hip_net.segment(x)
+
     @staticmethod
     def canonical_name(key):
         if key.endswith("num_batches_tracked"):

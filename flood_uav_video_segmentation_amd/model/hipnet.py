@@ -98,6 +98,21 @@ class HipNet:
         check(self._lib.fs_decoder_forward(self._h, ptr(f), b, fh, fw, ptr(out), stream_ptr()))
         return out
 
+    def segment(self, x):
+        """[B,3,H,W] -> [B,K,fh,fw] NCHW logits: model.decoder(model.encoder(x)) in one library call (the PSPNet head then
+        never builds the 4096-channel concat, include/floodseg.h)."""
+        self._need_ready()
+        if x.dim() != 4 or x.shape[1] != 3:
+            raise RuntimeError(f"floodseg segment: expected [B,3,H,W], got {tuple(x.shape)}")
+        if not x.is_cuda:
+            raise RuntimeError("floodseg segment: input must be on the GPU")
+        x = x.float().contiguous()
+        b, _, h, w = x.shape
+        _, fh, fw = self.feature_shape(h, w)
+        out = torch.empty((b, self.classes, fh, fw), dtype=torch.float32, device=x.device)
+        check(self._lib.fs_segment_forward(self._h, ptr(x), b, h, w, ptr(out), stream_ptr()))
+        return out
+
     # -- profiling ---------------------------------------------------------------------------
     def profile(self, on):
         self._need_ready()

@@ -33,6 +33,11 @@ class FlowPSPNet(HipSegNet):
         (re.compile(r"^encoder\.1\.(.*)$"), r"ppm.\1"),
     )
 
+    def segment(self, x):
+        """decoder(encoder(x)) in one library call (the fused head never builds the 4096-channel concat); FlowModel's segmentation-mode paths
+        (flow/model.py:39-40, 189-191, 202-204) use it when the wrapped network offers it."""
+        return self._hip_net.segment(x)
+
     @staticmethod
     def canonical_name(key):
         """Map any alias FlowPSPNet's state_dict holds (1046 keys, 362 tensors) to

@@ -73,6 +73,12 @@ size_t fs_workspace_bytes(fs_handle h, int B, int H, int W);
 int fs_encoder_forward(fs_handle h, const float* in_nchw, int B, int H, int W, float* out_nhwc, fs_stream stream);
 /* model.decoder(f):  in NHWC [B,fh,fw,C]  ->  out NCHW [B,K,fh,fw] */
 int fs_decoder_forward(fs_handle h, const float* feat_nhwc, int B, int fh, int fw, float* out_nchw, fs_stream stream);
+/* model.decoder(model.encoder(x)) in one call -- the composition the segmentation-mode paths evaluate
+ * (flow/model.py:39-40 forward_segmentation, :189-191 and :202-204 predict_segmentation; single-frame inference):
+ * in NCHW [B,3,H,W] -> out NCHW [B,K,fh,fw] with (fh, fw) from fs_feature_shape.  Same result as the two calls above; the
+ * PSPNet head skips the 4096-channel concat: model/pspnet.py:28-34 (PPM upsample + cat) and :70-73 (3x3 conv) are linear,
+ * so the pyramid's share of the conv is evaluated on the pooled b x b maps and added before BatchNorm + ReLU. */
+int fs_segment_forward(fs_handle h, const float* in_nchw, int B, int H, int W, float* out_nchw, fs_stream stream);
 
 /* ---- per-op profiling (HIP events on `stream` around every launch of the next forward calls) -- */
 int fs_profile_enable(fs_handle h, int on);

@@ -130,3 +130,16 @@ def test_deeplabv3_r101_against_oracle_parity_unpinned():
     net2 = FlowDeepLabv3(HP(101, 5)).eval()
     net2.load_state_dict(ref_keys)
     assert torch.equal(net2.decoder(net2.encoder(x.cuda())), net.decoder(feat))
+
+
+@pytest.mark.parametrize("size,b", [((713, 713), 2), ((161, 225), 1), ((97, 130), 3)])
+def test_fused_segment_route_equals_decoder_of_encoder(psp, size, b):
+    """fs_segment_forward (PSPNet: pyramid share of the head conv evaluated on the pooled maps, no 4096-channel concat) must
+    give what fs_decoder_forward(fs_encoder_forward(x)) gives -- divisible (90x90) and ragged (21x29, 13x17) feature maps."""
+    net, _ = psp
+    x = synth.make_clip(b, size, seed=21).cuda()
+    two_step = net.decoder(net.encoder(x))
+    fused = net.segment(x)
+    assert fused.shape == two_step.shape and fused.dtype == torch.float32
+    assert rel_err(fused.cpu(), two_step.cpu()) < 2e-5
+    assert (fused.max(1)[1] == two_step.max(1)[1]).float().mean().item() > 0.9995

@@ -21,12 +21,12 @@ def main():
     net.load_state_dict(synth.make_pspnet_state(50, 5, 0))
     x = synth.make_clip(b, 713, seed=1000).cuda()
     for _ in range(2):
-        net.decoder(net.encoder(x))
+        net.segment(x)
     torch.cuda.synchronize()
     reps = 5
     net._hip_net.profile(True)
     for _ in range(reps):
-        net.decoder(net.encoder(x))
+        net.segment(x)
     rows = net._hip_net.profile_dump()
     nops = len(rows) // reps
     tot = 0.0
