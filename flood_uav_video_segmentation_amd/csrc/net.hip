@@ -257,7 +257,8 @@ size_t encoder_buf_elems(const fs_net* h, int B, int H, int W) {
     return std::max(a, std::max(b, c));
 }
 
-size_t small_elems_for(int B) { return (size_t)B * 50 * (2048 + 512 + 9 * 512) + 1024; }  // pooled, reduced, Z (fused head)
+// pooled maps (1+4+9+36 cells x 2048), then per pyramid level a fixed-stride slot of 36 cells: reduced (x512) and Z (x9*512)
+size_t small_elems_for(int B) { return (size_t)B * (50 * 2048 + 4 * 36 * (512 + 9 * 512)) + 1024; }
 
 }  // namespace
 
@@ -408,12 +409,14 @@ int net_finalize(fs_handle h, hipStream_t s) {
             FS_TRY(launch_winograd_filter(sl, m.wino_U, O, 2048, s));
             FS_HIP(hipStreamSynchronize(s));
             FS_HIP(hipFree(sl));
+            float* zw = nullptr;  // the four [9*O][512] matrices back to back: groups of one grouped GEMM
+            FS_TRY(dev_alloc(h, &zw, (size_t)4 * 9 * O * 512));
             for (int i = 0; i < 4; ++i) {
                 ConvBN& z = h->ppm_z[i];
                 z.name = "decoder.0.weight[:, ppm" + std::to_string(h->bins[i]) + "]";
                 z.Cin = 512;
                 z.Cout = 9 * O;
-                FS_TRY(dev_alloc(h, &z.w, (size_t)9 * O * 512));
+                z.w = zw + (size_t)i * 9 * O * 512;
                 FS_TRY(launch_pack_slice_tap_major(w->d, z.w, O, 4096, 2048 + 512 * i, 512, 9, s));
             }
         }
@@ -572,7 +575,7 @@ int encoder_core(fs_handle h, const float* in_nchw, int B, int H, int W, float* 
             pool_off[i] = po;
             red_off[i] = ro;
             po += (size_t)B * h->bins[i] * h->bins[i] * 2048;
-            ro += (size_t)B * h->bins[i] * h->bins[i] * 512;
+            ro += (size_t)B * 36 * 512;  // fixed stride per level: the fused head runs the four Z GEMMs as one grouped launch
         }
     }
     const bool even = curH % 6 == 0 && curW % 6 == 0 && h->bins[0] == 1 && h->bins[1] == 2 && h->bins[2] == 3 && h->bins[3] == 6;
@@ -644,18 +647,24 @@ int net_segment(fs_handle h, const float* in_nchw, int B, int H, int W, float* o
     const size_t px = (size_t)B * fh * fw;
     // Z_b = reduced_b x W_b: [B*bin*bin] x [9*O]
     float* reduced = h->small + (size_t)B * 50 * 2048;
-    float* zbuf = reduced + (size_t)B * 50 * 512;
+    float* zbuf = reduced + (size_t)4 * B * 36 * 512;
     const float* Z[4];
-    {
-        size_t ro = 0, zo = 0;
-        for (int i = 0; i < 4; ++i) {
-            const int rows = B * h->bins[i] * h->bins[i];
-            const ConvBN& z = h->ppm_z[i];
-            FS_TRY(run_conv(h, z, reduced + ro, 512, 1, rows, 1, zbuf + zo, z.Cout, nullptr, 0, s));
-            Z[i] = zbuf + zo;
-            ro += (size_t)rows * 512;
-            zo += (size_t)rows * z.Cout;
-        }
+    {   // one grouped GEMM, 4 groups x [B*36 rows (the level's B*bin^2 real ones first)] x [9*O] x 512
+        const ConvBN& z = h->ppm_z[0];
+        const int rows = B * 36;
+        ConvParams p{};
+        p.in = reduced; p.ld_in = 512; p.wgt = z.w; p.out = zbuf; p.ld_out = z.Cout;
+        p.B = 1; p.H = rows; p.W = 1; p.Cin = 512; p.Ho = rows; p.Wo = 1; p.Cout = z.Cout;
+        p.KH = p.KW = 1; p.stride = 1; p.dil = 1;
+        p.groups = 4;
+        p.g_in = (long long)rows * 512;
+        p.g_wgt = (long long)z.Cout * 512;
+        p.g_out = (long long)rows * z.Cout;
+        FS_TRY(prof_begin(h, "decoder.0.weight[:, ppm]", conv_igemm_tile_name(p), 2.0 * B * 50 * 512.0 * z.Cout,
+                          4.0 * (4.0 * z.Cout * 512 + B * 50.0 * (512 + z.Cout)), s));
+        FS_TRY(launch_conv_igemm(p, s));
+        FS_TRY(prof_end(h, s));
+        for (int i = 0; i < 4; ++i) Z[i] = zbuf + (size_t)i * p.g_out;
     }
     ConvBN raw = h->cls_main;  // raw sums: BatchNorm + ReLU are applied after the pyramid term has been added
     raw.scale = raw.shift = nullptr;

@@ -201,7 +201,8 @@ int launch_ppm_pool_combine(const float* cell_mean, float* out1, float* out2, fl
 }
 
 // -------------------------------------------------------------------------------------------
-// Small-M 1x1 conv: one wave per output channel n, weight row held in registers, loop over m.
+// Small-M 1x1 conv: one wave per output channel n, weight row held in registers, loop over the rows of this
+// block's row chunk (blockIdx.y): the rows are independent, so chunking them shortens the serial chain per wave.
 // -------------------------------------------------------------------------------------------
 template <int KV /* float4 per lane = K/256 */>
 __global__ __launch_bounds__(256) void rowdot_1x1_kernel(const float* __restrict__ in, int ld_in, const float* __restrict__ wgt,
@@ -214,7 +215,9 @@ __global__ __launch_bounds__(256) void rowdot_1x1_kernel(const float* __restrict
 #pragma unroll
     for (int i = 0; i < KV; ++i) w[i] = *reinterpret_cast<const f32x4*>(wgt + (size_t)n * K + (i * 64 + lane) * 4);
     const float sc = scale ? scale[n] : 1.f, sh = shift ? shift[n] : 0.f;
-    for (int m = 0; m < M; ++m) {
+    const int per = (M + gridDim.y - 1) / gridDim.y;
+    const int m_end = min(M, (int)(blockIdx.y + 1) * per);
+    for (int m = blockIdx.y * per; m < m_end; ++m) {
         float acc = 0.f;
 #pragma unroll
         for (int i = 0; i < KV; ++i) {
@@ -234,7 +237,7 @@ __global__ __launch_bounds__(256) void rowdot_1x1_kernel(const float* __restrict
 int launch_rowdot_1x1(const float* in, int ld_in, const float* wgt, const float* scale, const float* shift, float* out,
                       int ld_out, int M, int K, int N, int relu, hipStream_t s) {
     FS_REQUIRE(K % 256 == 0 && K <= 4096, "rowdot_1x1: K=%d must be a multiple of 256 and <= 4096", K);
-    const dim3 grid(cdiv(N, 4)), block(256);
+    const dim3 grid(cdiv(N, 4), std::max(1, std::min(12, M / 6))), block(256);  // ~6+ rows per wave
 #define FS_ROWDOT(KV)                                                                                             \
     case KV:                                                                                                      \
         hipLaunchKernelGGL((rowdot_1x1_kernel<KV>), grid, block, 0, s, in, ld_in, wgt, scale, shift, out, ld_out, M, K, N, relu); \
@@ -416,7 +419,7 @@ int launch_pack_slice_tap_major(const float* w, float* out, int O, int I, int c0
 // One block = PPM_P consecutive pixels of a row x all C channels (a float4 per thread): every Z row is loaded once per
 // block and reused for the pixels that touch the same cell; the coordinate math is block-uniform (scalar unit).
 // -------------------------------------------------------------------------------------------
-constexpr int PPM_P = 6;
+constexpr int PPM_P = 15;
 struct PpmTermParams {
     float* T; int ld;        // [B*H*W][ld]: raw conv output in, finished activations out
     const float* Z[4];       // [B*bin*bin][9*C]
@@ -439,34 +442,44 @@ __global__ __launch_bounds__(256) void ppm_term_finish_kernel(PpmTermParams p) {
     for (int bi = 0; bi < 4; ++bi) {
         const int bin = p.bin[bi];
         const float* Zb = p.Z[bi] + (size_t)b * bin * bin * 9 * p.C + c;
-        for (int r = 0; r < 3; ++r) {
-            const int Y = y + r - 1;
-            if (Y < 0 || Y >= p.H) continue;  // zero padding of the conv
-            const LinCoord cy = lin_coord(Y, bin, p.sy[bi], 1);
-            for (int s = 0; s < 3; ++s) {
-                LinCoord cx[PPM_P];
-                bool ok[PPM_P];
-                int jmin = bin, jmax = -1;
+        for (int s = 0; s < 3; ++s) {
+            // column weights of the block's pixels for this tap column: source cells jmin..jmax
+            LinCoord cx[PPM_P];
+            bool ok[PPM_P];
+            int jmin = bin, jmax = -1;
 #pragma unroll
-                for (int px = 0; px < PPM_P; ++px) {
-                    const int X = x0 + px + s - 1;
-                    ok[px] = X >= 0 && X < p.W && x0 + px < p.W;
-                    cx[px] = lin_coord(ok[px] ? X : 0, bin, p.sx[bi], 1);
-                    if (ok[px]) {
-                        jmin = min(jmin, cx[px].i0);
-                        jmax = max(jmax, cx[px].i1);
-                    }
+            for (int px = 0; px < PPM_P; ++px) {
+                const int X = x0 + px + s - 1;
+                ok[px] = X >= 0 && X < p.W && x0 + px < p.W;
+                cx[px] = lin_coord(ok[px] ? X : 0, bin, p.sx[bi], 1);
+                if (ok[px]) {
+                    jmin = min(jmin, cx[px].i0);
+                    jmax = max(jmax, cx[px].i1);
                 }
-                const int tap = r * 3 + s;
-                for (int i = cy.i0; i <= cy.i1; ++i) {
-                    const float wy = lin_weight(cy, i);
-                    for (int j = jmin; j <= jmax; ++j) {
-                        const f32x4 z = *reinterpret_cast<const f32x4*>(Zb + ((size_t)(i * bin + j) * 9 + tap) * p.C);
+            }
+            for (int jb = jmin; jb <= jmax; jb += 4) {  // 4 source columns at a time (one pass at the BASELINE geometry)
+                float wx[PPM_P][4];
 #pragma unroll
-                        for (int px = 0; px < PPM_P; ++px) {
-                            const float w = ok[px] ? wy * lin_weight(cx[px], j) : 0.f;
+                for (int px = 0; px < PPM_P; ++px)
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) acc[px][e] = fmaf(w, z[e], acc[px][e]);
+                    for (int jj = 0; jj < 4; ++jj) wx[px][jj] = (ok[px] && jb + jj <= jmax) ? lin_weight(cx[px], jb + jj) : 0.f;
+                for (int r = 0; r < 3; ++r) {
+                    const int Y = y + r - 1;
+                    if (Y < 0 || Y >= p.H) continue;  // zero padding of the conv
+                    const LinCoord cy = lin_coord(Y, bin, p.sy[bi], 1);
+                    const int tap = r * 3 + s;
+                    for (int i = cy.i0; i <= cy.i1; ++i) {
+                        const float wy = lin_weight(cy, i);
+#pragma unroll
+                        for (int jj = 0; jj < 4; ++jj) {
+                            if (jb + jj > jmax) break;
+                            const f32x4 z = *reinterpret_cast<const f32x4*>(Zb + ((size_t)(i * bin + jb + jj) * 9 + tap) * p.C);
+#pragma unroll
+                            for (int px = 0; px < PPM_P; ++px) {
+                                const float w = wy * wx[px][jj];
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) acc[px][e] = fmaf(w, z[e], acc[px][e]);
+                            }
                         }
                     }
                 }

@@ -53,7 +53,7 @@ def main():
     psp.load_state_dict(synth.make_pspnet_state(50, 5, 0))
 
     def single(i):  # configs[0] semantics on the GPU: one frame per step, PSPNet.forward + argmax
-        lo = psp.decoder(psp.encoder(keys[i % 5:i % 5 + 1]))
+        lo = psp.segment(keys[i % 5:i % 5 + 1])
         _, mask = ops.seg_tail(lo, None, [], [], 1, (713, 713), True, want_logits=False, want_mask=True)
         host[:1].copy_(mask, non_blocking=True)
         torch.cuda.current_stream().synchronize()
