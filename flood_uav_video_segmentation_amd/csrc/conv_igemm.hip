@@ -279,6 +279,49 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(ConvParams p, int tiles_m,
 // bid+256) was measured too: the epilogue then competes with the other workgroup's MFMAs for issue slots and grows
 // 2-4x; net -3 % (K=512) to -4 % (K=256).
 // ---------------------------------------------------------------------------------------------------------
+#if defined(__HIP_DEVICE_COMPILE__)
+// Epilogue of the DMA kernel: y = act(acc * scale + shift (+ residual)) stored through a buffer descriptor whose range
+// check IS the row / channel guard (num_records = M * ld * 4: rows >= M fall outside, lanes with n >= Cout carry the
+// sentinel offset), so there is no per-element branch, no 64-bit address arithmetic and the activation is resolved at
+// compile time: 5 instructions per element instead of ~85 (the first version spent ~11 k cycles per 128x128 tile here,
+// as much as two K chunks).  The row offset is added on the VALU: the scalar offset of a buffer op is not range-checked.
+template <int ACT, bool RES, int TM, int TN>
+__device__ __forceinline__ void igemm_epilogue(const f32x16 (&acc)[TM][TN], const ConvParams& p, int M, int m_base, int n_base) {
+    constexpr unsigned SENT = 0x80000000u;
+    const __amdgpu_buffer_rsrc_t o_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.out, 0, (unsigned)((long long)M * p.ld_out * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(RES ? p.res : p.out), 0, (unsigned)((long long)M * (RES ? p.ld_res : p.ld_out) * 4), 0x00020000);
+    const unsigned row_o = (unsigned)p.ld_out * 4u, row_r = (unsigned)p.ld_res * 4u;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n_base + j * 32;
+        const bool nok = n < p.Cout;
+        const float sc_n = (nok && p.scale) ? p.scale[n] : 1.f;
+        const float sh_n = (nok && p.shift) ? p.shift[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int mb = m_base + i * 32;
+            const unsigned vo = nok ? (unsigned)mb * row_o + (unsigned)n * 4u : SENT;
+            float rv[16];
+            if (RES) {
+                const unsigned vr = nok ? (unsigned)mb * row_r + (unsigned)n * 4u : SENT;
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    rv[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_rsrc, vr + (unsigned)((e & 3) + 8 * (e >> 2)) * row_r, 0, 0));
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                float v = acc[i][j][e] * sc_n + sh_n;
+                if (RES) v += rv[e];
+                if (ACT == 1) v = fmaxf(v, 0.f);
+                else if (ACT == 2) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752f));  // nn.GELU (erf form)
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), o_rsrc, vo + (unsigned)((e & 3) + 8 * (e >> 2)) * row_o, 0, 0);
+            }
+        }
+    }
+}
+#endif
+
 #ifdef FS_TRACE
 // tools/probe_conv_trace.hip only (never in libfloodseg.so): per-workgroup timeline, 8 x u64 per workgroup:
 // [0] start, [1] first stage landed, [2] main loop done, [3] epilogue done (shader clock, s_memtime),
@@ -466,37 +509,18 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_dma_f32(ConvParams 
 #undef FS_FRAGS
 #undef FS_MMA
 
-    // ---- epilogue (identical to conv_igemm_f32)
+    // ---- epilogue
     if ((p.dbg & 16) && p.ld_out >= 0) return;  // timing experiment: skip the epilogue (the test keeps the main loop alive)
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int n = n0 + wn * WN + j * 32 + l31;
-        const bool nok = n < p.Cout;
-        const float sc_n = (nok && p.scale) ? p.scale[n] : 1.f;
-        const float sh_n = (nok && p.shift) ? p.shift[n] : 0.f;
-        const int nc = nok ? n : 0;
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int mb = m0 + wm * WM + i * 32 + 4 * hh;
-            float rv[16];
-            if (p.res) {
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int m = min(mb + (e & 3) + 8 * (e >> 2), M - 1);
-                    rv[e] = p.res[(size_t)m * p.ld_res + nc];
-                }
-            } else {
-#pragma unroll
-                for (int e = 0; e < 16; ++e) rv[e] = 0.f;
-            }
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int m = mb + (e & 3) + 8 * (e >> 2);
-                float v = acc[i][j][e] * sc_n + sh_n + rv[e];
-                if (p.relu == 1) v = fmaxf(v, 0.f);
-                else if (p.relu == 2) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752f));
-                if (nok && m < M) p.out[(size_t)m * p.ld_out + n] = v;
-            }
+    {
+        const int m_base = m0 + wm * WM + 4 * hh, n_base = n0 + wn * WN + l31;
+        if (p.res) {
+            if (p.relu == 1) igemm_epilogue<1, true>(acc, p, M, m_base, n_base);
+            else if (p.relu == 2) igemm_epilogue<2, true>(acc, p, M, m_base, n_base);
+            else igemm_epilogue<0, true>(acc, p, M, m_base, n_base);
+        } else {
+            if (p.relu == 1) igemm_epilogue<1, false>(acc, p, M, m_base, n_base);
+            else if (p.relu == 2) igemm_epilogue<2, false>(acc, p, M, m_base, n_base);
+            else igemm_epilogue<0, false>(acc, p, M, m_base, n_base);
         }
     }
 #ifdef FS_TRACE
@@ -554,6 +578,10 @@ int launch_conv_igemm(const ConvParams& p, hipStream_t s, int tile) {
                "conv_igemm: input tensor must be smaller than 2 GiB");
     FS_REQUIRE((int64_t)p.Cout * p.KH * p.KW * p.Cin * 4 < (int64_t)1 << 31, "conv_igemm: filter bank must be smaller than 2 GiB");
     FS_REQUIRE(p.KH * p.KW <= 32, "conv_igemm: at most 32 filter taps");
+    // the epilogue stores (and reads the residual) through 32-bit-offset buffer descriptors as well
+    FS_REQUIRE((int64_t)p.B * p.Ho * p.Wo * p.ld_out * 4 < (int64_t)1 << 31 && ((uintptr_t)p.out & 3) == 0,
+               "conv_igemm: output tensor must be smaller than 2 GiB");
+    FS_REQUIRE(p.res == nullptr || (int64_t)p.B * p.Ho * p.Wo * p.ld_res * 4 < (int64_t)1 << 31, "conv_igemm: residual tensor must be smaller than 2 GiB");
     if (!(p.res == nullptr || p.ld_res >= p.Cout)) return fail("conv_igemm: bad ld_res");
     const int var = (tile >> 8) & 1 ? 0 : ((tile >> 9) & 1 ? 1 : 2);  // default PIPE 2; tile bit 8 -> PIPE 0, bit 9 -> PIPE 1
     tile &= 0xff;

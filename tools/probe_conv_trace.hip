@@ -2,7 +2,8 @@
 // Built with -DFS_TRACE (instrumentation that never ships in libfloodseg.so):
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 -DFS_TRACE -I flood_uav_video_segmentation_amd/csrc -I include \
 //         tools/probe_conv_trace.hip -o tools/bin/probe_conv_trace
-// usage: probe_conv_trace B H W Cin Cout K pad dil tile  > trace.csv     (analysed by tools/analyze_conv_trace.py)
+// usage: probe_conv_trace B H W Cin Cout K pad dil tile [dbg [groups]]  > trace.csv   (analysed by tools/analyze_conv_trace.py)
+//        groups > 1: grouped GEMM as the Winograd path launches it (use K = 1, W = 1, H = rows per group)
 #include "../flood_uav_video_segmentation_amd/csrc/conv_igemm.hip"
 
 #include <algorithm>
@@ -29,7 +30,8 @@ int main(int argc, char** argv) {
     const int B = atoi(argv[1]), H = atoi(argv[2]), W = atoi(argv[3]), Cin = atoi(argv[4]), Cout = atoi(argv[5]), K = atoi(argv[6]),
               pad = atoi(argv[7]), dil = atoi(argv[8]), tile = atoi(argv[9]);
     const int Ho = H + 2 * pad - dil * (K - 1), Wo = W + 2 * pad - dil * (K - 1);
-    const size_t n_in = (size_t)B * H * W * Cin, n_w = (size_t)Cout * K * K * Cin, n_out = (size_t)B * Ho * Wo * Cout;
+    const int groups = argc > 11 ? atoi(argv[11]) : 1;
+    const size_t n_in = (size_t)groups * B * H * W * Cin, n_w = (size_t)groups * Cout * K * K * Cin, n_out = (size_t)groups * B * Ho * Wo * Cout;
     float *in, *wgt, *out;
     if (hipMalloc(&in, n_in * 4) || hipMalloc(&wgt, n_w * 4) || hipMalloc(&out, n_out * 4)) return 3;
     {   // pseudo-random operands: MFMA power (hence the sustained clock) depends on the data toggling
@@ -43,6 +45,12 @@ int main(int argc, char** argv) {
     p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Ho = Ho; p.Wo = Wo; p.Cout = Cout;
     p.KH = p.KW = K; p.stride = 1; p.pad = pad; p.dil = dil; p.relu = 1;
     p.dbg = argc > 10 ? atoi(argv[10]) : 0;
+    if (groups > 1) {
+        p.groups = groups;
+        p.g_in = (long long)B * H * W * Cin;
+        p.g_wgt = (long long)Cout * K * K * Cin;
+        p.g_out = (long long)B * Ho * Wo * Cout;
+    }
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
     for (int i = 0; i < 20; ++i) if (fs::launch_conv_igemm(p, 0, tile)) return 4;
@@ -54,7 +62,7 @@ int main(int argc, char** argv) {
     float ms = 0;
     hipEventElapsedTime(&ms, e0, e1);
     const int M = B * Ho * Wo;
-    const double gf = 2.0 * M * Cout * K * K * Cin * 1e-9;
+    const double gf = 2.0 * groups * M * Cout * K * K * Cin * 1e-9;
     std::vector<unsigned long long> tr(8 * 65536);
     if (hipMemcpyFromSymbol(tr.data(), HIP_SYMBOL(fs::fs_trace_buf), tr.size() * 8) != hipSuccess) return 5;
     printf("# %s M=%d N=%d K=%d  %.4f ms  %.1f TFLOP/s (single launch incl. launch overhead)\n", fs::conv_igemm_tile_name(p, tile), M, Cout,
