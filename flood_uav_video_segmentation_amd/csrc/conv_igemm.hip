@@ -385,24 +385,34 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_dma_f32(ConvParams 
     const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(p.in - pad_off), 0, a_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.wgt, 0, (unsigned)((long long)p.Cout * K * 4), 0x00020000);
     unsigned a_voff[RA], a_mask[RA];
+    if (p.KH * p.KW == 1 && p.stride == 1 && p.pad == 0) {
+        // 1x1 stride-1 conv / plain GEMM (most launches): output pixel m IS input pixel m, no coordinate split needed
 #pragma unroll
-    for (int j = 0; j < RA; ++j) {
-        const int m = m0 + r0 + RSTEP * j;
-        const bool v = m < M;
-        const int mm = v ? m : 0;
-        const int hw = p.Ho * p.Wo;
-        const int b = mm / hw;
-        const int rem = mm - b * hw;
-        const int oy = rem / p.Wo;
-        const int ox = rem - oy * p.Wo;
-        a_voff[j] = (unsigned)(((b * p.H * p.W + oy * p.stride * p.W + ox * p.stride) * p.ld_in + swz * 4) * 4);
-        unsigned mask = 0;
-        for (int r = 0; r < p.KH; ++r)
-            for (int q2 = 0; q2 < p.KW; ++q2) {
-                const int iy = oy * p.stride - p.pad + r * p.dil, ix = ox * p.stride - p.pad + q2 * p.dil;
-                if (v && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) mask |= 1u << (r * p.KW + q2);
-            }
-        a_mask[j] = mask;
+        for (int j = 0; j < RA; ++j) {
+            const int m = m0 + r0 + RSTEP * j;
+            a_voff[j] = (unsigned)((m * p.ld_in + swz * 4) * 4);  // rows >= M: the tap mask keeps them out of range
+            a_mask[j] = m < M ? 1u : 0u;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < RA; ++j) {
+            const int m = m0 + r0 + RSTEP * j;
+            const bool v = m < M;
+            const int mm = v ? m : 0;
+            const int hw = p.Ho * p.Wo;
+            const int b = mm / hw;
+            const int rem = mm - b * hw;
+            const int oy = rem / p.Wo;
+            const int ox = rem - oy * p.Wo;
+            a_voff[j] = (unsigned)(((b * p.H * p.W + oy * p.stride * p.W + ox * p.stride) * p.ld_in + swz * 4) * 4);
+            // tap (r, q) is inside the image iff its row is and its column is: KH + KW tests instead of KH * KW
+            unsigned colmask = 0, mask = 0;
+            for (int q2 = 0; q2 < p.KW; ++q2)
+                if ((unsigned)(ox * p.stride - p.pad + q2 * p.dil) < (unsigned)p.W) colmask |= 1u << q2;
+            for (int r = 0; r < p.KH; ++r)
+                if ((unsigned)(oy * p.stride - p.pad + r * p.dil) < (unsigned)p.H) mask |= colmask << (r * p.KW);
+            a_mask[j] = v ? mask : 0u;
+        }
     }
     unsigned b_voff[RB];
 #pragma unroll
