@@ -271,13 +271,13 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(ConvParams p, int tiles_m,
 // Elimination runs on the decoder conv (profiles/): VGPR-staged loads cost ~9 %, the ds_write pass ~5 %.
 // Workgroup timelines (tools/probe_conv_trace.hip, profiles/r01_conv_wg_timeline.txt): with two workgroups per CU the
 // main loop keeps the MFMA pipe busy 93 % of its cycles and only 1.6 % of them are spent in the per-chunk wait+barrier;
-// a lone workgroup reaches 83 %.  What short-K layers lose is outside the loop: ~6 k cycles of prologue (index math +
-// first DMA) and ~11-17 k cycles of epilogue per tile, during which the co-resident workgroup is in the same phase
-// (both were dispatched together), i.e. 4 % of a K=2048 tile, 17 % at K=512, 27 % at K=256.  In that lock-step all
-// 512 resident workgroups store their 64 KB tiles at once (33 MB in ~4.7 us = HBM write peak), so the epilogue is
-// bandwidth-bound, which is why vector stores did not shorten it.  De-phasing the two workgroups of a CU (delaying
-// bid+256) was measured too: the epilogue then competes with the other workgroup's MFMAs for issue slots and grows
-// 2-4x; net -3 % (K=512) to -4 % (K=256).
+// a lone workgroup reaches 83 %.  What short-K layers lose is outside the loop, because the co-resident workgroup is
+// in the same phase (both were dispatched together): prologue (index math + first DMA) and epilogue.  The first
+// epilogue (per-element guards, 64-bit addresses, run-time activation switch: ~85 instructions per element) took
+// 11-17 k cycles per 128x128 tile and the prologue 6 k -- 27 % of a K=256 tile; with the buffer-descriptor epilogue
+// below (5 instructions per element) and the division-free 1x1 prologue they are 3-8 k and 4 k (+6 % end to end).
+// De-phasing the two workgroups of a CU (delaying bid+256 by 4-40 k cycles) was measured before and after that change:
+// null to negative every time (the late workgroup's prologue/epilogue slow down under the neighbour's DMA + MFMA stream).
 // ---------------------------------------------------------------------------------------------------------
 #if defined(__HIP_DEVICE_COMPILE__)
 // Epilogue of the DMA kernel: y = act(acc * scale + shift (+ residual)) stored through a buffer descriptor whose range
