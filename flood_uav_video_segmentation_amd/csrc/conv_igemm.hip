@@ -484,19 +484,24 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_dma_f32(ConvParams 
 #ifdef FS_TRACE
     tr_ready = __builtin_readcyclecounter();
 #endif
+    // Software pipeline across the chunk boundary: the barrier that hands stage cur^1 over (and frees stage cur) sits
+    // between sub-steps 2 and 3; the DMA of chunk kc+2 and the first fragment reads of chunk kc+1 are issued right
+    // behind it and hide under the 16 MFMAs of sub-step 3, so the MFMA pipe does not drain at a chunk boundary.
     int cur = 0;
+    f32x4 a0[TM], b0[TN], a1[TM], b1[TN];
+    if (nchunks > 1) {
+        FS_DMA_ALL(1)
+        FS_DMA_ADVANCE()
+    }
+    FS_FRAGS(0, 0, a0, b0)
     for (int kc = 0; kc < nchunks; ++kc) {
-        // The whole DMA of chunk kc+1 is issued up front and lands under the 64 MFMAs below.  (Spreading the eight
-        // DMA instructions over the four MFMA groups was measured 5 % SLOWER on the decoder conv: 121.7 vs 128.7.)
-        if (kc + 1 < nchunks) {
-            FS_DMA_ALL(cur ^ 1)
-            FS_DMA_ADVANCE()
-        }
-        f32x4 a0[TM], b0[TN], a1[TM], b1[TN];
-        FS_FRAGS(cur, 0, a0, b0)
+        // sub-step 0's fragments were requested under the previous chunk's last MFMAs: start multiplying at once and
+        // slip the reads of sub-step 1 in behind the first MFMA (a wait placed before them would cover the new reads too)
         FS_FRAGS(cur, 1, a1, b1)
-        __builtin_amdgcn_sched_barrier(0);
         FS_MMA(a0, b0)
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 4 * TM * TN - 1, 0);
         __builtin_amdgcn_sched_barrier(0);
         FS_FRAGS(cur, 2, a0, b0)
         __builtin_amdgcn_sched_barrier(0);
@@ -506,8 +511,15 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_dma_f32(ConvParams 
         __builtin_amdgcn_sched_barrier(0);
         FS_MMA(a0, b0)
         __builtin_amdgcn_sched_barrier(0);
+        FS_TRACE_SYNC()  // __syncthreads: all fragment reads of stage `cur` are done (lgkmcnt(0)) and chunk kc+1 has landed (vmcnt(0))
+        if (kc + 2 < nchunks) {
+            FS_DMA_ALL(cur)
+            FS_DMA_ADVANCE()
+        }
+        if (kc + 1 < nchunks) FS_FRAGS(cur ^ 1, 0, a0, b0)
+        __builtin_amdgcn_sched_barrier(0);
         FS_MMA(a1, b1)
-        FS_TRACE_SYNC()  // __syncthreads: own DMA landed (vmcnt(0)), then everyone's; stage `cur` is free for the next DMA
+        __builtin_amdgcn_sched_barrier(0);
         cur ^= 1;
     }
 #ifdef FS_TRACE
