@@ -157,22 +157,25 @@ FS_API int fs_conv2d_nhwc(const float* in, int ld_in, const float* wgt_ohwi, con
     p.dbg = (tile >> 11) & 31;     // timing experiments (kernels.h)
     return fs::launch_conv_igemm(p, S(stream), tile & 0x3ff);
 }
-FS_API size_t fs_winograd_workspace_floats(int B, int H, int W, int Cin, int Cout, int dil) {
-    if (B < 1 || H < 1 || W < 1 || dil < 1) return 0;
-    const size_t T = (size_t)fs::winograd_tiles(B, H, W, dil);
-    return 36 * T * ((size_t)Cin + (size_t)Cout) + 36 * (size_t)Cout * Cin;
+FS_API size_t fs_winograd_workspace_floats(int B, int H, int W, int Cin, int Cout, int dil, int tile_m) {
+    if (B < 1 || H < 1 || W < 1 || dil < 1 || !(tile_m == 0 || tile_m == 4 || tile_m == 6)) return 0;
+    const int mt = tile_m ? tile_m : fs::winograd_pick_m(B, H, W, dil);
+    const size_t G = (size_t)(mt + 2) * (mt + 2), T = (size_t)fs::winograd_tiles(B, H, W, dil, mt);
+    return G * T * ((size_t)Cin + (size_t)Cout) + G * (size_t)Cout * Cin;
 }
 FS_API int fs_conv3x3_winograd_nhwc(const float* in, int ld_in, const float* wgt_oihw, const float* scale, const float* shift,
-                                    float* out, int ld_out, int B, int H, int W, int Cin, int Cout, int dil, int relu,
+                                    float* out, int ld_out, int B, int H, int W, int Cin, int Cout, int dil, int relu, int tile_m,
                                     float* workspace, fs_stream stream) {
-    if (!in || !wgt_oihw || !out || !workspace || B < 1 || H < 1 || W < 1 || dil < 1 || Cin % 32 != 0 || Cout % 4 != 0)
-        return fs::fail("fs_conv3x3_winograd_nhwc: bad arguments (Cin %% 32, Cout %% 4 required)");
-    const size_t T = (size_t)fs::winograd_tiles(B, H, W, dil);
+    if (!in || !wgt_oihw || !out || !workspace || B < 1 || H < 1 || W < 1 || dil < 1 || Cin % 32 != 0 || Cout % 4 != 0 ||
+        !(tile_m == 0 || tile_m == 4 || tile_m == 6))
+        return fs::fail("fs_conv3x3_winograd_nhwc: bad arguments (Cin %% 32, Cout %% 4, tile_m in {0, 4, 6} required)");
+    const int mt = tile_m ? tile_m : fs::winograd_pick_m(B, H, W, dil);
+    const size_t G = (size_t)(mt + 2) * (mt + 2), T = (size_t)fs::winograd_tiles(B, H, W, dil, mt);
     float* U = workspace;
-    float* V = U + 36 * (size_t)Cout * Cin;
-    float* Mb = V + 36 * T * Cin;
-    if (int rc = fs::launch_winograd_filter(wgt_oihw, U, Cout, Cin, S(stream))) return rc;
-    if (int rc = fs::launch_winograd_input(in, ld_in, V, B, H, W, Cin, dil, S(stream))) return rc;
+    float* V = U + G * (size_t)Cout * Cin;
+    float* Mb = V + G * T * Cin;
+    if (int rc = fs::launch_winograd_filter(wgt_oihw, U, Cout, Cin, mt, S(stream))) return rc;
+    if (int rc = fs::launch_winograd_input(in, ld_in, V, B, H, W, Cin, dil, mt, S(stream))) return rc;
     fs::ConvParams p{};
     p.in = V;
     p.ld_in = Cin;
@@ -189,12 +192,12 @@ FS_API int fs_conv3x3_winograd_nhwc(const float* in, int ld_in, const float* wgt
     p.KH = p.KW = 1;
     p.stride = 1;
     p.dil = 1;
-    p.groups = 36;
+    p.groups = (int)G;
     p.g_in = (long long)T * Cin;
     p.g_wgt = (long long)Cout * Cin;
     p.g_out = (long long)T * Cout;
     if (int rc = fs::launch_conv_igemm(p, S(stream))) return rc;
-    return fs::launch_winograd_output(Mb, scale, shift, out, ld_out, B, H, W, Cout, relu, dil, S(stream));
+    return fs::launch_winograd_output(Mb, scale, shift, out, ld_out, B, H, W, Cout, relu, dil, mt, S(stream));
 }
 FS_API int fs_stem_conv_nchw(const float* in_nchw, const float* wgt_hwio, const float* scale, const float* shift,
                              float* out_nhwc, int B, int H, int W, int Cout, int KH, int KW, int stride, int pad,

@@ -170,21 +170,32 @@ int launch_mask_head(const float* pp, const float* cc, const float* gamma, const
 
 
 // ---------------------------------------------------------------------------------
-// Winograd F(4x4, 3x3) for stride-1, undilated, pad-1 3x3 convolutions with many input channels (the PSPNet
-// decoder conv 4096 -> 512: 42 % of the network FLOPs).  36 GEMMs [tiles x Cin] x [Cin x Cout] on the fp32 MFMA
-// kernel replace the direct conv: 4x fewer multiplies (2.25x after tile-edge waste), fp32 error ~7e-6 relative.
-//   V[xi][t][c]  = (B^T d B)[xi]      input transform,  xi in 0..35, t = (b, ty, tx) 4x4-output tiles
+// Winograd F(m x m, 3x3), m = 4 or 6, for stride-1 3x3 convolutions with pad == dil and many input channels (the PSPNet
+// head conv and the dilated bottleneck conv2 layers).  (m+2)^2 GEMMs [tiles x Cin] x [Cin x Cout] on the fp32 MFMA
+// kernel replace the direct conv: 2.25 (m = 4) or 1.78 (m = 6) multiplies per output instead of 9; fp32 error ~1e-5
+// relative (m = 4) / ~1.5e-5 (m = 6), direct 3e-7.
+//   V[xi][t][c]  = (B^T d B)[xi]      input transform,  xi in 0..(m+2)^2-1, t = (b, phase, ty, tx) m x m-output tiles
 //   M[xi][t][o]  = sum_c V[xi][t][c] * U[xi][o][c]      (grouped conv_igemm_dma_f32)
 //   out          = act(scale * (A^T M A) + shift)       output transform
 // ---------------------------------------------------------------------------------
-int launch_winograd_filter(const float* w_oihw, float* U /*[36][O][I]*/, int O, int I, hipStream_t s);
+int launch_winograd_filter(const float* w_oihw, float* U /*[(m+2)^2][O][I]*/, int O, int I, int mt, hipStream_t s);
 // dil > 1 (pad == dil): the conv is d*d independent undilated convs on the pixel lattices (py + d*i, px + d*j);
 // tiles are enumerated (b, py, px, ty, tx).
-int launch_winograd_input(const float* in, int ld_in, float* V /*[36][T][C]*/, int B, int H, int W, int C, int dil, hipStream_t s);
-int launch_winograd_output(const float* M /*[36][T][N]*/, const float* scale, const float* shift, float* out, int ld_out, int B,
-                           int H, int W, int N, int relu, int dil, hipStream_t s);
-static inline int winograd_tiles(int B, int H, int W, int dil) {
-    return B * dil * dil * ((cdiv(H, dil) + 3) / 4) * ((cdiv(W, dil) + 3) / 4);
+int launch_winograd_input(const float* in, int ld_in, float* V /*[(m+2)^2][T][C]*/, int B, int H, int W, int C, int dil, int mt,
+                          hipStream_t s);
+int launch_winograd_output(const float* M /*[(m+2)^2][T][N]*/, const float* scale, const float* shift, float* out, int ld_out, int B,
+                           int H, int W, int N, int relu, int dil, int mt, hipStream_t s);
+static inline int winograd_tiles(int B, int H, int W, int dil, int mt) {
+    return B * dil * dil * ((cdiv(H, dil) + mt - 1) / mt) * ((cdiv(W, dil) + mt - 1) / mt);
+}
+// GEMM rows the grouped launch really multiplies: (m+2)^2 groups x tiles rounded up to the 64-row tile
+static inline double winograd_gemm_rows(int B, int H, int W, int dil, int mt) {
+    return (double)(mt + 2) * (mt + 2) * (double)(cdiv(winograd_tiles(B, H, W, dil, mt), 64) * 64);
+}
+// the cheaper tile size for this map (a 90x90 map is 15x15 tiles of 6x6 exactly, but 23x23 of 4x4).  Decided on the
+// geometry of ONE image, so that a frame's result does not depend on the batch it is processed in.
+static inline int winograd_pick_m(int /*B*/, int H, int W, int dil) {
+    return winograd_gemm_rows(1, H, W, dil, 6) < winograd_gemm_rows(1, H, W, dil, 4) ? 6 : 4;
 }
 
 }  // namespace fs

@@ -29,7 +29,8 @@ struct ConvBN {
     float* shift = nullptr;
     int Cin = 0, Cout = 0, KH = 1, KW = 1, stride = 1, pad = 0, dil = 1, relu = 0;
     int korder = 0;  // 1: filters packed chunk-major (3x3 convs)
-    float* wino_U = nullptr;  // [36][Cout][Cin] Winograd F(4,3) filters (3x3 stride-1 convs with pad == dil and Cin >= 256)
+    float* wino_U = nullptr;   // [36][Cout][Cin] Winograd F(4,3) filters (3x3 stride-1 convs with pad == dil and Cin >= 256)
+    float* wino_U6 = nullptr;  // [64][Cout][Cin] F(6,3) filters of the same conv; the cheaper tiling for the map at hand is used
     int out_size(int in) const { return (in + 2 * pad - dil * (KH - 1) - 1) / stride + 1; }
 };
 
@@ -108,6 +109,7 @@ struct fs_net {
     float* wino_ws = nullptr;  // V [36][T][Cin] followed by M [36][T][Cout]
     size_t wino_ws_elems = 0;
     bool use_winograd = true;  // FS_NO_WINOGRAD=1 in the environment selects the direct conv everywhere
+    int wino_force_m = 0;      // FS_WINOGRAD_TILE=4|6 forces F(4,3) / F(6,3); 0 = the cheaper one for the map at hand
     bool use_fused_head = true;  // FS_NO_FUSED_HEAD=1: fs_segment_forward runs encoder + decoder over the 4096-channel concat (A/B)
 
     // workspace

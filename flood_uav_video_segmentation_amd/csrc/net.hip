@@ -69,7 +69,9 @@ int make_conv(fs_net* h, ConvBN& c, const std::string& wname, const std::string&
     }
     if (!hwio && c.KH == 3 && c.KW == 3 && stride == 1 && pad == dil && dil <= 4 && c.Cin >= 256 && c.Cin % 32 == 0 && c.Cout % 4 == 0) {
         FS_TRY(dev_alloc(h, &c.wino_U, (size_t)36 * c.Cout * c.Cin));
-        FS_TRY(launch_winograd_filter(w->d, c.wino_U, c.Cout, c.Cin, s));
+        FS_TRY(launch_winograd_filter(w->d, c.wino_U, c.Cout, c.Cin, 4, s));
+        FS_TRY(dev_alloc(h, &c.wino_U6, (size_t)64 * c.Cout * c.Cin));
+        FS_TRY(launch_winograd_filter(w->d, c.wino_U6, c.Cout, c.Cin, 6, s));
     }
     if (!bn.empty()) {
         const RawTensor *g, *b, *m, *v;
@@ -130,8 +132,10 @@ namespace {
 // 3x3 s1 p1 conv as Winograd F(4x4,3x3): input transform -> 36 grouped GEMMs -> output transform (+BN, ReLU)
 int run_conv_winograd(fs_net* h, const ConvBN& c, const float* in, int ld_in, int B, int H, int W, float* out, int ld_out,
                       hipStream_t s) {
-    const int T = winograd_tiles(B, H, W, c.dil);
-    const size_t v_elems = (size_t)36 * T * c.Cin, m_elems = (size_t)36 * T * c.Cout;
+    const int mt = h->wino_force_m ? h->wino_force_m : winograd_pick_m(B, H, W, c.dil);
+    const int G = (mt + 2) * (mt + 2);
+    const int T = winograd_tiles(B, H, W, c.dil, mt);
+    const size_t v_elems = (size_t)G * T * c.Cin, m_elems = (size_t)G * T * c.Cout;
     if (v_elems + m_elems > h->wino_ws_elems) {
         FS_HIP(hipDeviceSynchronize());
         if (h->wino_ws) FS_HIP(hipFree(h->wino_ws));
@@ -142,12 +146,12 @@ int run_conv_winograd(fs_net* h, const ConvBN& c, const float* in, int ld_in, in
     float* V = h->wino_ws;
     float* Mb = h->wino_ws + v_elems;
     FS_TRY(prof_begin(h, c.name + ".wino_in", "winograd_input", 0, 4.0 * ((double)B * H * W * c.Cin + (double)v_elems), s));
-    FS_TRY(launch_winograd_input(in, ld_in, V, B, H, W, c.Cin, c.dil, s));
+    FS_TRY(launch_winograd_input(in, ld_in, V, B, H, W, c.Cin, c.dil, mt, s));
     FS_TRY(prof_end(h, s));
     ConvParams p{};
     p.in = V;
     p.ld_in = c.Cin;
-    p.wgt = c.wino_U;
+    p.wgt = mt == 6 ? c.wino_U6 : c.wino_U;
     p.out = Mb;
     p.ld_out = c.Cout;
     p.B = 1;
@@ -160,16 +164,16 @@ int run_conv_winograd(fs_net* h, const ConvBN& c, const float* in, int ld_in, in
     p.KH = p.KW = 1;
     p.stride = 1;
     p.dil = 1;
-    p.groups = 36;
+    p.groups = G;
     p.g_in = (long long)T * c.Cin;
     p.g_wgt = (long long)c.Cout * c.Cin;
     p.g_out = (long long)T * c.Cout;
-    const double flops = 2.0 * 36 * (double)T * c.Cin * c.Cout;
-    FS_TRY(prof_begin(h, c.name + ".wino_gemm", conv_igemm_tile_name(p), flops, 4.0 * ((double)v_elems + 36.0 * c.Cout * c.Cin + (double)m_elems), s));
+    const double flops = 2.0 * G * (double)T * c.Cin * c.Cout;
+    FS_TRY(prof_begin(h, c.name + ".wino_gemm", conv_igemm_tile_name(p), flops, 4.0 * ((double)v_elems + (double)G * c.Cout * c.Cin + (double)m_elems), s));
     FS_TRY(launch_conv_igemm(p, s));
     FS_TRY(prof_end(h, s));
     FS_TRY(prof_begin(h, c.name + ".wino_out", "winograd_output", 0, 4.0 * ((double)m_elems + (double)B * H * W * c.Cout), s));
-    FS_TRY(launch_winograd_output(Mb, c.scale, c.shift, out, ld_out, B, H, W, c.Cout, c.relu, c.dil, s));
+    FS_TRY(launch_winograd_output(Mb, c.scale, c.shift, out, ld_out, B, H, W, c.Cout, c.relu, c.dil, mt, s));
     return prof_end(h, s);
 }
 
@@ -180,7 +184,10 @@ int run_conv(fs_net* h, const ConvBN& c, const float* in, int ld_in, int B, int 
     // (measured: the ASPP convs with dilation 12/24/36 on a 90x90 map are FASTER direct -- 358 vs 335 FPS for configs[2] --
     //  so the lattice decomposition is limited to dilation <= 4)
     if (c.wino_U && h->use_winograd && !res && c.dil <= 4 &&
-        36.0 * winograd_tiles(B, H, W, c.dil) < 0.8 * 9.0 * (double)B * c.out_size(H) * c.out_size(W))
+        (double)((h->wino_force_m ? h->wino_force_m : winograd_pick_m(B, H, W, c.dil)) + 2) *
+                ((h->wino_force_m ? h->wino_force_m : winograd_pick_m(B, H, W, c.dil)) + 2) *
+                winograd_tiles(B, H, W, c.dil, h->wino_force_m ? h->wino_force_m : winograd_pick_m(B, H, W, c.dil)) <
+            0.8 * 9.0 * (double)B * c.out_size(H) * c.out_size(W))
         return run_conv_winograd(h, c, in, ld_in, B, H, W, out, ld_out, s);
     ConvParams p{};
     p.in = in;
@@ -274,6 +281,8 @@ int net_create(const fs_config* cfg, fs_handle* out) {
     h->cfg = *cfg;
     const char* nw = getenv("FS_NO_WINOGRAD");
     h->use_winograd = !(nw && nw[0] == '1');
+    const char* wm = getenv("FS_WINOGRAD_TILE");  // A/B switch: 4 or 6 forces that tile size, unset = per-map choice
+    h->wino_force_m = (wm && (wm[0] == '4' || wm[0] == '6')) ? wm[0] - '0' : 0;
     const char* nf = getenv("FS_NO_FUSED_HEAD");
     h->use_fused_head = !(nf && nf[0] == '1');
     h->deep_stem = cfg->arch == FS_ARCH_PSPNET;
@@ -397,7 +406,7 @@ int net_finalize(fs_handle h, hipStream_t s) {
             m = h->cls_conv;
             m.name = "decoder.0.weight[:, :2048]";
             m.Cin = 2048;
-            m.w = m.wino_U = nullptr;
+            m.w = m.wino_U = m.wino_U6 = nullptr;
             float* sl = nullptr;  // OIHW slice [O][2048][3][3]
             FS_HIP(hipMalloc(reinterpret_cast<void**>(&sl), (size_t)O * 2048 * 9 * sizeof(float)));
             FS_HIP(hipMemcpy2DAsync(sl, (size_t)2048 * 9 * sizeof(float), w->d, (size_t)4096 * 9 * sizeof(float),
@@ -406,7 +415,9 @@ int net_finalize(fs_handle h, hipStream_t s) {
             m.korder = 1;
             FS_TRY(launch_pack_oihw_chunk_major(sl, m.w, O, 2048, 3, 3, s));
             FS_TRY(dev_alloc(h, &m.wino_U, (size_t)36 * O * 2048));
-            FS_TRY(launch_winograd_filter(sl, m.wino_U, O, 2048, s));
+            FS_TRY(launch_winograd_filter(sl, m.wino_U, O, 2048, 4, s));
+            FS_TRY(dev_alloc(h, &m.wino_U6, (size_t)64 * O * 2048));
+            FS_TRY(launch_winograd_filter(sl, m.wino_U6, O, 2048, 6, s));
             FS_HIP(hipStreamSynchronize(s));
             FS_HIP(hipFree(sl));
             float* zw = nullptr;  // the four [9*O][512] matrices back to back: groups of one grouped GEMM

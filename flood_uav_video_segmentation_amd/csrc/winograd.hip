@@ -1,80 +1,129 @@
-// Winograd F(4x4, 3x3) transforms (Lavin & Gray matrices) around the grouped fp32-MFMA GEMM.
-// Replaces the direct 3x3 stride-1 pad-1 convolution + eval BatchNorm + ReLU of the PSPNet classifier head
-// (reference model/pspnet.py:70-73: Conv2d(4096, 512, 3, padding=1, bias=False), BatchNorm2d, ReLU).
-// All three kernels are HBM-bound elementwise-style passes over float4 channel groups (NHWC).
+// Winograd F(m x m, 3x3) transforms, m = 4 (Lavin & Gray matrices) or m = 6 (points 0, +-1, +-2, +-1/2, inf, the NNPACK
+// set), around the grouped fp32-MFMA GEMM.  Replaces the direct 3x3 stride-1 pad == dil convolution + eval BatchNorm +
+// ReLU of the PSPNet classifier head (reference model/pspnet.py:70-73: Conv2d(4096, 512, 3, padding=1, bias=False),
+// BatchNorm2d, ReLU) and of the dilated bottleneck conv2 layers (model/resnet.py:67-69 after model/pspnet.py:55-64).
+// F(6,3) needs 64 products per 36 outputs (1.78 per output) against 36 per 16 (2.25) for F(4,3), and a 90x90 map is
+// exactly 15 x 15 tiles of 6x6; its fp32 error is ~1.5x that of F(4,3) (measured 1.5e-5 vs 1.0e-5 relative on a
+// 512-channel conv; direct: 3e-7).  All kernels are HBM-bound elementwise-style passes over channel groups (NHWC).
 #include "kernels.h"
 
 namespace fs {
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-// The 2-D transforms keep 36 values live per thread: float2 per thread (not float4) keeps that under 128 VGPRs.
-typedef f32x2 wv_t;
-constexpr int WV = 2;
+// The 2-D transforms keep (m+2)^2 values live per thread: float2 per thread for F(4,3), one float for F(6,3).
+template <int WV> struct WVec;
+template <> struct WVec<1> { typedef float type; };
+template <> struct WVec<2> { typedef f32x2 type; };
 
-// B^T d (1-D, 6 -> 6) for F(4,3)
-__device__ __forceinline__ void wino_bt(const wv_t d[6], wv_t t[6]) {
-    t[0] = 4.f * d[0] - 5.f * d[2] + d[4];
-    t[1] = -4.f * (d[1] + d[2]) + d[3] + d[4];
-    t[2] = 4.f * (d[1] - d[2]) - d[3] + d[4];
-    t[3] = -2.f * d[1] - d[2] + 2.f * d[3] + d[4];
-    t[4] = 2.f * d[1] - d[2] - 2.f * d[3] + d[4];
-    t[5] = 4.f * d[1] - 5.f * d[3] + d[5];
-}
+template <int MT> struct Wino;
 
-// A^T m (1-D, 6 -> 4)
-__device__ __forceinline__ void wino_at(const wv_t m[6], wv_t y[4]) {
-    y[0] = m[0] + m[1] + m[2] + m[3] + m[4];
-    y[1] = m[1] - m[2] + 2.f * (m[3] - m[4]);
-    y[2] = m[1] + m[2] + 4.f * (m[3] + m[4]);
-    y[3] = m[1] - m[2] + 8.f * (m[3] - m[4]) + m[5];
-}
+// ---------------------------------------------------------------- F(4,3)
+template <> struct Wino<4> {
+    static constexpr int A = 6, WV = 2;
+    template <typename T> __device__ static __forceinline__ void bt(const T d[6], T t[6]) {  // B^T d
+        t[0] = 4.f * d[0] - 5.f * d[2] + d[4];
+        t[1] = -4.f * (d[1] + d[2]) + d[3] + d[4];
+        t[2] = 4.f * (d[1] - d[2]) - d[3] + d[4];
+        t[3] = -2.f * d[1] - d[2] + 2.f * d[3] + d[4];
+        t[4] = 2.f * d[1] - d[2] - 2.f * d[3] + d[4];
+        t[5] = 4.f * d[1] - 5.f * d[3] + d[5];
+    }
+    template <typename T> __device__ static __forceinline__ void at(const T m[6], T y[4]) {  // A^T m
+        y[0] = m[0] + m[1] + m[2] + m[3] + m[4];
+        y[1] = m[1] - m[2] + 2.f * (m[3] - m[4]);
+        y[2] = m[1] + m[2] + 4.f * (m[3] + m[4]);
+        y[3] = m[1] - m[2] + 8.f * (m[3] - m[4]) + m[5];
+    }
+    __device__ static __forceinline__ void g(double g0, double g1, double g2, double u[6]) {  // G g
+        u[0] = g0 / 4;
+        u[1] = -(g0 + g1 + g2) / 6;
+        u[2] = -(g0 - g1 + g2) / 6;
+        u[3] = g0 / 24 + g1 / 12 + g2 / 6;
+        u[4] = g0 / 24 - g1 / 12 + g2 / 6;
+        u[5] = g2;
+    }
+};
 
-// ---- filter transform U = G g G^T, once at load: thread per (o, c)
+// ---------------------------------------------------------------- F(6,3)
+template <> struct Wino<6> {
+    static constexpr int A = 8, WV = 1;
+    template <typename T> __device__ static __forceinline__ void bt(const T d[8], T t[8]) {
+        const T a = d[2] - 4.25f * d[4] + d[6], b = d[1] - 4.25f * d[3] + d[5];
+        const T c = 0.25f * d[2] - 1.25f * d[4] + d[6], e = 0.5f * d[1] - 2.5f * d[3] + 2.f * d[5];
+        const T f = 4.f * d[2] - 5.f * d[4] + d[6], h = 2.f * d[1] - 2.5f * d[3] + 0.5f * d[5];
+        t[0] = d[0] - d[6] + 5.25f * (d[4] - d[2]);
+        t[1] = a + b;
+        t[2] = a - b;
+        t[3] = c + e;
+        t[4] = c - e;
+        t[5] = f + h;
+        t[6] = f - h;
+        t[7] = d[7] - d[1] + 5.25f * (d[3] - d[5]);
+    }
+    template <typename T> __device__ static __forceinline__ void at(const T m[8], T y[6]) {
+        const T s1 = m[1] + m[2], d1 = m[1] - m[2], s2 = m[3] + m[4], d2 = m[3] - m[4], s3 = m[5] + m[6], d3 = m[5] - m[6];
+        y[0] = m[0] + s1 + s2 + s3;
+        y[1] = d1 + 2.f * d2 + 0.5f * d3;
+        y[2] = s1 + 4.f * s2 + 0.25f * s3;
+        y[3] = d1 + 8.f * d2 + 0.125f * d3;
+        y[4] = s1 + 16.f * s2 + 0.0625f * s3;
+        y[5] = d1 + 32.f * d2 + 0.03125f * d3 + m[7];
+    }
+    __device__ static __forceinline__ void g(double g0, double g1, double g2, double u[8]) {
+        u[0] = g0;
+        u[1] = -2.0 / 9 * (g0 + g1 + g2);
+        u[2] = -2.0 / 9 * (g0 - g1 + g2);
+        u[3] = g0 / 90 + g1 / 45 + 2 * g2 / 45;
+        u[4] = g0 / 90 - g1 / 45 + 2 * g2 / 45;
+        u[5] = 32 * g0 / 45 + 16 * g1 / 45 + 8 * g2 / 45;
+        u[6] = 32 * g0 / 45 - 16 * g1 / 45 + 8 * g2 / 45;
+        u[7] = g2;
+    }
+};
+
+// ---- filter transform U = G g G^T, once at load, in double (rounded once to fp32): thread per (o, c)
+template <int MT>
 __global__ __launch_bounds__(256) void winograd_filter_kernel(const float* __restrict__ w, float* __restrict__ U, int O, int I) {
+    constexpr int A = Wino<MT>::A;
     const int64_t total = (int64_t)O * I;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const float* g = w + i * 9;  // OIHW: [o][c][3][3]
-        float t[6][3];
+        double t[A][3];
 #pragma unroll
         for (int s = 0; s < 3; ++s) {
-            const float g0 = g[0 * 3 + s], g1 = g[1 * 3 + s], g2 = g[2 * 3 + s];
-            t[0][s] = g0 * 0.25f;
-            t[1][s] = (g0 + g1 + g2) * (-1.f / 6.f);
-            t[2][s] = (g0 - g1 + g2) * (-1.f / 6.f);
-            t[3][s] = g0 * (1.f / 24.f) + g1 * (1.f / 12.f) + g2 * (1.f / 6.f);
-            t[4][s] = g0 * (1.f / 24.f) - g1 * (1.f / 12.f) + g2 * (1.f / 6.f);
-            t[5][s] = g2;
+            double col[A];
+            Wino<MT>::g(g[0 * 3 + s], g[1 * 3 + s], g[2 * 3 + s], col);
+#pragma unroll
+            for (int r = 0; r < A; ++r) t[r][s] = col[r];
         }
 #pragma unroll
-        for (int r = 0; r < 6; ++r) {
-            const float a0 = t[r][0], a1 = t[r][1], a2 = t[r][2];
-            float u[6];
-            u[0] = a0 * 0.25f;
-            u[1] = (a0 + a1 + a2) * (-1.f / 6.f);
-            u[2] = (a0 - a1 + a2) * (-1.f / 6.f);
-            u[3] = a0 * (1.f / 24.f) + a1 * (1.f / 12.f) + a2 * (1.f / 6.f);
-            u[4] = a0 * (1.f / 24.f) - a1 * (1.f / 12.f) + a2 * (1.f / 6.f);
-            u[5] = a2;
+        for (int r = 0; r < A; ++r) {
+            double u[A];
+            Wino<MT>::g(t[r][0], t[r][1], t[r][2], u);
 #pragma unroll
-            for (int q = 0; q < 6; ++q) U[(size_t)(r * 6 + q) * total + i] = u[q];
+            for (int q = 0; q < A; ++q) U[(size_t)(r * A + q) * total + i] = (float)u[q];
         }
     }
 }
 
-int launch_winograd_filter(const float* w_oihw, float* U, int O, int I, hipStream_t s) {
+int launch_winograd_filter(const float* w_oihw, float* U, int O, int I, int mt, hipStream_t s) {
+    FS_REQUIRE(mt == 4 || mt == 6, "winograd: tile size must be 4 or 6");
     const int64_t total = (int64_t)O * I;
-    hipLaunchKernelGGL(winograd_filter_kernel, dim3((unsigned)std::min<int64_t>(cdiv64(total, 256), 65535)), dim3(256), 0, s, w_oihw, U, O, I);
+    const dim3 grid((unsigned)std::min<int64_t>(cdiv64(total, 256), 65535));
+    if (mt == 4) hipLaunchKernelGGL(winograd_filter_kernel<4>, grid, dim3(256), 0, s, w_oihw, U, O, I);
+    else hipLaunchKernelGGL(winograd_filter_kernel<6>, grid, dim3(256), 0, s, w_oihw, U, O, I);
     FS_HIP(hipGetLastError());
     return 0;
 }
 
-// ---- input transform: thread per (tile, float2 channel pair); 36 coalesced loads (zero outside the image)
+// ---- input transform: thread per (tile, channel group); (m+2)^2 coalesced loads (zero outside the image)
+template <int MT>
 __global__ __launch_bounds__(256) void winograd_input_kernel(const float* __restrict__ in, int ld_in, float* __restrict__ V, int B, int H,
                                                              int W, int CV, int th, int tw, int dil) {
+    constexpr int A = Wino<MT>::A, WV = Wino<MT>::WV;
+    typedef typename WVec<WV>::type wv_t;
     // dilation d: the conv splits into d*d independent undilated convs on the pixel lattices (py + d*i, px + d*j);
-    // tile t = (b, py, px, ty, tx) covers lattice rows 4*ty-1 .. 4*ty+4 of phase (py, px)
+    // tile t = (b, py, px, ty, tx) covers lattice rows m*ty-1 .. m*ty+m of phase (py, px)
     const int64_t T = (int64_t)B * dil * dil * th * tw;
     const int64_t total = T * CV;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
@@ -83,51 +132,56 @@ __global__ __launch_bounds__(256) void winograd_input_kernel(const float* __rest
         const int tx = (int)(t % tw), ty = (int)((t / tw) % th);
         const int ph = (int)((t / ((int64_t)tw * th)) % (dil * dil)), b = (int)(t / ((int64_t)tw * th * dil * dil));
         const int py = ph / dil, px = ph - py * dil;
-        const int y0 = py + dil * (ty * 4 - 1), x0 = px + dil * (tx * 4 - 1);  // pad = dil <=> lattice pad 1
+        const int y0 = py + dil * (ty * MT - 1), x0 = px + dil * (tx * MT - 1);  // pad = dil <=> lattice pad 1
         const float* base = in + (size_t)b * H * W * ld_in + cv * WV;
-        wv_t tmp[6][6];  // rows transformed: tmp[r][x] = (B^T d)[r][x]
+        wv_t tmp[A][A];  // rows transformed: tmp[r][x] = (B^T d)[r][x]
 #pragma unroll
-        for (int x = 0; x < 6; ++x) {
-            wv_t col[6];
+        for (int x = 0; x < A; ++x) {
+            wv_t col[A];
             const int ix = x0 + dil * x;
 #pragma unroll
-            for (int y = 0; y < 6; ++y) {
+            for (int y = 0; y < A; ++y) {
                 const int iy = y0 + dil * y;
                 const bool ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
                 const size_t off = ok ? ((size_t)iy * W + ix) * ld_in : 0;
                 const wv_t v = *reinterpret_cast<const wv_t*>(base + off);
-                col[y] = ok ? v : wv_t{0.f, 0.f};
+                col[y] = ok ? v : wv_t(0.f);
             }
-            wv_t tc[6];
-            wino_bt(col, tc);
+            wv_t tc[A];
+            Wino<MT>::bt(col, tc);
 #pragma unroll
-            for (int r = 0; r < 6; ++r) tmp[r][x] = tc[r];
+            for (int r = 0; r < A; ++r) tmp[r][x] = tc[r];
         }
 #pragma unroll
-        for (int r = 0; r < 6; ++r) {
-            wv_t o[6];
-            wino_bt(tmp[r], o);
+        for (int r = 0; r < A; ++r) {
+            wv_t o[A];
+            Wino<MT>::bt(tmp[r], o);
 #pragma unroll
-            for (int q = 0; q < 6; ++q)
-                *reinterpret_cast<wv_t*>(V + ((size_t)(r * 6 + q) * T + t) * CV * WV + cv * WV) = o[q];
+            for (int q = 0; q < A; ++q) *reinterpret_cast<wv_t*>(V + ((size_t)(r * A + q) * T + t) * CV * WV + cv * WV) = o[q];
         }
     }
 }
 
-int launch_winograd_input(const float* in, int ld_in, float* V, int B, int H, int W, int C, int dil, hipStream_t s) {
+int launch_winograd_input(const float* in, int ld_in, float* V, int B, int H, int W, int C, int dil, int mt, hipStream_t s) {
     FS_REQUIRE(C % 4 == 0 && ld_in % 4 == 0 && dil >= 1, "winograd_input: C must be a multiple of 4");
-    const int th = (cdiv(H, dil) + 3) / 4, tw = (cdiv(W, dil) + 3) / 4;
-    const int64_t total = (int64_t)B * dil * dil * th * tw * (C / WV);
-    hipLaunchKernelGGL(winograd_input_kernel, dim3((unsigned)std::min<int64_t>(cdiv64(total, 256), 1 << 20)), dim3(256), 0, s, in, ld_in, V,
-                       B, H, W, C / WV, th, tw, dil);
+    FS_REQUIRE(mt == 4 || mt == 6, "winograd: tile size must be 4 or 6");
+    const int th = (cdiv(H, dil) + mt - 1) / mt, tw = (cdiv(W, dil) + mt - 1) / mt;
+    const int wv = mt == 4 ? Wino<4>::WV : Wino<6>::WV;
+    const int64_t total = (int64_t)B * dil * dil * th * tw * (C / wv);
+    const dim3 grid((unsigned)std::min<int64_t>(cdiv64(total, 256), 1 << 20));
+    if (mt == 4) hipLaunchKernelGGL(winograd_input_kernel<4>, grid, dim3(256), 0, s, in, ld_in, V, B, H, W, C / wv, th, tw, dil);
+    else hipLaunchKernelGGL(winograd_input_kernel<6>, grid, dim3(256), 0, s, in, ld_in, V, B, H, W, C / wv, th, tw, dil);
     FS_HIP(hipGetLastError());
     return 0;
 }
 
-// ---- output transform + scale/shift + activation: thread per (tile, float2 output-channel pair)
+// ---- output transform + scale/shift + activation: thread per (tile, output-channel group)
+template <int MT>
 __global__ __launch_bounds__(256) void winograd_output_kernel(const float* __restrict__ M, const float* __restrict__ scale,
                                                               const float* __restrict__ shift, float* __restrict__ out, int ld_out, int B,
                                                               int H, int W, int NV, int th, int tw, int relu, int dil) {
+    constexpr int A = Wino<MT>::A, WV = Wino<MT>::WV;
+    typedef typename WVec<WV>::type wv_t;
     const int64_t T = (int64_t)B * dil * dil * th * tw;
     const int64_t total = T * NV;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
@@ -136,34 +190,31 @@ __global__ __launch_bounds__(256) void winograd_output_kernel(const float* __res
         const int tx = (int)(t % tw), ty = (int)((t / tw) % th);
         const int ph = (int)((t / ((int64_t)tw * th)) % (dil * dil)), b = (int)(t / ((int64_t)tw * th * dil * dil));
         const int py = ph / dil, px = ph - py * dil;
-        wv_t tmp[4][6];  // tmp[a][q] = (A^T m)[a][q]
+        wv_t tmp[MT][A];  // tmp[a][q] = (A^T m)[a][q]
 #pragma unroll
-        for (int q = 0; q < 6; ++q) {
-            wv_t col[6];
+        for (int q = 0; q < A; ++q) {
+            wv_t col[A];
 #pragma unroll
-            for (int r = 0; r < 6; ++r) col[r] = *reinterpret_cast<const wv_t*>(M + ((size_t)(r * 6 + q) * T + t) * NV * WV + nv * WV);
-            wv_t y[4];
-            wino_at(col, y);
+            for (int r = 0; r < A; ++r) col[r] = *reinterpret_cast<const wv_t*>(M + ((size_t)(r * A + q) * T + t) * NV * WV + nv * WV);
+            wv_t y[MT];
+            Wino<MT>::at(col, y);
 #pragma unroll
-            for (int a = 0; a < 4; ++a) tmp[a][q] = y[a];
+            for (int a = 0; a < MT; ++a) tmp[a][q] = y[a];
         }
-        const wv_t sc = scale ? *reinterpret_cast<const wv_t*>(scale + nv * WV) : wv_t{1.f, 1.f};
-        const wv_t sh = shift ? *reinterpret_cast<const wv_t*>(shift + nv * WV) : wv_t{0.f, 0.f};
+        const wv_t sc = scale ? *reinterpret_cast<const wv_t*>(scale + nv * WV) : wv_t(1.f);
+        const wv_t sh = shift ? *reinterpret_cast<const wv_t*>(shift + nv * WV) : wv_t(0.f);
 #pragma unroll
-        for (int a = 0; a < 4; ++a) {
-            wv_t y[4];
-            wino_at(tmp[a], y);
-            const int oy = py + dil * (ty * 4 + a);
+        for (int a = 0; a < MT; ++a) {
+            wv_t y[MT];
+            Wino<MT>::at(tmp[a], y);
+            const int oy = py + dil * (ty * MT + a);
             if (oy >= H) continue;
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const int ox = px + dil * (tx * 4 + c);
+            for (int c = 0; c < MT; ++c) {
+                const int ox = px + dil * (tx * MT + c);
                 if (ox >= W) continue;
                 wv_t v = y[c] * sc + sh;
-                if (relu) {
-#pragma unroll
-                    for (int e = 0; e < WV; ++e) v[e] = fmaxf(v[e], 0.f);
-                }
+                if (relu) v = __builtin_elementwise_max(v, wv_t(0.f));
                 *reinterpret_cast<wv_t*>(out + ((size_t)(b * H + oy) * W + ox) * ld_out + nv * WV) = v;
             }
         }
@@ -171,12 +222,17 @@ __global__ __launch_bounds__(256) void winograd_output_kernel(const float* __res
 }
 
 int launch_winograd_output(const float* M, const float* scale, const float* shift, float* out, int ld_out, int B, int H, int W, int N,
-                           int relu, int dil, hipStream_t s) {
+                           int relu, int dil, int mt, hipStream_t s) {
     FS_REQUIRE(N % 4 == 0 && ld_out % 4 == 0 && dil >= 1, "winograd_output: N must be a multiple of 4");
-    const int th = (cdiv(H, dil) + 3) / 4, tw = (cdiv(W, dil) + 3) / 4;
-    const int64_t total = (int64_t)B * dil * dil * th * tw * (N / WV);
-    hipLaunchKernelGGL(winograd_output_kernel, dim3((unsigned)std::min<int64_t>(cdiv64(total, 256), 1 << 20)), dim3(256), 0, s, M, scale,
-                       shift, out, ld_out, B, H, W, N / WV, th, tw, relu, dil);
+    FS_REQUIRE(mt == 4 || mt == 6, "winograd: tile size must be 4 or 6");
+    const int th = (cdiv(H, dil) + mt - 1) / mt, tw = (cdiv(W, dil) + mt - 1) / mt;
+    const int wv = mt == 4 ? Wino<4>::WV : Wino<6>::WV;
+    const int64_t total = (int64_t)B * dil * dil * th * tw * (N / wv);
+    const dim3 grid((unsigned)std::min<int64_t>(cdiv64(total, 256), 1 << 20));
+    if (mt == 4)
+        hipLaunchKernelGGL(winograd_output_kernel<4>, grid, dim3(256), 0, s, M, scale, shift, out, ld_out, B, H, W, N / wv, th, tw, relu, dil);
+    else
+        hipLaunchKernelGGL(winograd_output_kernel<6>, grid, dim3(256), 0, s, M, scale, shift, out, ld_out, B, H, W, N / wv, th, tw, relu, dil);
     FS_HIP(hipGetLastError());
     return 0;
 }

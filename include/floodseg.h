@@ -131,11 +131,12 @@ int fs_pack_conv_weight(const float* oihw, float* ohwi, int O, int I, int KH, in
 int fs_conv2d_nhwc(const float* in, int ld_in, const float* wgt_ohwi, const float* scale, const float* shift,
                    const float* res, int ld_res, float* out, int ld_out, int B, int H, int W, int Cin, int Cout, int KH,
                    int KW, int stride, int pad, int dil, int relu, int tile, fs_stream stream);
-/* 3x3 stride-1 conv with padding == dilation as Winograd F(4x4,3x3) (transforms + 36 grouped MFMA GEMMs); the network uses it
- * for every such conv with Cin >= 256.  workspace: fs_winograd_workspace_floats(...) floats of device memory. */
-size_t fs_winograd_workspace_floats(int B, int H, int W, int Cin, int Cout, int dil);
+/* 3x3 stride-1 conv with padding == dilation as Winograd F(m x m,3x3) (transforms + (m+2)^2 grouped MFMA GEMMs); the network
+ * uses it for every such conv with Cin >= 256.  tile_m: 4, 6, or 0 = whichever needs fewer GEMM rows for this map (a 90x90
+ * map is exactly 15x15 tiles of 6x6).  workspace: fs_winograd_workspace_floats(..., same tile_m) floats of device memory. */
+size_t fs_winograd_workspace_floats(int B, int H, int W, int Cin, int Cout, int dil, int tile_m);
 int fs_conv3x3_winograd_nhwc(const float* in, int ld_in, const float* wgt_oihw, const float* scale, const float* shift, float* out,
-                             int ld_out, int B, int H, int W, int Cin, int Cout, int dil, int relu, float* workspace,
+                             int ld_out, int B, int H, int W, int Cin, int Cout, int dil, int relu, int tile_m, float* workspace,
                              fs_stream stream);
 /* wgt_hwio: [KH][KW][3][Cout] (weight.permute(2,3,1,0)) */
 int fs_stem_conv_nchw(const float* in_nchw, const float* wgt_hwio, const float* scale, const float* shift, float* out_nhwc,
