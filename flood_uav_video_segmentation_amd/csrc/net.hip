@@ -492,6 +492,44 @@ size_t net_workspace_bytes(fs_handle h, int B, int H, int W) {
 
 // ---------------------------------------------------------------------------------------------
 namespace {
+// Pyramid pooling up to the reduced maps (model/pspnet.py:22-26): adaptive average pools (bins 1, 2, 3, 6) of the 2048
+// backbone channels -> 1x1 conv + BN + ReLU.  Layout in h->small: pooled maps back to back (1 + 4 + 9 + 36 cells per
+// image x 2048), then per level a fixed-stride slot of B*36 rows x 512 (the fused head's grouped Z GEMM wants one stride).
+int pyramid_reduce(fs_net* h, const float* feat, int ld_feat, int B, int H, int W, hipStream_t s) {
+    float* pooled = h->small;
+    float* reduced = h->small + (size_t)B * 50 * 2048;
+    size_t pool_off[4];
+    {
+        size_t po = 0;
+        for (int i = 0; i < 4; ++i) {
+            pool_off[i] = po;
+            po += (size_t)B * h->bins[i] * h->bins[i] * 2048;
+        }
+    }
+    const bool even = H % 6 == 0 && W % 6 == 0 && h->bins[0] == 1 && h->bins[1] == 2 && h->bins[2] == 3 && h->bins[3] == 6;
+    if (even) {  // one pass over the 2048-channel map instead of four
+        FS_TRY(prof_begin(h, "ppm.pool6+combine", "adaptive_avgpool", 0, 4.0 * B * H * W * 2048.0, s));
+        FS_TRY(launch_adaptive_avgpool(feat, ld_feat, pooled + pool_off[3], B, H, W, 2048, 6, s));
+        FS_TRY(launch_ppm_pool_combine(pooled + pool_off[3], pooled + pool_off[0], pooled + pool_off[1], pooled + pool_off[2], B, 2048, s));
+        FS_TRY(prof_end(h, s));
+    }
+    for (int i = 0; i < 4; ++i) {
+        const int bin = h->bins[i];
+        const int cells = bin * bin;
+        if (!even) {
+            FS_TRY(prof_begin(h, "ppm.pool" + std::to_string(bin), "adaptive_avgpool", 0, 4.0 * B * H * W * 2048.0, s));
+            FS_TRY(launch_adaptive_avgpool(feat, ld_feat, pooled + pool_off[i], B, H, W, 2048, bin, s));
+            FS_TRY(prof_end(h, s));
+        }
+        const ConvBN& c = h->ppm[i];
+        FS_TRY(prof_begin(h, c.name, "rowdot_1x1", 2.0 * B * cells * 2048.0 * 512.0, 4.0 * 2048.0 * 512.0, s));
+        FS_TRY(launch_rowdot_1x1(pooled + pool_off[i], 2048, c.w, c.scale, c.shift, reduced + (size_t)i * B * 36 * 512, 512, B * cells, 2048,
+                                 512, 1, s));
+        FS_TRY(prof_end(h, s));
+    }
+    return 0;
+}
+
 // ResNet backbone (+ pyramid pooling for PSPNet).  out != nullptr: the reference's encoder output (PSPNet: 4096-channel
 // concat with the upsampled pyramid; ld_out = feat_channels()).  out == nullptr (fused PSPNet route): the 2048 backbone
 // channels stay in a workspace buffer (*feat2048, ld 2048) and the pyramid stops at the pooled+reduced maps in h->small.
@@ -573,44 +611,14 @@ int encoder_core(fs_handle h, const float* in_nchw, int B, int H, int W, float* 
         out = F1;
     }
     if (!psp) return 0;
-    const int ld_feat = fused ? 2048 : 4096;
-
+    if (fused) return 0;  // net_segment runs the pyramid itself (on its side stream) and never upsamples it
     // ---- pyramid pooling: pooled -> 1x1 conv + BN + ReLU -> bilinear(ac=True) into channels 2048+512*i
-    float* pooled = h->small;
+    FS_TRY(pyramid_reduce(h, out, 4096, B, curH, curW, s));
     float* reduced = h->small + (size_t)B * 50 * 2048;
-    // pooled layout: bins in order (1, 2, 3, 6): offsets 0, B*1*2048, B*5*2048, B*14*2048
-    size_t pool_off[4], red_off[4];
-    {
-        size_t po = 0, ro = 0;
-        for (int i = 0; i < 4; ++i) {
-            pool_off[i] = po;
-            red_off[i] = ro;
-            po += (size_t)B * h->bins[i] * h->bins[i] * 2048;
-            ro += (size_t)B * 36 * 512;  // fixed stride per level: the fused head runs the four Z GEMMs as one grouped launch
-        }
-    }
-    const bool even = curH % 6 == 0 && curW % 6 == 0 && h->bins[0] == 1 && h->bins[1] == 2 && h->bins[2] == 3 && h->bins[3] == 6;
-    if (even) {  // one pass over the 2048-channel map instead of four
-        FS_TRY(prof_begin(h, "ppm.pool6+combine", "adaptive_avgpool", 0, 4.0 * B * curH * curW * 2048.0, s));
-        FS_TRY(launch_adaptive_avgpool(out, ld_feat, pooled + pool_off[3], B, curH, curW, 2048, 6, s));
-        FS_TRY(launch_ppm_pool_combine(pooled + pool_off[3], pooled + pool_off[0], pooled + pool_off[1], pooled + pool_off[2], B, 2048, s));
-        FS_TRY(prof_end(h, s));
-    }
     for (int i = 0; i < 4; ++i) {
         const int bin = h->bins[i];
-        const int cells = bin * bin;
-        if (!even) {
-            FS_TRY(prof_begin(h, "ppm.pool" + std::to_string(bin), "adaptive_avgpool", 0, 4.0 * B * curH * curW * 2048.0, s));
-            FS_TRY(launch_adaptive_avgpool(out, ld_feat, pooled + pool_off[i], B, curH, curW, 2048, bin, s));
-            FS_TRY(prof_end(h, s));
-        }
-        const ConvBN& c = h->ppm[i];
-        FS_TRY(prof_begin(h, c.name, "rowdot_1x1", 2.0 * B * cells * 2048.0 * 512.0, 4.0 * 2048.0 * 512.0, s));
-        FS_TRY(launch_rowdot_1x1(pooled + pool_off[i], 2048, c.w, c.scale, c.shift, reduced + red_off[i], 512, B * cells, 2048, 512, 1, s));
-        FS_TRY(prof_end(h, s));
-        if (fused) continue;  // the head consumes the reduced maps directly (net_segment)
         FS_TRY(prof_begin(h, "ppm.up" + std::to_string(bin), "upsample_into", 0, 4.0 * B * curH * curW * 512.0, s));
-        FS_TRY(launch_upsample_into(reduced + red_off[i], bin, bin, out + 2048 + 512 * i, 4096, B, curH, curW, 512, 1, s));
+        FS_TRY(launch_upsample_into(reduced + (size_t)i * B * 36 * 512, bin, bin, out + 2048 + 512 * i, 4096, B, curH, curW, 512, 1, s));
         FS_TRY(prof_end(h, s));
     }
     return 0;
@@ -650,6 +658,10 @@ int net_segment(fs_handle h, const float* in_nchw, int B, int H, int W, float* o
     FS_TRY(ensure_workspace(h, encoder_buf_elems(h, B, H, W), small_elems_for(B)));
     float* feat = nullptr;
     FS_TRY(encoder_core(h, in_nchw, B, H, W, nullptr, &feat, s));
+    // (Running the pyramid branch -- pool, four tiny 1x1 convs, the Z GEMM, ~0.12 ms -- on a side stream under the head's
+    //  Winograd GEMM was measured: +0.2 %, not worth a second stream in the handle.)
+    hipStream_t ps = s;
+    FS_TRY(pyramid_reduce(h, feat, 2048, B, fh, fw, ps));
     // free workspace buffers now: every h->buf[] except `feat`
     float* T = nullptr;
     for (int i = 0; i < 4; ++i)
@@ -672,9 +684,9 @@ int net_segment(fs_handle h, const float* in_nchw, int B, int H, int W, float* o
         p.g_wgt = (long long)z.Cout * 512;
         p.g_out = (long long)rows * z.Cout;
         FS_TRY(prof_begin(h, "decoder.0.weight[:, ppm]", conv_igemm_tile_name(p), 2.0 * B * 50 * 512.0 * z.Cout,
-                          4.0 * (4.0 * z.Cout * 512 + B * 50.0 * (512 + z.Cout)), s));
-        FS_TRY(launch_conv_igemm(p, s));
-        FS_TRY(prof_end(h, s));
+                          4.0 * (4.0 * z.Cout * 512 + B * 50.0 * (512 + z.Cout)), ps));
+        FS_TRY(launch_conv_igemm(p, ps));
+        FS_TRY(prof_end(h, ps));
         for (int i = 0; i < 4; ++i) Z[i] = zbuf + (size_t)i * p.g_out;
     }
     ConvBN raw = h->cls_main;  // raw sums: BatchNorm + ReLU are applied after the pyramid term has been added
