@@ -84,8 +84,10 @@ int launch_pack_oihw_chunk_major(const float* w, float* out, int O, int I, int K
 // out[(tap*O + o)*nc + c] = w[o][c0 + c][tap]: input-channel slice of an OIHW bank as a [taps*O][nc] 1x1 filter matrix
 int launch_pack_slice_tap_major(const float* w, float* out, int O, int I, int c0, int nc, int taps, hipStream_t s);
 // T = act(scale * (T + sum_b conv-of-upsampled-pyramid term from Z_b) + shift), see net_ops.hip (PSPNet head)
-int launch_ppm_term_finish(float* T, int ld, const float* const Z[4], const int bins[4], const float* scale, const float* shift, int B,
-                           int H, int W, int C, int relu, hipStream_t s);
+// scratch: ppm_term_scratch_floats(B, H, C) floats (row-collapsed pyramid term)
+size_t ppm_term_scratch_floats(int B, int H, int C);
+int launch_ppm_term_finish(float* T, int ld, const float* const Z[4], const int bins[4], float* scratch, const float* scale,
+                           const float* shift, int B, int H, int W, int C, int relu, hipStream_t s);
 int launch_nchw_to_nhwc(const float* in, float* out, int ld_out, int B, int C, int HW, hipStream_t s);
 int launch_nhwc_to_nchw(const float* in, int ld_in, float* out, int B, int C, int HW, hipStream_t s);
 

@@ -663,9 +663,13 @@ int net_segment(fs_handle h, const float* in_nchw, int B, int H, int W, float* o
     hipStream_t ps = s;
     FS_TRY(pyramid_reduce(h, feat, 2048, B, fh, fw, ps));
     // free workspace buffers now: every h->buf[] except `feat`
-    float* T = nullptr;
+    float *T = nullptr, *R = nullptr;  // head conv output; row-collapsed pyramid term
     for (int i = 0; i < 4; ++i)
-        if (h->buf[i] != feat) T = h->buf[i];
+        if (h->buf[i] != feat) {
+            R = T;
+            T = h->buf[i];
+        }
+    FS_REQUIRE(ppm_term_scratch_floats(B, fh, h->cls_main.Cout) <= h->buf_elems, "fs_segment_forward: workspace too small for the pyramid term");
     const int K = h->cfg.classes, O = h->cls_main.Cout;
     const size_t px = (size_t)B * fh * fw;
     // Z_b = reduced_b x W_b: [B*bin*bin] x [9*O]
@@ -694,7 +698,7 @@ int net_segment(fs_handle h, const float* in_nchw, int B, int H, int W, float* o
     raw.relu = 0;
     FS_TRY(run_conv(h, raw, feat, 2048, B, fh, fw, T, O, nullptr, 0, s));
     FS_TRY(prof_begin(h, "decoder.0.pyramid_term", "ppm_term_finish", 2.0 * px * O * 144.0, 4.0 * 2.0 * px * O, s));
-    FS_TRY(launch_ppm_term_finish(T, O, Z, h->bins, h->cls_main.scale, h->cls_main.shift, B, fh, fw, O, 1, s));
+    FS_TRY(launch_ppm_term_finish(T, O, Z, h->bins, R, h->cls_main.scale, h->cls_main.shift, B, fh, fw, O, 1, s));
     FS_TRY(prof_end(h, s));
     FS_TRY(prof_begin(h, "decoder.4", "classifier_nchw", 2.0 * px * (double)O * K, 4.0 * px * O, s));
     FS_TRY(launch_classifier_nchw(T, O, h->cls_w, h->cls_b, out_nchw, B, fh * fw, O, K, s));

@@ -416,20 +416,45 @@ int launch_pack_slice_tap_major(const float* w, float* out, int O, int I, int c0
 // and a_b the bilinear (align_corners=True) weights of F.interpolate.  This kernel adds the second term to the raw main
 // conv output and applies BatchNorm scale/shift + ReLU in place.  The 2048 pyramid channels of the reference's 4096-
 // channel concat never exist: half of the head's GEMM and of its Winograd input transform disappear.
-// One block = PPM_P consecutive pixels of a row x all C channels (a float4 per thread): every Z row is loaded once per
-// block and reused for the pixels that touch the same cell; the coordinate math is block-uniform (scalar unit).
+// Two passes, using that the bilinear weights are separable:
+//   R_b[y][j][s][o] = sum_r [row y+r-1 inside] sum_i wy_b(y+r-1; i) Z_b[(i, j)][(r, s)][o]      ppm_rows_kernel (tiny)
+//   term[y][x][o]   = sum_b sum_s [column x+s-1 inside] sum_j wx_b(x+s-1; j) R_b[y][j][s][o]    ppm_term_finish_kernel
+// i.e. 6 products per row entry and then <= 24 per output, instead of <= 144 per output in one pass (0.12 -> see profiles).
+// Finish pass: one block = PPM_P consecutive pixels of a row x all C channels (a float4 per thread).
 // -------------------------------------------------------------------------------------------
-constexpr int PPM_P = 15;
+constexpr int PPM_P = 6;    // pixels of one row per block in the finish pass
+constexpr int PPM_J = 12;   // 1 + 2 + 3 + 6 source columns over the four levels
 struct PpmTermParams {
     float* T; int ld;        // [B*H*W][ld]: raw conv output in, finished activations out
     const float* Z[4];       // [B*bin*bin][9*C]
-    int bin[4];
+    float* R;                // [B*H][PPM_J][3][C] scratch
+    int bin[4], joff[4];     // joff: first column slot of the level in R
     float sy[4], sx[4];      // resize_scale(bin, H, 1), resize_scale(bin, W, 1)
     const float* scale; const float* shift;
     int B, H, W, C, relu;
 };
 
-__device__ __forceinline__ float lin_weight(const LinCoord& c, int i) { return (i == c.i0 ? c.w0 : 0.f) + (i == c.i1 ? c.w1 : 0.f); }
+__global__ __launch_bounds__(256) void ppm_rows_kernel(PpmTermParams p) {
+    const int js = blockIdx.x, y = blockIdx.y, b = blockIdx.z;  // js = column slot * 3 + tap column
+    const int slot = js / 3, s = js - slot * 3;
+    const int c = threadIdx.x * 4;
+    if (c >= p.C) return;
+    int bi = 3;
+    while (slot < p.joff[bi]) --bi;
+    const int bin = p.bin[bi], j = slot - p.joff[bi];
+    const float* Zb = p.Z[bi] + (size_t)b * bin * bin * 9 * p.C + c;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int r = 0; r < 3; ++r) {
+        const int Y = y + r - 1;
+        if (Y < 0 || Y >= p.H) continue;  // zero padding of the conv
+        const LinCoord cy = lin_coord(Y, bin, p.sy[bi], 1);
+        const f32x4 z0 = *reinterpret_cast<const f32x4*>(Zb + ((size_t)(cy.i0 * bin + j) * 9 + r * 3 + s) * p.C);
+        const f32x4 z1 = *reinterpret_cast<const f32x4*>(Zb + ((size_t)(cy.i1 * bin + j) * 9 + r * 3 + s) * p.C);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] = fmaf(cy.w1, z1[e], fmaf(cy.w0, z0[e], acc[e]));
+    }
+    *reinterpret_cast<f32x4*>(p.R + (((size_t)(b * p.H + y) * PPM_J + slot) * 3 + s) * p.C + c) = acc;
+}
 
 __global__ __launch_bounds__(256) void ppm_term_finish_kernel(PpmTermParams p) {
     const int xt = blockIdx.x, y = blockIdx.y, b = blockIdx.z;
@@ -439,11 +464,10 @@ __global__ __launch_bounds__(256) void ppm_term_finish_kernel(PpmTermParams p) {
     f32x4 acc[PPM_P];
 #pragma unroll
     for (int px = 0; px < PPM_P; ++px) acc[px] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float* Rrow = p.R + (size_t)(b * p.H + y) * PPM_J * 3 * p.C + c;
     for (int bi = 0; bi < 4; ++bi) {
         const int bin = p.bin[bi];
-        const float* Zb = p.Z[bi] + (size_t)b * bin * bin * 9 * p.C + c;
         for (int s = 0; s < 3; ++s) {
-            // column weights of the block's pixels for this tap column: source cells jmin..jmax
             LinCoord cx[PPM_P];
             bool ok[PPM_P];
             int jmin = bin, jmax = -1;
@@ -457,31 +481,13 @@ __global__ __launch_bounds__(256) void ppm_term_finish_kernel(PpmTermParams p) {
                     jmax = max(jmax, cx[px].i1);
                 }
             }
-            for (int jb = jmin; jb <= jmax; jb += 4) {  // 4 source columns at a time (one pass at the BASELINE geometry)
-                float wx[PPM_P][4];
+            for (int j = jmin; j <= jmax; ++j) {
+                const f32x4 z = *reinterpret_cast<const f32x4*>(Rrow + ((size_t)(p.joff[bi] + j) * 3 + s) * p.C);
 #pragma unroll
-                for (int px = 0; px < PPM_P; ++px)
+                for (int px = 0; px < PPM_P; ++px) {
+                    const float w = ok[px] ? (j == cx[px].i0 ? cx[px].w0 : 0.f) + (j == cx[px].i1 ? cx[px].w1 : 0.f) : 0.f;
 #pragma unroll
-                    for (int jj = 0; jj < 4; ++jj) wx[px][jj] = (ok[px] && jb + jj <= jmax) ? lin_weight(cx[px], jb + jj) : 0.f;
-                for (int r = 0; r < 3; ++r) {
-                    const int Y = y + r - 1;
-                    if (Y < 0 || Y >= p.H) continue;  // zero padding of the conv
-                    const LinCoord cy = lin_coord(Y, bin, p.sy[bi], 1);
-                    const int tap = r * 3 + s;
-                    for (int i = cy.i0; i <= cy.i1; ++i) {
-                        const float wy = lin_weight(cy, i);
-#pragma unroll
-                        for (int jj = 0; jj < 4; ++jj) {
-                            if (jb + jj > jmax) break;
-                            const f32x4 z = *reinterpret_cast<const f32x4*>(Zb + ((size_t)(i * bin + jb + jj) * 9 + tap) * p.C);
-#pragma unroll
-                            for (int px = 0; px < PPM_P; ++px) {
-                                const float w = wy * wx[px][jj];
-#pragma unroll
-                                for (int e = 0; e < 4; ++e) acc[px][e] = fmaf(w, z[e], acc[px][e]);
-                            }
-                        }
-                    }
+                    for (int e = 0; e < 4; ++e) acc[px][e] = fmaf(w, z[e], acc[px][e]);
                 }
             }
         }
@@ -502,20 +508,29 @@ __global__ __launch_bounds__(256) void ppm_term_finish_kernel(PpmTermParams p) {
     }
 }
 
-int launch_ppm_term_finish(float* T, int ld, const float* const Z[4], const int bins[4], const float* scale, const float* shift, int B,
-                           int H, int W, int C, int relu, hipStream_t s) {
+size_t ppm_term_scratch_floats(int B, int H, int C) { return (size_t)B * H * PPM_J * 3 * C; }
+
+int launch_ppm_term_finish(float* T, int ld, const float* const Z[4], const int bins[4], float* scratch, const float* scale,
+                           const float* shift, int B, int H, int W, int C, int relu, hipStream_t s) {
     FS_REQUIRE(C % 4 == 0 && C <= 1024 && ld % 4 == 0 && ((uintptr_t)T & 15) == 0, "ppm_term_finish: C must be a multiple of 4, <= 1024");
     FS_REQUIRE(H <= 65535 && B <= 65535, "ppm_term_finish: map too large for the launch grid");
+    FS_REQUIRE(bins[0] + bins[1] + bins[2] + bins[3] == PPM_J && scratch, "ppm_term_finish: pyramid levels must add up to %d columns", PPM_J);
     PpmTermParams p{};
-    p.T = T; p.ld = ld; p.scale = scale; p.shift = shift;
+    p.T = T; p.ld = ld; p.R = scratch; p.scale = scale; p.shift = shift;
     p.B = B; p.H = H; p.W = W; p.C = C; p.relu = relu;
+    int jo = 0;
     for (int i = 0; i < 4; ++i) {
         p.Z[i] = Z[i];
         p.bin[i] = bins[i];
+        p.joff[i] = jo;
+        jo += bins[i];
         p.sy[i] = resize_scale(bins[i], H, 1);
         p.sx[i] = resize_scale(bins[i], W, 1);
     }
-    hipLaunchKernelGGL(ppm_term_finish_kernel, dim3(cdiv(W, PPM_P), H, B), dim3(((C / 4 + 63) / 64) * 64), 0, s, p);
+    const dim3 block(((C / 4 + 63) / 64) * 64);
+    hipLaunchKernelGGL(ppm_rows_kernel, dim3(PPM_J * 3, H, B), block, 0, s, p);
+    FS_HIP(hipGetLastError());
+    hipLaunchKernelGGL(ppm_term_finish_kernel, dim3(cdiv(W, PPM_P), H, B), block, 0, s, p);
     FS_HIP(hipGetLastError());
     return 0;
 }
