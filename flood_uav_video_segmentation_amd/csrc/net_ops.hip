@@ -125,21 +125,21 @@ int launch_maxpool3x3s2(const float* in, int ld_in, float* out, int ld_out, int 
 
 // -------------------------------------------------------------------------------------------
 // AdaptiveAvgPool2d(bin): windows [floor(i*H/bin), ceil((i+1)*H/bin)).
-// Block = 64 pixel lanes x 4 float4 channel lanes (16 channels); grid (bin*bin, C/16, B): even the
-// bin = 1 case (one 90x90 window) spreads over C/16 * B blocks with 127 pixels per thread.
+// Block = 32 pixel lanes x 8 float4 channel lanes (32 channels = one 128-B line per pixel); grid (bin*bin, C/32, B):
+// even the bin = 1 case (one 90x90 window) spreads over C/32 * B blocks with 254 pixels per thread.
 // -------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void adaptive_avgpool_kernel(const float* __restrict__ in, int ld_in, float* __restrict__ out,
                                                                int H, int W, int C, int bin) {
-    __shared__ f32x4 part[64][4];
+    __shared__ f32x4 part[32][8];
     const int cell = blockIdx.x, b = blockIdx.z;
     const int by = cell / bin, bx = cell - by * bin;
     const int ys = (by * H) / bin, ye = ((by + 1) * H + bin - 1) / bin;
     const int xs = (bx * W) / bin, xe = ((bx + 1) * W + bin - 1) / bin;
     const int wh = ye - ys, ww = xe - xs;
-    const int cl = threadIdx.x & 3, pg = threadIdx.x >> 2;
-    const int c = blockIdx.y * 16 + cl * 4;
+    const int cl = threadIdx.x & 7, pg = threadIdx.x >> 3;
+    const int c = blockIdx.y * 32 + cl * 4;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    for (int i = pg; i < wh * ww; i += 64) {
+    for (int i = pg; i < wh * ww; i += 32) {
         const int y = ys + i / ww, x = xs + i % ww;
         const f32x4 v = *reinterpret_cast<const f32x4*>(in + ((size_t)(b * H + y) * W + x) * ld_in + c);
         acc += v;
@@ -148,7 +148,7 @@ __global__ __launch_bounds__(256) void adaptive_avgpool_kernel(const float* __re
     __syncthreads();
     if (pg == 0) {
         f32x4 sum = part[0][cl];
-        for (int g = 1; g < 64; ++g) sum += part[g][cl];
+        for (int g = 1; g < 32; ++g) sum += part[g][cl];
         const float inv = 1.f / (float)(wh * ww);
         sum *= inv;
         *reinterpret_cast<f32x4*>(out + ((size_t)b * bin * bin + cell) * C + c) = sum;
@@ -156,8 +156,8 @@ __global__ __launch_bounds__(256) void adaptive_avgpool_kernel(const float* __re
 }
 
 int launch_adaptive_avgpool(const float* in, int ld_in, float* out, int B, int H, int W, int C, int bin, hipStream_t s) {
-    FS_REQUIRE(C % 16 == 0 && ld_in % 4 == 0, "adaptive_avgpool: C=%d must be a multiple of 16", C);
-    hipLaunchKernelGGL(adaptive_avgpool_kernel, dim3(bin * bin, C / 16, B), dim3(256), 0, s, in, ld_in, out, H, W, C, bin);
+    FS_REQUIRE(C % 32 == 0 && ld_in % 4 == 0, "adaptive_avgpool: C=%d must be a multiple of 32", C);
+    hipLaunchKernelGGL(adaptive_avgpool_kernel, dim3(bin * bin, C / 32, B), dim3(256), 0, s, in, ld_in, out, H, W, C, bin);
     FS_HIP(hipGetLastError());
     return 0;
 }
