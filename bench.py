@@ -91,8 +91,8 @@ def cpu_baseline(state, windows_cpu):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary variants (1072x1920 post-processing, key-frame cache)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",

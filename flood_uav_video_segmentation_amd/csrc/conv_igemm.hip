@@ -292,6 +292,21 @@ __device__ __forceinline__ void igemm_epilogue(const f32x16 (&acc)[TM][TN], cons
     const __amdgpu_buffer_rsrc_t r_rsrc =
         __builtin_amdgcn_make_buffer_rsrc((void*)(RES ? p.res : p.out), 0, (unsigned)((long long)M * (RES ? p.ld_res : p.ld_out) * 4), 0x00020000);
     const unsigned row_o = (unsigned)p.ld_out * 4u, row_r = (unsigned)p.ld_res * 4u;
+    // residual tile first, all TM*TN*16 loads in flight together (one latency instead of one per 32x32 block)
+    float rv[RES ? TM : 1][RES ? TN : 1][16];
+    if (RES) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n_base + j * 32;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const unsigned vr = n < p.Cout ? (unsigned)(m_base + i * 32) * row_r + (unsigned)n * 4u : SENT;
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    rv[i][j][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_rsrc, vr + (unsigned)((e & 3) + 8 * (e >> 2)) * row_r, 0, 0));
+            }
+        }
+    }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int n = n_base + j * 32;
@@ -302,17 +317,10 @@ __device__ __forceinline__ void igemm_epilogue(const f32x16 (&acc)[TM][TN], cons
         for (int i = 0; i < TM; ++i) {
             const int mb = m_base + i * 32;
             const unsigned vo = nok ? (unsigned)mb * row_o + (unsigned)n * 4u : SENT;
-            float rv[16];
-            if (RES) {
-                const unsigned vr = nok ? (unsigned)mb * row_r + (unsigned)n * 4u : SENT;
-#pragma unroll
-                for (int e = 0; e < 16; ++e)
-                    rv[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_rsrc, vr + (unsigned)((e & 3) + 8 * (e >> 2)) * row_r, 0, 0));
-            }
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 float v = acc[i][j][e] * sc_n + sh_n;
-                if (RES) v += rv[e];
+                if (RES) v += rv[i][j][e];
                 if (ACT == 1) v = fmaxf(v, 0.f);
                 else if (ACT == 2) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752f));  // nn.GELU (erf form)
                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), o_rsrc, vo + (unsigned)((e & 3) + 8 * (e >> 2)) * row_o, 0, 0);
