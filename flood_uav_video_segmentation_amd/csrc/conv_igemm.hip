@@ -13,8 +13,12 @@
 // sums over k, so any k permutation is legal.
 // D layout (32x32): col(n) = lane&31, row(m) = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
 //   -> each store instruction writes two 128-B channel runs: coalesced NHWC epilogue.
-// Pipeline: register prefetch of chunk k+1 (global_load_dwordx4) is in flight while chunk k is
-// multiplied out of LDS (64 MFMAs = 4096 cycles per wave per chunk at 128x128).
+// History (measured on MI355X, profiles/r01_conv_*.txt): the bring-up kernel staged tiles through VGPRs with two barriers
+// per chunk (120 TFLOP/s on the decoder conv); double-buffered LDS + register-pinned fragment prefetch alone: null;
+// global_load_lds with a zero page: 128; buffer_load...lds with range-check padding: 138.  Tried and measured null,
+// removed: start-time stagger of co-resident blocks; s_setprio around the MFMAs; an LDS-transposed epilogue with 16-B
+// stores; persistent tiles with the next tile's first DMA issued before the epilogue; a 256x128 eight-wave tile (kept as
+// tile 5, not selected); raster panels sized to the XCD's co-resident tiles.
 #include "kernels.h"
 
 #include <algorithm>
@@ -25,242 +29,8 @@ namespace fs {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-// PIPE = 0: one LDS buffer, two barriers per chunk (bring-up structure, kept for A/B).
-// PIPE = 1: two LDS buffers, ONE barrier per chunk, the next chunk is written to the other buffer at the head
-//           of the compute phase, and MFMA fragments are double-buffered in registers so that the LDS read
-//           latency of sub-step s+1 hides under the 16 MFMAs of sub-step s.
-// (Tried and measured null, removed: start-time stagger of co-resident blocks; s_setprio around the MFMAs; an
-//  LDS-transposed epilogue with 16-B residual loads / stores -- 4x fewer global instructions, same time; persistent
-//  tiles with the next tile's first DMA issued before the epilogue -- same time as one tile per workgroup.)
-template <int BM, int BN, int PIPE>
-__global__ __launch_bounds__(256) void conv_igemm_f32(ConvParams p, int tiles_m, int tiles_n) {
-    constexpr int BK = 32;
-    constexpr int WM = BM / 2, WN = BN / 2;
-    constexpr int TM = WM / 32, TN = WN / 32;
-    constexpr int RA = BM / 32, RB = BN / 32;  // staged rows per thread
-    constexpr int PM = 8;                      // m-tiles per raster panel
-
-    constexpr int STAGE = (BM + BN) * BK;  // floats per LDS stage
-    __shared__ __attribute__((aligned(1024))) float lds[STAGE * (PIPE ? 2 : 1)];
-    float* As = lds;
-    float* Bs = lds + BM * BK;
-
-    // ---- XCD-aware tile order: blocks b and b+8 share an XCD (and its L2); give each XCD a
-    // contiguous run of logical tiles, rastered m-fastest inside 8 x tiles_n panels so that
-    // the ~32 tiles resident on one XCD share 8 pixel slabs and 4 weight slabs.
-    const int nblk = gridDim.x;
-    const int bid = blockIdx.x;
-    const int q = nblk >> 3, rr = nblk & 7, xcd = bid & 7;
-    const int lid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (bid >> 3);
-    const int panel = lid / (PM * tiles_n);
-    const int within = lid - panel * (PM * tiles_n);
-    const int prow = min(PM, tiles_m - panel * PM);
-    const int m_tile = panel * PM + within % prow;
-    const int n_tile = within / prow;
-    const int m0 = m_tile * BM, n0 = n_tile * BN;
-
-    const int t = threadIdx.x;
-    const int lane = t & 63;
-    const int wv = t >> 6;
-    const int wm = wv >> 1, wn = wv & 1;
-    const int l31 = lane & 31, hh = lane >> 5;
-
-    const int M = p.B * p.Ho * p.Wo;
-    const int K = p.KH * p.KW * p.Cin;
-    const int cpt = p.Cin >> 5;  // chunks per filter tap
-    const int nchunks = p.KH * p.KW * cpt;
-
-    // ---- staging assignment: thread (r0 = t>>3, c = t&7) moves the 16-B chunk c of rows r0+32j
-    const int sc = t & 7;
-    const int r0 = t >> 3;
-    int a_iy0[RA], a_ix0[RA], a_pix[RA];
-    unsigned a_valid = 0;
-#pragma unroll
-    for (int j = 0; j < RA; ++j) {
-        const int m = m0 + r0 + 32 * j;
-        const bool v = m < M;
-        const int mm = v ? m : 0;
-        const int hw = p.Ho * p.Wo;
-        const int b = mm / hw;
-        const int rem = mm - b * hw;
-        const int oy = rem / p.Wo;
-        const int ox = rem - oy * p.Wo;
-        a_iy0[j] = oy * p.stride - p.pad;
-        a_ix0[j] = ox * p.stride - p.pad;
-        a_pix[j] = b * p.H * p.W;
-        a_valid |= (v ? 1u : 0u) << j;
-    }
-    const float* b_src[RB];
-    unsigned b_valid = 0;
-#pragma unroll
-    for (int j = 0; j < RB; ++j) {
-        const int n = n0 + r0 + 32 * j;
-        const bool v = n < p.Cout;
-        b_src[j] = p.wgt + (size_t)(v ? n : 0) * K + sc * 4;
-        b_valid |= (v ? 1u : 0u) << j;
-    }
-
-    f32x4 ra[RA], rb[RB];
-    unsigned ra_ok = 0;
-    int tap_r = 0, tap_s = 0, cc = 0;  // position of the chunk being loaded
-
-    auto load_chunk = [&](int kc) {
-        const int dy = tap_r * p.dil, dx = tap_s * p.dil;
-        ra_ok = 0;
-#pragma unroll
-        for (int j = 0; j < RA; ++j) {
-            const int iy = a_iy0[j] + dy, ix = a_ix0[j] + dx;
-            const bool ok = ((a_valid >> j) & 1u) && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-            const size_t pix = ok ? (size_t)(a_pix[j] + iy * p.W + ix) : 0;
-            ra[j] = *reinterpret_cast<const f32x4*>(p.in + pix * p.ld_in + cc * 32 + sc * 4);
-            ra_ok |= (ok ? 1u : 0u) << j;
-        }
-#pragma unroll
-        for (int j = 0; j < RB; ++j) rb[j] = *reinterpret_cast<const f32x4*>(b_src[j] + (size_t)kc * 32);
-        // advance (cc, tap_s, tap_r) to the next chunk
-        if (p.korder == 0) {  // k = (r, s, c): channel chunks innermost
-            if (++cc == cpt) {
-                cc = 0;
-                if (++tap_s == p.KW) { tap_s = 0; ++tap_r; }
-            }
-        } else {  // k = (c/32, r, s, c%32): the 9 taps of one 32-channel slab are consecutive -> L2 reuse of the pixel lines
-            if (++tap_s == p.KW) {
-                tap_s = 0;
-                if (++tap_r == p.KH) { tap_r = 0; ++cc; }
-            }
-        }
-    };
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-    const int sw = (l31 >> 1) & 7;  // read-side swizzle key (row base is a multiple of 32)
-    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-
-    auto store_stage = [&](float* a_dst, float* b_dst) {
-#pragma unroll
-        for (int j = 0; j < RA; ++j) {
-            const int row = r0 + 32 * j;
-            const f32x4 v = ((ra_ok >> j) & 1u) ? ra[j] : zero4;
-            *reinterpret_cast<f32x4*>(&a_dst[row * BK + 4 * (sc ^ ((row >> 1) & 7))]) = v;
-        }
-#pragma unroll
-        for (int j = 0; j < RB; ++j) {
-            const int row = r0 + 32 * j;
-            const f32x4 v = ((b_valid >> j) & 1u) ? rb[j] : zero4;
-            *reinterpret_cast<f32x4*>(&b_dst[row * BK + 4 * (sc ^ ((row >> 1) & 7))]) = v;
-        }
-    };
-    auto load_frags = [&](const float* a_src, const float* b_src_, int s_, f32x4 (&a)[TM], f32x4 (&b)[TN]) {
-        const int cidx = (2 * s_ + hh) ^ sw;
-#pragma unroll
-        for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const f32x4*>(&a_src[(wm * WM + i * 32 + l31) * BK + 4 * cidx]);
-#pragma unroll
-        for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const f32x4*>(&b_src_[(wn * WN + j * 32 + l31) * BK + 4 * cidx]);
-    };
-    auto mma = [&](const f32x4 (&a)[TM], const f32x4 (&b)[TN]) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
-    };
-
-    if (PIPE == 0) {
-        load_chunk(0);
-        for (int kc = 0; kc < nchunks; ++kc) {
-            __syncthreads();  // everyone finished reading the previous chunk
-            store_stage(As, Bs);
-            __syncthreads();
-            if (kc + 1 < nchunks) load_chunk(kc + 1);  // in flight under the MFMAs below
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                f32x4 a[TM], b[TN];
-                load_frags(As, Bs, s, a, b);
-                mma(a, b);
-            }
-        }
-    } else {
-        load_chunk(0);
-        store_stage(As, Bs);
-        if (nchunks > 1) load_chunk(1);
-        __syncthreads();
-        int cur = 0;
-        for (int kc = 0; kc < nchunks; ++kc) {
-            const float* a_cur = As + cur * STAGE;
-            const float* b_cur = Bs + cur * STAGE;
-            f32x4 a0[TM], b0[TN], a1[TM], b1[TN];
-            load_frags(a_cur, b_cur, 0, a0, b0);
-            if (kc + 1 < nchunks) {
-                if (!(p.dbg & 8)) store_stage(As + (cur ^ 1) * STAGE, Bs + (cur ^ 1) * STAGE);  // chunk kc+1 (registers loaded one chunk ago)
-                if (kc + 2 < nchunks && !(p.dbg & 4)) load_chunk(kc + 2);
-            }
-            // sched_barrier(0) pins "reads of sub-step s+1, then the 16 MFMAs of sub-step s": left alone, hipcc
-            // sinks each read group to just before its consumers and the MFMA pipe drains on every sub-step.
-            if (!(p.dbg & 1)) load_frags(a_cur, b_cur, 1, a1, b1); else { for (int i = 0; i < TM; ++i) a1[i] = a0[i]; for (int j = 0; j < TN; ++j) b1[j] = b0[j]; }
-            __builtin_amdgcn_sched_barrier(0);
-            mma(a0, b0);
-            __builtin_amdgcn_sched_barrier(0);
-            if (!(p.dbg & 1)) load_frags(a_cur, b_cur, 2, a0, b0);
-            __builtin_amdgcn_sched_barrier(0);
-            mma(a1, b1);
-            __builtin_amdgcn_sched_barrier(0);
-            if (!(p.dbg & 1)) load_frags(a_cur, b_cur, 3, a1, b1);
-            __builtin_amdgcn_sched_barrier(0);
-            mma(a0, b0);
-            __builtin_amdgcn_sched_barrier(0);
-            mma(a1, b1);
-            __syncthreads();  // stage cur^1 complete and stage cur no longer read
-            cur ^= 1;
-        }
-    }
-
-    // ---- epilogue: scale/shift (eval BatchNorm or bias), residual, ReLU, NHWC store
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int n = n0 + wn * WN + j * 32 + l31;
-        const bool nok = n < p.Cout;
-        const float sc_n = (nok && p.scale) ? p.scale[n] : 1.f;
-        const float sh_n = (nok && p.shift) ? p.shift[n] : 0.f;
-        const int nc = nok ? n : 0;
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int mb = m0 + wm * WM + i * 32 + 4 * hh;
-            // all 16 residual loads are issued back to back on clamped (always valid) addresses,
-            // so the compiler does not serialise a vmcnt(0) round trip per element
-            float rv[16];
-            if (p.res) {
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int m = min(mb + (e & 3) + 8 * (e >> 2), M - 1);
-                    rv[e] = p.res[(size_t)m * p.ld_res + nc];
-                }
-            } else {
-#pragma unroll
-                for (int e = 0; e < 16; ++e) rv[e] = 0.f;
-            }
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int m = mb + (e & 3) + 8 * (e >> 2);
-                float v = acc[i][j][e] * sc_n + sh_n + rv[e];
-                if (p.relu == 1) v = fmaxf(v, 0.f);
-                else if (p.relu == 2) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752f));  // nn.GELU (erf form)
-                if (nok && m < M) p.out[(size_t)m * p.ld_out + n] = v;
-            }
-        }
-    }
-}
-
-
 // ---------------------------------------------------------------------------------------------------------
-// conv_igemm_dma_f32: same tiling / fragments / epilogue as above, but the tiles go global -> LDS DIRECTLY
+// conv_igemm_dma_f32: the tiles go global -> LDS DIRECTLY
 // (buffer_load_dwordx4 ... offen lds: no VGPR staging, no ds_write pass, no vmcnt ladder), two LDS stages, one
 // barrier per 32-deep chunk, fragment reads double-buffered in registers.  One wave-instruction of the DMA writes
 // a lane-linear 1 KiB (8 rows x 128 B), so the XOR swizzle is applied to the per-lane SOURCE offset.
@@ -613,14 +383,12 @@ int launch_conv_igemm(const ConvParams& p, hipStream_t s, int tile) {
                "conv_igemm: output tensor must be smaller than 2 GiB");
     FS_REQUIRE(p.res == nullptr || (int64_t)p.B * p.Ho * p.Wo * p.ld_res * 4 < (int64_t)1 << 31, "conv_igemm: residual tensor must be smaller than 2 GiB");
     if (!(p.res == nullptr || p.ld_res >= p.Cout)) return fail("conv_igemm: bad ld_res");
-    const int var = (tile >> 8) & 1 ? 0 : ((tile >> 9) & 1 ? 1 : 2);  // default PIPE 2; tile bit 8 -> PIPE 0, bit 9 -> PIPE 1
     tile &= 0xff;
     if (tile <= 0 || tile > 5) tile = pick_tile(p);
     const int M = p.B * p.Ho * p.Wo;
     const int bm = kTiles[tile].bm, bn = kTiles[tile].bn;
     const int tm = cdiv(M, bm), tn = cdiv(p.Cout, bn);
     const int groups = p.groups > 1 ? p.groups : 1;
-    FS_REQUIRE(groups == 1 || var == 2, "conv_igemm: grouped GEMM needs the DMA kernel");
     FS_REQUIRE(groups == 1 || p.res == nullptr, "conv_igemm: grouped GEMM has no residual input");
     const dim3 grid(tm * tn * groups), block(256);
     if (tile == 5) {  // 8-wave workgroup, one per CU
@@ -629,13 +397,7 @@ int launch_conv_igemm(const ConvParams& p, hipStream_t s, int tile) {
         return 0;
     }
     const size_t dyn = (p.dbg & 2) ? 56 * 1024 : 0;  // timing experiment: push occupancy to one block per CU
-#define FS_CONV_LAUNCH(BM_, BN_)                                                                        \
-    if (var == 2)                                                                                       \
-        hipLaunchKernelGGL((conv_igemm_dma_f32<BM_, BN_>), grid, block, dyn, s, p, tm, tn);             \
-    else if (var == 1)                                                                                  \
-        hipLaunchKernelGGL((conv_igemm_f32<BM_, BN_, 1>), grid, block, dyn, s, p, tm, tn);              \
-    else                                                                                                \
-        hipLaunchKernelGGL((conv_igemm_f32<BM_, BN_, 0>), grid, block, dyn, s, p, tm, tn);
+#define FS_CONV_LAUNCH(BM_, BN_) hipLaunchKernelGGL((conv_igemm_dma_f32<BM_, BN_>), grid, block, dyn, s, p, tm, tn);
     switch (tile) {
         case 1: FS_CONV_LAUNCH(128, 128) break;
         case 2: FS_CONV_LAUNCH(128, 64) break;

@@ -29,7 +29,8 @@ struct ConvParams {
     // grouped GEMM (Winograd: one GEMM per transform position): group g uses in + g*g_in, wgt + g*g_wgt, out + g*g_out
     int groups;  // 0 or 1 = plain
     long long g_in, g_wgt, g_out;  // strides in floats
-    int dbg;     // timing experiments only (results are wrong when != 0): 1 = no fragment reloads, 2 = one block per CU
+    int dbg;     // timing experiments only (results are wrong when != 0): 2 = one block per CU, 16 = skip the epilogue,
+                 // 32 | n << 8 = start workgroups bid+256.. n*1024 cycles late (tools/probe_conv_trace.hip builds only)
 };
 // tile: 0 = heuristic, 1 = 128x128, 2 = 128x64, 3 = 64x64, 4 = 64x128
 int launch_conv_igemm(const ConvParams& p, hipStream_t s, int tile = 0);
