@@ -128,6 +128,10 @@ int fs_canvas_finish(double* canvas, const double* count, int n, int K, int64_t 
 
 /* ---- building blocks (exposed for op-level parity tests and for other host code) ---------------- */
 int fs_pack_conv_weight(const float* oihw, float* ohwi, int O, int I, int KH, int KW, fs_stream stream);
+/* Conv2d (+ per-channel scale/shift, + residual, + ReLU (relu = 1) / GELU (2)) on the fp32 matrix cores; Cin % 32 == 0.
+ * in/out/res are NHWC with pixel strides ld_*; wgt_ohwi from fs_pack_conv_weight.  tile: 0 = cost-model choice, 1..5 force the
+ * workgroup tile 128x128, 128x64, 64x64, 64x128, 256x128 (tests / sweeps); bit 10 = filters are packed chunk-major
+ * ([O][I/32][KH][KW][32]); bits 11+ = timing experiments that break the result (0 in any real call). */
 int fs_conv2d_nhwc(const float* in, int ld_in, const float* wgt_ohwi, const float* scale, const float* shift,
                    const float* res, int ld_res, float* out, int ld_out, int B, int H, int W, int Cin, int Cout, int KH,
                    int KW, int stride, int pad, int dil, int relu, int tile, fs_stream stream);
