@@ -30,6 +30,7 @@ CONV_CASES = [
     (2, 45, 45, 256, 512, 1, 2, 0, 1, False, False),
     (1, 9, 9, 2048, 96, 3, 1, 12, 12, True, False),   # ASPP-style: dilation larger than the map
     (1, 1, 1, 32, 32, 1, 1, 0, 1, False, False),      # single pixel
+    (2, 40, 33, 64, 96, 3, 1, 18, 18, True, False),   # taps outside the map for whole tiles (top / bottom rows)
 ]
 
 
@@ -50,6 +51,26 @@ def test_conv_igemm(case, tile):
         ref = ref.relu()
     got = ops.conv2d_nhwc(x.to(DEV), wt.to(DEV), sc.to(DEV), sh.to(DEV), r.to(DEV) if res else None, stride, pad, dil, relu, tile)
     assert rel(got, ref) < CONV_TOL
+
+
+@pytest.mark.parametrize("dil", [1, 7, 18, 36])
+def test_conv_chunk_major_filters_over_dilations(dil):
+    """The layout the network uses for 3x3 convs ([O][I/32][KH][KW][32], tile bit 10) with dilations from 'all taps live' to
+    'only the centre tap ever lands inside the map' (ASPP at 90x90 sits in between: whole tap rows are dead per tile)."""
+    lib = _lib.load()
+    b, h, w, cin, cout = 2, 40, 33, 96, 64
+    g = torch.Generator().manual_seed(dil)
+    x = torch.randn(b, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (cin * 9)) ** 0.5
+    ref = F.conv2d(x, wt, None, 1, dil, dil).relu()
+    xd = ops.as_nhwc(x.to(DEV))
+    wd = wt.view(cout, cin // 32, 32, 3, 3).permute(0, 1, 3, 4, 2).contiguous().to(DEV)
+    out = torch.empty((b, h, w, cout), device=DEV)
+    for tile in (0, 1, 3):
+        out.fill_(-3.0)
+        check(lib.fs_conv2d_nhwc(ptr(xd), cin, ptr(wd), None, None, None, 0, ptr(out), cout, b, h, w, cin, cout, 3, 3, 1, dil, dil, 1,
+                                 tile | (1 << 10), stream_ptr()))
+        assert rel(out.permute(0, 3, 1, 2), ref) < CONV_TOL
 
 
 def test_conv_writes_only_its_channel_slice_and_supports_inplace_residual():

@@ -21,6 +21,9 @@ SHAPES = {  # b, h, w, cin, cout, k, stride, pad, dil
     "l2c2": (2, 90, 90, 128, 128, 3, 1, 1, 1),
     "l1c3": (2, 179, 179, 64, 256, 1, 1, 0, 1),
     "stem3": (2, 357, 357, 64, 128, 3, 1, 1, 1),
+    "aspp12": (2, 90, 90, 2048, 256, 3, 1, 12, 12),
+    "aspp24": (2, 90, 90, 2048, 256, 3, 1, 24, 24),
+    "aspp36": (2, 90, 90, 2048, 256, 3, 1, 36, 36),
 }
 
 
