@@ -9,7 +9,7 @@ if [ "$1" != "noprofile" ]; then
 timeout -k 10 600 python -m pytest tests -m gpu -q -p no:cacheprovider -x > $O/pytest_gpu.txt 2>&1; echo "pytest exit=$?"; tail -3 $O/pytest_gpu.txt
 timeout -k 10 300 python __graft_entry__.py smoke > $O/smoke.txt 2>&1; echo "smoke exit=$?"; tail -2 $O/smoke.txt
 fi
-timeout -k 10 400 python bench.py --steps 20 --warmup 3 > $O/bench.json 2> $O/bench.err; echo "bench exit=$?"; cat $O/bench.json; tail -3 $O/bench.err
+timeout -k 10 400 python bench.py > $O/bench.json 2> $O/bench.err; echo "bench exit=$?"; cat $O/bench.json; tail -3 $O/bench.err
 if [ "$1" != "noprofile" ]; then
 cd /tmp && export TMPDIR=/tmp
 rm -rf $O/prof
