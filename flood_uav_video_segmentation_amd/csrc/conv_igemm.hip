@@ -58,6 +58,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // sentinel offset), so there is no per-element branch, no 64-bit address arithmetic and the activation is resolved at
 // compile time: 5 instructions per element instead of ~85 (the first version spent ~11 k cycles per 128x128 tile here,
 // as much as two K chunks).  The row offset is added on the VALU: the scalar offset of a buffer op is not range-checked.
+// Each dword store instruction covers two full 128-B lines.  (Measured and rejected: transposed accumulators -- filter
+// fragment as the MFMA's A operand -- so that a lane owns 4 consecutive channels of one pixel and stores 16 B: 4x fewer
+// store instructions but 32 separate 32-B segments each; epilogue 8 k -> 12-15 k cycles, 818 -> 790 FPS.  And an
+// epilogue interleaved with the next tile's main loop was priced with fake stores: it slows the loop by what it saves.)
 template <int ACT, bool RES, int TM, int TN>
 __device__ __forceinline__ void igemm_epilogue(const f32x16 (&acc)[TM][TN], const ConvParams& p, int M, int m_base, int n_base) {
     constexpr unsigned SENT = 0x80000000u;
