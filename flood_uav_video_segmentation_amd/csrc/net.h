@@ -110,6 +110,7 @@ struct fs_net {
     size_t wino_ws_elems = 0;
     bool use_winograd = true;  // FS_NO_WINOGRAD=1 in the environment selects the direct conv everywhere
     int wino_force_m = 0;      // FS_WINOGRAD_TILE=4|6 forces F(4,3) / F(6,3); 0 = the cheaper one for the map at hand
+    double wino_far_factor = 0.7;  // Winograd is taken for dilation > 4 only if its GEMM rows are below this share of the direct conv's
     bool use_fused_head = true;  // FS_NO_FUSED_HEAD=1: fs_segment_forward runs encoder + decoder over the 4096-channel concat (A/B)
 
     // workspace

@@ -67,7 +67,7 @@ int make_conv(fs_net* h, ConvBN& c, const std::string& wname, const std::string&
     } else {
         FS_TRY(launch_pack_oihw_to_ohwi(w->d, c.w, c.Cout, c.Cin, c.KH, c.KW, s));
     }
-    if (!hwio && c.KH == 3 && c.KW == 3 && stride == 1 && pad == dil && dil <= 4 && c.Cin >= 256 && c.Cin % 32 == 0 && c.Cout % 4 == 0) {
+    if (!hwio && c.KH == 3 && c.KW == 3 && stride == 1 && pad == dil && c.Cin >= 256 && c.Cin % 32 == 0 && c.Cout % 4 == 0) {
         FS_TRY(dev_alloc(h, &c.wino_U, (size_t)36 * c.Cout * c.Cin));
         FS_TRY(launch_winograd_filter(w->d, c.wino_U, c.Cout, c.Cin, 4, s));
         FS_TRY(dev_alloc(h, &c.wino_U6, (size_t)64 * c.Cout * c.Cin));
@@ -181,14 +181,14 @@ int run_conv(fs_net* h, const ConvBN& c, const float* in, int ld_in, int B, int 
              const float* res, int ld_res, hipStream_t s) {
     // Winograd pays when its 36 GEMM rows per 4x4 tile undercut the 9 taps per pixel of the direct conv even after the
     // tile-edge / lattice-phase waste (large dilations on a small map leave mostly-empty tiles): 36*T < 0.8 * 9*M
-    // (measured: the ASPP convs with dilation 12/24/36 on a 90x90 map are FASTER direct -- 358 vs 335 FPS for configs[2] --
-    //  so the lattice decomposition is limited to dilation <= 4)
-    if (c.wino_U && h->use_winograd && !res && c.dil <= 4 &&
-        (double)((h->wino_force_m ? h->wino_force_m : winograd_pick_m(B, H, W, c.dil)) + 2) *
-                ((h->wino_force_m ? h->wino_force_m : winograd_pick_m(B, H, W, c.dil)) + 2) *
-                winograd_tiles(B, H, W, c.dil, h->wino_force_m ? h->wino_force_m : winograd_pick_m(B, H, W, c.dil)) <
-            0.8 * 9.0 * (double)B * c.out_size(H) * c.out_size(W))
-        return run_conv_winograd(h, c, in, ld_in, B, H, W, out, ld_out, s);
+    if (c.wino_U && h->use_winograd && !res) {
+        const int mt = h->wino_force_m ? h->wino_force_m : winograd_pick_m(B, H, W, c.dil);
+        const double wino_rows = (double)(mt + 2) * (mt + 2) * winograd_tiles(B, H, W, c.dil, mt);
+        const double direct_rows = 9.0 * (double)B * c.out_size(H) * c.out_size(W);
+        // dilation <= 4 (the dilated ResNet stages, the heads): 0.8; the ASPP dilations leave the lattices of a 90x90 map
+        // only 8, 4 and 3 pixels wide and the transforms touch every pixel through 2048 channels, so they must save more
+        if (wino_rows < (c.dil <= 4 ? 0.8 : h->wino_far_factor) * direct_rows) return run_conv_winograd(h, c, in, ld_in, B, H, W, out, ld_out, s);
+    }
     ConvParams p{};
     p.in = in;
     p.ld_in = ld_in;
@@ -283,6 +283,8 @@ int net_create(const fs_config* cfg, fs_handle* out) {
     h->use_winograd = !(nw && nw[0] == '1');
     const char* wm = getenv("FS_WINOGRAD_TILE");  // A/B switch: 4 or 6 forces that tile size, unset = per-map choice
     h->wino_force_m = (wm && (wm[0] == '4' || wm[0] == '6')) ? wm[0] - '0' : 0;
+    const char* wf = getenv("FS_WINOGRAD_FAR");  // experiment knob: row-saving factor required for dilation > 4
+    h->wino_far_factor = wf ? atof(wf) : 0.7;
     const char* nf = getenv("FS_NO_FUSED_HEAD");
     h->use_fused_head = !(nf && nf[0] == '1');
     h->deep_stem = cfg->arch == FS_ARCH_PSPNET;

@@ -210,6 +210,8 @@ WINO_TOL = 5e-5  # F(4x4,3x3) in fp32: ~7e-6 relative on unit-scale data, F(6x6,
     (1, 31, 27, 512, 64, 4, True),      # dilation 4 -> 16 phases, some with a single tile row
     (1, 9, 9, 1024, 32, 1, False),
     (1, 3, 5, 256, 32, 4, False),       # image smaller than the dilation lattice step
+    (1, 45, 40, 256, 64, 12, True),     # ASPP-style dilations: 144 lattice phases of 4x4 / 3x4 pixels
+    (2, 30, 30, 256, 32, 24, False),    # 576 phases, most of them 1x1 or 2x2 pixels
 ])
 @pytest.mark.parametrize("tile_m", [4, 6, 0])
 def test_winograd_conv3x3(case, tile_m):
