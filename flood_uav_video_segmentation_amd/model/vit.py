@@ -12,7 +12,6 @@ BASELINE's "ViT-S/16" is patch 16, d_model 384).  `.encoder` / `.decoder` expose
 [B,D,gh,gw] feature map so that FlowModel's feature propagation can run on it -- an EXTENSION: the reference
 never wires ViT into the flow path (flow/base.py:94-103), so that combination is parity-unpinned.
 """
-import torch
 from torch import nn
 
 from .. import _lib, ops

@@ -3,7 +3,6 @@ oracle and the reference-generated golden fixtures.  fp32 end to end.
 
 Tolerance: decoder logits max-abs error <= 1e-3 x max|logit|; masks >= 99.9 % equal.
 Measured errors are ~1e-5, the asserts use 2e-4 to leave room for summation-order differences."""
-import numpy as np
 import pytest
 import torch
 
