@@ -142,3 +142,15 @@ def test_fused_segment_route_equals_decoder_of_encoder(psp, size, b):
     assert fused.shape == two_step.shape and fused.dtype == torch.float32
     assert rel_err(fused.cpu(), two_step.cpu()) < 2e-5
     assert (fused.max(1)[1] == two_step.max(1)[1]).float().mean().item() > 0.9995
+
+
+def test_full_hd_frame_no_cropping_route(psp):
+    """no_cropping=True on the 1072x1920 frames of the dataset (flow/base.py:271-272): the largest map the path sees
+    (stem output 536x960x128, feature map 134x240, ragged pyramid windows).  Both routes run and agree."""
+    net, _ = psp
+    x = synth.make_clip(1, (1072, 1920), seed=23).cuda()
+    fused = net.segment(x)
+    two_step = net.decoder(net.encoder(x))
+    assert fused.shape == (1, 5, 134, 240)
+    assert torch.isfinite(fused).all()
+    assert rel_err(fused.cpu(), two_step.cpu()) < 2e-5
