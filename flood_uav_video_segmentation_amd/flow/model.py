@@ -77,25 +77,32 @@ class FlowModel(nn.Module):
 
     # ------------------------------------------------------------------------------------ eval forward
     def forward(self, frame_current, frame_prev, frame_next, mvs_left, mvs_right, left_index, right_index):
-        """One interpolated frame per sample from two key frames (reference :35-88, eval path)."""
+        """One interpolated frame per sample from two key frames (reference :35-53, eval path)."""
         if self.training:
             raise NotImplementedError("FlowModel(HIP) is an inference path; call .eval() (training branch: flow/model.py:37-43)")
         left = [int(i) for i in left_index]
         right = [int(i) for i in right_index]
         total = [a + b for a, b in zip(left, right)]
+        if self.feature_based:
+            return self.forward_feature(frame_prev, frame_next, mvs_left, mvs_right, left, right, total)
+        return self.forward_segmentation(frame_prev, frame_next, mvs_left, mvs_right, left, right, total)
+
+    def forward_feature(self, frame_prev, frame_next, mvs_left, mvs_right, left_index, right_index, n_list):
+        """Warp + weight the encoder FEATURES of the two key frames, decode their sum (reference :55-70)."""
         h, w = frame_prev.shape[2], frame_prev.shape[3]
         nb = frame_prev.shape[0]
-        if self.feature_based:
-            feats = self._encode(frame_prev, frame_next)
-            f_prev, f_next = feats[:nb], feats[nb:]
-            mixed = ops.blend(self.warp_batch(f_prev, mvs_left, left, total), 1.0,
-                              self.warp_batch(f_next, mvs_right, right, total), 1.0)
-            out = self.model.decoder(mixed)
-        else:
-            lows = self._segment(frame_prev, frame_next)
-            o_prev, o_next = lows[:nb], lows[nb:]
-            out = ops.blend(self.warp_batch(o_prev, mvs_left, left, total), 1.0,
-                            self.warp_batch(o_next, mvs_right, right, total), 1.0)
+        feats = self._encode(frame_prev, frame_next)
+        mixed = ops.blend(self.warp_batch(feats[:nb], mvs_left, left_index, n_list), 1.0,
+                          self.warp_batch(feats[nb:], mvs_right, right_index, n_list), 1.0)
+        return {"pred": self._fit(self.model.decoder(mixed), h, w)}
+
+    def forward_segmentation(self, frame_prev, frame_next, mvs_left, mvs_right, left_index, right_index, n_list):
+        """Segment the two key frames, warp + weight the LOGITS and add them (reference :73-88)."""
+        h, w = frame_prev.shape[2], frame_prev.shape[3]
+        nb = frame_prev.shape[0]
+        lows = self._segment(frame_prev, frame_next)
+        out = ops.blend(self.warp_batch(lows[:nb], mvs_left, left_index, n_list), 1.0,
+                        self.warp_batch(lows[nb:], mvs_right, right_index, n_list), 1.0)
         return {"pred": self._fit(out, h, w)}
 
     def warp_batch(self, input, mvs, index_list, n_list):

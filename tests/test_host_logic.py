@@ -54,6 +54,18 @@ def test_flowmodel_attributes_match_the_reference_contract():
         assert list(getattr(net, attr).parameters()) == []
     x = torch.zeros(1, 5, 4, 4)
     assert fm.warp(x, None) is x  # no_warp: identity
+    # the reference's public methods, same positional signatures (flow/model.py:24-249)
+    import inspect
+
+    want = {"forward": ["frame_current", "frame_prev", "frame_next", "mvs_left", "mvs_right", "left_index", "right_index"],
+            "forward_feature": ["frame_prev", "frame_next", "mvs_left", "mvs_right", "left_index", "right_index", "n_list"],
+            "forward_segmentation": ["frame_prev", "frame_next", "mvs_left", "mvs_right", "left_index", "right_index", "n_list"],
+            "warp_batch": ["input", "mvs", "index_list", "n_list"],
+            "predict_feature": ["frame_prev", "frame_next", "mvs_left", "mvs_right", "n", "profiler"],
+            "predict_segmentation": ["frame_prev", "frame_next", "mvs_left", "mvs_right", "n", "profiler"],
+            "warp": ["frame", "motion_vectors"]}
+    for name, params in want.items():
+        assert list(inspect.signature(getattr(fm, name)).parameters) == params, name
 
 
 def test_pretrained_flag_is_refused_loudly():
