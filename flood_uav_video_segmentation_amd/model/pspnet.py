@@ -10,7 +10,7 @@ the aux head, PSPNetSemi and the training-mode branches are out of scope.
 """
 import re
 
-from .. import _lib
+from .. import _lib, ops
 from .hipnet import HipSegNet, HipStage
 
 
@@ -51,3 +51,31 @@ class FlowPSPNet(HipSegNet):
         if re.match(r"^(layer[0-4]|ppm|decoder)\.", key):
             return key
         return None
+
+
+class PSPNet(FlowPSPNet):
+    """Single-frame PSPNet (reference model/pspnet.py:38-110; BASELINE configs[0]): `forward(x) -> {"pred": logits}` with
+    the logits brought back to the input size (zoom_factor 8: h = (H-1)/8*8+1 = H, :88-90, :99-100).  Its state_dict names
+    the head `cls.*` (the FlowPSPNet alias is `decoder.*`); the training-only `aux.*` head is ignored."""
+
+    zoom_factor = 8
+
+    @staticmethod
+    def canonical_name(key):
+        if key.startswith("aux."):
+            return None
+        if key.startswith("cls."):
+            key = "decoder." + key[len("cls."):]
+        return FlowPSPNet.canonical_name(key)
+
+    def forward(self, x):
+        if self.training:
+            raise NotImplementedError("PSPNet(HIP) is an inference path; call .eval() (training adds the aux head: model/pspnet.py:102-106)")
+        hh, ww = x.shape[2], x.shape[3]
+        assert (hh - 1) % 8 == 0 and (ww - 1) % 8 == 0  # model/pspnet.py:88
+        h = int((hh - 1) / 8 * self.zoom_factor + 1)
+        w = int((ww - 1) / 8 * self.zoom_factor + 1)
+        out = self.segment(x)
+        if self.zoom_factor != 1:
+            out = ops.resize_bilinear(out, (h, w), align_corners=True)
+        return {"pred": out}
