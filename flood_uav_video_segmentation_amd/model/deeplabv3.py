@@ -4,7 +4,7 @@ encoder = torchvision ResNet backbone ["out"] (output stride 8), decoder = DeepL
 PARITY UNPINNED: torchvision is not vendored by the reference and absent offline, so the architecture
 is restated from its public definition and checked only against oracle/deeplab_oracle.py.
 """
-from .. import _lib
+from .. import _lib, ops
 from .hipnet import HipSegNet
 
 
@@ -33,3 +33,24 @@ class FlowDeepLabv3(HipSegNet):
         if key.startswith(("backbone.", "classifier.")):
             return key
         return None
+
+
+class DeepLabv3(FlowDeepLabv3):
+    """Single-frame DeepLabv3 (reference model/deeplabv3.py:11-33): `forward(x) -> {"pred": out}`, where torchvision's
+    segmentation wrapper brings the classifier output back to the input size with bilinear interpolation,
+    align_corners=False.  Checkpoint keys `model.backbone.*` / `model.classifier.*`; `model.aux_classifier.*` is
+    training-only and ignored.  PARITY UNPINNED like FlowDeepLabv3 (torchvision absent)."""
+
+    @staticmethod
+    def canonical_name(key):
+        if key.startswith("model.aux_classifier."):
+            return None
+        if key.startswith("model."):
+            key = key[len("model."):]
+        return FlowDeepLabv3.canonical_name(key)
+
+    def forward(self, x):
+        if self.training:
+            raise NotImplementedError("DeepLabv3(HIP) is an inference path; call .eval() (training adds the aux output: model/deeplabv3.py:27-31)")
+        out = self.segment(x)
+        return {"pred": ops.resize_bilinear(out, (x.shape[2], x.shape[3]), align_corners=False)}

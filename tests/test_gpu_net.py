@@ -176,3 +176,21 @@ def test_single_frame_pspnet_class_configs0(psp):
     assert rel_err(out.cpu(), ref) < LOGIT_TOL
     with pytest.raises(AssertionError):
         net(torch.zeros(1, 3, 100, 100, device="cuda"))  # (H - 1) % 8 != 0, as the reference asserts
+
+
+def test_single_frame_deeplabv3_class_parity_unpinned():
+    """Reference model/deeplabv3.py:11-33 (`DeepLabv3.forward`): checkpoint keys `model.backbone.*` / `model.classifier.*`
+    (+ an ignored `model.aux_classifier.*`), output interpolated to the input size with align_corners=False as torchvision's
+    wrapper does.  PARITY UNPINNED (torchvision absent): HIP path vs oracle/deeplab_oracle.py."""
+    from flood_uav_video_segmentation_amd.model.deeplabv3 import DeepLabv3
+
+    state = synth.make_deeplab_state(50, 5, seed=1)
+    keys = {"model." + k: v for k, v in state.items()}
+    keys["model.aux_classifier.0.weight"] = torch.zeros(256, 1024, 3, 3)
+    net = DeepLabv3(HP(50, 5)).eval()
+    net.load_state_dict(keys)
+    x = synth.make_clip(1, (97, 113), seed=10)
+    out = net(x.cuda())["pred"]
+    lo = deeplab_oracle.decoder(deeplab_oracle.encoder(x, state, 50), state)
+    ref = torch.nn.functional.interpolate(lo, (97, 113), mode="bilinear", align_corners=False)
+    assert out.shape == (1, 5, 97, 113) and rel_err(out.cpu(), ref) < LOGIT_TOL
