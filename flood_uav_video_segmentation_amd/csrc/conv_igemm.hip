@@ -62,28 +62,32 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // fragment as the MFMA's A operand -- so that a lane owns 4 consecutive channels of one pixel and stores 16 B: 4x fewer
 // store instructions but 32 separate 32-B segments each; epilogue 8 k -> 12-15 k cycles, 818 -> 790 FPS.  And an
 // epilogue interleaved with the next tile's main loop was priced with fake stores: it slows the loop by what it saves.)
-template <int ACT, bool RES, int TM, int TN>
-__device__ __forceinline__ void igemm_epilogue(const f32x16 (&acc)[TM][TN], const ConvParams& p, int M, int m_base, int n_base) {
+// Residual tile (the bottleneck shortcut): TM*TN*16 dword loads per lane, issued by the main loop one chunk before its
+// end so that they land under the last MFMAs instead of at the head of the epilogue.
+template <int TM, int TN>
+__device__ __forceinline__ void igemm_load_residual(float (&rv)[TM][TN][16], const ConvParams& p, int M, int m_base, int n_base) {
     constexpr unsigned SENT = 0x80000000u;
-    const __amdgpu_buffer_rsrc_t o_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.out, 0, (unsigned)((long long)M * p.ld_out * 4), 0x00020000);
-    const __amdgpu_buffer_rsrc_t r_rsrc =
-        __builtin_amdgcn_make_buffer_rsrc((void*)(RES ? p.res : p.out), 0, (unsigned)((long long)M * (RES ? p.ld_res : p.ld_out) * 4), 0x00020000);
-    const unsigned row_o = (unsigned)p.ld_out * 4u, row_r = (unsigned)p.ld_res * 4u;
-    // residual tile first, all TM*TN*16 loads in flight together (one latency instead of one per 32x32 block)
-    float rv[RES ? TM : 1][RES ? TN : 1][16];
-    if (RES) {
+    const __amdgpu_buffer_rsrc_t r_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.res, 0, (unsigned)((long long)M * p.ld_res * 4), 0x00020000);
+    const unsigned row_r = (unsigned)p.ld_res * 4u;
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int n = n_base + j * 32;
+    for (int j = 0; j < TN; ++j) {
+        const int n = n_base + j * 32;
 #pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const unsigned vr = n < p.Cout ? (unsigned)(m_base + i * 32) * row_r + (unsigned)n * 4u : SENT;
+        for (int i = 0; i < TM; ++i) {
+            const unsigned vr = n < p.Cout ? (unsigned)(m_base + i * 32) * row_r + (unsigned)n * 4u : SENT;
 #pragma unroll
-                for (int e = 0; e < 16; ++e)
-                    rv[i][j][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_rsrc, vr + (unsigned)((e & 3) + 8 * (e >> 2)) * row_r, 0, 0));
-            }
+            for (int e = 0; e < 16; ++e)
+                rv[i][j][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_rsrc, vr + (unsigned)((e & 3) + 8 * (e >> 2)) * row_r, 0, 0));
         }
     }
+}
+
+template <int ACT, bool RES, int TM, int TN>
+__device__ __forceinline__ void igemm_epilogue(const f32x16 (&acc)[TM][TN], const float (&rv)[TM][TN][16], const ConvParams& p, int M,
+                                               int m_base, int n_base) {
+    constexpr unsigned SENT = 0x80000000u;
+    const __amdgpu_buffer_rsrc_t o_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.out, 0, (unsigned)((long long)M * p.ld_out * 4), 0x00020000);
+    const unsigned row_o = (unsigned)p.ld_out * 4u;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int n = n_base + j * 32;
@@ -274,10 +278,13 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_dma_f32(ConvParams 
     // behind it and hide under the 16 MFMAs of sub-step 3, so the MFMA pipe does not drain at a chunk boundary.
     int cur = 0;
     f32x4 a0[TM], b0[TN], a1[TM], b1[TN];
+    float rv[TM][TN][16];  // residual tile, requested where the last DMA would have been (see below)
+    const int em_base = m0 + wm * WM + 4 * hh, en_base = n0 + wn * WN + l31;
     if (nchunks > 1) {
         FS_DMA_ALL(1)
         FS_DMA_ADVANCE()
     }
+    if (p.res && nchunks <= 2) igemm_load_residual(rv, p, M, em_base, en_base);
     FS_FRAGS(0, 0, a0, b0)
     for (int kc = 0; kc < nchunks; ++kc) {
         // sub-step 0's fragments were requested under the previous chunk's last MFMAs: start multiplying at once and
@@ -301,6 +308,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_dma_f32(ConvParams 
             FS_DMA_ALL(cur)
             FS_DMA_ADVANCE()
         }
+        if (p.res && kc + 3 == nchunks) igemm_load_residual(rv, p, M, em_base, en_base);  // one and a quarter chunks to land
         if (kc + 1 < nchunks) FS_FRAGS(cur ^ 1, 0, a0, b0)
         __builtin_amdgcn_sched_barrier(0);
         FS_MMA(a1, b1)
@@ -318,17 +326,14 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_dma_f32(ConvParams 
 
     // ---- epilogue
     if ((p.dbg & 16) && p.ld_out >= 0) return;  // timing experiment: skip the epilogue (the test keeps the main loop alive)
-    {
-        const int m_base = m0 + wm * WM + 4 * hh, n_base = n0 + wn * WN + l31;
-        if (p.res) {
-            if (p.relu == 1) igemm_epilogue<1, true>(acc, p, M, m_base, n_base);
-            else if (p.relu == 2) igemm_epilogue<2, true>(acc, p, M, m_base, n_base);
-            else igemm_epilogue<0, true>(acc, p, M, m_base, n_base);
-        } else {
-            if (p.relu == 1) igemm_epilogue<1, false>(acc, p, M, m_base, n_base);
-            else if (p.relu == 2) igemm_epilogue<2, false>(acc, p, M, m_base, n_base);
-            else igemm_epilogue<0, false>(acc, p, M, m_base, n_base);
-        }
+    if (p.res) {
+        if (p.relu == 1) igemm_epilogue<1, true>(acc, rv, p, M, em_base, en_base);
+        else if (p.relu == 2) igemm_epilogue<2, true>(acc, rv, p, M, em_base, en_base);
+        else igemm_epilogue<0, true>(acc, rv, p, M, em_base, en_base);
+    } else {
+        if (p.relu == 1) igemm_epilogue<1, false>(acc, rv, p, M, em_base, en_base);
+        else if (p.relu == 2) igemm_epilogue<2, false>(acc, rv, p, M, em_base, en_base);
+        else igemm_epilogue<0, false>(acc, rv, p, M, em_base, en_base);
     }
 #ifdef FS_TRACE
     if (t == 0) {

@@ -2,7 +2,7 @@
 // Built with -DFS_TRACE (instrumentation that never ships in libfloodseg.so):
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 -DFS_TRACE -I flood_uav_video_segmentation_amd/csrc -I include \
 //         tools/probe_conv_trace.hip -o tools/bin/probe_conv_trace
-// usage: probe_conv_trace B H W Cin Cout K pad dil tile [dbg [groups]]  > trace.csv   (analysed by tools/analyze_conv_trace.py)
+// usage: probe_conv_trace B H W Cin Cout K pad dil tile [dbg [groups [residual]]]  > trace.csv   (analysed by tools/analyze_conv_trace.py)
 //        groups > 1: grouped GEMM as the Winograd path launches it (use K = 1, W = 1, H = rows per group)
 #include "../flood_uav_video_segmentation_amd/csrc/conv_igemm.hip"
 
@@ -45,6 +45,12 @@ int main(int argc, char** argv) {
     p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Ho = Ho; p.Wo = Wo; p.Cout = Cout;
     p.KH = p.KW = K; p.stride = 1; p.pad = pad; p.dil = dil; p.relu = 1;
     p.dbg = argc > 10 ? atoi(argv[10]) : 0;
+    if (argc > 12 && atoi(argv[12])) {  // residual input (a bottleneck's conv3): same shape as the output
+        float* res = nullptr;
+        if (hipMalloc(&res, n_out * 4) != hipSuccess || hipMemset(res, 0, n_out * 4) != hipSuccess) return 3;
+        p.res = res;
+        p.ld_res = Cout;
+    }
     if (groups > 1) {
         p.groups = groups;
         p.g_in = (long long)B * H * W * Cin;
