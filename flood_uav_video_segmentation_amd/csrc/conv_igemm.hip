@@ -83,8 +83,8 @@ __device__ __forceinline__ void igemm_load_residual(float (&rv)[TM][TN][16], con
 }
 
 template <int ACT, bool RES, int TM, int TN>
-__device__ __forceinline__ void igemm_epilogue(const f32x16 (&acc)[TM][TN], const float (&rv)[TM][TN][16], const ConvParams& p, int M,
-                                               int m_base, int n_base) {
+__device__ __forceinline__ void igemm_epilogue(const f32x16 (&acc)[TM][TN], const float (&rv)[TM][TN][16], const float (&sc)[TN],
+                                               const float (&sh)[TN], const ConvParams& p, int M, int m_base, int n_base) {
     constexpr unsigned SENT = 0x80000000u;
     const __amdgpu_buffer_rsrc_t o_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.out, 0, (unsigned)((long long)M * p.ld_out * 4), 0x00020000);
     const unsigned row_o = (unsigned)p.ld_out * 4u;
@@ -92,15 +92,13 @@ __device__ __forceinline__ void igemm_epilogue(const f32x16 (&acc)[TM][TN], cons
     for (int j = 0; j < TN; ++j) {
         const int n = n_base + j * 32;
         const bool nok = n < p.Cout;
-        const float sc_n = (nok && p.scale) ? p.scale[n] : 1.f;
-        const float sh_n = (nok && p.shift) ? p.shift[n] : 0.f;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const int mb = m_base + i * 32;
             const unsigned vo = nok ? (unsigned)mb * row_o + (unsigned)n * 4u : SENT;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                float v = acc[i][j][e] * sc_n + sh_n;
+                float v = acc[i][j][e] * sc[j] + sh[j];
                 if (RES) v += rv[i][j][e];
                 if (ACT == 1) v = fmaxf(v, 0.f);
                 else if (ACT == 2) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752f));  // nn.GELU (erf form)
@@ -117,11 +115,17 @@ __device__ __forceinline__ void igemm_epilogue(const f32x16 (&acc)[TM][TN], cons
 // [4] cycles spent in the per-chunk wait+barrier, [5] HW_ID | XCC_ID << 32, [6] start (100 MHz wall clock), [7] end (wall)
 __device__ unsigned long long fs_trace_buf[8 * 65536];
 #define FS_TRACE_DECL unsigned long long tr_start = __builtin_readcyclecounter(), tr_wall = wall_clock64(), tr_ready = 0, tr_loop = 0, tr_wait = 0;
-#define FS_TRACE_SYNC() { const unsigned long long tw = __builtin_readcyclecounter(); __syncthreads(); tr_wait += __builtin_readcyclecounter() - tw; }
+#define FS_TRACE_SYNC() { const unsigned long long tw = __builtin_readcyclecounter(); FS_DMA_PUBLISH() tr_wait += __builtin_readcyclecounter() - tw; }
 #else
 #define FS_TRACE_DECL
-#define FS_TRACE_SYNC() __syncthreads();
+#define FS_TRACE_SYNC() FS_DMA_PUBLISH()
 #endif
+// A wave's buffer_load...lds writes are complete when ITS vmcnt reaches 0; the other waves may read them only after that.
+// __syncthreads() does not imply it: the compiler tracks LDS-DMA only against the SAME wave's later ds_reads and is free
+// to wait for vmcnt after the barrier (it did, in the 128x64 instantiation, once two unrelated global loads were added
+// ahead of the loop -- a race between a wave's DMA and its neighbours' fragment reads).  So the wait is explicit:
+// s_waitcnt vmcnt(0) (expcnt / lgkmcnt fields left at "no wait"), then the barrier.
+#define FS_DMA_PUBLISH() { __builtin_amdgcn_s_waitcnt(0x0F70); __syncthreads(); }
 // WGM x WGN waves per workgroup (2x2 = 256 threads, two workgroups per CU; 4x2 = 512 threads, one per CU).
 template <int BM, int BN, int WGM = 2, int WGN = 2>
 __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_dma_f32(ConvParams p, int tiles_m, int tiles_n) {
@@ -269,7 +273,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_dma_f32(ConvParams 
 
     FS_DMA_ALL(0)
     FS_DMA_ADVANCE()
-    __syncthreads();  // s_waitcnt vmcnt(0) + s_barrier: stage 0 has landed for every wave
+    FS_DMA_PUBLISH()  // stage 0 has landed for every wave
 #ifdef FS_TRACE
     tr_ready = __builtin_readcyclecounter();
 #endif
@@ -280,6 +284,13 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_dma_f32(ConvParams 
     f32x4 a0[TM], b0[TN], a1[TM], b1[TN];
     float rv[TM][TN][16];  // residual tile, requested where the last DMA would have been (see below)
     const int em_base = m0 + wm * WM + 4 * hh, en_base = n0 + wn * WN + l31;
+    float sc_n[TN], sh_n[TN];  // per-channel scale / shift of this lane's columns: fetched now, needed after the loop
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = en_base + j * 32;
+        sc_n[j] = (n < p.Cout && p.scale) ? p.scale[n] : 1.f;
+        sh_n[j] = (n < p.Cout && p.shift) ? p.shift[n] : 0.f;
+    }
     if (nchunks > 1) {
         FS_DMA_ALL(1)
         FS_DMA_ADVANCE()
@@ -327,13 +338,13 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_dma_f32(ConvParams 
     // ---- epilogue
     if ((p.dbg & 16) && p.ld_out >= 0) return;  // timing experiment: skip the epilogue (the test keeps the main loop alive)
     if (p.res) {
-        if (p.relu == 1) igemm_epilogue<1, true>(acc, rv, p, M, em_base, en_base);
-        else if (p.relu == 2) igemm_epilogue<2, true>(acc, rv, p, M, em_base, en_base);
-        else igemm_epilogue<0, true>(acc, rv, p, M, em_base, en_base);
+        if (p.relu == 1) igemm_epilogue<1, true>(acc, rv, sc_n, sh_n, p, M, em_base, en_base);
+        else if (p.relu == 2) igemm_epilogue<2, true>(acc, rv, sc_n, sh_n, p, M, em_base, en_base);
+        else igemm_epilogue<0, true>(acc, rv, sc_n, sh_n, p, M, em_base, en_base);
     } else {
-        if (p.relu == 1) igemm_epilogue<1, false>(acc, rv, p, M, em_base, en_base);
-        else if (p.relu == 2) igemm_epilogue<2, false>(acc, rv, p, M, em_base, en_base);
-        else igemm_epilogue<0, false>(acc, rv, p, M, em_base, en_base);
+        if (p.relu == 1) igemm_epilogue<1, false>(acc, rv, sc_n, sh_n, p, M, em_base, en_base);
+        else if (p.relu == 2) igemm_epilogue<2, false>(acc, rv, sc_n, sh_n, p, M, em_base, en_base);
+        else igemm_epilogue<0, false>(acc, rv, sc_n, sh_n, p, M, em_base, en_base);
     }
 #ifdef FS_TRACE
     if (t == 0) {

@@ -235,3 +235,29 @@ def test_winograd_conv3x3(case, tile_m):
                                        tile_m, ptr(ws), stream_ptr()))
     assert rel(out[..., 16:16 + cout].permute(0, 3, 1, 2), ref) < WINO_TOL
     assert (out[..., :16] == -7.0).all() and (out[..., 16 + cout:] == -7.0).all()
+
+
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize("shape", [
+    # b, h, w, cin, cout, k, pad, res  -- the layer shapes of a 713x713 window, where every CU holds 2-5 workgroups at once
+    (2, 90, 90, 2048, 512, 1, 0, False),
+    (2, 90, 90, 512, 2048, 1, 0, True),
+    (2, 90, 90, 256, 1024, 1, 0, True),
+    (2, 179, 179, 64, 64, 3, 1, False),
+])
+def test_conv_at_network_size_is_exact_and_repeatable(shape, tile):
+    """Full-occupancy launches: results must match torch AND be bit-identical from run to run (a wave's direct-to-LDS
+    loads racing its neighbours' fragment reads showed up exactly here, as run-to-run differences)."""
+    b, h, w, cin, cout, k, pad, res = shape
+    g = torch.Generator().manual_seed(cin + cout + tile)
+    x = torch.randn(b, cin, h, w, generator=g).to(DEV)
+    wt = (torch.randn(cout, cin, k, k, generator=g) * (2.0 / (cin * k * k)) ** 0.5).to(DEV)
+    sc, sh = (torch.rand(cout, generator=g) + 0.5).to(DEV), (torch.randn(cout, generator=g) * 0.1).to(DEV)
+    r = torch.randn(b, cout, h, w, generator=g).to(DEV) if res else None
+    ref = F.conv2d(x.double(), wt.double(), None, 1, pad, 1) * sc.view(1, -1, 1, 1).double() + sh.view(1, -1, 1, 1).double()
+    if res:
+        ref = ref + r.double()
+    ref = ref.relu()
+    outs = [ops.conv2d_nhwc(x, wt, sc, sh, r, 1, pad, 1, True, tile) for _ in range(3)]
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2])
+    assert ((outs[0].double() - ref).abs().max() / ref.abs().max()).item() < CONV_TOL

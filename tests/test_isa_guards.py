@@ -1,0 +1,49 @@
+"""Static guards on the compiled gfx950 code (no GPU needed): properties of the ISA that the source cannot express and
+that a compiler upgrade or an innocent-looking edit could silently break."""
+import glob
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+LIB = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "flood_uav_video_segmentation_amd", "libfloodseg.so")
+
+
+def _device_disassembly(tmp_path):
+    if not os.path.exists(OBJDUMP):
+        pytest.skip("llvm-objdump not available")
+    so = os.path.join(tmp_path, "libfloodseg.so")
+    shutil.copy(LIB, so)
+    subprocess.run([OBJDUMP, "--offloading", so], check=True, capture_output=True, cwd=tmp_path)
+    text = []
+    for co in sorted(glob.glob(os.path.join(tmp_path, "libfloodseg.so.*amdgcn*"))):
+        text.append(subprocess.run([OBJDUMP, "-d", co], check=True, capture_output=True, text=True).stdout)
+    assert text, "no gfx950 code object found in libfloodseg.so"
+    return "\n".join(text)
+
+
+def test_conv_kernel_waits_for_its_lds_dma_before_every_barrier(tmp_path):
+    """conv_igemm_dma_f32 stages tiles with `buffer_load ... lds`.  Another wave may read what this wave's DMA wrote only
+    after this wave's vmcnt reached 0, and `__syncthreads()` does not imply that wait (the compiler once sank it below the
+    barrier in the 128x64 instantiation: a race that showed as run-to-run differences at 713x713).  The source now issues
+    an explicit s_waitcnt; this test checks the ISA: every s_barrier of every instantiation is preceded by vmcnt(0)."""
+    dis = _device_disassembly(str(tmp_path))
+    kernels = re.split(r"\n(?=[0-9a-f]+ <[^>]+>:)", dis)
+    checked = 0
+    for k in kernels:
+        head = k.split("\n", 1)[0]
+        if "conv_igemm_dma_f32" not in head:
+            continue
+        lines = [l.split("\t", 1)[-1].strip() if "\t" in l else l.strip() for l in k.splitlines()[1:]]
+        ops = [re.sub(r"\s*//.*", "", l) for l in lines if l]
+        barriers = [i for i, o in enumerate(ops) if o.startswith("s_barrier")]
+        assert barriers, f"no barrier found in {head}"
+        for i in barriers:
+            window = [o for o in ops[max(0, i - 4):i] if o.startswith("s_waitcnt")]
+            assert any("vmcnt(0)" in o for o in window), f"{head}: s_barrier without a preceding s_waitcnt vmcnt(0): {ops[max(0, i - 4):i + 1]}"
+        assert any("buffer_load_dwordx4" in o and "lds" in o for o in ops), f"{head}: the direct-to-LDS loads are gone"
+        checked += 1
+    assert checked >= 5, f"expected the five tile instantiations, found {checked}"
