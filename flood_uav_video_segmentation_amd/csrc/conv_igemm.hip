@@ -124,8 +124,9 @@ __device__ unsigned long long fs_trace_buf[8 * 65536];
 // __syncthreads() does not imply it: the compiler tracks LDS-DMA only against the SAME wave's later ds_reads and is free
 // to wait for vmcnt after the barrier (it did, in the 128x64 instantiation, once two unrelated global loads were added
 // ahead of the loop -- a race between a wave's DMA and its neighbours' fragment reads).  So the wait is explicit:
-// s_waitcnt vmcnt(0) (expcnt / lgkmcnt fields left at "no wait"), then the barrier.
-#define FS_DMA_PUBLISH() { __builtin_amdgcn_s_waitcnt(0x0F70); __syncthreads(); }
+// s_waitcnt vmcnt(0) lgkmcnt(0) (this wave's fragment reads of the stage that is about to be overwritten are done as
+// well; expcnt left at "no wait"), then the barrier.
+#define FS_DMA_PUBLISH() { __builtin_amdgcn_s_waitcnt(0x0070); __syncthreads(); }
 // WGM x WGN waves per workgroup (2x2 = 256 threads, two workgroups per CU; 4x2 = 512 threads, one per CU).
 template <int BM, int BN, int WGM = 2, int WGN = 2>
 __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_dma_f32(ConvParams p, int tiles_m, int tiles_n) {

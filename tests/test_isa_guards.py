@@ -44,6 +44,7 @@ def test_conv_kernel_waits_for_its_lds_dma_before_every_barrier(tmp_path):
         for i in barriers:
             window = [o for o in ops[max(0, i - 4):i] if o.startswith("s_waitcnt")]
             assert any("vmcnt(0)" in o for o in window), f"{head}: s_barrier without a preceding s_waitcnt vmcnt(0): {ops[max(0, i - 4):i + 1]}"
+            assert any("lgkmcnt(0)" in o for o in window), f"{head}: s_barrier without a preceding s_waitcnt lgkmcnt(0): {ops[max(0, i - 4):i + 1]}"
         assert any("buffer_load_dwordx4" in o and "lds" in o for o in ops), f"{head}: the direct-to-LDS loads are gone"
         checked += 1
     assert checked >= 5, f"expected the five tile instantiations, found {checked}"
