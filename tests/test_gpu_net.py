@@ -140,6 +140,7 @@ def test_fused_segment_route_equals_decoder_of_encoder(psp, size, b):
     two_step = net.decoder(net.encoder(x))
     fused = net.segment(x)
     assert fused.shape == two_step.shape and fused.dtype == torch.float32
+    assert torch.equal(net.segment(x), fused)  # bit-repeatable from call to call
     assert rel_err(fused.cpu(), two_step.cpu()) < 2e-5
     assert (fused.max(1)[1] == two_step.max(1)[1]).float().mean().item() > 0.9995
 
