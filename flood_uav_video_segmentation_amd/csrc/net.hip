@@ -657,7 +657,8 @@ int net_segment(fs_handle h, const float* in_nchw, int B, int H, int W, float* o
     const Geometry g = geometry(h, H, W);
     fh = g.H3;
     fw = g.W3;
-    FS_TRY(ensure_workspace(h, encoder_buf_elems(h, B, H, W), small_elems_for(B)));
+    // four rotating buffers: the backbone's largest map, and (tiny inputs) the row-collapsed pyramid term of the head
+    FS_TRY(ensure_workspace(h, std::max(encoder_buf_elems(h, B, H, W), ppm_term_scratch_floats(B, fh, h->cls_main.Cout)), small_elems_for(B)));
     float* feat = nullptr;
     FS_TRY(encoder_core(h, in_nchw, B, H, W, nullptr, &feat, s));
     // (Running the pyramid branch -- pool, four tiny 1x1 convs, the Z GEMM, ~0.12 ms -- on a side stream under the head's

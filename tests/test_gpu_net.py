@@ -131,10 +131,11 @@ def test_deeplabv3_r101_against_oracle_parity_unpinned():
     assert torch.equal(net2.decoder(net2.encoder(x.cuda())), net.decoder(feat))
 
 
-@pytest.mark.parametrize("size,b", [((713, 713), 2), ((161, 225), 1), ((97, 130), 3)])
+@pytest.mark.parametrize("size,b", [((713, 713), 2), ((161, 225), 1), ((97, 130), 3), ((33, 41), 2)])
 def test_fused_segment_route_equals_decoder_of_encoder(psp, size, b):
     """fs_segment_forward (PSPNet: pyramid share of the head conv evaluated on the pooled maps, no 4096-channel concat) must
-    give what fs_decoder_forward(fs_encoder_forward(x)) gives -- divisible (90x90) and ragged (21x29, 13x17) feature maps."""
+    give what fs_decoder_forward(fs_encoder_forward(x)) gives -- divisible (90x90) and ragged (21x29, 13x17) feature maps, and the
+    smallest input the encoder accepts (33 px: a 5x6 map, smaller than the 6x6 pyramid level)."""
     net, _ = psp
     x = synth.make_clip(b, size, seed=21).cuda()
     two_step = net.decoder(net.encoder(x))
