@@ -357,3 +357,16 @@ def test_test_step_mirror_against_oracle_parity_unpinned(tmp_path, crop, nw):
     assert np.array_equal(inter, hist[0]) and np.array_equal(union, hist[1]) and np.array_equal(target, hist[2])
     miou, macc, acc, iou_c, acc_c = ev.summary(0)
     assert abs(miou - float(np.mean(hist[0] / (hist[1] + 1e-10)))) < 1e-12 and ev.summary(1) is None
+
+
+def test_full_window_is_bit_repeatable_under_back_to_back_load(psp_flow):
+    """configs[1] window at 713x713, 12 times back to back without host synchronisation in between: every repetition must
+    give the same logits bit for bit (no race between launches, workspaces or direct-to-LDS stages)."""
+    net, _ = psp_flow
+    fm = FlowModel(net, feature_based=False, no_warp=True).eval()
+    keys = synth.make_clip(6, 713, seed=1000, only=[0, 5]).cuda()
+    dl, dr = [[g.cuda() for g in gs] for gs in synth.dummy_grids(5)]
+    outs = [fm.predict(keys[0:1], keys[1:2], dl, dr, 5, None)["pred"] for _ in range(12)]
+    torch.cuda.synchronize()
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0])
