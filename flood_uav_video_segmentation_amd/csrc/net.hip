@@ -236,6 +236,9 @@ int ensure_workspace(fs_net* h, size_t buf_elems, size_t small_elems) {
         if (h->small) FS_HIP(hipFree(h->small));
         h->small = nullptr;
         FS_HIP(hipMalloc(reinterpret_cast<void**>(&h->small), small_elems * sizeof(float)));
+        // zeroed once: the fixed-stride pyramid slots have rows no kernel ever writes (levels with fewer than 36 cells) and
+        // the grouped Z GEMM multiplies them like any other row
+        FS_HIP(hipMemset(h->small, 0, small_elems * sizeof(float)));
         h->small_elems = small_elems;
     }
     return 0;
