@@ -10,7 +10,9 @@
 namespace fs {
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-// The 2-D transforms keep (m+2)^2 values live per thread: float2 per thread for F(4,3), one float for F(6,3).
+// The 2-D transforms keep (m+2)^2 values live per thread; WVI / WVO = channels per thread in the input / output transform
+// (float2 where the register budget allows: F(6,3)'s input transform at 175 VGPRs still gains from 8-byte accesses, its
+// output transform at 214 VGPRs does not).
 template <int WV> struct WVec;
 template <> struct WVec<1> { typedef float type; };
 template <> struct WVec<2> { typedef f32x2 type; };
@@ -19,7 +21,7 @@ template <int MT> struct Wino;
 
 // ---------------------------------------------------------------- F(4,3)
 template <> struct Wino<4> {
-    static constexpr int A = 6, WV = 2;
+    static constexpr int A = 6, WVI = 2, WVO = 2;
     template <typename T> __device__ static __forceinline__ void bt(const T d[6], T t[6]) {  // B^T d
         t[0] = 4.f * d[0] - 5.f * d[2] + d[4];
         t[1] = -4.f * (d[1] + d[2]) + d[3] + d[4];
@@ -46,7 +48,7 @@ template <> struct Wino<4> {
 
 // ---------------------------------------------------------------- F(6,3)
 template <> struct Wino<6> {
-    static constexpr int A = 8, WV = 1;
+    static constexpr int A = 8, WVI = 2, WVO = 1;
     template <typename T> __device__ static __forceinline__ void bt(const T d[8], T t[8]) {
         const T a = d[2] - 4.25f * d[4] + d[6], b = d[1] - 4.25f * d[3] + d[5];
         const T c = 0.25f * d[2] - 1.25f * d[4] + d[6], e = 0.5f * d[1] - 2.5f * d[3] + 2.f * d[5];
@@ -120,7 +122,7 @@ int launch_winograd_filter(const float* w_oihw, float* U, int O, int I, int mt, 
 template <int MT>
 __global__ __launch_bounds__(256) void winograd_input_kernel(const float* __restrict__ in, int ld_in, float* __restrict__ V, int B, int H,
                                                              int W, int CV, int th, int tw, int dil) {
-    constexpr int A = Wino<MT>::A, WV = Wino<MT>::WV;
+    constexpr int A = Wino<MT>::A, WV = Wino<MT>::WVI;
     typedef typename WVec<WV>::type wv_t;
     // dilation d: the conv splits into d*d independent undilated convs on the pixel lattices (py + d*i, px + d*j);
     // tile t = (b, py, px, ty, tx) covers lattice rows m*ty-1 .. m*ty+m of phase (py, px)
@@ -166,7 +168,7 @@ int launch_winograd_input(const float* in, int ld_in, float* V, int B, int H, in
     FS_REQUIRE(C % 4 == 0 && ld_in % 4 == 0 && dil >= 1, "winograd_input: C must be a multiple of 4");
     FS_REQUIRE(mt == 4 || mt == 6, "winograd: tile size must be 4 or 6");
     const int th = (cdiv(H, dil) + mt - 1) / mt, tw = (cdiv(W, dil) + mt - 1) / mt;
-    const int wv = mt == 4 ? Wino<4>::WV : Wino<6>::WV;
+    const int wv = mt == 4 ? Wino<4>::WVI : Wino<6>::WVI;
     const int64_t total = (int64_t)B * dil * dil * th * tw * (C / wv);
     const dim3 grid((unsigned)std::min<int64_t>(cdiv64(total, 256), 1 << 20));
     if (mt == 4) hipLaunchKernelGGL(winograd_input_kernel<4>, grid, dim3(256), 0, s, in, ld_in, V, B, H, W, C / wv, th, tw, dil);
@@ -180,7 +182,7 @@ template <int MT>
 __global__ __launch_bounds__(256) void winograd_output_kernel(const float* __restrict__ M, const float* __restrict__ scale,
                                                               const float* __restrict__ shift, float* __restrict__ out, int ld_out, int B,
                                                               int H, int W, int NV, int th, int tw, int relu, int dil) {
-    constexpr int A = Wino<MT>::A, WV = Wino<MT>::WV;
+    constexpr int A = Wino<MT>::A, WV = Wino<MT>::WVO;
     typedef typename WVec<WV>::type wv_t;
     const int64_t T = (int64_t)B * dil * dil * th * tw;
     const int64_t total = T * NV;
@@ -226,7 +228,7 @@ int launch_winograd_output(const float* M, const float* scale, const float* shif
     FS_REQUIRE(N % 4 == 0 && ld_out % 4 == 0 && dil >= 1, "winograd_output: N must be a multiple of 4");
     FS_REQUIRE(mt == 4 || mt == 6, "winograd: tile size must be 4 or 6");
     const int th = (cdiv(H, dil) + mt - 1) / mt, tw = (cdiv(W, dil) + mt - 1) / mt;
-    const int wv = mt == 4 ? Wino<4>::WV : Wino<6>::WV;
+    const int wv = mt == 4 ? Wino<4>::WVO : Wino<6>::WVO;
     const int64_t total = (int64_t)B * dil * dil * th * tw * (N / wv);
     const dim3 grid((unsigned)std::min<int64_t>(cdiv64(total, 256), 1 << 20));
     if (mt == 4)
