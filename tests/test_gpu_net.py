@@ -196,3 +196,24 @@ def test_single_frame_deeplabv3_class_parity_unpinned():
     lo = deeplab_oracle.decoder(deeplab_oracle.encoder(x, state, 50), state)
     ref = torch.nn.functional.interpolate(lo, (97, 113), mode="bilinear", align_corners=False)
     assert out.shape == (1, 5, 97, 113) and rel_err(out.cpu(), ref) < LOGIT_TOL
+
+
+def test_two_handles_on_two_streams_do_not_interfere(psp):
+    """The two-windows-in-flight mode of bench.py: two library handles (own workspaces) driven from two HIP streams at the
+    same time must each give what a handle gives alone."""
+    net, state = psp
+    net2 = FlowPSPNet(HP(50, 5)).eval()
+    net2.load_state_dict(state)
+    xa = synth.make_clip(2, (321, 321), seed=31).cuda()
+    xb = synth.make_clip(2, (321, 321), seed=32).cuda()
+    ra, rb = net.segment(xa), net2.segment(xb)
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    outs_a, outs_b = [], []
+    for _ in range(4):
+        side.wait_stream(torch.cuda.current_stream())
+        outs_a.append(net.segment(xa))
+        with torch.cuda.stream(side):
+            outs_b.append(net2.segment(xb))
+    torch.cuda.synchronize()
+    assert all(torch.equal(o, ra) for o in outs_a) and all(torch.equal(o, rb) for o in outs_b)
