@@ -217,3 +217,16 @@ def test_two_handles_on_two_streams_do_not_interfere(psp):
             outs_b.append(net2.segment(xb))
     torch.cuda.synchronize()
     assert all(torch.equal(o, ra) for o in outs_a) and all(torch.equal(o, rb) for o in outs_b)
+
+
+def test_deeplabv3_aspp_on_the_winograd_lattice_path_parity_unpinned():
+    """At 257x257 the feature map is 33x33: the dilation-12 ASPP conv then takes the Winograd lattice decomposition (144
+    phases of 3x3 pixels) while dilation 24 / 36 stay direct -- the mix configs[2] runs at 713x713.  HIP vs oracle."""
+    state = synth.make_deeplab_state(50, 5, seed=2)
+    net = FlowDeepLabv3(HP(50, 5)).eval()
+    net.load_state_dict(state)
+    x = synth.make_clip(1, (257, 257), seed=11)
+    got = net.segment(x.cuda()).cpu()
+    ref = deeplab_oracle.decoder(deeplab_oracle.encoder(x, state, 50), state)
+    assert got.shape == ref.shape == (1, 5, 33, 33)
+    assert rel_err(got, ref) < LOGIT_TOL
