@@ -370,3 +370,39 @@ def test_full_window_is_bit_repeatable_under_back_to_back_load(psp_flow):
     torch.cuda.synchronize()
     for o in outs[1:]:
         assert torch.equal(o, outs[0])
+
+
+def test_predict_video_entry_point_on_a_fake_video(tmp_path):
+    """tools/predict_video.py = the role of the reference's predict_flow.sh run on the HIP path: frames + grids on disk ->
+    colourised masks on disk + the temporal-consistency summary (flow/base.py:236-343)."""
+    import os
+    import subprocess
+    import sys
+
+    from PIL import Image
+
+    from flood_uav_video_segmentation_amd.flow import grids
+
+    base = os.path.join(tmp_path, "data", "frames", "vid")
+    for d in ("images", "grids", "inv_grids"):
+        os.makedirs(os.path.join(base, d))
+    rng = np.random.default_rng(4)
+    mv = np.concatenate([np.full((300, 1), -1), np.full((300, 2), 16), rng.integers(0, 1900, (300, 4)), np.zeros((300, 3), int)], 1)
+    clip = synth.make_clip(11, (161, 225), seed=71)
+    for i in range(11):
+        img = ((clip[i].permute(1, 2, 0) * 40 + 128).clamp(0, 255)).to(torch.uint8).numpy()
+        Image.fromarray(img).save(os.path.join(base, "images", f"{i}.jpg"), quality=95)
+        g, gi = grids.motion_vectors_to_grids(mv, 1072, 1920)
+        grids.save_grid(os.path.join(base, "grids", f"{i}.npy"), g)
+        grids.save_grid(os.path.join(base, "inv_grids", f"{i}.npy"), gi)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = os.path.join(tmp_path, "out")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "predict_video.py"), "--data-root", os.path.join(tmp_path, "data"),
+                        "--video-id", "vid", "--frame-delta", "5", "--synthetic-weights", "--no-cropping", "--size", "161", "225",
+                        "--out", out], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "10 frames of vid" in r.stdout and "temporal consistency mIoU" in r.stdout
+    pngs = sorted(os.listdir(out), key=lambda n: int(n.split(".")[0]))
+    assert pngs == [f"{i}.png" for i in range(10)]
+    im = np.array(Image.open(os.path.join(out, "3.png")))
+    assert im.shape == (161, 225, 3) and set(map(tuple, im.reshape(-1, 3))) <= set(map(tuple, __import__("flood_uav_video_segmentation_amd.flow.predict", fromlist=["PALETTE"]).PALETTE))
