@@ -406,3 +406,37 @@ def test_predict_video_entry_point_on_a_fake_video(tmp_path):
     assert pngs == [f"{i}.png" for i in range(10)]
     im = np.array(Image.open(os.path.join(out, "3.png")))
     assert im.shape == (161, 225, 3) and set(map(tuple, im.reshape(-1, 3))) <= set(map(tuple, __import__("flood_uav_video_segmentation_amd.flow.predict", fromlist=["PALETTE"]).PALETTE))
+
+
+def test_test_flow_entry_point_on_a_fake_labelled_video(tmp_path):
+    """tools/test_flow.py = the reference's `test` run (flow/base.py:156-176) without Lightning: list file + labels + frames +
+    grids on disk -> mIoU line."""
+    import os
+    import subprocess
+    import sys
+
+    from PIL import Image
+
+    H, W = 160, 272
+    base = os.path.join(tmp_path, "frames", "florida")
+    for d in ("images", "grids", "inv_grids"):
+        os.makedirs(os.path.join(base, d))
+    os.makedirs(os.path.join(tmp_path, "masks"))
+    clip = synth.make_clip(16, (H, W), seed=81)
+    for i in range(16):
+        img = ((clip[i].permute(1, 2, 0) * 40 + 128).clamp(0, 255)).to(torch.uint8).numpy()
+        Image.fromarray(img).save(os.path.join(base, "images", f"{i}.jpg"), quality=95)
+        ml, mr = synth.make_grids(2, 67, 120, seed=90 + i, frame=(H, W), jitter=0.01)
+        np.save(os.path.join(base, "grids", f"{i}.npy"), ml[0][0].double().numpy())
+        np.save(os.path.join(base, "inv_grids", f"{i}.npy"), mr[0][0].double().numpy())
+    rng = np.random.default_rng(9)
+    with open(os.path.join(tmp_path, "test.txt"), "w") as fh:
+        for j, f in enumerate([5, 9]):
+            Image.fromarray(rng.integers(0, 5, (H, W)).astype(np.uint8)).save(os.path.join(tmp_path, "masks", f"{j}.png"))
+            fh.write(f"masks/{j}.png florida {f}\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "test_flow.py"), "--data-root", str(tmp_path), "--list",
+                        os.path.join(tmp_path, "test.txt"), "--frame-delta", "5", "--synthetic-weights", "--no-cropping", "--size", str(H),
+                        str(W)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "test1: 2 labelled frames" in r.stdout and "mIoU" in r.stdout
