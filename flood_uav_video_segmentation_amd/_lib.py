@@ -21,12 +21,15 @@ c_f32 = ctypes.c_float
 
 class FsConfig(ctypes.Structure):
     _fields_ = [("arch", c_int), ("layers", c_int), ("classes", c_int), ("patch", c_int), ("d_model", c_int),
-                ("n_layers", c_int), ("dec_layers", c_int), ("image_size", c_int)]
+                ("n_layers", c_int), ("dec_layers", c_int), ("image_size", c_int), ("flags", c_int), ("winograd_tile", c_int)]
 
 
 ARCH_PSPNET = 0
 ARCH_DEEPLABV3 = 1
 ARCH_SEGMENTER = 2
+OPT_NO_WINOGRAD = 1      # FS_OPT_NO_WINOGRAD
+OPT_NO_FUSED_HEAD = 2    # FS_OPT_NO_FUSED_HEAD
+CONV_CHUNK_MAJOR = 0x400  # FS_CONV_CHUNK_MAJOR
 
 # name -> (restype, argtypes); must list every symbol of include/floodseg.h
 _SIGNATURES = {
@@ -41,6 +44,8 @@ _SIGNATURES = {
     "fs_encoder_forward": (c_int, [c_void, c_void, c_int, c_int, c_int, c_void, c_void]),
     "fs_decoder_forward": (c_int, [c_void, c_void, c_int, c_int, c_int, c_void, c_void]),
     "fs_segment_forward": (c_int, [c_void, c_void, c_int, c_int, c_int, c_void, c_void]),
+    "fs_encoder_forward2": (c_int, [c_void, c_void, c_int, c_void, c_int, c_int, c_int, c_void, c_void]),
+    "fs_segment_forward2": (c_int, [c_void, c_void, c_int, c_void, c_int, c_int, c_int, c_void, c_void]),
     "fs_profile_enable": (c_int, [c_void, c_int]),
     "fs_profile_dump": (c_int, [c_void, ctypes.c_char_p, ctypes.c_size_t]),
     "fs_grid_sample_nchw": (c_int, [c_void, c_int, c_int, c_int, c_int, c_void, c_int, c_int, c_void, c_int, c_void]),
@@ -99,8 +104,30 @@ def check(rc):
         raise RuntimeError("floodseg: " + (msg.decode() if msg else f"error {rc}"))
 
 
-def stream_ptr():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+def stream_ptr(device=None):
+    """Current HIP stream of `device` (default: the current device) as the void* the C ABI takes."""
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def one_device(*tensors, handle_device=None, what="floodseg"):
+    """All tensors (None entries skipped) must live on ONE HIP device -- and on the handle's, when given.  Returns it.
+    The library launches on the calling thread's current device, so every wrapper runs its call under
+    `with torch.cuda.device(dev)`: a cuda:1 tensor while cuda:0 is current must never reach a device-0 launch."""
+    dev = None
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError(f"{what}: tensors must live on the GPU (no CPU fallback exists)")
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise RuntimeError(f"{what}: tensors on different devices ({dev} and {t.device})")
+    if dev is None:
+        raise RuntimeError(f"{what}: no device tensor given")
+    if handle_device is not None and dev != handle_device:
+        raise RuntimeError(f"{what}: tensor on {dev} but the network's weights live on {handle_device}")
+    return dev
 
 
 def ptr(t):

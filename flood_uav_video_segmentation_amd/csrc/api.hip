@@ -7,7 +7,7 @@
 
 static inline hipStream_t S(fs_stream s) { return reinterpret_cast<hipStream_t>(s); }
 
-FS_API int fs_version(void) { return 100; }
+FS_API int fs_version(void) { return 200; }
 FS_API const char* fs_last_error(void) { return fs::last_error().c_str(); }
 
 FS_API int fs_create(const fs_config* cfg, fs_handle* out) { return fs::net_create(cfg, out); }
@@ -20,13 +20,23 @@ FS_API int fs_finalize(fs_handle h, fs_stream stream) { return fs::net_finalize(
 FS_API int fs_feature_shape(fs_handle h, int H, int W, int* C, int* fh, int* fw) { return fs::net_feature_shape(h, H, W, C, fh, fw); }
 FS_API size_t fs_workspace_bytes(fs_handle h, int B, int H, int W) { return fs::net_workspace_bytes(h, B, H, W); }
 FS_API int fs_encoder_forward(fs_handle h, const float* in_nchw, int B, int H, int W, float* out_nhwc, fs_stream stream) {
-    return fs::net_encoder(h, in_nchw, B, H, W, out_nhwc, S(stream));
+    return fs::net_encoder(h, in_nchw, nullptr, B, B, H, W, out_nhwc, S(stream));
+}
+FS_API int fs_encoder_forward2(fs_handle h, const float* in_a, int Ba, const float* in_b, int Bb, int H, int W, float* out_nhwc,
+                               fs_stream stream) {
+    if (Ba < 0 || Bb < 0) return fs::fail("fs_encoder_forward2: negative batch");
+    return fs::net_encoder(h, in_a, Bb ? in_b : nullptr, Ba, Ba + Bb, H, W, out_nhwc, S(stream));
 }
 FS_API int fs_decoder_forward(fs_handle h, const float* feat_nhwc, int B, int fh, int fw, float* out_nchw, fs_stream stream) {
     return fs::net_decoder(h, feat_nhwc, B, fh, fw, out_nchw, S(stream));
 }
 FS_API int fs_segment_forward(fs_handle h, const float* in_nchw, int B, int H, int W, float* out_nchw, fs_stream stream) {
-    return fs::net_segment(h, in_nchw, B, H, W, out_nchw, S(stream));
+    return fs::net_segment(h, in_nchw, nullptr, B, B, H, W, out_nchw, S(stream));
+}
+FS_API int fs_segment_forward2(fs_handle h, const float* in_a, int Ba, const float* in_b, int Bb, int H, int W, float* out_nchw,
+                               fs_stream stream) {
+    if (Ba < 0 || Bb < 0) return fs::fail("fs_segment_forward2: negative batch");
+    return fs::net_segment(h, in_a, Bb ? in_b : nullptr, Ba, Ba + Bb, H, W, out_nchw, S(stream));
 }
 FS_API int fs_profile_enable(fs_handle h, int on) {
     if (!h) return fs::fail("fs_profile_enable: null handle");
@@ -153,9 +163,11 @@ FS_API int fs_conv2d_nhwc(const float* in, int ld_in, const float* wgt_ohwi, con
     p.Ho = (H + 2 * pad - dil * (KH - 1) - 1) / stride + 1;
     p.Wo = (W + 2 * pad - dil * (KW - 1) - 1) / stride + 1;
     if (p.Ho < 1 || p.Wo < 1) return fs::fail("fs_conv2d_nhwc: empty output");
-    p.korder = (tile >> 10) & 1;  // bring-up knob: weights packed chunk-major (see kernels.h)
-    p.dbg = (tile >> 11) & 31;     // timing experiments (kernels.h)
-    return fs::launch_conv_igemm(p, S(stream), tile & 0x3ff);
+    // tile = workgroup tile id 0..5, optionally | FS_CONV_CHUNK_MAJOR; anything else is refused (no hidden experiment bits)
+    if ((tile & ~FS_CONV_CHUNK_MAJOR) < 0 || (tile & ~FS_CONV_CHUNK_MAJOR) > 5)
+        return fs::fail("fs_conv2d_nhwc: tile must be 0..5, optionally | FS_CONV_CHUNK_MAJOR (got 0x%x)", tile);
+    p.korder = (tile & FS_CONV_CHUNK_MAJOR) ? 1 : 0;
+    return fs::launch_conv_igemm(p, S(stream), tile & ~FS_CONV_CHUNK_MAJOR);
 }
 FS_API size_t fs_winograd_workspace_floats(int B, int H, int W, int Cin, int Cout, int dil, int tile_m) {
     if (B < 1 || H < 1 || W < 1 || dil < 1 || !(tile_m == 0 || tile_m == 4 || tile_m == 6)) return 0;
@@ -205,6 +217,8 @@ FS_API int fs_stem_conv_nchw(const float* in_nchw, const float* wgt_hwio, const 
     if (!in_nchw || !wgt_hwio || !scale || !shift || !out_nhwc || B < 1) return fs::fail("fs_stem_conv_nchw: bad arguments");
     fs::StemParams p{};
     p.in = in_nchw;
+    p.in2 = nullptr;
+    p.B1 = B;
     p.wgt = wgt_hwio;
     p.scale = scale;
     p.shift = shift;

@@ -337,7 +337,9 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_dma_f32(ConvParams 
 #undef FS_MMA
 
     // ---- epilogue
+#ifdef FS_TRACE
     if ((p.dbg & 16) && p.ld_out >= 0) return;  // timing experiment: skip the epilogue (the test keeps the main loop alive)
+#endif
     if (p.res) {
         if (p.relu == 1) igemm_epilogue<1, true>(acc, rv, sc_n, sh_n, p, M, em_base, en_base);
         else if (p.relu == 2) igemm_epilogue<2, true>(acc, rv, sc_n, sh_n, p, M, em_base, en_base);
@@ -420,7 +422,11 @@ int launch_conv_igemm(const ConvParams& p, hipStream_t s, int tile) {
         FS_HIP(hipGetLastError());
         return 0;
     }
+#ifdef FS_TRACE
     const size_t dyn = (p.dbg & 2) ? 56 * 1024 : 0;  // timing experiment: push occupancy to one block per CU
+#else
+    const size_t dyn = 0;
+#endif
 #define FS_CONV_LAUNCH(BM_, BN_) hipLaunchKernelGGL((conv_igemm_dma_f32<BM_, BN_>), grid, block, dyn, s, p, tm, tn);
     switch (tile) {
         case 1: FS_CONV_LAUNCH(128, 128) break;

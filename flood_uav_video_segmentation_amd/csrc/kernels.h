@@ -29,8 +29,10 @@ struct ConvParams {
     // grouped GEMM (Winograd: one GEMM per transform position): group g uses in + g*g_in, wgt + g*g_wgt, out + g*g_out
     int groups;  // 0 or 1 = plain
     long long g_in, g_wgt, g_out;  // strides in floats
-    int dbg;     // timing experiments only (results are wrong when != 0): 2 = one block per CU, 16 = skip the epilogue,
-                 // 32 | n << 8 = start workgroups bid+256.. n*1024 cycles late (tools/probe_conv_trace.hip builds only)
+#ifdef FS_TRACE  // tools/probe_conv_trace.hip builds only -- the field does not exist in libfloodseg.so
+    int dbg;     // timing experiments (results are wrong when != 0): 2 = one block per CU, 16 = skip the epilogue,
+                 // 32 | n << 8 = start workgroups bid+256.. n*1024 cycles late
+#endif
 };
 // tile: 0 = heuristic, 1 = 128x128, 2 = 128x64, 3 = 64x64, 4 = 64x128
 int launch_conv_igemm(const ConvParams& p, hipStream_t s, int tile = 0);
@@ -41,7 +43,9 @@ const char* conv_igemm_tile_name(const ConvParams& p, int tile = 0);
 // (model/resnet.py:110 3x3 s2 p1; torchvision ResNet 7x7 s2 p3), + BN + ReLU, NHWC out.
 // ---------------------------------------------------------------------------------
 struct StemParams {
-    const float* in;  // NCHW [B,3,H,W]
+    const float* in;   // NCHW [B1,3,H,W]: images 0 .. B1-1
+    const float* in2;  // NCHW [B-B1,3,H,W]: images B1 .. B-1 (the second key frame of a window is a separate tensor in the
+    int B1;            // reference's API, flow/model.py:189-204; reading both in place replaces a torch.cat); B1 == B: unused
     const float* wgt; // [KH*KW*3][Cout]  (tap-major, Cout fastest)
     const float* scale; const float* shift;
     float* out; int ld_out;  // NHWC [B,Ho,Wo,Cout]
@@ -154,7 +158,8 @@ int launch_iou_hist(const uint8_t* pred, const uint8_t* target, int64_t numel, i
 // ---------------------------------------------------------------------------------
 // Zero-padded (right/bottom) im2col of non-overlapping PxP patches: NCHW frame -> [B*gh*gw][3*P*P],
 // column order (c, py, px) = Conv2d(k=s=P) weight flattening (segm/model/vit.py:28-35, utils.py:65-76).
-int launch_patchify(const float* in, float* out, int B, int H, int W, int P, int gh, int gw, hipStream_t s);
+// in: images 0 .. B1-1, in2: images B1 .. B-1 (nullptr when B1 == B), as in StemParams
+int launch_patchify(const float* in, const float* in2, int B1, float* out, int B, int H, int W, int P, int gh, int gw, hipStream_t s);
 // X[b][0] = cls + pos[0];  X[b][1+i] = emb[b*N+i] + pos[1+i]   (segm/model/vit.py:112-131)
 int launch_vit_assemble(const float* emb, const float* cls, const float* pos, float* X, int B, int N, int D, hipStream_t s);
 // Z[b][i<N] = Y[b*N+i];  Z[b][N+k] = cls_emb[k]                (segm/model/decoder.py:84-86)
@@ -181,7 +186,8 @@ int launch_mask_head(const float* pp, const float* cc, const float* gamma, const
 //   M[xi][t][o]  = sum_c V[xi][t][c] * U[xi][o][c]      (grouped conv_igemm_dma_f32)
 //   out          = act(scale * (A^T M A) + shift)       output transform
 // ---------------------------------------------------------------------------------
-int launch_winograd_filter(const float* w_oihw, float* U /*[(m+2)^2][O][I]*/, int O, int I, int mt, hipStream_t s);
+// chunk_major != 0: `w` is the direct kernel's packed bank [O][I/32][3][3][32] (ConvParams::korder == 1) instead of OIHW
+int launch_winograd_filter(const float* w, float* U /*[(m+2)^2][O][I]*/, int O, int I, int mt, hipStream_t s, int chunk_major = 0);
 // dil > 1 (pad == dil): the conv is d*d independent undilated convs on the pixel lattices (py + d*i, px + d*j);
 // tiles are enumerated (b, py, px, ty, tx).
 int launch_winograd_input(const float* in, int ld_in, float* V /*[(m+2)^2][T][C]*/, int B, int H, int W, int C, int dil, int mt,

@@ -3,6 +3,7 @@
 // (from the public torchvision definition, parity unpinned) model/deeplabv3.py:11-54.
 #pragma once
 #include <map>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -21,6 +22,13 @@ struct RawTensor {
     }
 };
 
+// Winograd filter banks of one conv, built on first use for the tile size the map at hand selects (a handle that only ever
+// sees one geometry never pays for the other bank).  Shared by the copies of a ConvBN the executor makes.
+struct WinoBank {
+    float* U4 = nullptr;  // [36][Cout][Cin]  F(4x4,3x3)
+    float* U6 = nullptr;  // [64][Cout][Cin]  F(6x6,3x3)
+};
+
 // conv + (eval BatchNorm | bias) + optional ReLU, ready to launch
 struct ConvBN {
     std::string name;
@@ -29,8 +37,7 @@ struct ConvBN {
     float* shift = nullptr;
     int Cin = 0, Cout = 0, KH = 1, KW = 1, stride = 1, pad = 0, dil = 1, relu = 0;
     int korder = 0;  // 1: filters packed chunk-major (3x3 convs)
-    float* wino_U = nullptr;   // [36][Cout][Cin] Winograd F(4,3) filters (3x3 stride-1 convs with pad == dil and Cin >= 256)
-    float* wino_U6 = nullptr;  // [64][Cout][Cin] F(6,3) filters of the same conv; the cheaper tiling for the map at hand is used
+    std::shared_ptr<WinoBank> wino;  // non-null: 3x3 stride-1 conv with pad == dil and Cin >= 256 (Winograd-eligible)
     int out_size(int in) const { return (in + 2 * pad - dil * (KH - 1) - 1) / stride + 1; }
 };
 
@@ -108,10 +115,11 @@ struct fs_net {
     size_t vit_ws_elems = 0;
     float* wino_ws = nullptr;  // V [36][T][Cin] followed by M [36][T][Cout]
     size_t wino_ws_elems = 0;
-    bool use_winograd = true;  // FS_NO_WINOGRAD=1 in the environment selects the direct conv everywhere
-    int wino_force_m = 0;      // FS_WINOGRAD_TILE=4|6 forces F(4,3) / F(6,3); 0 = the cheaper one for the map at hand
-    double wino_far_factor = 0.7;  // Winograd is taken for dilation > 4 only if its GEMM rows are below this share of the direct conv's
-    bool use_fused_head = true;  // FS_NO_FUSED_HEAD=1: fs_segment_forward runs encoder + decoder over the 4096-channel concat (A/B)
+    // explicit options of fs_config (include/floodseg.h): nothing is read from the environment
+    bool use_winograd = true;    // !(flags & FS_OPT_NO_WINOGRAD)
+    int wino_force_m = 0;        // winograd_tile: 4 | 6 forces F(4,3) / F(6,3); 0 = the cheaper one for the map at hand
+    bool use_fused_head = true;  // !(flags & FS_OPT_NO_FUSED_HEAD)
+    int device = 0;              // HIP device the handle's memory lives on (current device at fs_create)
 
     // workspace
     float* buf[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -132,13 +140,16 @@ struct fs_net {
 namespace fs {
 int net_create(const fs_config* cfg, fs_handle* out);
 int net_destroy(fs_handle h);
+int check_device(fs_net* h, const char* what);
 int net_load_weight(fs_handle h, const char* name, const float* data, const int64_t* shape, int ndim, int on_device,
                     hipStream_t s);
 int net_finalize(fs_handle h, hipStream_t s);
 int net_feature_shape(fs_handle h, int H, int W, int* C, int* fh, int* fw);
 size_t net_workspace_bytes(fs_handle h, int B, int H, int W);
-int net_encoder(fs_handle h, const float* in_nchw, int B, int H, int W, float* out_nhwc, hipStream_t s);
-int net_segment(fs_handle h, const float* in_nchw, int B, int H, int W, float* out_nchw, hipStream_t s);
+// Frames: images 0 .. B1-1 from in_nchw, images B1 .. B-1 from in2 (nullptr when B1 == B): the two key frames of a window are
+// two tensors in the reference's API (flow/model.py:189-204) and are read in place instead of being concatenated first.
+int net_encoder(fs_handle h, const float* in_nchw, const float* in2, int B1, int B, int H, int W, float* out_nhwc, hipStream_t s);
+int net_segment(fs_handle h, const float* in_nchw, const float* in2, int B1, int B, int H, int W, float* out_nchw, hipStream_t s);
 int net_decoder(fs_handle h, const float* feat, int B, int fh, int fw, float* out_nchw, hipStream_t s);
 int net_profile_dump(fs_handle h, char* buf, size_t n);
 
@@ -149,6 +160,6 @@ int prof_begin(fs_net* h, const std::string& name, const char* kernel, double fl
 int prof_end(fs_net* h, hipStream_t s);
 int vit_finalize(fs_handle h, hipStream_t s);
 int vit_feature_shape(fs_handle h, int H, int W, int* C, int* fh, int* fw);
-int vit_encoder(fs_handle h, const float* in_nchw, int B, int H, int W, float* out_tokens, hipStream_t s);
+int vit_encoder(fs_handle h, const float* in_nchw, const float* in2, int B1, int B, int H, int W, float* out_tokens, hipStream_t s);
 int vit_decoder(fs_handle h, const float* tokens, int B, int gh, int gw, float* out_nchw, hipStream_t s);
 }  // namespace fs

@@ -43,6 +43,23 @@ int to_host(const RawTensor& t, std::vector<float>& v) {
 
 namespace {
 
+bool wino_eligible(const ConvBN& c, bool hwio) {
+    return !hwio && c.KH == 3 && c.KW == 3 && c.stride == 1 && c.pad == c.dil && c.Cin >= 256 && c.Cin % 32 == 0 && c.Cout % 4 == 0;
+}
+
+// The F(mt x mt, 3x3) filter bank of a Winograd-eligible conv, transformed (in double, rounded once) from the direct kernel's
+// chunk-major bank the first time this tile size is needed.  Stream-ordered: the transform runs on `s` ahead of its first use.
+int wino_bank(fs_net* h, const ConvBN& c, int mt, hipStream_t s, const float** U) {
+    float*& slot = mt == 6 ? c.wino->U6 : c.wino->U4;
+    if (!slot) {
+        FS_REQUIRE(c.korder == 1, "winograd: conv '%s' has no chunk-major filter bank", c.name.c_str());
+        FS_TRY(dev_alloc(h, &slot, (size_t)(mt + 2) * (mt + 2) * c.Cout * c.Cin));
+        FS_TRY(launch_winograd_filter(c.w, slot, c.Cout, c.Cin, mt, s, 1));
+    }
+    *U = slot;
+    return 0;
+}
+
 // conv weight + BatchNorm prefix (or bias name, or neither)
 int make_conv(fs_net* h, ConvBN& c, const std::string& wname, const std::string& bn, const std::string& bias, int stride,
               int pad, int dil, int relu, bool hwio, hipStream_t s) {
@@ -67,12 +84,7 @@ int make_conv(fs_net* h, ConvBN& c, const std::string& wname, const std::string&
     } else {
         FS_TRY(launch_pack_oihw_to_ohwi(w->d, c.w, c.Cout, c.Cin, c.KH, c.KW, s));
     }
-    if (!hwio && c.KH == 3 && c.KW == 3 && stride == 1 && pad == dil && c.Cin >= 256 && c.Cin % 32 == 0 && c.Cout % 4 == 0) {
-        FS_TRY(dev_alloc(h, &c.wino_U, (size_t)36 * c.Cout * c.Cin));
-        FS_TRY(launch_winograd_filter(w->d, c.wino_U, c.Cout, c.Cin, 4, s));
-        FS_TRY(dev_alloc(h, &c.wino_U6, (size_t)64 * c.Cout * c.Cin));
-        FS_TRY(launch_winograd_filter(w->d, c.wino_U6, c.Cout, c.Cin, 6, s));
-    }
+    if (wino_eligible(c, hwio)) c.wino = std::make_shared<WinoBank>();  // the banks themselves: wino_bank(), on first use
     if (!bn.empty()) {
         const RawTensor *g, *b, *m, *v;
         FS_TRY(fetch(h, bn + ".weight", &g));
@@ -135,6 +147,8 @@ int run_conv_winograd(fs_net* h, const ConvBN& c, const float* in, int ld_in, in
     const int mt = h->wino_force_m ? h->wino_force_m : winograd_pick_m(B, H, W, c.dil);
     const int G = (mt + 2) * (mt + 2);
     const int T = winograd_tiles(B, H, W, c.dil, mt);
+    const float* U = nullptr;
+    FS_TRY(wino_bank(h, c, mt, s, &U));
     const size_t v_elems = (size_t)G * T * c.Cin, m_elems = (size_t)G * T * c.Cout;
     if (v_elems + m_elems > h->wino_ws_elems) {
         FS_HIP(hipDeviceSynchronize());
@@ -151,7 +165,7 @@ int run_conv_winograd(fs_net* h, const ConvBN& c, const float* in, int ld_in, in
     ConvParams p{};
     p.in = V;
     p.ld_in = c.Cin;
-    p.wgt = mt == 6 ? c.wino_U6 : c.wino_U;
+    p.wgt = U;
     p.out = Mb;
     p.ld_out = c.Cout;
     p.B = 1;
@@ -181,13 +195,13 @@ int run_conv(fs_net* h, const ConvBN& c, const float* in, int ld_in, int B, int 
              const float* res, int ld_res, hipStream_t s) {
     // Winograd pays when its 36 GEMM rows per 4x4 tile undercut the 9 taps per pixel of the direct conv even after the
     // tile-edge / lattice-phase waste (large dilations on a small map leave mostly-empty tiles): 36*T < 0.8 * 9*M
-    if (c.wino_U && h->use_winograd && !res) {
+    if (c.wino && h->use_winograd && !res) {
         const int mt = h->wino_force_m ? h->wino_force_m : winograd_pick_m(B, H, W, c.dil);
         const double wino_rows = (double)(mt + 2) * (mt + 2) * winograd_tiles(B, H, W, c.dil, mt);
         const double direct_rows = 9.0 * (double)B * c.out_size(H) * c.out_size(W);
         // dilation <= 4 (the dilated ResNet stages, the heads): 0.8; the ASPP dilations leave the lattices of a 90x90 map
         // only 8, 4 and 3 pixels wide and the transforms touch every pixel through 2048 channels, so they must save more
-        if (wino_rows < (c.dil <= 4 ? 0.8 : h->wino_far_factor) * direct_rows) return run_conv_winograd(h, c, in, ld_in, B, H, W, out, ld_out, s);
+        if (wino_rows < (c.dil <= 4 ? 0.8 : 0.7) * direct_rows) return run_conv_winograd(h, c, in, ld_in, B, H, W, out, ld_out, s);
     }
     ConvParams p{};
     p.in = in;
@@ -280,18 +294,28 @@ int net_create(const fs_config* cfg, fs_handle* out) {
     FS_REQUIRE(cfg->arch == FS_ARCH_SEGMENTER || cfg->layers == 50 || cfg->layers == 101 || cfg->layers == 152,
                "fs_create: layers must be 50, 101 or 152");
     FS_REQUIRE(cfg->classes >= 1 && cfg->classes <= 255, "fs_create: classes out of range");
+    FS_REQUIRE((cfg->flags & ~(FS_OPT_NO_WINOGRAD | FS_OPT_NO_FUSED_HEAD)) == 0, "fs_create: unknown option bits 0x%x", cfg->flags);
+    FS_REQUIRE(cfg->winograd_tile == 0 || cfg->winograd_tile == 4 || cfg->winograd_tile == 6, "fs_create: winograd_tile must be 0, 4 or 6");
     fs_net* h = new fs_net();
     h->cfg = *cfg;
-    const char* nw = getenv("FS_NO_WINOGRAD");
-    h->use_winograd = !(nw && nw[0] == '1');
-    const char* wm = getenv("FS_WINOGRAD_TILE");  // A/B switch: 4 or 6 forces that tile size, unset = per-map choice
-    h->wino_force_m = (wm && (wm[0] == '4' || wm[0] == '6')) ? wm[0] - '0' : 0;
-    const char* wf = getenv("FS_WINOGRAD_FAR");  // experiment knob: row-saving factor required for dilation > 4
-    h->wino_far_factor = wf ? atof(wf) : 0.7;
-    const char* nf = getenv("FS_NO_FUSED_HEAD");
-    h->use_fused_head = !(nf && nf[0] == '1');
+    h->use_winograd = !(cfg->flags & FS_OPT_NO_WINOGRAD);
+    h->wino_force_m = cfg->winograd_tile;
+    h->use_fused_head = !(cfg->flags & FS_OPT_NO_FUSED_HEAD);
+    if (hipGetDevice(&h->device) != hipSuccess) {
+        delete h;
+        return fail("fs_create: no HIP device");
+    }
     h->deep_stem = cfg->arch == FS_ARCH_PSPNET;
     *out = h;
+    return 0;
+}
+
+// The handle's weights and workspace live on ONE device and every launch goes to the calling thread's current device:
+// a call made while another device is current would run device-A kernels on device-B pointers.  Refuse it.
+int check_device(fs_net* h, const char* what) {
+    int cur = -1;
+    FS_HIP(hipGetDevice(&cur));
+    FS_REQUIRE(cur == h->device, "%s: the handle was created on HIP device %d but device %d is current", what, h->device, cur);
     return 0;
 }
 
@@ -320,6 +344,7 @@ int net_load_weight(fs_handle h, const char* name, const float* data, const int6
                     hipStream_t s) {
     FS_REQUIRE(h && name && data && (shape || ndim == 0), "fs_load_weight: null argument");
     FS_REQUIRE(!h->finalized, "fs_load_weight: network already finalized");
+    FS_TRY(check_device(h, "fs_load_weight"));
     RawTensor t;
     t.shape.assign(shape, shape + ndim);
     const int64_t n = t.numel();
@@ -338,6 +363,7 @@ int net_load_weight(fs_handle h, const char* name, const float* data, const int6
 int net_finalize(fs_handle h, hipStream_t s) {
     FS_REQUIRE(h, "fs_finalize: null handle");
     FS_REQUIRE(!h->finalized, "fs_finalize: already finalized");
+    FS_TRY(check_device(h, "fs_finalize"));
     FS_HIP(hipStreamSynchronize(s));
     if (h->cfg.arch == FS_ARCH_SEGMENTER) {
         FS_TRY(vit_finalize(h, s));
@@ -411,20 +437,15 @@ int net_finalize(fs_handle h, hipStream_t s) {
             m = h->cls_conv;
             m.name = "decoder.0.weight[:, :2048]";
             m.Cin = 2048;
-            m.w = m.wino_U = m.wino_U6 = nullptr;
-            float* sl = nullptr;  // OIHW slice [O][2048][3][3]
-            FS_HIP(hipMalloc(reinterpret_cast<void**>(&sl), (size_t)O * 2048 * 9 * sizeof(float)));
-            FS_HIP(hipMemcpy2DAsync(sl, (size_t)2048 * 9 * sizeof(float), w->d, (size_t)4096 * 9 * sizeof(float),
-                                    (size_t)2048 * 9 * sizeof(float), (size_t)O, hipMemcpyDeviceToDevice, s));
+            m.w = nullptr;
+            m.wino = std::make_shared<WinoBank>();  // its own banks (Cin = 2048), built on first use like every other conv's
+            // In the chunk-major layout [O][I/32][3][3][32] the first 2048 input channels of output channel o are the first
+            // 64 chunk blocks of its row: the backbone half of the bank is a strided copy of the full one, no repack.
             FS_TRY(dev_alloc(h, &m.w, (size_t)O * 2048 * 9));
             m.korder = 1;
-            FS_TRY(launch_pack_oihw_chunk_major(sl, m.w, O, 2048, 3, 3, s));
-            FS_TRY(dev_alloc(h, &m.wino_U, (size_t)36 * O * 2048));
-            FS_TRY(launch_winograd_filter(sl, m.wino_U, O, 2048, 4, s));
-            FS_TRY(dev_alloc(h, &m.wino_U6, (size_t)64 * O * 2048));
-            FS_TRY(launch_winograd_filter(sl, m.wino_U6, O, 2048, 6, s));
-            FS_HIP(hipStreamSynchronize(s));
-            FS_HIP(hipFree(sl));
+            FS_REQUIRE(h->cls_conv.korder == 1, "decoder.0: chunk-major bank expected");
+            FS_HIP(hipMemcpy2DAsync(m.w, (size_t)2048 * 9 * sizeof(float), h->cls_conv.w, (size_t)4096 * 9 * sizeof(float),
+                                    (size_t)2048 * 9 * sizeof(float), (size_t)O, hipMemcpyDeviceToDevice, s));
             float* zw = nullptr;  // the four [9*O][512] matrices back to back: groups of one grouped GEMM
             FS_TRY(dev_alloc(h, &zw, (size_t)4 * 9 * O * 512));
             for (int i = 0; i < 4; ++i) {
@@ -538,7 +559,7 @@ int pyramid_reduce(fs_net* h, const float* feat, int ld_feat, int B, int H, int 
 // ResNet backbone (+ pyramid pooling for PSPNet).  out != nullptr: the reference's encoder output (PSPNet: 4096-channel
 // concat with the upsampled pyramid; ld_out = feat_channels()).  out == nullptr (fused PSPNet route): the 2048 backbone
 // channels stay in a workspace buffer (*feat2048, ld 2048) and the pyramid stops at the pooled+reduced maps in h->small.
-int encoder_core(fs_handle h, const float* in_nchw, int B, int H, int W, float* out, float** feat2048, hipStream_t s) {
+int encoder_core(fs_handle h, const float* in_nchw, const float* in2, int B1, int B, int H, int W, float* out, float** feat2048, hipStream_t s) {
     const bool fused = out == nullptr;
     const Geometry g = geometry(h, H, W);
     FS_TRY(ensure_workspace(h, encoder_buf_elems(h, B, H, W), small_elems_for(B)));
@@ -550,6 +571,8 @@ int encoder_core(fs_handle h, const float* in_nchw, int B, int H, int W, float* 
         const ConvBN& c = h->stem[0];
         StemParams p{};
         p.in = in_nchw;
+        p.in2 = in2;
+        p.B1 = B1;
         p.wgt = c.w;
         p.scale = c.scale;
         p.shift = c.shift;
@@ -630,18 +653,22 @@ int encoder_core(fs_handle h, const float* in_nchw, int B, int H, int W, float* 
 }
 }  // namespace
 
-int net_encoder(fs_handle h, const float* in_nchw, int B, int H, int W, float* out, hipStream_t s) {
+int net_encoder(fs_handle h, const float* in_nchw, const float* in2, int B1, int B, int H, int W, float* out, hipStream_t s) {
     FS_REQUIRE(h && h->finalized, "fs_encoder_forward: network not finalized");
-    if (h->cfg.arch == FS_ARCH_SEGMENTER) return vit_encoder(h, in_nchw, B, H, W, out, s);
-    FS_REQUIRE(in_nchw && out && B >= 1 && H >= 33 && W >= 33, "fs_encoder_forward: bad arguments (B=%d H=%d W=%d)", B, H, W);
-    return encoder_core(h, in_nchw, B, H, W, out, nullptr, s);
+    FS_TRY(check_device(h, "fs_encoder_forward"));
+    FS_REQUIRE(B >= 1 && B1 >= 0 && B1 <= B && (B1 == 0 || in_nchw) && (B1 == B || in2), "fs_encoder_forward: bad frame batch (B1=%d of B=%d)", B1, B);
+    if (h->cfg.arch == FS_ARCH_SEGMENTER) return vit_encoder(h, in_nchw, in2, B1, B, H, W, out, s);
+    FS_REQUIRE(out && H >= 33 && W >= 33, "fs_encoder_forward: bad arguments (B=%d H=%d W=%d)", B, H, W);
+    return encoder_core(h, in_nchw, in2, B1, B, H, W, out, nullptr, s);
 }
 
 // decoder(encoder(x)) in one call (flow/model.py:39-40, 189-191, 202-204; single-frame inference).  PSPNet takes the
 // fused route (no 4096-channel concat, see net_ops.hip); the other heads run encoder + decoder over an internal feature map.
-int net_segment(fs_handle h, const float* in_nchw, int B, int H, int W, float* out_nchw, hipStream_t s) {
+int net_segment(fs_handle h, const float* in_nchw, const float* in2, int B1, int B, int H, int W, float* out_nchw, hipStream_t s) {
     FS_REQUIRE(h && h->finalized, "fs_segment_forward: network not finalized");
-    FS_REQUIRE(in_nchw && out_nchw && B >= 1 && H >= 1 && W >= 1, "fs_segment_forward: bad arguments (B=%d H=%d W=%d)", B, H, W);
+    FS_TRY(check_device(h, "fs_segment_forward"));
+    FS_REQUIRE(out_nchw && B >= 1 && H >= 1 && W >= 1, "fs_segment_forward: bad arguments (B=%d H=%d W=%d)", B, H, W);
+    FS_REQUIRE(B1 >= 0 && B1 <= B && (B1 == 0 || in_nchw) && (B1 == B || in2), "fs_segment_forward: bad frame batch (B1=%d of B=%d)", B1, B);
     int C = 0, fh = 0, fw = 0;
     if (h->cfg.arch != FS_ARCH_PSPNET || !h->use_fused_head) {
         FS_TRY(net_feature_shape(h, H, W, &C, &fh, &fw));
@@ -653,7 +680,7 @@ int net_segment(fs_handle h, const float* in_nchw, int B, int H, int W, float* o
             FS_HIP(hipMalloc(reinterpret_cast<void**>(&h->seg_feat), need * sizeof(float)));
             h->seg_feat_elems = need;
         }
-        FS_TRY(net_encoder(h, in_nchw, B, H, W, h->seg_feat, s));
+        FS_TRY(net_encoder(h, in_nchw, in2, B1, B, H, W, h->seg_feat, s));
         return net_decoder(h, h->seg_feat, B, fh, fw, out_nchw, s);
     }
     FS_REQUIRE(H >= 33 && W >= 33, "fs_segment_forward: bad arguments (B=%d H=%d W=%d)", B, H, W);
@@ -663,7 +690,7 @@ int net_segment(fs_handle h, const float* in_nchw, int B, int H, int W, float* o
     // four rotating buffers: the backbone's largest map, and (tiny inputs) the row-collapsed pyramid term of the head
     FS_TRY(ensure_workspace(h, std::max(encoder_buf_elems(h, B, H, W), ppm_term_scratch_floats(B, fh, h->cls_main.Cout)), small_elems_for(B)));
     float* feat = nullptr;
-    FS_TRY(encoder_core(h, in_nchw, B, H, W, nullptr, &feat, s));
+    FS_TRY(encoder_core(h, in_nchw, in2, B1, B, H, W, nullptr, &feat, s));
     // (Running the pyramid branch -- pool, four tiny 1x1 convs, the Z GEMM, ~0.12 ms -- on a side stream under the head's
     //  Winograd GEMM was measured: +0.2 %, not worth a second stream in the handle.)
     hipStream_t ps = s;
@@ -714,6 +741,7 @@ int net_segment(fs_handle h, const float* in_nchw, int B, int H, int W, float* o
 // ---------------------------------------------------------------------------------------------
 int net_decoder(fs_handle h, const float* feat, int B, int fh, int fw, float* out_nchw, hipStream_t s) {
     FS_REQUIRE(h && h->finalized, "fs_decoder_forward: network not finalized");
+    FS_TRY(check_device(h, "fs_decoder_forward"));
     if (h->cfg.arch == FS_ARCH_SEGMENTER) return vit_decoder(h, feat, B, fh, fw, out_nchw, s);
     FS_REQUIRE(feat && out_nchw && B >= 1 && fh >= 1 && fw >= 1, "fs_decoder_forward: bad arguments");
     const int K = h->cfg.classes;

@@ -35,7 +35,7 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(StemParams p) {
 #pragma unroll
     for (int c = 0; c < CPT; ++c) acc[c] = 0.f;
     const size_t plane = (size_t)p.H * p.W;
-    const float* inb = p.in + (size_t)b * 3 * plane;
+    const float* inb = b < p.B1 ? p.in + (size_t)b * 3 * plane : p.in2 + (size_t)(b - p.B1) * 3 * plane;
     for (int ky = 0; ky < p.KH; ++ky) {
         const int iy = iy0 + ky;
         const bool yok = (unsigned)iy < (unsigned)p.H;
@@ -74,6 +74,7 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(StemParams p) {
 int launch_stem_conv(const StemParams& p, hipStream_t s) {
     FS_REQUIRE(p.Cout % 16 == 0 && p.Cout <= 256 && 256 % (p.Cout / 16) == 0, "stem_conv: unsupported Cout=%d", p.Cout);
     FS_REQUIRE(p.ld_out % 4 == 0, "stem_conv: ld_out must be a multiple of 4");
+    FS_REQUIRE(p.B1 >= 0 && p.B1 <= p.B && (p.B1 == p.B || p.in2) && (p.B1 == 0 || p.in), "stem_conv: bad frame split B1=%d of B=%d", p.B1, p.B);
     const int M = p.B * p.Ho * p.Wo;
     const int groups = p.Cout / 16, ppb = 256 / groups;
     const size_t lds = (size_t)p.KH * p.KW * 3 * p.Cout * sizeof(float);

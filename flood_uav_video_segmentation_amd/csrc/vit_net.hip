@@ -169,8 +169,8 @@ int vit_feature_shape(fs_handle h, int H, int W, int* C, int* fh, int* fw) {
     return 0;
 }
 
-int vit_encoder(fs_handle h, const float* in_nchw, int B, int H, int W, float* out_tokens, hipStream_t s) {
-    FS_REQUIRE(in_nchw && out_tokens && B >= 1 && H >= 1 && W >= 1, "fs_encoder_forward(segmenter): bad arguments");
+int vit_encoder(fs_handle h, const float* in_nchw, const float* in2, int B1, int B, int H, int W, float* out_tokens, hipStream_t s) {
+    FS_REQUIRE((in_nchw || B1 == 0) && out_tokens && B >= 1 && H >= 1 && W >= 1, "fs_encoder_forward(segmenter): bad arguments");
     const int P = h->cfg.patch, D = h->cfg.d_model;
     const int gh = (H + P - 1) / P, gw = (W + P - 1) / P, N = gh * gw;
     VitWs ws;
@@ -191,7 +191,7 @@ int vit_encoder(fs_handle h, const float* in_nchw, int B, int H, int W, float* o
         pos = h->pos_cur;
     }
     FS_TRY(prof_begin(h, "patchify", "patchify", 0, 8.0 * B * N * 3.0 * P * P, s));
-    FS_TRY(launch_patchify(in_nchw, ws.patches, B, H, W, P, gh, gw, s));
+    FS_TRY(launch_patchify(in_nchw, in2, B1, ws.patches, B, H, W, P, gh, gw, s));
     FS_TRY(prof_end(h, s));
     FS_TRY(run_linear(h, h->patch_embed, ws.patches, B * N, ws.emb, nullptr, 0, s));
     FS_TRY(launch_vit_assemble(ws.emb, h->cls_token, pos, ws.X, B, N, D, s));

@@ -9,8 +9,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // ------------------------------------------------------------------ patchify (zero padded right/bottom)
-__global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int H, int W,
-                                                       int P, int gh, int gw) {
+__global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__ in, const float* __restrict__ in2, int B1,
+                                                       float* __restrict__ out, int B, int H, int W, int P, int gh, int gw) {
     const int Kc = 3 * P * P;
     const int64_t total = (int64_t)B * gh * gw * Kc;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
@@ -19,14 +19,16 @@ __global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__
         const int px = col % P, py = (col / P) % P, c = col / (P * P);
         const int gx = (int)(row % gw), gy = (int)((row / gw) % gh), b = (int)(row / ((int64_t)gw * gh));
         const int y = gy * P + py, x = gx * P + px;
-        out[i] = (y < H && x < W) ? in[((size_t)(b * 3 + c) * H + y) * W + x] : 0.f;
+        const float* src = b < B1 ? in + (size_t)b * 3 * H * W : in2 + (size_t)(b - B1) * 3 * H * W;
+        out[i] = (y < H && x < W) ? src[((size_t)c * H + y) * W + x] : 0.f;
     }
 }
 
-int launch_patchify(const float* in, float* out, int B, int H, int W, int P, int gh, int gw, hipStream_t s) {
+int launch_patchify(const float* in, const float* in2, int B1, float* out, int B, int H, int W, int P, int gh, int gw, hipStream_t s) {
+    FS_REQUIRE(B1 >= 0 && B1 <= B && (B1 == B || in2) && (B1 == 0 || in), "patchify: bad frame split B1=%d of B=%d", B1, B);
     const int64_t total = (int64_t)B * gh * gw * 3 * P * P;
-    hipLaunchKernelGGL(patchify_kernel, dim3((unsigned)std::min<int64_t>(cdiv64(total, 256), 16384)), dim3(256), 0, s, in, out, B, H, W,
-                       P, gh, gw);
+    hipLaunchKernelGGL(patchify_kernel, dim3((unsigned)std::min<int64_t>(cdiv64(total, 256), 16384)), dim3(256), 0, s, in, in2, B1,
+                       out, B, H, W, P, gh, gw);
     FS_HIP(hipGetLastError());
     return 0;
 }

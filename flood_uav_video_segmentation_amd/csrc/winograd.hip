@@ -85,16 +85,18 @@ template <> struct Wino<6> {
 
 // ---- filter transform U = G g G^T, once at load, in double (rounded once to fp32): thread per (o, c)
 template <int MT>
-__global__ __launch_bounds__(256) void winograd_filter_kernel(const float* __restrict__ w, float* __restrict__ U, int O, int I) {
+__global__ __launch_bounds__(256) void winograd_filter_kernel(const float* __restrict__ w, float* __restrict__ U, int O, int I, int chunk_major) {
     constexpr int A = Wino<MT>::A;
     const int64_t total = (int64_t)O * I;
+    const int ts = chunk_major ? 32 : 1;  // distance between two taps of one (o, c)
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-        const float* g = w + i * 9;  // OIHW: [o][c][3][3]
+        // OIHW: [o][c][3][3];  chunk-major: [o][c/32][3][3][c%32] -- (o*I + c)/32 = o*(I/32) + c/32 since I % 32 == 0
+        const float* g = chunk_major ? w + (i >> 5) * 288 + (i & 31) : w + i * 9;
         double t[A][3];
 #pragma unroll
         for (int s = 0; s < 3; ++s) {
             double col[A];
-            Wino<MT>::g(g[0 * 3 + s], g[1 * 3 + s], g[2 * 3 + s], col);
+            Wino<MT>::g(g[(0 * 3 + s) * ts], g[(1 * 3 + s) * ts], g[(2 * 3 + s) * ts], col);
 #pragma unroll
             for (int r = 0; r < A; ++r) t[r][s] = col[r];
         }
@@ -108,12 +110,13 @@ __global__ __launch_bounds__(256) void winograd_filter_kernel(const float* __res
     }
 }
 
-int launch_winograd_filter(const float* w_oihw, float* U, int O, int I, int mt, hipStream_t s) {
+int launch_winograd_filter(const float* w_oihw, float* U, int O, int I, int mt, hipStream_t s, int chunk_major) {
     FS_REQUIRE(mt == 4 || mt == 6, "winograd: tile size must be 4 or 6");
+    FS_REQUIRE(!chunk_major || I % 32 == 0, "winograd_filter: a chunk-major bank needs Cin %% 32 == 0");
     const int64_t total = (int64_t)O * I;
     const dim3 grid((unsigned)std::min<int64_t>(cdiv64(total, 256), 65535));
-    if (mt == 4) hipLaunchKernelGGL(winograd_filter_kernel<4>, grid, dim3(256), 0, s, w_oihw, U, O, I);
-    else hipLaunchKernelGGL(winograd_filter_kernel<6>, grid, dim3(256), 0, s, w_oihw, U, O, I);
+    if (mt == 4) hipLaunchKernelGGL(winograd_filter_kernel<4>, grid, dim3(256), 0, s, w_oihw, U, O, I, chunk_major);
+    else hipLaunchKernelGGL(winograd_filter_kernel<6>, grid, dim3(256), 0, s, w_oihw, U, O, I, chunk_major);
     FS_HIP(hipGetLastError());
     return 0;
 }

@@ -50,17 +50,21 @@ class FlowModel(nn.Module):
 
     # ------------------------------------------------------------------------------------ helpers
     def _encode(self, *frames):
-        """Encoder over the key frames as ONE batch -> [sum(B_i), C, fh, fw] (slice it, do not re-cat)."""
+        """Encoder over the key frames as ONE batch -> [sum(B_i), C, fh, fw] (slice it, do not re-cat).  The HIP mirrors read the
+        separate frame tensors in place (`encode_frames`); any other module gets the concatenation."""
+        many = getattr(self.model, "encode_frames", None)
+        if many is not None:
+            return many(*frames)
         x = frames[0] if len(frames) == 1 else torch.cat(frames, 0)
         return self.model.encoder(x)
 
     def _segment(self, *frames):
         """decoder(encoder(frames)) as ONE batch -> low-resolution logits [sum(B_i), K, fh, fw].  Networks that offer a
         fused `segment` (the HIP mirrors) are called once; any other module goes through .encoder / .decoder."""
-        x = frames[0] if len(frames) == 1 else torch.cat(frames, 0)
         seg = getattr(self.model, "segment", None)
         if seg is not None:
-            return seg(x)
+            return seg(*frames)  # separate tensors are read in place (fs_segment_forward2): no torch.cat on the window path
+        x = frames[0] if len(frames) == 1 else torch.cat(frames, 0)
         return self.model.decoder(self.model.encoder(x))
 
     @staticmethod
@@ -68,6 +72,12 @@ class FlowModel(nn.Module):
         if t.shape[2] != h or t.shape[3] != w:
             t = ops.resize_bilinear(t, (h, w), align_corners=True)
         return t
+
+    def _fit_out(self, out, h, w):
+        """Decoder output -> frame size.  The reference resizes (flow/model.py:68,179); a network that pads its input to a
+        patch multiple (the Segmenter mirror) offers `fit_output` and gets its padding cropped instead."""
+        fit = getattr(self.model, "fit_output", None)
+        return fit(out, h, w) if fit is not None else self._fit(out, h, w)
 
     def warp(self, frame, motion_vectors):
         """grid_sample(bilinear, border, align_corners=False); identity when no_warp (reference :244-249)."""
@@ -94,7 +104,7 @@ class FlowModel(nn.Module):
         feats = self._encode(frame_prev, frame_next)
         mixed = ops.blend(self.warp_batch(feats[:nb], mvs_left, left_index, n_list), 1.0,
                           self.warp_batch(feats[nb:], mvs_right, right_index, n_list), 1.0)
-        return {"pred": self._fit(self.model.decoder(mixed), h, w)}
+        return {"pred": self._fit_out(self.model.decoder(mixed), h, w)}
 
     def forward_segmentation(self, frame_prev, frame_next, mvs_left, mvs_right, left_index, right_index, n_list):
         """Segment the two key frames, warp + weight the LOGITS and add them (reference :73-88)."""
@@ -197,5 +207,5 @@ class FlowModel(nn.Module):
                     stack[i:i + 1].copy_(m)
             else:
                 stack = torch.cat(maps, 0)
-            out = self._fit(self.model.decoder(stack), h, w)
+            out = self._fit_out(self.model.decoder(stack), h, w)
         return {"pred": out}

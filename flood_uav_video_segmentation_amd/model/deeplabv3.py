@@ -17,10 +17,10 @@ class FlowDeepLabv3(HipSegNet):
             # the reference fetches pytorch/vision:v0.10.0 through torch.hub here (model/deeplabv3.py:15)
             raise RuntimeError("FlowDeepLabv3(HIP): pretrained=True is not supported, load a state_dict instead")
 
-    def segment(self, x):
+    def segment(self, *frames):
         """decoder(encoder(x)) in one library call (encoder + decoder over a library-owned feature map); FlowModel's segmentation-mode paths
         (flow/model.py:39-40, 189-191, 202-204) use it when the wrapped network offers it."""
-        return self._hip_net.segment(x)
+        return self._hip_net.segment(*frames)
 
     @staticmethod
     def canonical_name(key):

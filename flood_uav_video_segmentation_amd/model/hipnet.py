@@ -9,49 +9,80 @@ import torch
 from torch import nn
 
 from .. import _lib, ops
-from .._lib import check, ptr, stream_ptr
+from .._lib import check, one_device, ptr, stream_ptr
+
+
+def hip_options(hparams):
+    """Explicit A/B options of the library (include/floodseg.h: fs_config.flags / .winograd_tile), taken from optional
+    attributes of the reference-style `hparams` object: `hip_no_winograd`, `hip_no_fused_head`, `hip_winograd_tile`."""
+    return dict(no_winograd=bool(getattr(hparams, "hip_no_winograd", False)),
+                no_fused_head=bool(getattr(hparams, "hip_no_fused_head", False)),
+                winograd_tile=int(getattr(hparams, "hip_winograd_tile", 0)))
 
 
 class HipNet:
-    def __init__(self, arch, layers, classes, patch=0, d_model=0, n_layers=0, dec_layers=0, image_size=0):
+    def __init__(self, arch, layers, classes, patch=0, d_model=0, n_layers=0, dec_layers=0, image_size=0, no_winograd=False,
+                 no_fused_head=False, winograd_tile=0):
         self.arch, self.layers, self.classes = arch, int(layers), int(classes)
         self.vit = (int(patch), int(d_model), int(n_layers), int(dec_layers), int(image_size))
+        self.flags = (_lib.OPT_NO_WINOGRAD if no_winograd else 0) | (_lib.OPT_NO_FUSED_HEAD if no_fused_head else 0)
+        self.winograd_tile = int(winograd_tile)
         self._h = None
         self.ready = False
         self._lib = None
+        self.device = None  # torch.device the handle's weights and workspace live on (set by load())
 
     # -- lifecycle ---------------------------------------------------------------------------
     def _create(self):
         lib = self._lib = _lib.load()
-        cfg = _lib.FsConfig(self.arch, self.layers, self.classes, *self.vit)
+        cfg = _lib.FsConfig(self.arch, self.layers, self.classes, *self.vit, self.flags, self.winograd_tile)
         h = ctypes.c_void_p()
         check(lib.fs_create(ctypes.byref(cfg), ctypes.byref(h)))
         self._h = h
 
-    def load(self, canonical_state):
-        """canonical_state: {canonical name -> tensor (any device)}; replaces any previous weights."""
+    def load(self, canonical_state, device=None):
+        """canonical_state: {canonical name -> tensor (any device)}; replaces any previous weights.  The handle is created
+        on `device`: the device of the first GPU tensor in the state dict, else the current device -- and stays there."""
         if not torch.cuda.is_available():
             raise RuntimeError("floodseg: a HIP device is required (there is no CPU fallback for this path)")
         self.close()
-        self._create()
-        lib = self._lib
-        keep = []  # the copies are asynchronous: every source tensor must outlive the synchronize below
-        for name, t in canonical_state.items():
-            t = t.detach()
-            if t.dtype != torch.float32:
-                t = t.float()
-            t = t.contiguous()
-            keep.append(t)
-            shape = (ctypes.c_int64 * max(t.dim(), 1))(*t.shape)
-            check(lib.fs_load_weight(self._h, name.encode(), ptr(t), shape, t.dim(), int(t.is_cuda), stream_ptr()))
-        torch.cuda.current_stream().synchronize()
-        del keep
-        check(lib.fs_finalize(self._h, stream_ptr()))
+        if device is None:
+            on_gpu = {t.device for t in canonical_state.values() if t.is_cuda}
+            if len(on_gpu) > 1:
+                raise RuntimeError(f"floodseg: state_dict tensors live on several devices ({sorted(map(str, on_gpu))})")
+            device = on_gpu.pop() if on_gpu else torch.device("cuda", torch.cuda.current_device())
+        device = torch.device(device)
+        if device.type != "cuda":
+            raise RuntimeError(f"floodseg: the network can only live on a HIP device, not {device}")
+        if device.index is None:
+            device = torch.device("cuda", torch.cuda.current_device())
+        with torch.cuda.device(device):
+            self._create()
+            lib = self._lib
+            keep = []  # the copies are asynchronous: every source tensor must outlive the synchronize below
+            for name, t in canonical_state.items():
+                t = t.detach()
+                if t.is_cuda and t.device != device:
+                    raise RuntimeError(f"floodseg: weight '{name}' lives on {t.device}, the network on {device}")
+                if t.dtype != torch.float32:
+                    t = t.float()
+                t = t.contiguous()
+                keep.append(t)
+                shape = (ctypes.c_int64 * max(t.dim(), 1))(*t.shape)
+                check(lib.fs_load_weight(self._h, name.encode(), ptr(t), shape, t.dim(), int(t.is_cuda), stream_ptr()))
+            torch.cuda.current_stream().synchronize()
+            del keep
+            check(lib.fs_finalize(self._h, stream_ptr()))
+        self.device = device
         self.ready = True
 
     def close(self):
         if self._h is not None and self._lib is not None:
-            self._lib.fs_destroy(self._h)
+            if self.device is not None:
+                with torch.cuda.device(self.device):
+                    self._lib.fs_destroy(self._h)
+            else:
+                self._lib.fs_destroy(self._h)
         self._h = None
         self.ready = False
 
@@ -72,18 +103,35 @@ class HipNet:
         check(self._lib.fs_feature_shape(self._h, h, w, ctypes.byref(c), ctypes.byref(fh), ctypes.byref(fw)))
         return c.value, fh.value, fw.value
 
-    def encode(self, x):
-        """[B,3,H,W] NCHW -> [B,C,fh,fw] logical NCHW stored channels_last (model.encoder(x))."""
+    def _frames(self, frames, what):
+        """Validate a batch given as one or two [B_i,3,H,W] tensors (a longer list is concatenated: rare, not the window path)."""
+        if len(frames) > 2:
+            frames = (torch.cat([f.float() for f in frames], 0),)
+        for x in frames:
+            if x.dim() != 4 or x.shape[1] != 3:
+                raise RuntimeError(f"floodseg {what}: expected [B,3,H,W], got {tuple(x.shape)}")
+            if not x.is_cuda:
+                raise RuntimeError(f"floodseg {what}: input must be on the GPU")
+            if x.shape[2:] != frames[0].shape[2:]:
+                raise RuntimeError(f"floodseg {what}: frames of different sizes in one batch")
+        return frames
+
+    def encode(self, *frames):
+        """[B,3,H,W] NCHW -> [B,C,fh,fw] logical NCHW stored channels_last (model.encoder(x)).  Two tensors (the two key
+        frames of a window) go through as ONE batch, read in place (fs_encoder_forward2): no torch.cat."""
         self._need_ready()
-        if x.dim() != 4 or x.shape[1] != 3:
-            raise RuntimeError(f"floodseg encoder: expected [B,3,H,W], got {tuple(x.shape)}")
-        if not x.is_cuda:
-            raise RuntimeError("floodseg encoder: input must be on the GPU")
-        x = x.float().contiguous()
-        b, _, h, w = x.shape
-        c, fh, fw = self.feature_shape(h, w)
-        out = ops.empty_nhwc(b, c, fh, fw, x.device)
-        check(self._lib.fs_encoder_forward(self._h, ptr(x), b, h, w, ptr(out), stream_ptr()))
+        frames = self._frames(frames, "encoder")
+        with torch.cuda.device(one_device(*frames, handle_device=self.device, what="floodseg encoder")):
+            xs = [x.float().contiguous() for x in frames]
+            h, w = xs[0].shape[2], xs[0].shape[3]
+            b = sum(x.shape[0] for x in xs)
+            c, fh, fw = self.feature_shape(h, w)
+            out = ops.empty_nhwc(b, c, fh, fw, xs[0].device)
+            if len(xs) == 1:
+                check(self._lib.fs_encoder_forward(self._h, ptr(xs[0]), b, h, w, ptr(out), stream_ptr()))
+            else:
+                check(self._lib.fs_encoder_forward2(self._h, ptr(xs[0]), xs[0].shape[0], ptr(xs[1]), xs[1].shape[0], h, w, ptr(out),
+                                                    stream_ptr()))
         return out
 
     def decode(self, f):
@@ -92,25 +140,29 @@ class HipNet:
         c_expected = {_lib.ARCH_PSPNET: 4096, _lib.ARCH_DEEPLABV3: 2048}.get(self.arch, self.vit[1])
         if f.dim() != 4 or f.shape[1] != c_expected:
             raise RuntimeError(f"floodseg decoder: expected [B,{c_expected},h,w], got {tuple(f.shape)}")
-        f = ops.as_nhwc(f)
-        b, _, fh, fw = f.shape
-        out = torch.empty((b, self.classes, fh, fw), dtype=torch.float32, device=f.device)
-        check(self._lib.fs_decoder_forward(self._h, ptr(f), b, fh, fw, ptr(out), stream_ptr()))
+        with torch.cuda.device(one_device(f, handle_device=self.device, what="floodseg decoder")):
+            f = ops.as_nhwc(f)
+            b, _, fh, fw = f.shape
+            out = torch.empty((b, self.classes, fh, fw), dtype=torch.float32, device=f.device)
+            check(self._lib.fs_decoder_forward(self._h, ptr(f), b, fh, fw, ptr(out), stream_ptr()))
         return out
 
-    def segment(self, x):
+    def segment(self, *frames):
         """[B,3,H,W] -> [B,K,fh,fw] NCHW logits: model.decoder(model.encoder(x)) in one library call (the PSPNet head then
-        never builds the 4096-channel concat, include/floodseg.h)."""
+        never builds the 4096-channel concat, include/floodseg.h).  Two tensors = one batch read in place, as in encode()."""
         self._need_ready()
-        if x.dim() != 4 or x.shape[1] != 3:
-            raise RuntimeError(f"floodseg segment: expected [B,3,H,W], got {tuple(x.shape)}")
-        if not x.is_cuda:
-            raise RuntimeError("floodseg segment: input must be on the GPU")
-        x = x.float().contiguous()
-        b, _, h, w = x.shape
-        _, fh, fw = self.feature_shape(h, w)
-        out = torch.empty((b, self.classes, fh, fw), dtype=torch.float32, device=x.device)
-        check(self._lib.fs_segment_forward(self._h, ptr(x), b, h, w, ptr(out), stream_ptr()))
+        frames = self._frames(frames, "segment")
+        with torch.cuda.device(one_device(*frames, handle_device=self.device, what="floodseg segment")):
+            xs = [x.float().contiguous() for x in frames]
+            h, w = xs[0].shape[2], xs[0].shape[3]
+            b = sum(x.shape[0] for x in xs)
+            _, fh, fw = self.feature_shape(h, w)
+            out = torch.empty((b, self.classes, fh, fw), dtype=torch.float32, device=xs[0].device)
+            if len(xs) == 1:
+                check(self._lib.fs_segment_forward(self._h, ptr(xs[0]), b, h, w, ptr(out), stream_ptr()))
+            else:
+                check(self._lib.fs_segment_forward2(self._h, ptr(xs[0]), xs[0].shape[0], ptr(xs[1]), xs[1].shape[0], h, w, ptr(out),
+                                                    stream_ptr()))
         return out
 
     # -- profiling ---------------------------------------------------------------------------
@@ -121,7 +173,8 @@ class HipNet:
     def profile_dump(self):
         """[(name, kernel, flops, bytes, ms)] for every launch recorded since profile(True)."""
         buf = ctypes.create_string_buffer(1 << 20)
-        check(self._lib.fs_profile_dump(self._h, buf, len(buf)))
+        with torch.cuda.device(self.device):
+            check(self._lib.fs_profile_dump(self._h, buf, len(buf)))
         rows = []
         for line in buf.value.decode().splitlines():
             name, kernel, flops, nbytes, ms = line.rsplit(" ", 4)
@@ -156,10 +209,13 @@ class HipSegNet(nn.Module):
 
     def __init__(self, hparams):
         super().__init__()
-        self._hip_net = HipNet(self.ARCH, hparams.layers, hparams.classes)
+        self._hip_net = HipNet(self.ARCH, hparams.layers, hparams.classes, **hip_options(hparams))
         self.encoder = HipStage(self._hip_net.encode, "encoder")
         self.decoder = HipStage(self._hip_net.decode, "decoder")
-        self._host_state = {}
+
+    def encode_frames(self, *frames):
+        """model.encoder over a batch given as separate tensors (FlowModel: frame_prev, frame_next) -- read in place."""
+        return self._hip_net.encode(*frames)
 
     @staticmethod
     def canonical_name(key):

@@ -33,10 +33,10 @@ class FlowPSPNet(HipSegNet):
         (re.compile(r"^encoder\.1\.(.*)$"), r"ppm.\1"),
     )
 
-    def segment(self, x):
+    def segment(self, *frames):
         """decoder(encoder(x)) in one library call (the fused head never builds the 4096-channel concat); FlowModel's segmentation-mode paths
         (flow/model.py:39-40, 189-191, 202-204) use it when the wrapped network offers it."""
-        return self._hip_net.segment(x)
+        return self._hip_net.segment(*frames)
 
     @staticmethod
     def canonical_name(key):

@@ -29,9 +29,8 @@ class VITSegmentModel(HipSegNet):
         self.dropout = dropout  # identity in eval
         self.d_model = d_model
         self._hip_net = HipNet(self.ARCH, 0, num_classes, patch_size, d_model, n_layers, dec_layers, image_size)
-        self.encoder = HipStage(self._encode_map, "encoder")
+        self.encoder = HipStage(self._hip_net.encode, "encoder")  # [B,3,H,W] -> [B, D, gh, gw], stored as [B, gh*gw, D]
         self.decoder = HipStage(self._decode_map, "decoder")
-        self._frame_hw = None
 
     @staticmethod
     def canonical_name(key):
@@ -43,24 +42,21 @@ class VITSegmentModel(HipSegNet):
             return key
         return None
 
-    # -- FlowModel-facing callables (feature map view of the tokens)
-    def _encode_map(self, x):
-        self._frame_hw = (x.shape[2], x.shape[3])
-        return self._hip_net.encode(x)  # [B, D, gh, gw], stored as [B, gh*gw, D]
-
+    # -- FlowModel-facing callables (feature map view of the tokens).  Stateless: the decoder returns the masks at the PADDED
+    # frame size (gh*P x gw*P, segm/model/segmenter.py:45) and `fit_output` removes the padding for the frame size the
+    # caller knows (segmenter.py:46 unpadding) -- no per-object record of "the last frame seen", so two sizes / two streams
+    # can interleave.
     def _decode_map(self, f):
         masks = self._hip_net.decode(f)  # [B, K, gh, gw]
         gh, gw = masks.shape[2], masks.shape[3]
-        full = ops.resize_bilinear(masks, (gh * self.patch_size, gw * self.patch_size), align_corners=False)
-        if self._frame_hw is not None:
-            full = full[:, :, : self._frame_hw[0], : self._frame_hw[1]]
-        return full
+        return ops.resize_bilinear(masks, (gh * self.patch_size, gw * self.patch_size), align_corners=False)
+
+    def fit_output(self, out, h, w):
+        """Decoder output -> frame size: crop the right/bottom zero padding (segm/model/utils.py:79-89)."""
+        return out[:, :, :h, :w]
 
     def forward(self, x):
         if self.training:
             raise NotImplementedError("VITSegmentModel(HIP) is an inference path; call .eval()")
         h, w = x.shape[2], x.shape[3]
-        masks = self._hip_net.decode(self._hip_net.encode(x))
-        gh, gw = masks.shape[2], masks.shape[3]
-        full = ops.resize_bilinear(masks, (gh * self.patch_size, gw * self.patch_size), align_corners=False)
-        return {"pred": full[:, :, :h, :w]}
+        return {"pred": self.fit_output(self._decode_map(self._hip_net.encode(x)), h, w)}

@@ -8,7 +8,7 @@ import ctypes
 import torch
 
 from . import _lib
-from ._lib import check, ptr, stream_ptr
+from ._lib import check, one_device, ptr, stream_ptr
 
 
 def _f32c(t, name="tensor"):
@@ -47,18 +47,20 @@ def grid_sample(inp, grid, align_corners=False):
     gb, hg, wg, two = grid.shape
     if two != 2 or gb != b:
         raise RuntimeError(f"floodseg.grid_sample: grid shape {tuple(grid.shape)} does not match input batch {b}")
-    grid = _f32c(grid, "grid")
-    if b == 0:  # empty batch: nothing to launch (torch returns an empty tensor too)
-        return torch.empty((0, c, hg, wg), dtype=torch.float32, device=inp.device)
-    if inp.dim() == 4 and c % 4 == 0 and c >= 64 and is_channels_last_dense(inp):
-        src = inp if inp.dtype == torch.float32 else inp.float()
-        out = empty_nhwc(b, c, hg, wg, inp.device)
-        check(lib.fs_grid_sample_nhwc(ptr(src), c, b, c, hi, wi, ptr(grid), hg, wg, ptr(out), c, int(align_corners), stream_ptr()))
+    dev = one_device(inp, grid, what="floodseg.grid_sample")
+    with torch.cuda.device(dev):
+        grid = _f32c(grid, "grid")
+        if b == 0:  # empty batch: nothing to launch (torch returns an empty tensor too)
+            return torch.empty((0, c, hg, wg), dtype=torch.float32, device=dev)
+        if inp.dim() == 4 and c % 4 == 0 and c >= 64 and is_channels_last_dense(inp):
+            src = inp if inp.dtype == torch.float32 else inp.float()
+            out = empty_nhwc(b, c, hg, wg, dev)
+            check(lib.fs_grid_sample_nhwc(ptr(src), c, b, c, hi, wi, ptr(grid), hg, wg, ptr(out), c, int(align_corners), stream_ptr()))
+            return out
+        src = _f32c(inp, "input")
+        out = torch.empty((b, c, hg, wg), dtype=torch.float32, device=dev)
+        check(lib.fs_grid_sample_nchw(ptr(src), b, c, hi, wi, ptr(grid), hg, wg, ptr(out), int(align_corners), stream_ptr()))
         return out
-    src = _f32c(inp, "input")
-    out = torch.empty((b, c, hg, wg), dtype=torch.float32, device=inp.device)
-    check(lib.fs_grid_sample_nchw(ptr(src), b, c, hi, wi, ptr(grid), hg, wg, ptr(out), int(align_corners), stream_ptr()))
-    return out
 
 
 def resize_bilinear(inp, size, align_corners=True):
@@ -66,36 +68,45 @@ def resize_bilinear(inp, size, align_corners=True):
     lib = _lib.load()
     b, c, hi, wi = inp.shape
     ho, wo = int(size[0]), int(size[1])
-    if b == 0:
-        _f32c(inp, "input")
-        return torch.empty((0, c, ho, wo), dtype=torch.float32, device=inp.device)
-    if c % 4 == 0 and c >= 64 and is_channels_last_dense(inp):
-        src = inp if inp.dtype == torch.float32 else inp.float()
-        out = empty_nhwc(b, c, ho, wo, inp.device)
-        check(lib.fs_resize_bilinear_nhwc(ptr(src), c, b, c, hi, wi, ptr(out), c, ho, wo, int(align_corners), stream_ptr()))
+    dev = one_device(inp, what="floodseg.resize_bilinear")
+    with torch.cuda.device(dev):
+        if b == 0:
+            return torch.empty((0, c, ho, wo), dtype=torch.float32, device=dev)
+        if c % 4 == 0 and c >= 64 and is_channels_last_dense(inp):
+            src = inp if inp.dtype == torch.float32 else inp.float()
+            out = empty_nhwc(b, c, ho, wo, dev)
+            check(lib.fs_resize_bilinear_nhwc(ptr(src), c, b, c, hi, wi, ptr(out), c, ho, wo, int(align_corners), stream_ptr()))
+            return out
+        src = _f32c(inp, "input")
+        out = torch.empty((b, c, ho, wo), dtype=torch.float32, device=dev)
+        check(lib.fs_resize_bilinear_nchw(ptr(src), b * c, hi, wi, ptr(out), ho, wo, int(align_corners), stream_ptr()))
         return out
-    src = _f32c(inp, "input")
-    out = torch.empty((b, c, ho, wo), dtype=torch.float32, device=inp.device)
-    check(lib.fs_resize_bilinear_nchw(ptr(src), b * c, hi, wi, ptr(out), ho, wo, int(align_corners), stream_ptr()))
-    return out
 
 
 def blend(a, wa, b=None, wb=0.0):
     """wa*a + wb*b with the reference's rounding order (flow/model.py:104,168,234-236)."""
     lib = _lib.load()
-    if b is not None and (a.shape != b.shape or a.stride() != b.stride()):
-        b = b.contiguous(memory_format=torch.channels_last) if is_channels_last_dense(a) else b.contiguous()
-        if a.stride() != b.stride():
+    if b is not None and a.shape != b.shape:
+        raise RuntimeError(f"floodseg.blend: shapes differ ({tuple(a.shape)} vs {tuple(b.shape)})")
+    dev = one_device(a, b, what="floodseg.blend")
+    with torch.cuda.device(dev):
+        # the kernel walks both operands as flat arrays: bring BOTH to one dense layout (channels_last kept when `a` has it,
+        # so the feature-mode maps are not transposed; any other view -- equal strides or not -- becomes plain contiguous)
+        if is_channels_last_dense(a):
+            if b is not None:
+                b = as_nhwc(b)
+        else:
             a = a.contiguous()
-            b = b.contiguous()
-    if not (a.is_contiguous() or is_channels_last_dense(a)):
-        a = a.contiguous()
-    a = a if a.dtype == torch.float32 else a.float()
-    out = torch.empty_like(a)
-    if a.numel() == 0:
+            if b is not None:
+                b = b.contiguous()
+        a = a if a.dtype == torch.float32 else a.float()
+        if b is not None and b.dtype != torch.float32:
+            b = b.float()
+        out = torch.empty_like(a)
+        if a.numel() == 0:
+            return out
+        check(lib.fs_blend(ptr(a), float(wa), ptr(b), float(wb), ptr(out), a.numel(), stream_ptr()))
         return out
-    check(lib.fs_blend(ptr(a), float(wa), ptr(b), float(wb), ptr(out), a.numel(), stream_ptr()))
-    return out
 
 
 def _ptr_array(tensors):
@@ -112,56 +123,60 @@ def seg_tail(lo_prev, lo_next, grids_left, grids_right, n, out_hw, no_warp, want
     Returns (logits [n,K,H,W] or None, mask uint8 [n,H,W] or None).
     """
     lib = _lib.load()
-    lo_prev = _f32c(lo_prev, "lo_prev")
-    _, k, h, w = lo_prev.shape
-    hh, ww = out_hw
-    dev = lo_prev.device
-    frames = n if lo_next is not None else 1
-    logits = torch.empty((frames, k, hh, ww), dtype=torch.float32, device=dev) if want_logits else None
-    mask = torch.empty((frames, hh, ww), dtype=torch.uint8, device=dev) if want_mask else None
-    gl = gr = None
-    hg = wg = 1
-    scratch = None
-    keep = []
-    if lo_next is not None:
-        lo_next = _f32c(lo_next, "lo_next")
-        if not no_warp:
-            if len(grids_left) != n - 1 or len(grids_right) != n - 1:
-                raise RuntimeError("floodseg.seg_tail: need n-1 grids per direction")
-            keep = [_f32c(g, "grid") for g in list(grids_left) + list(grids_right)]
-            hg, wg = keep[0].shape[1], keep[0].shape[2]
-            for g in keep:
-                if tuple(g.shape) != (1, hg, wg, 2):
-                    raise RuntimeError("floodseg.seg_tail: all grids must be [1,Hg,Wg,2] of one size")
-            gl = _ptr_array(keep[: n - 1])
-            gr = _ptr_array(keep[n - 1:])
-            scratch = torch.empty(2 * (n - 1) * k * hg * wg, dtype=torch.float32, device=dev)
-    check(lib.fs_seg_tail(ptr(lo_prev), ptr(lo_next), gl, gr, k, h, w, hg, wg, hh, ww, int(n), int(bool(no_warp)),
-                          ptr(logits), ptr(mask), ptr(scratch), stream_ptr()))
+    grids = [] if (lo_next is None or no_warp) else list(grids_left) + list(grids_right)
+    dev = one_device(lo_prev, lo_next, *grids, what="floodseg.seg_tail")
+    with torch.cuda.device(dev):
+        lo_prev = _f32c(lo_prev, "lo_prev")
+        _, k, h, w = lo_prev.shape
+        hh, ww = out_hw
+        frames = n if lo_next is not None else 1
+        logits = torch.empty((frames, k, hh, ww), dtype=torch.float32, device=dev) if want_logits else None
+        mask = torch.empty((frames, hh, ww), dtype=torch.uint8, device=dev) if want_mask else None
+        gl = gr = None
+        hg = wg = 1
+        scratch = None
+        keep = []
+        if lo_next is not None:
+            lo_next = _f32c(lo_next, "lo_next")
+            if not no_warp:
+                if len(grids_left) != n - 1 or len(grids_right) != n - 1:
+                    raise RuntimeError("floodseg.seg_tail: need n-1 grids per direction")
+                keep = [_f32c(g, "grid") for g in grids]
+                hg, wg = keep[0].shape[1], keep[0].shape[2]
+                for g in keep:
+                    if tuple(g.shape) != (1, hg, wg, 2):
+                        raise RuntimeError("floodseg.seg_tail: all grids must be [1,Hg,Wg,2] of one size")
+                gl = _ptr_array(keep[: n - 1])
+                gr = _ptr_array(keep[n - 1:])
+                scratch = torch.empty(2 * (n - 1) * k * hg * wg, dtype=torch.float32, device=dev)
+        check(lib.fs_seg_tail(ptr(lo_prev), ptr(lo_next), gl, gr, k, h, w, hg, wg, hh, ww, int(n), int(bool(no_warp)),
+                              ptr(logits), ptr(mask), ptr(scratch), stream_ptr()))
     return logits, mask
 
 
 def argmax_u8(logits):
     """logits.max(1)[1] as uint8 (flow/base.py:276-277)."""
     lib = _lib.load()
-    x = _f32c(logits)
-    b, k, h, w = x.shape
-    out = torch.empty((b, h, w), dtype=torch.uint8, device=x.device)
-    if b == 0:
-        return out
-    check(lib.fs_argmax_u8(ptr(x), b, k, h * w, ptr(out), stream_ptr()))
+    with torch.cuda.device(one_device(logits, what="floodseg.argmax_u8")):
+        x = _f32c(logits)
+        b, k, h, w = x.shape
+        out = torch.empty((b, h, w), dtype=torch.uint8, device=x.device)
+        if b == 0:
+            return out
+        check(lib.fs_argmax_u8(ptr(x), b, k, h * w, ptr(out), stream_ptr()))
     return out
 
 
 def resize_argmax_u8(logits, size):
     """F.interpolate(logits, size, bilinear, align_corners=True).max(1)[1] without the big intermediate."""
     lib = _lib.load()
-    x = _f32c(logits)
-    b, k, h, w = x.shape
-    out = torch.empty((b, int(size[0]), int(size[1])), dtype=torch.uint8, device=x.device)
-    if b == 0:
-        return out
-    check(lib.fs_resize_argmax_u8(ptr(x), b, k, h, w, ptr(out), int(size[0]), int(size[1]), stream_ptr()))
+    with torch.cuda.device(one_device(logits, what="floodseg.resize_argmax_u8")):
+        x = _f32c(logits)
+        b, k, h, w = x.shape
+        out = torch.empty((b, int(size[0]), int(size[1])), dtype=torch.uint8, device=x.device)
+        if b == 0:
+            return out
+        check(lib.fs_resize_argmax_u8(ptr(x), b, k, h, w, ptr(out), int(size[0]), int(size[1]), stream_ptr()))
     return out
 
 
@@ -172,11 +187,13 @@ def iou_hist(pred_u8, target_u8, classes, ignore_index=255, hist=None):
     t = target_u8.contiguous()
     if p.dtype != torch.uint8 or t.dtype != torch.uint8 or p.shape != t.shape:
         raise RuntimeError("floodseg.iou_hist: uint8 tensors of equal shape required")
-    if hist is None:
-        hist = torch.zeros((3, classes), dtype=torch.int64, device=p.device)
-    if p.numel() == 0:
-        return hist
-    check(lib.fs_iou_hist(ptr(p), ptr(t), p.numel(), classes, ignore_index, ptr(hist), stream_ptr()))
+    dev = one_device(p, t, hist, what="floodseg.iou_hist")
+    with torch.cuda.device(dev):
+        if hist is None:
+            hist = torch.zeros((3, classes), dtype=torch.int64, device=dev)
+        if p.numel() == 0:
+            return hist
+        check(lib.fs_iou_hist(ptr(p), ptr(t), p.numel(), classes, ignore_index, ptr(hist), stream_ptr()))
     return hist
 
 
@@ -184,16 +201,17 @@ def iou_hist(pred_u8, target_u8, classes, ignore_index=255, hist=None):
 def conv2d_nhwc(x, weight, scale=None, shift=None, residual=None, stride=1, pad=0, dil=1, relu=False, tile=0, out=None):
     """Conv2d on the fp32 matrix cores; x logical NCHW (stored NHWC), weight OIHW. Test/bring-up helper."""
     lib = _lib.load()
-    x = as_nhwc(x)
-    b, cin, h, w = x.shape
-    o, i, kh, kw = weight.shape
-    wp = torch.empty((o, kh, kw, i), dtype=torch.float32, device=x.device)
-    check(lib.fs_pack_conv_weight(ptr(_f32c(weight)), ptr(wp), o, i, kh, kw, stream_ptr()))
-    ho = (h + 2 * pad - dil * (kh - 1) - 1) // stride + 1
-    wo = (w + 2 * pad - dil * (kw - 1) - 1) // stride + 1
-    if out is None:
-        out = empty_nhwc(b, o, ho, wo, x.device)
-    res = as_nhwc(residual) if residual is not None else None
-    check(lib.fs_conv2d_nhwc(ptr(x), cin, ptr(wp), ptr(scale), ptr(shift), ptr(res), o, ptr(out), o, b, h, w, cin, o, kh, kw,
-                             stride, pad, dil, int(relu), tile, stream_ptr()))
+    with torch.cuda.device(one_device(x, weight, scale, shift, residual, out, what="floodseg.conv2d_nhwc")):
+        x = as_nhwc(x)
+        b, cin, h, w = x.shape
+        o, i, kh, kw = weight.shape
+        wp = torch.empty((o, kh, kw, i), dtype=torch.float32, device=x.device)
+        check(lib.fs_pack_conv_weight(ptr(_f32c(weight)), ptr(wp), o, i, kh, kw, stream_ptr()))
+        ho = (h + 2 * pad - dil * (kh - 1) - 1) // stride + 1
+        wo = (w + 2 * pad - dil * (kw - 1) - 1) // stride + 1
+        if out is None:
+            out = empty_nhwc(b, o, ho, wo, x.device)
+        res = as_nhwc(residual) if residual is not None else None
+        check(lib.fs_conv2d_nhwc(ptr(x), cin, ptr(wp), ptr(scale), ptr(shift), ptr(res), o, ptr(out), o, b, h, w, cin, o, kh, kw,
+                                 stride, pad, dil, int(relu), tile, stream_ptr()))
     return out

@@ -48,7 +48,16 @@ typedef struct fs_config {
     int n_layers;    /* encoder blocks (12)                                                    */
     int dec_layers;  /* mask-transformer blocks (2)                                            */
     int image_size;  /* construction size: pos_embed holds (image_size/P)^2 + 1 rows           */
+    /* Explicit A/B options of the convolutional networks (0 = the shipped default).  They select between arithmetically
+     * different but parity-tested evaluation routes; nothing is read from the process environment.                     */
+    int flags;          /* FS_OPT_* bits                                                                                */
+    int winograd_tile;  /* 0 = per-map choice of F(4x4,3x3) / F(6x6,3x3); 4 or 6 forces one tile size                   */
 } fs_config;
+
+enum {
+    FS_OPT_NO_WINOGRAD = 1,   /* every 3x3 conv on the direct implicit-GEMM kernel                                      */
+    FS_OPT_NO_FUSED_HEAD = 2  /* fs_segment_forward = fs_decoder_forward(fs_encoder_forward(x)) over the 4096-ch concat */
+};
 
 int fs_version(void);
 const char* fs_last_error(void);
@@ -79,6 +88,14 @@ int fs_decoder_forward(fs_handle h, const float* feat_nhwc, int B, int fh, int f
  * PSPNet head skips the 4096-channel concat: model/pspnet.py:28-34 (PPM upsample + cat) and :70-73 (3x3 conv) are linear,
  * so the pyramid's share of the conv is evaluated on the pooled b x b maps and added before BatchNorm + ReLU. */
 int fs_segment_forward(fs_handle h, const float* in_nchw, int B, int H, int W, float* out_nchw, fs_stream stream);
+/* The same two calls on a batch held in TWO tensors: images 0..Ba-1 = in_a [Ba,3,H,W], images Ba..Ba+Bb-1 = in_b [Bb,3,H,W].
+ * FlowModel hands its two key frames over as separate tensors (frame_prev, frame_next: flow/model.py:189-191 and :202-204 run
+ * the network once on each); both go through the network as one batch here, read in place -- no concatenation copy.
+ * Results are identical to the one-tensor calls on cat(in_a, in_b).  Bb may be 0 (in_b ignored). */
+int fs_encoder_forward2(fs_handle h, const float* in_a, int Ba, const float* in_b, int Bb, int H, int W, float* out_nhwc,
+                        fs_stream stream);
+int fs_segment_forward2(fs_handle h, const float* in_a, int Ba, const float* in_b, int Bb, int H, int W, float* out_nchw,
+                        fs_stream stream);
 
 /* ---- per-op profiling (HIP events on `stream` around every launch of the next forward calls) -- */
 int fs_profile_enable(fs_handle h, int on);
@@ -130,8 +147,9 @@ int fs_canvas_finish(double* canvas, const double* count, int n, int K, int64_t 
 int fs_pack_conv_weight(const float* oihw, float* ohwi, int O, int I, int KH, int KW, fs_stream stream);
 /* Conv2d (+ per-channel scale/shift, + residual, + ReLU (relu = 1) / GELU (2)) on the fp32 matrix cores; Cin % 32 == 0.
  * in/out/res are NHWC with pixel strides ld_*; wgt_ohwi from fs_pack_conv_weight.  tile: 0 = cost-model choice, 1..5 force the
- * workgroup tile 128x128, 128x64, 64x64, 64x128, 256x128 (tests / sweeps); bit 10 = filters are packed chunk-major
- * ([O][I/32][KH][KW][32]); bits 11+ = timing experiments that break the result (0 in any real call). */
+ * workgroup tile 128x128, 128x64, 64x64, 64x128, 256x128 (tests / sweeps); | FS_CONV_CHUNK_MAJOR = the filters are packed
+ * chunk-major ([O][I/32][KH][KW][32]).  Any other bit is refused with a non-zero return. */
+#define FS_CONV_CHUNK_MAJOR 0x400
 int fs_conv2d_nhwc(const float* in, int ld_in, const float* wgt_ohwi, const float* scale, const float* shift,
                    const float* res, int ld_res, float* out, int ld_out, int B, int H, int W, int Cin, int Cout, int KH,
                    int KW, int stride, int pad, int dil, int relu, int tile, fs_stream stream);

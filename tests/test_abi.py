@@ -35,7 +35,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_version_and_error_string_are_callable_without_a_gpu():
     lib = _lib.load()
-    assert lib.fs_version() >= 100
+    assert lib.fs_version() >= 200
     assert isinstance(lib.fs_last_error(), bytes)
 
 
@@ -48,6 +48,31 @@ def test_bad_config_is_rejected_with_a_message():
     cfg = _lib.FsConfig(_lib.ARCH_PSPNET, 34, 5)
     assert lib.fs_create(ctypes.byref(cfg), ctypes.byref(h)) != 0
     assert b"layers" in lib.fs_last_error()
+
+
+def test_unknown_option_bits_and_tile_sizes_are_rejected():
+    """The A/B routes are explicit fs_config options (nothing is read from the environment); anything undefined is refused."""
+    lib = _lib.load()
+    h = ctypes.c_void_p()
+    cfg = _lib.FsConfig(_lib.ARCH_PSPNET, 50, 5, 0, 0, 0, 0, 0, 4, 0)   # flags = 4: not an FS_OPT_* bit
+    assert lib.fs_create(ctypes.byref(cfg), ctypes.byref(h)) != 0 and b"option" in lib.fs_last_error()
+    cfg = _lib.FsConfig(_lib.ARCH_PSPNET, 50, 5, 0, 0, 0, 0, 0, 0, 5)   # winograd_tile = 5
+    assert lib.fs_create(ctypes.byref(cfg), ctypes.byref(h)) != 0 and b"winograd_tile" in lib.fs_last_error()
+    src = open(os.path.join(ROOT, "flood_uav_video_segmentation_amd", "csrc", "net.hip")).read()
+    assert "getenv" not in src  # the library's behaviour must not depend on the ambient environment
+
+
+def test_conv2d_refuses_every_bit_that_is_not_a_tile_id_or_the_chunk_major_flag():
+    """fs_conv2d_nhwc's `tile` once carried bring-up experiment bits that broke the result; the release ABI rejects them
+    before anything is launched (dummy non-null pointers: the call must fail in argument validation)."""
+    lib = _lib.load()
+    fake = ctypes.c_void_p(0x1000)
+    args = lambda tile: (fake, 32, fake, None, None, None, 0, fake, 32, 1, 8, 8, 32, 32, 1, 1, 1, 0, 1, 0, tile, None)  # noqa: E731
+    for bad in (6, 1 << 11, 1 << 12, (1 << 15) | 1, _lib.CONV_CHUNK_MAJOR | 7, 1 << 8, -1):
+        assert lib.fs_conv2d_nhwc(*args(bad)) != 0, bad
+        assert b"tile" in lib.fs_last_error()
+    sym = subprocess.run(["nm", "-DC", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    assert "fs_trace_buf" not in sym  # the FS_TRACE instrumentation never ships
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):

@@ -86,6 +86,37 @@ def test_no_silent_cpu_fallback():
         ops.grid_sample(torch.zeros(1, 5, 4, 4), torch.zeros(1, 2, 2, 2))
 
 
+def test_tensors_on_another_device_than_the_network_are_refused():
+    """the library launches on the current device, so a tensor on cuda:1 with a network on cuda:0 must raise
+    before any launch.  Device logic is plain Python: checked here with stand-in tensors (no GPU in this container)."""
+    from flood_uav_video_segmentation_amd._lib import one_device
+
+    class T:
+        def __init__(self, dev, cuda=True):
+            self.device, self.is_cuda = torch.device(dev), cuda
+
+    assert one_device(T("cuda:1"), None, T("cuda:1")) == torch.device("cuda:1")
+    with pytest.raises(RuntimeError, match="different devices"):
+        one_device(T("cuda:0"), T("cuda:1"))
+    with pytest.raises(RuntimeError, match="weights live on cuda:0"):
+        one_device(T("cuda:1"), handle_device=torch.device("cuda:0"))
+    with pytest.raises(RuntimeError, match="must live on the GPU"):
+        one_device(T("cpu", cuda=False))
+
+
+def test_hip_options_come_from_hparams_not_from_the_environment(monkeypatch):
+    from flood_uav_video_segmentation_amd import _lib
+    from flood_uav_video_segmentation_amd.model.hipnet import hip_options
+
+    class O(HP):
+        hip_no_winograd, hip_winograd_tile = True, 6
+    monkeypatch.setenv("FS_NO_FUSED_HEAD", "1")  # a round-1 knob: must be ignored now
+    net = FlowPSPNet(O())
+    assert hip_options(O()) == dict(no_winograd=True, no_fused_head=False, winograd_tile=6)
+    assert net._hip_net.flags == _lib.OPT_NO_WINOGRAD and net._hip_net.winograd_tile == 6
+    assert FlowPSPNet(HP())._hip_net.flags == 0
+
+
 def test_model_representation_eval_is_pass_through():
     inner = torch.nn.Identity()
     m = ModelRepresentation(inner, rep=None, rep_forward=None).eval()

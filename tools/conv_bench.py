@@ -61,7 +61,7 @@ def main():
         ms = e0.elapsed_time(e1) / iters
         fl = 2.0 * b * ho * wo * cout * k * k * cin
         alg_bytes = 4.0 * (b * h * w * cin + cout * k * k * cin + b * ho * wo * cout)
-        print(f"{nm:6s} tile{tile & 255} var{(tile >> 8) & 3} korder{(tile >> 10) & 1} dbg{(tile >> 11) & 63} {ms:8.4f} ms  {fl / ms / 1e9:7.1f} TFLOP/s  alg_bytes={alg_bytes / 1e6:.1f} MB", flush=True)
+        print(f"{nm:6s} tile{tile & 255} korder{(tile >> 10) & 1} {ms:8.4f} ms  {fl / ms / 1e9:7.1f} TFLOP/s  alg_bytes={alg_bytes / 1e6:.1f} MB", flush=True)
 
 
 if __name__ == "__main__":
