@@ -46,6 +46,8 @@ _SIGNATURES = {
     "fs_segment_forward": (c_int, [c_void, c_void, c_int, c_int, c_int, c_void, c_void]),
     "fs_encoder_forward2": (c_int, [c_void, c_void, c_int, c_void, c_int, c_int, c_int, c_void, c_void]),
     "fs_segment_forward2": (c_int, [c_void, c_void, c_int, c_void, c_int, c_int, c_int, c_void, c_void]),
+    "fs_segment_crops": (c_int, [c_void, c_void, c_void, c_int, c_int, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int), c_int, c_int,
+                                 c_void, c_void]),
     "fs_profile_enable": (c_int, [c_void, c_int]),
     "fs_profile_dump": (c_int, [c_void, ctypes.c_char_p, ctypes.c_size_t]),
     "fs_grid_sample_nchw": (c_int, [c_void, c_int, c_int, c_int, c_int, c_void, c_int, c_int, c_void, c_int, c_void]),
@@ -55,6 +57,11 @@ _SIGNATURES = {
     "fs_blend": (c_int, [c_void, c_f32, c_void, c_f32, c_void, c_i64, c_void]),
     "fs_seg_tail": (c_int, [c_void, c_void, ctypes.POINTER(c_void), ctypes.POINTER(c_void), c_int, c_int, c_int, c_int, c_int,
                             c_int, c_int, c_int, c_int, c_void, c_void, c_void, c_void]),
+    "fs_seg_tail_accumulate": (c_int, [c_void, c_void, ctypes.POINTER(c_void), ctypes.POINTER(c_void), c_int, c_int, c_int, c_int, c_int,
+                                       c_int, c_int, c_int, c_int, c_void, c_void, c_int, c_int, c_int, c_int, c_void, c_void]),
+    "fs_canvas_resize_argmax": (c_int, [c_void, c_int, c_int, c_int, c_int, c_void, c_int, c_int, c_void]),
+    "fs_crop_grids": (c_int, [ctypes.POINTER(c_void), c_int, c_int, c_int, c_int, c_int, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int),
+                              c_int, c_int, c_void, c_void]),
     "fs_argmax_u8": (c_int, [c_void, c_int, c_int, c_i64, c_void, c_void]),
     "fs_resize_argmax_u8": (c_int, [c_void, c_int, c_int, c_int, c_int, c_void, c_int, c_int, c_void]),
     "fs_iou_hist": (c_int, [c_void, c_void, c_i64, c_int, c_int, c_void, c_void]),

@@ -3,6 +3,8 @@
 #include "kernels.h"
 #include "net.h"
 
+#include <cmath>
+
 #define FS_API extern "C" __attribute__((visibility("default")))
 
 static inline hipStream_t S(fs_stream s) { return reinterpret_cast<hipStream_t>(s); }
@@ -20,23 +22,41 @@ FS_API int fs_finalize(fs_handle h, fs_stream stream) { return fs::net_finalize(
 FS_API int fs_feature_shape(fs_handle h, int H, int W, int* C, int* fh, int* fw) { return fs::net_feature_shape(h, H, W, C, fh, fw); }
 FS_API size_t fs_workspace_bytes(fs_handle h, int B, int H, int W) { return fs::net_workspace_bytes(h, B, H, W); }
 FS_API int fs_encoder_forward(fs_handle h, const float* in_nchw, int B, int H, int W, float* out_nhwc, fs_stream stream) {
-    return fs::net_encoder(h, in_nchw, nullptr, B, B, H, W, out_nhwc, S(stream));
+    return fs::net_encoder(h, fs::frames_plain(in_nchw, nullptr, B), B, H, W, out_nhwc, S(stream));
 }
 FS_API int fs_encoder_forward2(fs_handle h, const float* in_a, int Ba, const float* in_b, int Bb, int H, int W, float* out_nhwc,
                                fs_stream stream) {
     if (Ba < 0 || Bb < 0) return fs::fail("fs_encoder_forward2: negative batch");
-    return fs::net_encoder(h, in_a, Bb ? in_b : nullptr, Ba, Ba + Bb, H, W, out_nhwc, S(stream));
+    return fs::net_encoder(h, fs::frames_plain(in_a, Bb ? in_b : nullptr, Ba), Ba + Bb, H, W, out_nhwc, S(stream));
 }
 FS_API int fs_decoder_forward(fs_handle h, const float* feat_nhwc, int B, int fh, int fw, float* out_nchw, fs_stream stream) {
     return fs::net_decoder(h, feat_nhwc, B, fh, fw, out_nchw, S(stream));
 }
 FS_API int fs_segment_forward(fs_handle h, const float* in_nchw, int B, int H, int W, float* out_nchw, fs_stream stream) {
-    return fs::net_segment(h, in_nchw, nullptr, B, B, H, W, out_nchw, S(stream));
+    return fs::net_segment(h, fs::frames_plain(in_nchw, nullptr, B), B, H, W, out_nchw, S(stream));
 }
 FS_API int fs_segment_forward2(fs_handle h, const float* in_a, int Ba, const float* in_b, int Bb, int H, int W, float* out_nchw,
                                fs_stream stream) {
     if (Ba < 0 || Bb < 0) return fs::fail("fs_segment_forward2: negative batch");
-    return fs::net_segment(h, in_a, Bb ? in_b : nullptr, Ba, Ba + Bb, H, W, out_nchw, S(stream));
+    return fs::net_segment(h, fs::frames_plain(in_a, Bb ? in_b : nullptr, Ba), Ba + Bb, H, W, out_nchw, S(stream));
+}
+FS_API int fs_segment_crops(fs_handle h, const float* frame_a, const float* frame_b, int FH, int FW, int ncrops, const int* crop_y,
+                            const int* crop_x, int ch, int cw, float* out_nchw, fs_stream stream) {
+    if (!frame_a || !crop_y || !crop_x || ncrops < 1 || ncrops > 32 || FH < 1 || FW < 1 || FH > 32767 || FW > 32767)
+        return fs::fail("fs_segment_crops: bad arguments (1..32 crops, frame at most 32767 px)");
+    fs::FrameSrc src{};
+    src.in = frame_a;
+    src.in2 = frame_b;
+    src.ncrops = ncrops;
+    src.FH = FH;
+    src.FW = FW;
+    for (int c = 0; c < ncrops; ++c) {
+        if (crop_y[c] < 0 || crop_x[c] < 0 || crop_y[c] + ch > FH || crop_x[c] + cw > FW)
+            return fs::fail("fs_segment_crops: crop %d at (%d,%d) size %dx%d leaves the %dx%d frame", c, crop_y[c], crop_x[c], ch, cw, FH, FW);
+        src.cy[c] = (short)crop_y[c];
+        src.cx[c] = (short)crop_x[c];
+    }
+    return fs::net_segment(h, src, frame_b ? 2 * ncrops : ncrops, ch, cw, out_nchw, S(stream));
 }
 FS_API int fs_profile_enable(fs_handle h, int on) {
     if (!h) return fs::fail("fs_profile_enable: null handle");
@@ -95,6 +115,34 @@ FS_API int fs_seg_tail(const float* lo_prev, const float* lo_next, const float* 
     return fs::launch_seg_tail(p, S(stream));
 }
 
+FS_API int fs_seg_tail_accumulate(const float* lo_prev, const float* lo_next, const float* const* grids_left,
+                                  const float* const* grids_right, int K, int h, int w, int Hg, int Wg, int H, int W, int n, int no_warp,
+                                  double* canvas, double* count, int cH, int cW, int y0, int x0, float* scratch, fs_stream stream) {
+    if (!lo_prev || !canvas || !count || h < 1 || w < 1 || H < 1 || W < 1 || cH < 1 || cW < 1) return fs::fail("fs_seg_tail_accumulate: bad arguments");
+    fs::SegTailParams p{};
+    p.lo_prev = lo_prev;
+    p.lo_next = lo_next;
+    p.grids_left = grids_left;
+    p.grids_right = grids_right;
+    p.K = K;
+    p.h = h;
+    p.w = w;
+    p.Hg = Hg;
+    p.Wg = Wg;
+    p.H = H;
+    p.W = W;
+    p.n = n;
+    p.no_warp = no_warp;
+    p.scratch = scratch;
+    p.canvas = canvas;
+    p.count = count;
+    p.cH = cH;
+    p.cW = cW;
+    p.y0 = y0;
+    p.x0 = x0;
+    return fs::launch_seg_tail(p, S(stream));
+}
+
 FS_API int fs_argmax_u8(const float* in, int B, int K, int64_t HW, uint8_t* out, fs_stream stream) {
     if (!in || !out || B < 1 || HW < 1) return fs::fail("fs_argmax_u8: bad arguments");
     return fs::launch_argmax_u8(in, B, K, HW, out, S(stream));
@@ -128,6 +176,46 @@ FS_API int fs_softmax_accumulate(const float* logits, int n, int K, int h, int w
 FS_API int fs_canvas_finish(double* canvas, const double* count, int n, int K, int64_t HW, uint8_t* mask, fs_stream stream) {
     if (!canvas || !count || n < 1 || K < 1 || HW < 1) return fs::fail("fs_canvas_finish: bad arguments");
     return fs::launch_canvas_finish(canvas, count, n, K, HW, mask, S(stream));
+}
+
+FS_API int fs_canvas_resize_argmax(const double* canvas, int n, int K, int Hi, int Wi, uint8_t* mask, int Ho, int Wo, fs_stream stream) {
+    if (!canvas || !mask || n < 1 || K < 1 || Hi < 1 || Wi < 1 || Ho < 1 || Wo < 1) return fs::fail("fs_canvas_resize_argmax: bad arguments");
+    return fs::launch_canvas_resize_argmax(canvas, n, K, Hi, Wi, mask, Ho, Wo, S(stream));
+}
+FS_API int fs_crop_grids(const float* const* grids, int ngrids, int Hg, int Wg, int H, int W, int ncrops, const int* crop_y,
+                         const int* crop_x, int ch, int cw, float* out, fs_stream stream) {
+    if (!grids || !crop_y || !crop_x || !out || ngrids < 1 || ngrids > 32 || ncrops < 1 || ncrops > 32 || Hg < 1 || Wg < 1 || H < 1 || W < 1 ||
+        ch < 16 || cw < 16)
+        return fs::fail("fs_crop_grids: bad arguments (1..32 grids, 1..32 crops, crop >= 16 px)");
+    fs::CropGridParams p{};
+    for (int j = 0; j < ngrids; ++j) {
+        if (!grids[j]) return fs::fail("fs_crop_grids: null grid %d", j);
+        p.grids[j] = grids[j];
+    }
+    p.ngrids = ngrids;
+    p.Hg = Hg;
+    p.Wg = Wg;
+    p.H = H;
+    p.W = W;
+    p.ncrops = ncrops;
+    p.fh = ch / 16;  // flow/transform.py:226-227
+    p.fw = cw / 16;
+    p.out = out;
+    // flow/transform.py:223-233 in double, Python's round() = round-half-to-even = nearbyint in the default rounding mode
+    const double ppb_h = (double)H / Hg, ppb_w = (double)W / Wg;
+    for (int c = 0; c < ncrops; ++c) {
+        const int bho = (int)std::nearbyint(crop_y[c] / ppb_h), bwo = (int)std::nearbyint(crop_x[c] / ppb_w);
+        const int bh = (int)std::nearbyint((crop_y[c] + ch) / ppb_h) - bho, bw = (int)std::nearbyint((crop_x[c] + cw) / ppb_w) - bwo;
+        p.bho[c] = (short)bho;
+        p.bwo[c] = (short)bwo;
+        p.bh[c] = (short)bh;
+        p.bw[c] = (short)bw;
+        p.off_h[c] = (float)crop_y[c];
+        p.off_w[c] = (float)crop_x[c];
+        p.den_h[c] = (float)(bh * ppb_h);
+        p.den_w[c] = (float)(bw * ppb_w);
+    }
+    return fs::launch_crop_grids(p, S(stream));
 }
 
 FS_API int fs_pack_conv_weight(const float* oihw, float* ohwi, int O, int I, int KH, int KW, fs_stream stream) {
@@ -216,9 +304,7 @@ FS_API int fs_stem_conv_nchw(const float* in_nchw, const float* wgt_hwio, const 
                              fs_stream stream) {
     if (!in_nchw || !wgt_hwio || !scale || !shift || !out_nhwc || B < 1) return fs::fail("fs_stem_conv_nchw: bad arguments");
     fs::StemParams p{};
-    p.in = in_nchw;
-    p.in2 = nullptr;
-    p.B1 = B;
+    p.src = fs::frames_plain(in_nchw, nullptr, B);
     p.wgt = wgt_hwio;
     p.scale = scale;
     p.shift = shift;

@@ -228,19 +228,52 @@ __global__ __launch_bounds__(256) void seg_warp_step_kernel(const float* __restr
     }
 }
 
-// Fusion + upsample (+ argmax).  One thread per output pixel; KMAX classes kept in registers.
+// Fusion + upsample (+ argmax | + softmax accumulated into the sliding-crop canvas).  One thread per output pixel; KMAX
+// classes kept in registers.  Canvas mode (p.canvas != nullptr) is compute_predict_crop + the accumulation of compute_output
+// (flow/base.py:204-205, 226-234) without the [n,K,h,w] logits ever reaching HBM: softmax over K in fp32 exactly as
+// softmax_accumulate_kernel does it on materialised logits (max, exp(x - max), sum, divide), added to the float64 canvas at
+// the crop's offset; successive crops are successive launches on one stream, so overlapping pixels never race.
 template <int KMAX>
 __global__ __launch_bounds__(256) void seg_fuse_kernel(SegTailParams p, float sy_lo, float sx_lo, float sy_g, float sx_g) {
     const int64_t HW = (int64_t)p.H * p.W;
     const int K = p.K, n = p.n;
+    const size_t cHW = (size_t)p.cH * p.cW;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < HW; i += (int64_t)gridDim.x * 256) {
         const int x = (int)(i % p.W), y = (int)(i / p.W);
-        float a[KMAX], b[KMAX];
+        const size_t cpix = (size_t)(p.y0 + y) * p.cW + (p.x0 + x);
+        float a[KMAX], b[KMAX], v[KMAX];
+        // one output frame: logits v[0..K) of this pixel -> the requested outputs
+        auto emit = [&](int f) {
+            if (p.out_logits)
+#pragma unroll
+                for (int k = 0; k < KMAX; ++k)
+                    if (k < K) p.out_logits[((size_t)f * K + k) * HW + i] = v[k];
+            if (p.out_mask) {
+                float best = -INFINITY;
+                int arg = 0;
+#pragma unroll
+                for (int k = 0; k < KMAX; ++k)
+                    if (k < K && v[k] > best) { best = v[k]; arg = k; }
+                p.out_mask[(size_t)f * HW + i] = (uint8_t)arg;
+            }
+            if (p.canvas) {
+                float mx = v[0];
+#pragma unroll
+                for (int k = 1; k < KMAX; ++k)
+                    if (k < K) mx = fmaxf(mx, v[k]);
+                float sum = 0.f;
+#pragma unroll
+                for (int k = 0; k < KMAX; ++k)
+                    if (k < K) sum += expf(v[k] - mx);
+#pragma unroll
+                for (int k = 0; k < KMAX; ++k)
+                    if (k < K) p.canvas[((size_t)f * K + k) * cHW + cpix] += (double)(expf(v[k] - mx) / sum);
+                if (f == 0) p.count[cpix] += 1.0;
+            }
+        };
         // frame 0: the key frame itself
         {
             const LinCoord cy = lin_coord(y, p.h, sy_lo, 1), cx = lin_coord(x, p.w, sx_lo, 1);
-            float best = -INFINITY;
-            int arg = 0;
 #pragma unroll
             for (int k = 0; k < KMAX; ++k) {
                 if (k < K) {
@@ -252,11 +285,10 @@ __global__ __launch_bounds__(256) void seg_fuse_kernel(SegTailParams p, float sy
                         b[k] = bilerp(pn[cy.i0 * p.w + cx.i0], pn[cy.i0 * p.w + cx.i1], pn[cy.i1 * p.w + cx.i0],
                                       pn[cy.i1 * p.w + cx.i1], cy, cx);
                     }
-                    if (p.out_logits) p.out_logits[(size_t)k * HW + i] = a[k];
-                    if (a[k] > best) { best = a[k]; arg = k; }
+                    v[k] = a[k];
                 }
             }
-            if (p.out_mask) p.out_mask[i] = (uint8_t)arg;
+            emit(0);
         }
         if (!p.lo_next) continue;
         LinCoord gy_c, gx_c;
@@ -268,8 +300,6 @@ __global__ __launch_bounds__(256) void seg_fuse_kernel(SegTailParams p, float sy
         for (int f = 1; f < n; ++f) {
             const float wa = (float)((double)(n - f) / (double)n);
             const float wb = (float)((double)f / (double)n);
-            float best = -INFINITY;
-            int arg = 0;
 #pragma unroll
             for (int k = 0; k < KMAX; ++k) {
                 if (k < K) {
@@ -286,12 +316,10 @@ __global__ __launch_bounds__(256) void seg_fuse_kernel(SegTailParams p, float sy
                         vb = bilerp(pb[gy_c.i0 * p.Wg + gx_c.i0], pb[gy_c.i0 * p.Wg + gx_c.i1], pb[gy_c.i1 * p.Wg + gx_c.i0],
                                     pb[gy_c.i1 * p.Wg + gx_c.i1], gy_c, gx_c);
                     }
-                    const float v = __fadd_rn(__fmul_rn(wa, va), __fmul_rn(wb, vb));
-                    if (p.out_logits) p.out_logits[((size_t)f * K + k) * HW + i] = v;
-                    if (v > best) { best = v; arg = k; }
+                    v[k] = __fadd_rn(__fmul_rn(wa, va), __fmul_rn(wb, vb));
                 }
             }
-            if (p.out_mask) p.out_mask[(size_t)f * HW + i] = (uint8_t)arg;
+            emit(f);
         }
     }
 }
@@ -299,7 +327,8 @@ __global__ __launch_bounds__(256) void seg_fuse_kernel(SegTailParams p, float sy
 int launch_seg_tail(const SegTailParams& p, hipStream_t s) {
     FS_REQUIRE(p.K >= 1 && p.K <= 32, "seg_tail: K=%d out of range (1..32)", p.K);
     FS_REQUIRE(p.n >= 1, "seg_tail: n must be >= 1");
-    FS_REQUIRE(p.out_logits || p.out_mask, "seg_tail: no output requested");
+    FS_REQUIRE(p.out_logits || p.out_mask || p.canvas, "seg_tail: no output requested");
+    FS_REQUIRE(!p.canvas || (p.count && p.y0 >= 0 && p.x0 >= 0 && p.y0 + p.H <= p.cH && p.x0 + p.W <= p.cW), "seg_tail: crop outside the canvas");
     const float sy_lo = resize_scale(p.h, p.H, 1), sx_lo = resize_scale(p.w, p.W, 1);
     float sy_g = 0.f, sx_g = 0.f;
     const bool warp = p.lo_next && !p.no_warp && p.n > 1;
@@ -435,6 +464,85 @@ int launch_canvas_finish(double* canvas, const double* count, int n, int K, int6
     const int64_t total = (int64_t)n * HW;
     hipLaunchKernelGGL(canvas_finish_kernel, dim3((unsigned)std::min<int64_t>(cdiv64(total, 256), 16384)), dim3(256), 0, s, canvas, count, n,
                        K, HW, mask);
+    FS_HIP(hipGetLastError());
+    return 0;
+}
+
+// F.interpolate(canvas, (Ho, Wo), bilinear, align_corners=True).max(1)[1] on the float64 crop-averaged probabilities
+// (flow/base.py:275-276 after compute_output; ATen's upsample_bilinear2d with accscalar_t = double), without the
+// [n,K,Ho,Wo] float64 intermediate.
+__global__ __launch_bounds__(256) void canvas_resize_argmax_kernel(const double* __restrict__ canvas, int n, int K, int Hi, int Wi,
+                                                                   uint8_t* __restrict__ mask, int Ho, int Wo, double sy, double sx) {
+    const int64_t total = (int64_t)n * Ho * Wo;
+    const size_t HWi = (size_t)Hi * Wi;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int ox = (int)(i % Wo), oy = (int)((i / Wo) % Ho);
+        const int64_t f = i / ((int64_t)Wo * Ho);
+        const double h1r = sy * oy, w1r = sx * ox;
+        const int h1 = (int)h1r, w1 = (int)w1r;
+        const int h1p = h1 < Hi - 1 ? 1 : 0, w1p = w1 < Wi - 1 ? 1 : 0;
+        const double h1l = h1r - h1, h0l = 1.0 - h1l, w1l = w1r - w1, w0l = 1.0 - w1l;
+        double best = -INFINITY;
+        int arg = 0;
+        for (int k = 0; k < K; ++k) {
+            const double* pl = canvas + ((size_t)f * K + k) * HWi + (size_t)h1 * Wi + w1;
+            const double v = h0l * (w0l * pl[0] + w1l * pl[w1p]) + h1l * (w0l * pl[(size_t)h1p * Wi] + w1l * pl[(size_t)h1p * Wi + w1p]);
+            if (v > best) { best = v; arg = k; }
+        }
+        mask[i] = (uint8_t)arg;
+    }
+}
+
+int launch_canvas_resize_argmax(const double* canvas, int n, int K, int Hi, int Wi, uint8_t* mask, int Ho, int Wo, hipStream_t s) {
+    FS_REQUIRE(K >= 1 && K <= 255, "canvas_resize_argmax: K out of range");
+    const int64_t total = (int64_t)n * Ho * Wo;
+    const double sy = Ho > 1 ? (double)(Hi - 1) / (double)(Ho - 1) : 0.0, sx = Wo > 1 ? (double)(Wi - 1) / (double)(Wo - 1) : 0.0;
+    hipLaunchKernelGGL(canvas_resize_argmax_kernel, dim3((unsigned)std::min<int64_t>(cdiv64(total, 256), 16384)), dim3(256), 0, s, canvas,
+                       n, K, Hi, Wi, mask, Ho, Wo, sy, sx);
+    FS_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------ crop_motion_vector (flow/transform.py:215-261) for all
+// crops and all grids of a window in one launch: cut the block range [bho, bho+bh) x [bwo, bwo+bw) of a full-frame grid,
+// renormalise the (x, y) coordinates to the crop (fp32, numpy's op order: ((((g + 1) / 2) * size - offset) / den) * 2 - 1) and
+// resize to fh x fw with half-pixel-centre bilinear interpolation (cv2.resize INTER_LINEAR on float data).
+__global__ __launch_bounds__(256) void crop_grids_kernel(CropGridParams p) {
+    const int per = p.fh * p.fw;
+    const int total = p.ncrops * p.ngrids * per;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const int px = i % per, j = (i / per) % p.ngrids, c = i / (per * p.ngrids);
+        const int oy = px / p.fw, ox = px - oy * p.fw;
+        const float* g = p.grids[j];
+        const int bh = p.bh[c], bw = p.bw[c];
+        const float* base = g + ((size_t)p.bho[c] * p.Wg + p.bwo[c]) * 2;
+        auto at = [&](int yy, int xx, int comp) -> float {
+            const float raw = base[((size_t)yy * p.Wg + xx) * 2 + comp];
+            const float size = comp ? (float)p.H : (float)p.W, off = comp ? p.off_h[c] : p.off_w[c], den = comp ? p.den_h[c] : p.den_w[c];
+            return __fadd_rn(__fmul_rn(__fdiv_rn(__fadd_rn(__fmul_rn(__fdiv_rn(__fadd_rn(raw, 1.f), 2.f), size), -off), den), 2.f), -1.f);
+        };
+        float rx, ry;
+        if (bh == p.fh && bw == p.fw) {
+            rx = at(oy, ox, 0);
+            ry = at(oy, ox, 1);
+        } else {
+            const LinCoord cy = lin_coord(oy, bh, resize_scale(bh, p.fh, 0), 0), cx = lin_coord(ox, bw, resize_scale(bw, p.fw, 0), 0);
+            rx = bilerp(at(cy.i0, cx.i0, 0), at(cy.i0, cx.i1, 0), at(cy.i1, cx.i0, 0), at(cy.i1, cx.i1, 0), cy, cx);
+            ry = bilerp(at(cy.i0, cx.i0, 1), at(cy.i0, cx.i1, 1), at(cy.i1, cx.i0, 1), at(cy.i1, cx.i1, 1), cy, cx);
+        }
+        p.out[(size_t)i * 2 + 0] = rx;
+        p.out[(size_t)i * 2 + 1] = ry;
+    }
+}
+
+int launch_crop_grids(const CropGridParams& p, hipStream_t s) {
+    FS_REQUIRE(p.ncrops >= 1 && p.ncrops <= 32 && p.ngrids >= 1 && p.ngrids <= 32, "crop_grids: at most 32 crops x 32 grids per call");
+    FS_REQUIRE(p.fh >= 1 && p.fw >= 1 && p.out, "crop_grids: bad output geometry");
+    for (int c = 0; c < p.ncrops; ++c)
+        FS_REQUIRE(p.bho[c] >= 0 && p.bwo[c] >= 0 && p.bh[c] >= 1 && p.bw[c] >= 1 && p.bho[c] + p.bh[c] <= p.Hg && p.bwo[c] + p.bw[c] <= p.Wg,
+                   "crop_grids: block range of crop %d outside the %dx%d grid", c, p.Hg, p.Wg);
+    const int total = p.ncrops * p.ngrids * p.fh * p.fw;
+    hipLaunchKernelGGL(crop_grids_kernel, dim3(std::min(cdiv(total, 256), 4096)), dim3(256), 0, s, p);
     FS_HIP(hipGetLastError());
     return 0;
 }

@@ -42,10 +42,28 @@ const char* conv_igemm_tile_name(const ConvParams& p, int tile = 0);
 // Stem convolution with Cin = 3 read straight from the caller's NCHW frame
 // (model/resnet.py:110 3x3 s2 p1; torchvision ResNet 7x7 s2 p3), + BN + ReLU, NHWC out.
 // ---------------------------------------------------------------------------------
+// Where the B input images of a forward pass live.  Plain mode (ncrops == 0): images 0 .. B1-1 are in[b] and images
+// B1 .. B-1 are in2[b - B1], both NCHW [*,3,H,W] (the two key frames of a window are two tensors in the reference's API,
+// flow/model.py:189-204: reading both in place replaces a torch.cat).  Crop mode (ncrops > 0, the sliding-crop route of
+// flow/base.py:182-209): `in` and `in2` are two FULL frames [1,3,FH,FW]; image b < ncrops is the H x W window of `in` whose
+// top-left corner is (cy[b], cx[b]), image ncrops + b the same window of `in2` -- the crops are never copied out.
+struct FrameSrc {
+    const float* in;
+    const float* in2;
+    int B1;
+    int ncrops, FH, FW;
+    short cy[32], cx[32];
+};
+static inline FrameSrc frames_plain(const float* in, const float* in2, int B1) {
+    FrameSrc f{};
+    f.in = in;
+    f.in2 = in2;
+    f.B1 = B1;
+    return f;
+}
+
 struct StemParams {
-    const float* in;   // NCHW [B1,3,H,W]: images 0 .. B1-1
-    const float* in2;  // NCHW [B-B1,3,H,W]: images B1 .. B-1 (the second key frame of a window is a separate tensor in the
-    int B1;            // reference's API, flow/model.py:189-204; reading both in place replaces a torch.cat); B1 == B: unused
+    FrameSrc src;
     const float* wgt; // [KH*KW*3][Cout]  (tap-major, Cout fastest)
     const float* scale; const float* shift;
     float* out; int ld_out;  // NHWC [B,Ho,Wo,Cout]
@@ -128,6 +146,10 @@ struct SegTailParams {
     float* out_logits;      // [n, K, H, W] or nullptr
     uint8_t* out_mask;      // [n, H, W] argmax or nullptr
     float* scratch;         // >= 2*(n-1)*K*Hg*Wg floats when warping
+    // sliding-crop mode (flow/base.py:204-205, 226-234): canvas[n,K,cH,cW] += softmax_K(frame logits) at (y0, x0), count += 1
+    double* canvas;         // float64 [n, K, cH, cW] or nullptr
+    double* count;          // float64 [cH, cW]
+    int cH, cW, y0, x0;
 };
 int launch_seg_tail(const SegTailParams& p, hipStream_t s);
 
@@ -142,6 +164,19 @@ int launch_resize_argmax_u8(const float* in, int B, int K, int Hi, int Wi, uint8
 int launch_softmax_accumulate(const float* logits, int n, int K, int h, int w, double* canvas, double* count, int H, int W, int y0,
                               int x0, hipStream_t s);
 int launch_canvas_finish(double* canvas, const double* count, int n, int K, int64_t HW, uint8_t* mask, hipStream_t s);
+// argmax over K of the align_corners=True bilinear resize (in float64) of the crop-averaged canvas (flow/base.py:275-276)
+int launch_canvas_resize_argmax(const double* canvas, int n, int K, int Hi, int Wi, uint8_t* mask, int Ho, int Wo, hipStream_t s);
+// crop_motion_vector (flow/transform.py:215-261) for every crop x every grid of a window in one launch
+struct CropGridParams {
+    const float* grids[32];  // ngrids device pointers, each [Hg, Wg, 2] fp32
+    int ngrids, Hg, Wg;
+    int H, W;                // frame size the grids are normalised to
+    int ncrops, fh, fw;      // output grids [ncrops][ngrids][fh][fw][2]
+    short bho[32], bwo[32], bh[32], bw[32];          // block range per crop (Python-rounded on the host)
+    float off_h[32], off_w[32], den_h[32], den_w[32];  // pixel offset of the crop; bh * pixels-per-block, bw * pixels-per-block
+    float* out;
+};
+int launch_crop_grids(const CropGridParams& p, hipStream_t s);
 // rgb[i] = palette[mask[i]] (flow/base.py:308-312)
 int launch_colorize(const uint8_t* mask, const uint8_t* palette, int K, uint8_t* rgb, int64_t numel, hipStream_t s);
 // H.264 block motion vectors -> forward / inverse sampling grids (dataset/flow/extract_motion_vectors.py:21-43), float64

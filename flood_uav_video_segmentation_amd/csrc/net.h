@@ -146,10 +146,9 @@ int net_load_weight(fs_handle h, const char* name, const float* data, const int6
 int net_finalize(fs_handle h, hipStream_t s);
 int net_feature_shape(fs_handle h, int H, int W, int* C, int* fh, int* fw);
 size_t net_workspace_bytes(fs_handle h, int B, int H, int W);
-// Frames: images 0 .. B1-1 from in_nchw, images B1 .. B-1 from in2 (nullptr when B1 == B): the two key frames of a window are
-// two tensors in the reference's API (flow/model.py:189-204) and are read in place instead of being concatenated first.
-int net_encoder(fs_handle h, const float* in_nchw, const float* in2, int B1, int B, int H, int W, float* out_nhwc, hipStream_t s);
-int net_segment(fs_handle h, const float* in_nchw, const float* in2, int B1, int B, int H, int W, float* out_nchw, hipStream_t s);
+// src: where the B frames live (kernels.h FrameSrc: one tensor, two tensors, or crop windows of two full frames)
+int net_encoder(fs_handle h, const FrameSrc& src, int B, int H, int W, float* out_nhwc, hipStream_t s);
+int net_segment(fs_handle h, const FrameSrc& src, int B, int H, int W, float* out_nchw, hipStream_t s);
 int net_decoder(fs_handle h, const float* feat, int B, int fh, int fw, float* out_nchw, hipStream_t s);
 int net_profile_dump(fs_handle h, char* buf, size_t n);
 
@@ -160,6 +159,6 @@ int prof_begin(fs_net* h, const std::string& name, const char* kernel, double fl
 int prof_end(fs_net* h, hipStream_t s);
 int vit_finalize(fs_handle h, hipStream_t s);
 int vit_feature_shape(fs_handle h, int H, int W, int* C, int* fh, int* fw);
-int vit_encoder(fs_handle h, const float* in_nchw, const float* in2, int B1, int B, int H, int W, float* out_tokens, hipStream_t s);
+int vit_encoder(fs_handle h, const FrameSrc& src, int B, int H, int W, float* out_tokens, hipStream_t s);
 int vit_decoder(fs_handle h, const float* tokens, int B, int gh, int gw, float* out_nchw, hipStream_t s);
 }  // namespace fs

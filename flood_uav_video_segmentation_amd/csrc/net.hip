@@ -559,7 +559,7 @@ int pyramid_reduce(fs_net* h, const float* feat, int ld_feat, int B, int H, int 
 // ResNet backbone (+ pyramid pooling for PSPNet).  out != nullptr: the reference's encoder output (PSPNet: 4096-channel
 // concat with the upsampled pyramid; ld_out = feat_channels()).  out == nullptr (fused PSPNet route): the 2048 backbone
 // channels stay in a workspace buffer (*feat2048, ld 2048) and the pyramid stops at the pooled+reduced maps in h->small.
-int encoder_core(fs_handle h, const float* in_nchw, const float* in2, int B1, int B, int H, int W, float* out, float** feat2048, hipStream_t s) {
+int encoder_core(fs_handle h, const FrameSrc& src, int B, int H, int W, float* out, float** feat2048, hipStream_t s) {
     const bool fused = out == nullptr;
     const Geometry g = geometry(h, H, W);
     FS_TRY(ensure_workspace(h, encoder_buf_elems(h, B, H, W), small_elems_for(B)));
@@ -570,9 +570,7 @@ int encoder_core(fs_handle h, const float* in_nchw, const float* in2, int B1, in
     {
         const ConvBN& c = h->stem[0];
         StemParams p{};
-        p.in = in_nchw;
-        p.in2 = in2;
-        p.B1 = B1;
+        p.src = src;
         p.wgt = c.w;
         p.scale = c.scale;
         p.shift = c.shift;
@@ -653,22 +651,30 @@ int encoder_core(fs_handle h, const float* in_nchw, const float* in2, int B1, in
 }
 }  // namespace
 
-int net_encoder(fs_handle h, const float* in_nchw, const float* in2, int B1, int B, int H, int W, float* out, hipStream_t s) {
+namespace {
+int check_frames(const FrameSrc& f, int B, const char* what) {
+    if (f.ncrops) return 0;  // the stem launcher validates crop windows against the frame
+    FS_REQUIRE(B >= 1 && f.B1 >= 0 && f.B1 <= B && (f.B1 == 0 || f.in) && (f.B1 == B || f.in2), "%s: bad frame batch (B1=%d of B=%d)", what, f.B1, B);
+    return 0;
+}
+}  // namespace
+
+int net_encoder(fs_handle h, const FrameSrc& src, int B, int H, int W, float* out, hipStream_t s) {
     FS_REQUIRE(h && h->finalized, "fs_encoder_forward: network not finalized");
     FS_TRY(check_device(h, "fs_encoder_forward"));
-    FS_REQUIRE(B >= 1 && B1 >= 0 && B1 <= B && (B1 == 0 || in_nchw) && (B1 == B || in2), "fs_encoder_forward: bad frame batch (B1=%d of B=%d)", B1, B);
-    if (h->cfg.arch == FS_ARCH_SEGMENTER) return vit_encoder(h, in_nchw, in2, B1, B, H, W, out, s);
+    FS_TRY(check_frames(src, B, "fs_encoder_forward"));
+    if (h->cfg.arch == FS_ARCH_SEGMENTER) return vit_encoder(h, src, B, H, W, out, s);
     FS_REQUIRE(out && H >= 33 && W >= 33, "fs_encoder_forward: bad arguments (B=%d H=%d W=%d)", B, H, W);
-    return encoder_core(h, in_nchw, in2, B1, B, H, W, out, nullptr, s);
+    return encoder_core(h, src, B, H, W, out, nullptr, s);
 }
 
 // decoder(encoder(x)) in one call (flow/model.py:39-40, 189-191, 202-204; single-frame inference).  PSPNet takes the
 // fused route (no 4096-channel concat, see net_ops.hip); the other heads run encoder + decoder over an internal feature map.
-int net_segment(fs_handle h, const float* in_nchw, const float* in2, int B1, int B, int H, int W, float* out_nchw, hipStream_t s) {
+int net_segment(fs_handle h, const FrameSrc& src, int B, int H, int W, float* out_nchw, hipStream_t s) {
     FS_REQUIRE(h && h->finalized, "fs_segment_forward: network not finalized");
     FS_TRY(check_device(h, "fs_segment_forward"));
     FS_REQUIRE(out_nchw && B >= 1 && H >= 1 && W >= 1, "fs_segment_forward: bad arguments (B=%d H=%d W=%d)", B, H, W);
-    FS_REQUIRE(B1 >= 0 && B1 <= B && (B1 == 0 || in_nchw) && (B1 == B || in2), "fs_segment_forward: bad frame batch (B1=%d of B=%d)", B1, B);
+    FS_TRY(check_frames(src, B, "fs_segment_forward"));
     int C = 0, fh = 0, fw = 0;
     if (h->cfg.arch != FS_ARCH_PSPNET || !h->use_fused_head) {
         FS_TRY(net_feature_shape(h, H, W, &C, &fh, &fw));
@@ -680,7 +686,7 @@ int net_segment(fs_handle h, const float* in_nchw, const float* in2, int B1, int
             FS_HIP(hipMalloc(reinterpret_cast<void**>(&h->seg_feat), need * sizeof(float)));
             h->seg_feat_elems = need;
         }
-        FS_TRY(net_encoder(h, in_nchw, in2, B1, B, H, W, h->seg_feat, s));
+        FS_TRY(net_encoder(h, src, B, H, W, h->seg_feat, s));
         return net_decoder(h, h->seg_feat, B, fh, fw, out_nchw, s);
     }
     FS_REQUIRE(H >= 33 && W >= 33, "fs_segment_forward: bad arguments (B=%d H=%d W=%d)", B, H, W);
@@ -690,7 +696,7 @@ int net_segment(fs_handle h, const float* in_nchw, const float* in2, int B1, int
     // four rotating buffers: the backbone's largest map, and (tiny inputs) the row-collapsed pyramid term of the head
     FS_TRY(ensure_workspace(h, std::max(encoder_buf_elems(h, B, H, W), ppm_term_scratch_floats(B, fh, h->cls_main.Cout)), small_elems_for(B)));
     float* feat = nullptr;
-    FS_TRY(encoder_core(h, in_nchw, in2, B1, B, H, W, nullptr, &feat, s));
+    FS_TRY(encoder_core(h, src, B, H, W, nullptr, &feat, s));
     // (Running the pyramid branch -- pool, four tiny 1x1 convs, the Z GEMM, ~0.12 ms -- on a side stream under the head's
     //  Winograd GEMM was measured: +0.2 %, not worth a second stream in the handle.)
     hipStream_t ps = s;

@@ -34,15 +34,24 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(StemParams p) {
     float acc[CPT];
 #pragma unroll
     for (int c = 0; c < CPT; ++c) acc[c] = 0.f;
-    const size_t plane = (size_t)p.H * p.W;
-    const float* inb = b < p.B1 ? p.in + (size_t)b * 3 * plane : p.in2 + (size_t)(b - p.B1) * 3 * plane;
+    size_t plane = (size_t)p.H * p.W;
+    int rowW = p.W;
+    const float* inb;
+    if (p.src.ncrops) {  // crop window of a full frame: same taps, the frame's strides, zero padding at the CROP's border
+        const int c = b < p.src.ncrops ? b : b - p.src.ncrops;
+        plane = (size_t)p.src.FH * p.src.FW;
+        rowW = p.src.FW;
+        inb = (b < p.src.ncrops ? p.src.in : p.src.in2) + (size_t)p.src.cy[c] * rowW + p.src.cx[c];
+    } else {
+        inb = b < p.src.B1 ? p.src.in + (size_t)b * 3 * plane : p.src.in2 + (size_t)(b - p.src.B1) * 3 * plane;
+    }
     for (int ky = 0; ky < p.KH; ++ky) {
         const int iy = iy0 + ky;
         const bool yok = (unsigned)iy < (unsigned)p.H;
         for (int kx = 0; kx < p.KW; ++kx) {
             const int ix = ix0 + kx;
             const bool ok = yok && (unsigned)ix < (unsigned)p.W;
-            const size_t off = ok ? (size_t)iy * p.W + ix : 0;
+            const size_t off = ok ? (size_t)iy * rowW + ix : 0;
             const float x0 = ok ? inb[off] : 0.f;
             const float x1 = ok ? inb[plane + off] : 0.f;
             const float x2 = ok ? inb[2 * plane + off] : 0.f;
@@ -74,7 +83,15 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(StemParams p) {
 int launch_stem_conv(const StemParams& p, hipStream_t s) {
     FS_REQUIRE(p.Cout % 16 == 0 && p.Cout <= 256 && 256 % (p.Cout / 16) == 0, "stem_conv: unsupported Cout=%d", p.Cout);
     FS_REQUIRE(p.ld_out % 4 == 0, "stem_conv: ld_out must be a multiple of 4");
-    FS_REQUIRE(p.B1 >= 0 && p.B1 <= p.B && (p.B1 == p.B || p.in2) && (p.B1 == 0 || p.in), "stem_conv: bad frame split B1=%d of B=%d", p.B1, p.B);
+    const FrameSrc& f = p.src;
+    if (f.ncrops) {
+        FS_REQUIRE(f.ncrops <= 32 && f.in && (p.B == f.ncrops || (p.B == 2 * f.ncrops && f.in2)), "stem_conv: bad crop batch (%d crops, B=%d)", f.ncrops, p.B);
+        for (int c = 0; c < f.ncrops; ++c)
+            FS_REQUIRE(f.cy[c] >= 0 && f.cx[c] >= 0 && f.cy[c] + p.H <= f.FH && f.cx[c] + p.W <= f.FW, "stem_conv: crop %d (%d,%d)+%dx%d outside the %dx%d frame",
+                       c, f.cy[c], f.cx[c], p.H, p.W, f.FH, f.FW);
+    } else {
+        FS_REQUIRE(f.B1 >= 0 && f.B1 <= p.B && (f.B1 == p.B || f.in2) && (f.B1 == 0 || f.in), "stem_conv: bad frame split B1=%d of B=%d", f.B1, p.B);
+    }
     const int M = p.B * p.Ho * p.Wo;
     const int groups = p.Cout / 16, ppb = 256 / groups;
     const size_t lds = (size_t)p.KH * p.KW * 3 * p.Cout * sizeof(float);

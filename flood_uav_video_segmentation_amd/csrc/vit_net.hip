@@ -169,8 +169,12 @@ int vit_feature_shape(fs_handle h, int H, int W, int* C, int* fh, int* fw) {
     return 0;
 }
 
-int vit_encoder(fs_handle h, const float* in_nchw, const float* in2, int B1, int B, int H, int W, float* out_tokens, hipStream_t s) {
-    FS_REQUIRE((in_nchw || B1 == 0) && out_tokens && B >= 1 && H >= 1 && W >= 1, "fs_encoder_forward(segmenter): bad arguments");
+int vit_encoder(fs_handle h, const FrameSrc& src, int B, int H, int W, float* out_tokens, hipStream_t s) {
+    FS_REQUIRE(out_tokens && B >= 1 && H >= 1 && W >= 1, "fs_encoder_forward(segmenter): bad arguments");
+    FS_REQUIRE(src.ncrops == 0, "fs_segment_crops: the Segmenter has no sliding-crop route (the reference never wires ViT into flow/base.py:182-209)");
+    const float* in_nchw = src.in;
+    const float* in2 = src.in2;
+    const int B1 = src.B1;
     const int P = h->cfg.patch, D = h->cfg.d_model;
     const int gh = (H + P - 1) / P, gw = (W + P - 1) / P, N = gh * gw;
     VitWs ws;

@@ -15,42 +15,22 @@ from .. import _lib, ops
 from .._lib import check, ptr, stream_ptr
 
 
-def _py_round(x):
-    return int(round(x))  # Python's round = banker's rounding, as the reference uses (flow/transform.py:230-233)
+def _is_grid_list(lst):
+    return lst is not None and isinstance(lst, list) and len(lst) > 0 and lst[0].dim() >= 3
 
 
 def crop_motion_vector(mvs_left, mvs_right, height, width, crop_height, crop_width, height_offset, width_offset):
-    """Crop + renormalise + resize the block-motion grids for one crop window (flow/transform.py:215-261).
-    Grids are [1,Hg,Wg,2] tensors; new tensors are returned (the reference mutates CPU inputs in place, a quirk of
-    its numpy view; on GPU inputs it works on a copy -- the GPU behaviour is the one kept)."""
-    first = None
-    for lst in (mvs_left, mvs_right):
-        if lst is not None and isinstance(lst, list) and len(lst) > 0 and lst[0].dim() >= 3:
-            first = lst[0]
-            break
-    if first is None:
-        return mvs_left, mvs_right
-    mv_h, mv_w = first.shape[-3], first.shape[-2]
-    ppb_h, ppb_w = height / mv_h, width / mv_w
-    final_h, final_w = crop_height // 16, crop_width // 16
-    bho = _py_round(height_offset / ppb_h)
-    bwo = _py_round(width_offset / ppb_w)
-    bh = _py_round((height_offset + crop_height) / ppb_h) - bho
-    bw = _py_round((width_offset + crop_width) / ppb_w) - bwo
-
-    def one(m):
-        m = m.float()
-        c = m[:, bho:bho + bh, bwo:bwo + bw, :]
-        x = ((((c[..., 0] + 1) / 2) * width - width_offset) / (bw * ppb_w)) * 2 - 1
-        y = ((((c[..., 1] + 1) / 2) * height - height_offset) / (bh * ppb_h)) * 2 - 1
-        g = torch.stack((x, y), 1).contiguous()  # [1,2,bh,bw]
-        if (bh, bw) != (final_h, final_w):
-            # cv2.resize(INTER_LINEAR) on float data = half-pixel-centre bilinear = align_corners=False
-            g = ops.resize_bilinear(g, (final_h, final_w), align_corners=False)
-        return g.permute(0, 2, 3, 1).contiguous()
-
-    left = [one(m) for m in mvs_left] if mvs_left is not None else None
-    right = [one(m) for m in mvs_right] if mvs_right is not None else None
+    """Crop + renormalise + resize the block-motion grids for one crop window (flow/transform.py:215-261): block range by
+    Python's round(), coordinates renormalised to the crop in fp32, half-pixel bilinear resize (cv2.INTER_LINEAR) to
+    (crop // 16)^2 -- one HIP launch for all grids (fs_crop_grids).  Grids are [1,Hg,Wg,2] tensors; new tensors are returned
+    (the reference mutates CPU inputs in place, a quirk of its numpy view; on GPU inputs it works on a copy -- kept)."""
+    if not (_is_grid_list(mvs_left) or _is_grid_list(mvs_right)):
+        return mvs_left, mvs_right  # no_warp placeholders pass through (flow/transform.py:216-221)
+    nl = len(mvs_left) if mvs_left is not None else 0
+    both = list(mvs_left or []) + list(mvs_right or [])
+    out = ops.crop_grids(both, (height, width), [(height_offset, width_offset)], (crop_height, crop_width))[0]
+    left = [out[j][None] for j in range(nl)] if mvs_left is not None else None
+    right = [out[j][None] for j in range(nl, len(both))] if mvs_right is not None else None
     return left, right
 
 
@@ -70,29 +50,70 @@ def crop_windows(new_h, new_w, crop_h, crop_w, stride_rate=2 / 3):
 
 
 def compute_output(flow_model, n, frame_prev, frame_next, mvs_left, mvs_right, crop_h, crop_w, classes, profiler=None,
-                   want_mask=False, function=None):
-    """flow/base.py:182-209: returns the float64 [n,K,H,W] crop-averaged softmax (and, optionally, its per-frame
-    argmax as uint8 [n,H,W]).  `function(prev_crop, next_crop, mvs_left_crop, mvs_right_crop) -> logits [n,K,h,w]`
-    is the per-crop network call: default `compute_predict_crop` (:226-234, FlowModel.predict); test_step passes
-    `compute_test_crop` (:212-222, FlowModel.forward with left/right indices)."""
-    lib = _lib.load()
+                   want_mask=False, function=None, key_cache=None, out_size=None, crop_batch=8):
+    """flow/base.py:182-209: returns the float64 [n,K,H,W] crop-averaged softmax (and, with want_mask, the uint8 argmax of its
+    align_corners=True resize to `out_size` -- flow/base.py:275-276; out_size None = the frame size).
+
+    `function(prev_crop, next_crop, mvs_left_crop, mvs_right_crop) -> logits [n,K,h,w]` is the per-crop network call of the
+    generic route: default `compute_predict_crop` (:226-234, FlowModel.predict); test_step passes `compute_test_crop`
+    (:212-222, FlowModel.forward with left/right indices).
+
+    Batched route (default function, segmentation mode, a HIP network mirror): the crops of BOTH key frames go through the
+    network as batches of `crop_batch` windows per frame read in place from the full frames (fs_segment_crops), all crop
+    grids come from one launch (fs_crop_grids) and every crop's tail runs fused with softmax + accumulation
+    (fs_seg_tail_accumulate): per-crop logits never reach HBM.  key_cache (KeyframeCache.window): the previous key frame's
+    per-crop logits are reused from the last window.  Same arithmetic per crop as the generic route."""
     _, _, new_h, new_w = frame_prev.shape
     dev = frame_prev.device
-    canvas = torch.zeros((n, classes, new_h, new_w), dtype=torch.float64, device=dev)
-    count = torch.zeros((new_h, new_w), dtype=torch.float64, device=dev)
-    for (s_h, e_h, s_w, e_w) in crop_windows(new_h, new_w, crop_h, crop_w):
-        prev_c = frame_prev[:, :, s_h:e_h, s_w:e_w].contiguous()
-        next_c = frame_next[:, :, s_h:e_h, s_w:e_w].contiguous()
-        ml, mr = crop_motion_vector(mvs_left, mvs_right, new_h, new_w, e_h - s_h, e_w - s_w, s_h, s_w)
-        if function is None:
-            logits = flow_model.predict(prev_c, next_c, ml, mr, n, profiler)["pred"]
-        else:
-            logits = function(prev_c, next_c, ml, mr)
-        if logits.shape[2] != crop_h or logits.shape[3] != crop_w:
-            logits = ops.resize_bilinear(logits, (crop_h, crop_w), align_corners=True)
-        logits = logits.contiguous()
-        check(lib.fs_softmax_accumulate(ptr(logits), n, classes, crop_h, crop_w, ptr(canvas), ptr(count), new_h, new_w, s_h, s_w,
-                                        stream_ptr()))
-    mask = torch.empty((n, new_h, new_w), dtype=torch.uint8, device=dev) if want_mask else None
-    check(lib.fs_canvas_finish(ptr(canvas), ptr(count), n, classes, new_h * new_w, ptr(mask), stream_ptr()))
+    windows = crop_windows(new_h, new_w, crop_h, crop_w)
+    with torch.cuda.device(dev):
+        canvas = torch.zeros((n, classes, new_h, new_w), dtype=torch.float64, device=dev)
+        count = torch.zeros((new_h, new_w), dtype=torch.float64, device=dev)
+    net = getattr(flow_model, "model", None)
+    batched = (function is None and not getattr(flow_model, "feature_based", True) and hasattr(net, "segment_crops")
+               and frame_prev.shape[0] == 1 and frame_next is not None)
+    if batched:
+        yx = [(s_h, s_w) for (s_h, _, s_w, _) in windows]
+        nc = len(yx)
+        tag = ("crops", new_h, new_w, crop_h, crop_w)
+        lo_prev = key_cache.prev(tag) if key_cache is not None else None
+        parts_prev, parts_next = [], []
+        for c0 in range(0, nc, crop_batch):
+            sub = yx[c0:c0 + crop_batch]
+            if lo_prev is None:
+                lows = net.segment_crops(frame_prev, frame_next, sub, (crop_h, crop_w))
+                parts_prev.append(lows[:len(sub)])
+                parts_next.append(lows[len(sub):])
+            else:
+                parts_next.append(net.segment_crops(frame_next, None, sub, (crop_h, crop_w)))
+        if lo_prev is None:
+            lo_prev = parts_prev[0] if len(parts_prev) == 1 else torch.cat(parts_prev, 0)
+        lo_next = parts_next[0] if len(parts_next) == 1 else torch.cat(parts_next, 0)
+        if key_cache is not None:
+            key_cache.store_next(tag, lo_next)
+        no_warp = flow_model.no_warp or not _is_grid_list(mvs_left)
+        grids = None
+        if not no_warp:
+            grids = ops.crop_grids(list(mvs_left) + list(mvs_right), (new_h, new_w), yx, (crop_h, crop_w))  # [nc, 2(n-1), fh, fw, 2]
+        for c, (y0, x0) in enumerate(yx):
+            gl = [grids[c, j][None] for j in range(n - 1)] if grids is not None else mvs_left
+            gr = [grids[c, n - 1 + j][None] for j in range(n - 1)] if grids is not None else mvs_right
+            ops.seg_tail_accumulate(lo_prev[c:c + 1], lo_next[c:c + 1], gl, gr, n, (crop_h, crop_w), no_warp, canvas, count, y0, x0)
+    else:
+        lib = _lib.load()
+        for (s_h, e_h, s_w, e_w) in windows:
+            prev_c = frame_prev[:, :, s_h:e_h, s_w:e_w].contiguous()
+            next_c = frame_next[:, :, s_h:e_h, s_w:e_w].contiguous()
+            ml, mr = crop_motion_vector(mvs_left, mvs_right, new_h, new_w, e_h - s_h, e_w - s_w, s_h, s_w)
+            if function is None:
+                logits = flow_model.predict(prev_c, next_c, ml, mr, n, profiler)["pred"]
+            else:
+                logits = function(prev_c, next_c, ml, mr)
+            if logits.shape[2] != crop_h or logits.shape[3] != crop_w:
+                logits = ops.resize_bilinear(logits, (crop_h, crop_w), align_corners=True)
+            logits = logits.contiguous()
+            with torch.cuda.device(dev):
+                check(lib.fs_softmax_accumulate(ptr(logits), n, classes, crop_h, crop_w, ptr(canvas), ptr(count), new_h, new_w, s_h, s_w,
+                                                stream_ptr()))
+    mask = ops.canvas_finish(canvas, count, out_size, want_mask)
     return (canvas, mask) if want_mask else canvas

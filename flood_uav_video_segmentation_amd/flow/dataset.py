@@ -86,7 +86,10 @@ class PredictWindows:
         if not 0 <= index < self.length:
             raise IndexError(index)
         f_index, prev_real, next_real = self.indices(index)
-        item = {"frame_prev": self._frame(prev_real), "frame_next": self._frame(next_real), "frame_id": f_index}
+        # key_ids: the frames actually used as keys.  Window i's next key is window i+1's previous key (same index, same
+        # deterministic transform: :113-114), which is what FlowPredictor's key-frame cache is keyed on.
+        item = {"frame_prev": self._frame(prev_real), "frame_next": self._frame(next_real), "frame_id": f_index,
+                "key_ids": (prev_real, next_real)}
         if self.no_warp:
             # placeholders whose COUNT still encodes n (flow/dataset.py:198-205, flow/base.py:266)
             item["mvs_left"] = [torch.zeros(1, 1, device=self.device) for _ in range(self.frame_delta - 1)]

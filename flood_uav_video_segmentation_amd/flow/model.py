@@ -38,6 +38,45 @@ def _region(profiler, name):
     return profiler.profile(name)
 
 
+class KeyframeCache:
+    """One-slot cache of a key frame's network output.  Consecutive predict windows share a key frame -- window i's
+    `frame_next` is window i+1's `frame_prev`: same frame index, deterministic transform (flow/dataset.py:112-114) -- so a
+    video needs ONE new key-frame inference per window, not two.  The caller names the frames:
+
+        cache = KeyframeCache()
+        fm.predict(prev, nxt, mvl, mvr, n, profiler, key_cache=cache.window(prev_id, next_id))
+
+    What is kept is whatever the mode propagates: decoder logits (segmentation mode), encoder features (feature mode) or the
+    per-crop logits of the sliding-crop route; a tag keeps different modes / geometries apart.  Results are bit-identical to
+    the uncached call: a frame's network output does not depend on the batch it was computed in."""
+
+    def __init__(self):
+        self.frame_id, self.tag, self.value = None, None, None
+        self.hits = self.misses = 0
+
+    def clear(self):
+        self.frame_id, self.tag, self.value = None, None, None
+
+    def window(self, prev_id, next_id):
+        return _KeyWindow(self, prev_id, next_id)
+
+
+class _KeyWindow:
+    def __init__(self, cache, prev_id, next_id):
+        self.cache, self.prev_id, self.next_id = cache, prev_id, next_id
+
+    def prev(self, tag):
+        c = self.cache
+        if self.prev_id is not None and c.frame_id == self.prev_id and c.tag == tag:
+            c.hits += 1
+            return c.value
+        c.misses += 1
+        return None
+
+    def store_next(self, tag, value):
+        self.cache.frame_id, self.cache.tag, self.cache.value = self.next_id, tag, value
+
+
 class FlowModel(nn.Module):
     def __init__(self, model, feature_based=True, no_warp=False, no_interpolation_percentage=0.0):
         super().__init__()
@@ -66,6 +105,22 @@ class FlowModel(nn.Module):
             return seg(*frames)  # separate tensors are read in place (fs_segment_forward2): no torch.cat on the window path
         x = frames[0] if len(frames) == 1 else torch.cat(frames, 0)
         return self.model.decoder(self.model.encoder(x))
+
+    def _key_outputs(self, fn, tag, frame_prev, frame_next, key_cache):
+        """(out_prev, out_next) of `fn` = _segment / _encode for the two key frames of a window.  With a key_cache the
+        previous key frame's output is taken from the last window when it is the same frame, and only frame_next runs."""
+        if frame_next is None:
+            return fn(frame_prev)[0:1], None
+        if key_cache is not None:
+            cached = key_cache.prev(tag)
+            if cached is not None:
+                nxt = fn(frame_next)[0:1]
+                key_cache.store_next(tag, nxt)
+                return cached, nxt
+        outs = fn(frame_prev, frame_next)
+        if key_cache is not None:
+            key_cache.store_next(tag, outs[1:2])
+        return outs[0:1], outs[1:2]
 
     @staticmethod
     def _fit(t, h, w):
@@ -142,39 +197,31 @@ class FlowModel(nn.Module):
             return self.predict_feature(*args, **kwargs)
         return self.predict_segmentation(*args, **kwargs)
 
-    def predict_segmentation(self, frame_prev, frame_next, mvs_left, mvs_right, n, profiler=None):
+    def predict_segmentation(self, frame_prev, frame_next, mvs_left, mvs_right, n, profiler=None, key_cache=None):
         """Segment the key frames, propagate the LOGITS (reference :184-241).
-        Returns {"pred": [n,K,h,w]} ([1,K,h,w] when frame_next is None)."""
+        Returns {"pred": [n,K,h,w]} ([1,K,h,w] when frame_next is None).  key_cache: see KeyframeCache (extension)."""
         h, w = frame_prev.shape[2], frame_prev.shape[3]
-        frames = (frame_prev,) if frame_next is None else (frame_prev, frame_next)
         with _region(profiler, "predict_encoder"), _region(profiler, "predict_decoder"):
-            lows = self._segment(*frames)
-        lo_prev = lows[0:1]
-        lo_next = lows[1:2] if frame_next is not None else None
+            lo_prev, lo_next = self._key_outputs(self._segment, ("seg", h, w), frame_prev, frame_next, key_cache)
         with _region(profiler, "predict_warp"), _region(profiler, "predict_fusion"):
             logits, _ = ops.seg_tail(lo_prev, lo_next, mvs_left, mvs_right, n, (h, w), self.no_warp, want_logits=True)
         return {"pred": logits}
 
-    def predict_masks(self, frame_prev, frame_next, mvs_left, mvs_right, n, profiler=None):
+    def predict_masks(self, frame_prev, frame_next, mvs_left, mvs_right, n, profiler=None, key_cache=None):
         """Same pipeline, but the fused tail emits the per-frame argmax directly: uint8 [n,h,w].
         (Extension for the native-resolution timed region of bench.py; not a reference method.)"""
         h, w = frame_prev.shape[2], frame_prev.shape[3]
-        frames = (frame_prev,) if frame_next is None else (frame_prev, frame_next)
         with _region(profiler, "predict_encoder"), _region(profiler, "predict_decoder"):
-            lows = self._segment(*frames)
+            lo_prev, lo_next = self._key_outputs(self._segment, ("seg", h, w), frame_prev, frame_next, key_cache)
         with _region(profiler, "predict_fusion"):
-            _, mask = ops.seg_tail(lows[0:1], lows[1:2] if frame_next is not None else None, mvs_left, mvs_right, n, (h, w),
-                                   self.no_warp, want_logits=False, want_mask=True)
+            _, mask = ops.seg_tail(lo_prev, lo_next, mvs_left, mvs_right, n, (h, w), self.no_warp, want_logits=False, want_mask=True)
         return mask
 
-    def predict_feature(self, frame_prev, frame_next, mvs_left, mvs_right, n, profiler=None):
+    def predict_feature(self, frame_prev, frame_next, mvs_left, mvs_right, n, profiler=None, key_cache=None):
         """Propagate encoder FEATURES, decode all n maps in one batch (reference :116-181)."""
         h, w = frame_prev.shape[2], frame_prev.shape[3]
-        frames = (frame_prev,) if frame_next is None else (frame_prev, frame_next)
         with _region(profiler, "predict_encoder"):
-            feats = self._encode(*frames)
-        f = feats[0:1]
-        f_next = feats[1:2] if frame_next is not None else None
+            f, f_next = self._key_outputs(self._encode, ("feat", h, w), frame_prev, frame_next, key_cache)
         f_h, f_w = f.shape[2], f.shape[3]
         fwd, bwd = [], []
         if f_next is not None and not self.no_warp:

@@ -16,8 +16,16 @@ PALETTE = np.array([[0, 0, 0], [30, 95, 170], [65, 117, 5], [212, 98, 1], [255, 
 
 
 class FlowPredictor:
-    def __init__(self, flow_model, classes=5, out_size=(1072, 1920), crop=None, compute_metrics=True, ignore_index=255):
+    """cache_keyframes=True + `key_ids=(prev_frame_id, next_frame_id)` in predict_window: the network output of the previous
+    window's `frame_next` is reused when it is this window's `frame_prev` (flow/dataset.py:112-114 builds consecutive windows
+    that way), so a video costs one new key-frame inference per window; masks are bit-identical to the uncached run."""
+
+    def __init__(self, flow_model, classes=5, out_size=(1072, 1920), crop=None, compute_metrics=True, ignore_index=255,
+                 cache_keyframes=False):
+        from .model import KeyframeCache
+
         self.model = flow_model
+        self.key_cache = KeyframeCache() if cache_keyframes else None
         self.classes = classes
         self.out_size = tuple(out_size)
         self.crop = crop  # (crop_h, crop_w) -> sliding crops (no_cropping=False); None -> whole frame (no_cropping=True)
@@ -26,19 +34,19 @@ class FlowPredictor:
         self.last_output = None  # flow/base.py:247, :295
         self.hist = None         # int64[3,K]: intersection, |pred|, |target| accumulated over the run
 
-    def predict_window(self, frame_prev, frame_next, mvs_left, mvs_right, profiler=None, to_host=True):
+    def predict_window(self, frame_prev, frame_next, mvs_left, mvs_right, profiler=None, to_host=True, key_ids=None):
         assert frame_prev.shape[0] == 1                      # flow/base.py:263
         assert len(mvs_left) == len(mvs_right)               # :264
         n = len(mvs_left) + 1                                # :266 -- the list length encodes n, also for no_warp dummies
+        kc = self.key_cache.window(*key_ids) if (self.key_cache is not None and key_ids is not None) else None
         if self.crop is None:
-            logits = self.model.predict(frame_prev, frame_next, mvs_left, mvs_right, n, profiler)["pred"]
+            extra = {} if kc is None else {"key_cache": kc}
+            logits = self.model.predict(frame_prev, frame_next, mvs_left, mvs_right, n, profiler, **extra)["pred"]
             masks = ops.resize_argmax_u8(logits, self.out_size)       # :275-276 without the fp32 intermediate
         else:
-            canvas = crops.compute_output(self.model, n, frame_prev, frame_next, mvs_left, mvs_right, self.crop[0], self.crop[1],
-                                          self.classes, profiler)
-            if tuple(canvas.shape[2:]) != self.out_size:
-                canvas = torch.nn.functional.interpolate(canvas, self.out_size, mode="bilinear", align_corners=True)  # float64: rare path
-            masks = canvas.max(1)[1].to(torch.uint8)
+            # :273 compute_output, then :275-276 (float64 resize + argmax) fused into the canvas's last pass
+            _, masks = crops.compute_output(self.model, n, frame_prev, frame_next, mvs_left, mvs_right, self.crop[0], self.crop[1],
+                                            self.classes, profiler, want_mask=True, key_cache=kc, out_size=self.out_size)
         if self.compute_metrics:                                      # :280-295 temporal consistency between consecutive frames
             for p in range(n):
                 prev = masks[p - 1] if p > 0 else self.last_output

@@ -22,6 +22,11 @@ class FlowDeepLabv3(HipSegNet):
         (flow/model.py:39-40, 189-191, 202-204) use it when the wrapped network offers it."""
         return self._hip_net.segment(*frames)
 
+    def segment_crops(self, frame_a, frame_b, crop_yx, crop_hw):
+        """The same composition on crop windows of full frames, read in place: the sliding-crop route (flow/base.py:182-209)
+        batches its crops through the network with this."""
+        return self._hip_net.segment_crops(frame_a, frame_b, crop_yx, crop_hw)
+
     @staticmethod
     def canonical_name(key):
         if key.endswith("num_batches_tracked"):

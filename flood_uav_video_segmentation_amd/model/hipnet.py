@@ -165,6 +165,26 @@ class HipNet:
                                                     stream_ptr()))
         return out
 
+    def segment_crops(self, frame_a, frame_b, crop_yx, crop_hw):
+        """decoder(encoder(.)) of the crop windows of one or two FULL frames [1,3,H,W] as one batch, read in place
+        (fs_segment_crops; flow/base.py:199-200 clones each crop).  -> [ncrops * (2 if frame_b is given else 1), K, fh, fw]."""
+        self._need_ready()
+        frames = self._frames((frame_a,) if frame_b is None else (frame_a, frame_b), "segment_crops")
+        if any(f.shape[0] != 1 for f in frames):
+            raise RuntimeError("floodseg segment_crops: full frames must be [1,3,H,W] (flow/base.py:263)")
+        with torch.cuda.device(one_device(*frames, handle_device=self.device, what="floodseg segment_crops")):
+            xs_ = [x.float().contiguous() for x in frames]
+            fh_, fw_ = xs_[0].shape[2], xs_[0].shape[3]
+            nc = len(crop_yx)
+            ch, cw = int(crop_hw[0]), int(crop_hw[1])
+            ys = (ctypes.c_int * nc)(*[int(y) for y, _ in crop_yx])
+            xs = (ctypes.c_int * nc)(*[int(x) for _, x in crop_yx])
+            _, fh, fw = self.feature_shape(ch, cw)
+            out = torch.empty((nc * len(xs_), self.classes, fh, fw), dtype=torch.float32, device=xs_[0].device)
+            check(self._lib.fs_segment_crops(self._h, ptr(xs_[0]), ptr(xs_[1]) if len(xs_) > 1 else None, fh_, fw_, nc, ys, xs, ch, cw,
+                                             ptr(out), stream_ptr()))
+        return out
+
     # -- profiling ---------------------------------------------------------------------------
     def profile(self, on):
         self._need_ready()

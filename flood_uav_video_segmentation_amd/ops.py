@@ -154,6 +154,79 @@ def seg_tail(lo_prev, lo_next, grids_left, grids_right, n, out_hw, no_warp, want
     return logits, mask
 
 
+def seg_tail_accumulate(lo_prev, lo_next, grids_left, grids_right, n, crop_hw, no_warp, canvas, count, y0, x0):
+    """The same tail feeding the sliding-crop canvas (flow/base.py:204-205, 226-234): softmax over K of every output frame
+    of this crop is ADDED to canvas [n,K,H,W] (float64) at (y0, x0), count[H,W] += 1 over the crop -- in place."""
+    lib = _lib.load()
+    grids = [] if (lo_next is None or no_warp) else list(grids_left) + list(grids_right)
+    dev = one_device(lo_prev, lo_next, canvas, count, *grids, what="floodseg.seg_tail_accumulate")
+    if canvas.dtype != torch.float64 or count.dtype != torch.float64 or not canvas.is_contiguous() or not count.is_contiguous():
+        raise RuntimeError("floodseg.seg_tail_accumulate: canvas / count must be contiguous float64 tensors")
+    with torch.cuda.device(dev):
+        lo_prev = _f32c(lo_prev, "lo_prev")
+        _, k, h, w = lo_prev.shape
+        frames = n if lo_next is not None else 1
+        if tuple(canvas.shape[:2]) != (frames, k) or tuple(canvas.shape[2:]) != tuple(count.shape):
+            raise RuntimeError(f"floodseg.seg_tail_accumulate: canvas {tuple(canvas.shape)} / count {tuple(count.shape)} do not match [{frames},{k},H,W]")
+        gl = gr = None
+        hg = wg = 1
+        scratch = None
+        keep = []
+        if lo_next is not None:
+            lo_next = _f32c(lo_next, "lo_next")
+            if not no_warp:
+                if len(grids_left) != n - 1 or len(grids_right) != n - 1:
+                    raise RuntimeError("floodseg.seg_tail_accumulate: need n-1 grids per direction")
+                keep = [_f32c(g, "grid") for g in grids]
+                hg, wg = keep[0].shape[-3], keep[0].shape[-2]
+                for g in keep:
+                    if tuple(g.shape[-3:]) != (hg, wg, 2) or g.numel() != hg * wg * 2:
+                        raise RuntimeError("floodseg.seg_tail_accumulate: all grids must be [1,Hg,Wg,2] of one size")
+                gl = _ptr_array(keep[: n - 1])
+                gr = _ptr_array(keep[n - 1:])
+                scratch = torch.empty(2 * (n - 1) * k * hg * wg, dtype=torch.float32, device=dev)
+        check(lib.fs_seg_tail_accumulate(ptr(lo_prev), ptr(lo_next), gl, gr, k, h, w, hg, wg, int(crop_hw[0]), int(crop_hw[1]), int(n),
+                                         int(bool(no_warp)), ptr(canvas), ptr(count), canvas.shape[2], canvas.shape[3], int(y0), int(x0),
+                                         ptr(scratch), stream_ptr()))
+
+
+def crop_grids(grids, frame_hw, crop_yx, crop_hw):
+    """crop_motion_vector (flow/transform.py:215-261) for all crops x all grids of a window in ONE launch.
+    grids: list of [1,Hg,Wg,2] tensors normalised to the frame (H, W); crop_yx: [(y0, x0), ...]; returns fp32
+    [ncrops, len(grids), ch//16, cw//16, 2] -- out[c, j][None] is the grid the reference hands to the network for crop c."""
+    lib = _lib.load()
+    dev = one_device(*grids, what="floodseg.crop_grids")
+    with torch.cuda.device(dev):
+        keep = [_f32c(g, "grid") for g in grids]
+        hg, wg = keep[0].shape[-3], keep[0].shape[-2]
+        for g in keep:
+            if tuple(g.shape[-3:]) != (hg, wg, 2) or g.numel() != hg * wg * 2:
+                raise RuntimeError("floodseg.crop_grids: all grids must be [1,Hg,Wg,2] of one size")
+        nc = len(crop_yx)
+        ys = (ctypes.c_int * nc)(*[int(y) for y, _ in crop_yx])
+        xs = (ctypes.c_int * nc)(*[int(x) for _, x in crop_yx])
+        out = torch.empty((nc, len(keep), int(crop_hw[0]) // 16, int(crop_hw[1]) // 16, 2), dtype=torch.float32, device=dev)
+        check(lib.fs_crop_grids(_ptr_array(keep), len(keep), hg, wg, int(frame_hw[0]), int(frame_hw[1]), nc, ys, xs, int(crop_hw[0]),
+                                int(crop_hw[1]), ptr(out), stream_ptr()))
+    return out
+
+
+def canvas_finish(canvas, count, out_size=None, want_mask=False):
+    """canvas /= count in place (flow/base.py:208); optionally the uint8 argmax of its align_corners=True bilinear resize to
+    `out_size` evaluated in float64 (flow/base.py:275-276) -- the identity resize when out_size is the canvas size."""
+    lib = _lib.load()
+    dev = one_device(canvas, count, what="floodseg.canvas_finish")
+    n, k, h, w = canvas.shape
+    with torch.cuda.device(dev):
+        same = out_size is None or (int(out_size[0]), int(out_size[1])) == (h, w)
+        mask = torch.empty((n, h, w), dtype=torch.uint8, device=dev) if (want_mask and same) else None
+        check(lib.fs_canvas_finish(ptr(canvas), ptr(count), n, k, h * w, ptr(mask), stream_ptr()))
+        if want_mask and not same:
+            mask = torch.empty((n, int(out_size[0]), int(out_size[1])), dtype=torch.uint8, device=dev)
+            check(lib.fs_canvas_resize_argmax(ptr(canvas), n, k, h, w, ptr(mask), int(out_size[0]), int(out_size[1]), stream_ptr()))
+    return mask
+
+
 def argmax_u8(logits):
     """logits.max(1)[1] as uint8 (flow/base.py:276-277)."""
     lib = _lib.load()

@@ -44,14 +44,59 @@ def windows_of_clip(num_frames, frame_delta):
     return [(i * frame_delta, (i + 1) * frame_delta) for i in range(num_frames // frame_delta)]
 
 
-def barrier():
+def window_block(num_windows, rank, world_size):
+    """Frame-window sharding of ONE long clip: rank r takes the contiguous block
+    [num_windows*r // W, num_windows*(r+1) // W) -- blocks differ by at most one window and may be empty when W > windows."""
+    if not 0 <= rank < world_size:
+        raise ValueError(f"rank {rank} outside world of {world_size}")
+    return range(num_windows * rank // world_size, num_windows * (rank + 1) // world_size)
+
+
+def barrier(device=None):
+    """dist.barrier; on RCCL the rank's own device is named explicitly (device_ids) so that the barrier's internal
+    all-reduce can never run on another rank's GPU."""
     if dist.is_available() and dist.is_initialized():
-        dist.barrier()
+        if dist.get_backend() == "nccl":
+            dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+            dist.barrier(device_ids=[torch.device(dev).index])
+        else:
+            dist.barrier()
+
+
+def describe():
+    """What the launcher really set up, for the benchmark's JSON line: (backend name, world size as torch.distributed sees it)."""
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_backend(), dist.get_world_size()
+    return "none", 1
+
+
+def exchange_boundary(last_mask, has_windows, device="cpu"):
+    """Frame-window sharding drops nothing: the temporal-consistency metric (flow/base.py:280-295) pairs every frame with its
+    predecessor, and the predecessor of a rank's FIRST frame is the LAST frame of the nearest earlier rank that had windows.
+    Every rank contributes its last uint8 mask [H,W] (zeros + has_windows=False when its block is empty); returns the mask to
+    pair this rank's first frame with, or None (rank 0 / no earlier rank had windows / single process).  One all_gather of
+    H*W bytes per rank at the end of the run -- not in the per-window loop."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return None
+    rank, size = dist.get_rank(), dist.get_world_size()
+    mine = torch.as_tensor(last_mask, dtype=torch.uint8, device=device).contiguous()
+    flag = torch.tensor([1 if has_windows else 0], dtype=torch.uint8, device=device)
+    masks = [torch.empty_like(mine) for _ in range(size)]
+    flags = [torch.empty_like(flag) for _ in range(size)]
+    dist.all_gather(masks, mine)
+    dist.all_gather(flags, flag)
+    if not has_windows:
+        return None
+    for q in range(rank - 1, -1, -1):
+        if int(flags[q].item()):
+            return masks[q]
+    return None
 
 
 def reduce_run(hist, frames, seconds, device="cpu"):
-    """Combine per-rank results: (sum of int64[3,K] histograms, total frames, max seconds)."""
-    hist = torch.as_tensor(hist, dtype=torch.int64, device=device).clone()
+    """Combine per-rank results: (sum of int64[3,K] histograms, total frames, max seconds).  `device`: where the reduced
+    tensors live -- the rank's GPU under RCCL (on-device all-reduce), "cpu" under gloo."""
+    hist = torch.as_tensor(hist, dtype=torch.int64).to(device).clone()
     cnt = torch.tensor([int(frames)], dtype=torch.int64, device=device)
     sec = torch.tensor([float(seconds)], dtype=torch.float64, device=device)
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:

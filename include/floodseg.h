@@ -97,6 +97,14 @@ int fs_encoder_forward2(fs_handle h, const float* in_a, int Ba, const float* in_
 int fs_segment_forward2(fs_handle h, const float* in_a, int Ba, const float* in_b, int Bb, int H, int W, float* out_nchw,
                         fs_stream stream);
 
+/* Sliding-crop route (the reference's default `no_cropping=False`, flow/base.py:182-209): decoder(encoder(.)) of `ncrops`
+ * windows [ch x cw] of the full frame frame_a [1,3,FH,FW] -- and, when frame_b != NULL, of the same windows of frame_b -- as ONE
+ * batch, read in place from the frames (flow/base.py:199-200 clones every crop; here none is copied).  crop_y / crop_x: host
+ * arrays of the windows' top-left corners.  out: NCHW [ncrops * (frame_b ? 2 : 1), K, fh, fw], the crops of frame_a first;
+ * image i of the result is bit-identical to fs_segment_forward on the cloned crop.  Convolutional networks only. */
+int fs_segment_crops(fs_handle h, const float* frame_a, const float* frame_b, int FH, int FW, int ncrops, const int* crop_y,
+                     const int* crop_x, int ch, int cw, float* out_nchw, fs_stream stream);
+
 /* ---- per-op profiling (HIP events on `stream` around every launch of the next forward calls) -- */
 int fs_profile_enable(fs_handle h, int on);
 /* Synchronises the recorded events; writes one line per op: "name kernel flops bytes ms\n". */
@@ -122,6 +130,14 @@ int fs_seg_tail(const float* lo_prev, const float* lo_next, const float* const* 
                 const float* const* grids_right, int K, int h, int w, int Hg, int Wg, int H, int W, int n, int no_warp,
                 float* out_logits, uint8_t* out_mask, float* scratch, fs_stream stream);
 
+/* The same tail feeding the sliding-crop canvas instead of returning logits: compute_predict_crop's softmax over K
+ * (flow/base.py:226-234) of every output frame is added to canvas[n,K,cH,cW] (float64) at the crop's offset (y0, x0) and
+ * count[cH,cW] += 1 over the crop (flow/base.py:204-205) -- fs_seg_tail + fs_softmax_accumulate without the [n,K,H,W] logits
+ * in HBM, bit-identical to that pair.  Crops that overlap must be accumulated by successive calls on one stream. */
+int fs_seg_tail_accumulate(const float* lo_prev, const float* lo_next, const float* const* grids_left,
+                           const float* const* grids_right, int K, int h, int w, int Hg, int Wg, int H, int W, int n, int no_warp,
+                           double* canvas, double* count, int cH, int cW, int y0, int x0, float* scratch, fs_stream stream);
+
 int fs_argmax_u8(const float* in, int B, int K, int64_t HW, uint8_t* out, fs_stream stream);
 int fs_resize_argmax_u8(const float* in, int B, int K, int Hi, int Wi, uint8_t* out, int Ho, int Wo, fs_stream stream);
 /* hist3K: int64[3][K] = {intersection, |pred|, |target|}, accumulated (caller zeroes). */
@@ -142,6 +158,16 @@ int fs_mv_to_grids(const int* mv, int n, int stride, int hb, int wb, int block, 
 int fs_softmax_accumulate(const float* logits, int n, int K, int h, int w, double* canvas, double* count, int H, int W, int y0,
                           int x0, fs_stream stream);
 int fs_canvas_finish(double* canvas, const double* count, int n, int K, int64_t HW, uint8_t* mask, fs_stream stream);
+
+/* argmax over K of F.interpolate(canvas, (Ho, Wo), bilinear, align_corners=True) evaluated in float64 (flow/base.py:275-276
+ * on compute_output's result), without the [n,K,Ho,Wo] intermediate.  canvas must already be divided by the count. */
+int fs_canvas_resize_argmax(const double* canvas, int n, int K, int Hi, int Wi, uint8_t* mask, int Ho, int Wo, fs_stream stream);
+/* crop_motion_vector (flow/transform.py:215-261) for every crop x every grid of a window in one launch.  grids: host array of
+ * `ngrids` device pointers, each fp32 [Hg, Wg, 2] normalised to the H x W frame; crop c is the ch x cw window at
+ * (crop_y[c], crop_x[c]).  out: fp32 [ncrops][ngrids][ch/16][cw/16][2]: block range by Python's round(), coordinates
+ * renormalised to the crop, half-pixel bilinear resize (cv2.INTER_LINEAR) to (ch/16) x (cw/16). */
+int fs_crop_grids(const float* const* grids, int ngrids, int Hg, int Wg, int H, int W, int ncrops, const int* crop_y,
+                  const int* crop_x, int ch, int cw, float* out, fs_stream stream);
 
 /* ---- building blocks (exposed for op-level parity tests and for other host code) ---------------- */
 int fs_pack_conv_weight(const float* oihw, float* ohwi, int O, int I, int KH, int KW, fs_stream stream);

@@ -67,3 +67,16 @@ def rel_err(got, ref):
     got = torch.as_tensor(got).double()
     ref = torch.as_tensor(ref).double()
     return ((got - ref).abs().max() / ref.abs().max().clamp_min(1e-12)).item()
+
+
+def note(name, value):
+    """Record a measured parity error (GPU runs): appended to gpurun_out/parity_measured.txt so that the asserted tolerances can
+    be kept at a small multiple of what is actually measured (DESIGN.md section 5 quotes this file)."""
+    d = os.path.join(ROOT, "gpurun_out")
+    try:
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, "parity_measured.txt"), "a") as f:
+            f.write(f"{name} {value:.3e}\n")
+    except OSError:
+        pass
+    return value

@@ -1,0 +1,374 @@
+"""Full-size GPU parity: every BASELINE.json config at its own geometry (713x713 / 704x704 / 1072x1920), against the CPU oracle
+run on the same seeded inputs and, where the reference itself could be run (PSPNet), against its committed outputs.
+
+  configs[2]  DeepLabv3-ResNet101, key frames + optical-flow warp of the logits, n = 5, 44x44 grids   (PARITY UNPINNED: torchvision)
+  configs[3]  Segmenter ViT-S/16 (12 layers, d = 384, 6 heads) per frame @704 / @713 and key frames + feature propagation
+  A2          FlowPSPNet feature-based propagation at 713x713 (C = 4096 NHWC warps 90x90 -> 44x44)
+  8(f)-1      the reference's default real-video route: 8 overlapping 713x713 crops of a 1072x1920 frame, batched
+  key-frame cache (one new key frame per window), A/B options, ModelRepresentation on the GPU
+
+Tolerances are 3-5x the errors measured on MI355X (gpurun_out/parity_measured.txt, quoted in DESIGN.md section 5)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import load_golden, note, rel_err
+from flood_uav_video_segmentation_amd import ops, synth
+from flood_uav_video_segmentation_amd.flow import crops
+from flood_uav_video_segmentation_amd.flow.model import FlowModel, KeyframeCache
+from flood_uav_video_segmentation_amd.flow.predict import FlowPredictor
+from flood_uav_video_segmentation_amd.model.deeplabv3 import FlowDeepLabv3
+from flood_uav_video_segmentation_amd.model.pspnet import FlowPSPNet, PSPNet
+from flood_uav_video_segmentation_amd.model.vit import VITSegmentModel
+from flood_uav_video_segmentation_amd.model.wrapper import ModelRepresentation
+from oracle import crops_oracle, deeplab_oracle, flow_oracle, pspnet_oracle, vit_oracle
+
+pytestmark = pytest.mark.gpu
+torch.set_grad_enabled(False)
+
+LOGIT_TOL = 5e-5   # conv networks, fp32 with Winograd F(6,3): measured 0.9-1.3e-5 of max|logit|
+MASK_MIN = 0.9999  # per-pixel argmax agreement: measured >= 0.99998
+VIT_TOL = 3e-4     # Segmenter logits = LayerNorm over K = 5 cosine similarities: amplifies the fp32 noise of 14 blocks (measured ~6e-5)
+N = 5
+
+
+class HP:
+    def __init__(self, layers=50, classes=5, **opts):
+        self.layers, self.classes, self.pretrained = layers, classes, False
+        for k, v in opts.items():
+            setattr(self, k, v)
+
+
+def cu(ts):
+    return [t.cuda() for t in ts]
+
+
+def memo(fn):
+    """The oracle's per-frame network call, memoised on the input's storage: a 713x713 forward costs seconds on the CPU."""
+    cache = {}
+
+    def wrapped(x):
+        key = (x.data_ptr(), tuple(x.shape))
+        if key not in cache:
+            cache[key] = fn(x)
+        return cache[key]
+    return wrapped
+
+
+@pytest.fixture(scope="module")
+def psp():
+    state = synth.make_pspnet_state(50, 5, seed=0)
+    net = FlowPSPNet(HP()).eval()
+    net.load_state_dict(state)
+    return net, state
+
+
+# ------------------------------------------------------------------------------------------------ configs[2]
+def test_config2_deeplabv3_r101_warp_713_against_oracle_parity_unpinned():
+    """BASELINE configs[2] at its own size: FlowModel(FlowDeepLabv3(R101), feature_based=False, no_warp=False).predict, n = 5,
+    44x44 grids.  At 713x713 the 90x90 feature map sends ALL THREE dilated ASPP convs (12/24/36: lattices 8/4/3 pixels wide)
+    to the Winograd lattice path.  Reference: model/deeplabv3.py:47-54 + flow/model.py:184-241.  PARITY UNPINNED (torchvision
+    absent): the oracle restates the public architecture."""
+    state = synth.make_deeplab_state(101, 5, seed=0)
+    net = FlowDeepLabv3(HP(101)).eval()
+    net.load_state_dict(state)
+    clip = synth.make_clip(6, 713, seed=1000)
+    prev, nxt = clip[0:1], clip[5:6]
+    mvl, mvr = synth.make_grids(N, 44, 44, seed=2000)
+    fm = FlowModel(net, feature_based=False, no_warp=False).eval()
+    got = fm.predict(prev.cuda(), nxt.cuda(), cu(mvl), cu(mvr), N, None)["pred"]
+    assert got.shape == (N, 5, 713, 713)
+    enc = lambda x: x  # noqa: E731  (encoder and decoder are composed in `dec`, memoised per key frame)
+    dec = memo(lambda x: deeplab_oracle.decoder(deeplab_oracle.encoder(x, state, 101), state))
+    ref = flow_oracle.predict_segmentation(enc, dec, prev, nxt, mvl, mvr, N, False)["pred"]
+    lo = net.segment(prev.cuda(), nxt.cuda()).cpu()
+    assert lo.shape == (2, 5, 90, 90)
+    assert note("cfg2_deeplab_r101_713_lowres_logits", rel_err(lo, torch.cat([dec(prev), dec(nxt)], 0))) < LOGIT_TOL
+    assert note("cfg2_deeplab_r101_713_pred_logits", rel_err(got.cpu(), ref)) < LOGIT_TOL
+    agree = (ops.argmax_u8(got).cpu() == ref.max(1)[1].to(torch.uint8)).float().mean().item()
+    assert note("cfg2_deeplab_r101_713_mask_disagreement", 1 - agree) < 1 - MASK_MIN
+    hist = ops.iou_hist(ops.argmax_u8(got), ref.max(1)[1].to(torch.uint8).cuda(), 5).cpu().numpy().astype(np.float64)
+    miou = np.mean(hist[0] / (hist[1] + hist[2] - hist[0] + 1e-10))
+    assert note("cfg2_deeplab_r101_713_miou_delta_pp", (1 - miou) * 100) < 0.1  # north star: mIoU within 0.1 pp
+
+
+# ------------------------------------------------------------------------------------------------ configs[3]
+S16 = dict(patch=16, d_model=384, n_layers=12, dec_layers=2, image_size=704)
+
+
+@pytest.fixture(scope="module")
+def vit_s16():
+    state = synth.make_vit_state(5, 704, 16, 384, 12, 2, seed=3)
+    net = VITSegmentModel(5, 704, patch_size=16, d_model=384, n_layers=12, dec_layers=2).eval()
+    net.load_state_dict(state)
+    return net, state
+
+
+@pytest.mark.parametrize("size", [704, 713])
+def test_config3_vit_s16_per_frame_against_oracle(vit_s16, size):
+    """12-layer ViT-S/16 (d = 384, 6 heads) at 704 (44x44 = 1936 patches + cls: the 4-way key split + attention_combine) and
+    at 713 (padded to 720: 45x45 = 2025 patches, resized position embedding, unpadding).  model/vit.py:13-56 with S/16 dims,
+    segm/model/blocks.py:56-77."""
+    net, state = vit_s16
+    x = synth.make_clip(2, size, seed=310 + size)
+    got = net(x.cuda())["pred"]
+    ref = vit_oracle.forward(x, state, 16, 12, 2, 704, 5)["pred"]
+    assert got.shape == ref.shape == (2, 5, size, size)
+    pad = (-size) % 16
+    tok = net.encoder(x.cuda())
+    g = (size + pad) // 16
+    ref_tok = vit_oracle.encoder_tokens(F.pad(x, (0, pad, 0, pad)), state, 16, 12, 704)[:, 1:]
+    assert note(f"cfg3_vit_s16_{size}_tokens", rel_err(tok.permute(0, 2, 3, 1).reshape(2, g * g, 384).cpu(), ref_tok)) < 5e-5
+    assert note(f"cfg3_vit_s16_{size}_logits", rel_err(got.cpu(), ref)) < VIT_TOL
+    agree = (got.max(1)[1].cpu() == ref.max(1)[1]).float().mean().item()
+    assert note(f"cfg3_vit_s16_{size}_mask_disagreement", 1 - agree) < 1e-3
+
+
+@pytest.mark.parametrize("size", [704, 713])
+def test_config3_vit_s16_feature_flow_against_oracle_parity_unpinned(vit_s16, size):
+    """BASELINE configs[3]: key-frame ViT-S/16 + feature-based propagation at full size.  The reference has no such path
+    (flow/base.py:94-103): OUR definition -- the token map [B,D,gh,gw] through FlowModel.predict_feature (flow/model.py:116-181),
+    the Segmenter's own un-padding at the end -- checked against the oracle's predict_feature on the same callables."""
+    net, state = vit_s16
+    clip = synth.make_clip(6, size, seed=1000)
+    prev, nxt = clip[0:1], clip[5:6]
+    pad = (-size) % 16
+    g = (size + pad) // 16
+    mvl, mvr = synth.make_grids(N, 44, 44, seed=2000, frame=(size, size))
+    fm = FlowModel(net, feature_based=True, no_warp=False).eval()
+    got = fm.predict(prev.cuda(), nxt.cuda(), cu(mvl), cu(mvr), N, None)["pred"]
+
+    def enc(x):
+        t = vit_oracle.encoder_tokens(F.pad(x, (0, pad, 0, pad)), state, 16, 12, 704)[:, 1:]
+        return t.transpose(1, 2).reshape(x.shape[0], 384, g, g)
+
+    def dec(f):
+        b, d, gh, gw = f.shape
+        m = vit_oracle.mask_decoder(f.reshape(b, d, gh * gw).transpose(1, 2), state, gh, 2, 5)
+        return F.interpolate(m, size=(gh * 16, gw * 16), mode="bilinear")[:, :, :size, :size]
+
+    ref = flow_oracle.predict_feature(memo(enc), dec, prev, nxt, mvl, mvr, N, False)["pred"]
+    assert got.shape == ref.shape == (N, 5, size, size)
+    assert note(f"cfg3_vit_s16_{size}_feature_flow_logits", rel_err(got.cpu(), ref)) < VIT_TOL
+    agree = (got.max(1)[1].cpu() == ref.max(1)[1]).float().mean().item()
+    assert note(f"cfg3_vit_s16_{size}_feature_flow_mask_disagreement", 1 - agree) < 1e-3
+
+
+def test_vit_two_frame_sizes_interleaved_do_not_share_state(vit_s16):
+    """The frame size travels with the call (fit_output), not with the object: a 704 decode between the encode and the decode
+    of a 713 frame must not change the 713 result (round 1 kept `_frame_hw` on the module)."""
+    net, _ = vit_s16
+    a, b = synth.make_clip(1, 713, seed=5).cuda(), synth.make_clip(1, 704, seed=6).cuda()
+    want = net(a)["pred"]
+    fa = net.encoder(a)
+    net(b)
+    got = net.fit_output(net.decoder(fa), 713, 713)
+    assert torch.equal(got, want)
+
+
+# ------------------------------------------------------------------------------------------------ A2 at the BASELINE size
+def test_pspnet_feature_based_713_against_oracle(psp):
+    """A2 (flow/model.py:116-181) at 713x713: C = 4096 NHWC warps 90x90 -> 44x44, resizes back to 90x90, the key-frame feature
+    through the 67x120 identity grid, ONE batched decoder call on [5,4096,90,90]."""
+    net, state = psp
+    clip = synth.make_clip(6, 713, seed=1000)
+    prev, nxt = clip[0:1], clip[5:6]
+    mvl, mvr = synth.make_grids(N, 44, 44, seed=2000)
+    fm = FlowModel(net, feature_based=True, no_warp=False).eval()
+    got = fm.predict(prev.cuda(), nxt.cuda(), cu(mvl), cu(mvr), N, None)["pred"]
+    enc = memo(lambda x: pspnet_oracle.encoder(x, state, 50))
+    dec = lambda f: pspnet_oracle.decoder(f, state)  # noqa: E731
+    ref = flow_oracle.predict_feature(enc, dec, prev, nxt, mvl, mvr, N, False)["pred"]
+    assert got.shape == ref.shape == (N, 5, 713, 713)
+    assert note("a2_pspnet_feature_713_logits", rel_err(got.cpu(), ref)) < LOGIT_TOL
+    agree = (ops.argmax_u8(got).cpu() == ref.max(1)[1].to(torch.uint8)).float().mean().item()
+    assert note("a2_pspnet_feature_713_mask_disagreement", 1 - agree) < 1 - MASK_MIN
+
+
+# ------------------------------------------------------------------------------------------------ A10
+def test_model_representation_wraps_a_hip_network(psp):
+    """A10 (model/wrapper.py:50-51): in eval the wrapper returns the wrapped network's dict unchanged -- here around the HIP
+    single-frame PSPNet, against the reference golden at 713x713."""
+    _, state = psp
+    renamed = {("cls." + k[len("decoder."):] if k.startswith("decoder.") else k): v for k, v in state.items()}
+    inner = PSPNet(HP()).eval()
+    inner.load_state_dict(renamed)
+    wrapped = ModelRepresentation(inner, rep=None, rep_forward=None).eval()
+    x = synth.make_clip(6, 713, seed=1000)[0:1].cuda()
+    out = wrapped(x)
+    assert set(out) == {"pred"} and torch.equal(out["pred"], inner(x)["pred"])
+    z = load_golden("pspnet_713.npz")
+    ref = F.interpolate(torch.from_numpy(z["logits_lo"]), (713, 713), mode="bilinear", align_corners=True)
+    assert rel_err(out["pred"].cpu(), ref) < LOGIT_TOL
+    with pytest.raises(NotImplementedError):
+        wrapped.train()(x)
+
+
+# ------------------------------------------------------------------------------------------------ A/B options at full size
+@pytest.mark.parametrize("opts", [dict(hip_no_winograd=True), dict(hip_winograd_tile=4), dict(hip_winograd_tile=6),
+                                  dict(hip_no_fused_head=True), dict(hip_no_winograd=True, hip_no_fused_head=True)])
+def test_every_shipped_option_matches_the_reference_golden_at_713(psp, opts):
+    """Each arithmetic-changing route the library ships (direct conv instead of Winograd, F(4,3) / F(6,3) forced, head over
+    the 4096-channel concat instead of the fused pyramid term) against the reference's own 713x713 outputs."""
+    _, state = psp
+    net = FlowPSPNet(HP(**opts)).eval()
+    net.load_state_dict(state)
+    z = load_golden("pspnet_713.npz")
+    zp = load_golden("predict_713.npz")
+    clip = synth.make_clip(6, 713, seed=1000)
+    prev, nxt = clip[0:1].cuda(), clip[5:6].cuda()
+    lo = net.segment(prev)
+    tag = "+".join(f"{k}={v}" for k, v in opts.items())
+    assert note(f"option[{tag}]_713_logits_lo", rel_err(lo.cpu(), z["logits_lo"])) < LOGIT_TOL
+    dl, dr = synth.dummy_grids(N)
+    fm = FlowModel(net, feature_based=False, no_warp=True).eval()
+    mask = fm.predict_masks(prev, nxt, cu(dl), cu(dr), N)
+    assert note(f"option[{tag}]_713_cfg1_mask_disagreement", 1 - (mask.cpu().numpy() == zp["cfg2_mask"]).mean()) < 1 - MASK_MIN
+
+
+# ------------------------------------------------------------------------------------------------ key-frame cache
+@pytest.mark.parametrize("mode", ["segmentation_linear", "segmentation_warp", "feature"])
+def test_keyframe_cache_is_bit_identical_over_consecutive_windows(psp, mode):
+    """Window i's next key is window i+1's previous key (flow/dataset.py:112-114): with the cache each window segments ONE new
+    key frame; masks / logits must be bit-identical to the uncached path over >= 3 consecutive windows at 713x713."""
+    net, _ = psp
+    keys = synth.make_clip(16, 713, seed=1000, only=[0, 5, 10, 15]).cuda()
+    fb, nw = mode == "feature", mode == "segmentation_linear"
+    size = 713 if not fb else 321  # feature mode: 4096-channel maps, same code path at a smaller frame
+    if fb:
+        keys = synth.make_clip(16, size, seed=1000, only=[0, 5, 10, 15]).cuda()
+    grids = [synth.dummy_grids(N) if nw else synth.make_grids(N, 44 if not fb else 20, 44 if not fb else 20, seed=2000 + i, frame=(size, size))
+             for i in range(3)]
+    fm = FlowModel(net, feature_based=fb, no_warp=nw).eval()
+    cache = KeyframeCache()
+    for i in range(3):
+        prev, nxt = keys[i:i + 1], keys[i + 1:i + 2]
+        mvl, mvr = cu(grids[i][0]), cu(grids[i][1])
+        plain = fm.predict(prev, nxt, mvl, mvr, N, None)["pred"]
+        cached = fm.predict(prev, nxt, mvl, mvr, N, None, key_cache=cache.window(5 * i, 5 * i + 5))["pred"]
+        assert torch.equal(plain, cached), f"window {i}"
+    assert (cache.hits, cache.misses) == (2, 1)
+    # a window that does not continue the sequence must miss, not reuse a stale frame
+    again = fm.predict(keys[0:1], keys[1:2], cu(grids[0][0]), cu(grids[0][1]), N, None, key_cache=cache.window(0, 5))["pred"]
+    assert cache.misses == 2 and torch.equal(again, fm.predict(keys[0:1], keys[1:2], cu(grids[0][0]), cu(grids[0][1]), N, None)["pred"])
+
+
+def test_predictor_with_keyframe_cache_matches_uncached_run(psp):
+    """FlowPredictor(cache_keyframes=True) over 3 windows: the same 1072x1920 masks and the same temporal-consistency metric."""
+    net, _ = psp
+    keys = synth.make_clip(16, 713, seed=1000, only=[0, 5, 10, 15]).cuda()
+    dl, dr = (cu(g) for g in synth.dummy_grids(N))
+    fm = FlowModel(net, feature_based=False, no_warp=True).eval()
+    a, b = FlowPredictor(fm, 5, (1072, 1920)), FlowPredictor(fm, 5, (1072, 1920), cache_keyframes=True)
+    for i in range(3):
+        ma = a.predict_window(keys[i:i + 1], keys[i + 1:i + 2], dl, dr, to_host=False)
+        mb = b.predict_window(keys[i:i + 1], keys[i + 1:i + 2], dl, dr, to_host=False, key_ids=(5 * i, 5 * i + 5))
+        assert torch.equal(ma, mb)
+    assert b.key_cache.hits == 2 and torch.equal(a.hist, b.hist) and a.temporal_consistency() == b.temporal_consistency()
+
+
+# ------------------------------------------------------------------------------------------------ 8(f)-1 at full size
+@pytest.fixture(scope="module")
+def full_hd(psp):
+    net, state = psp
+    clip = synth.make_clip(6, (1072, 1920), seed=1200, only=[0, 5])
+    mvl, mvr = synth.make_grids(N, 67, 120, seed=2100, frame=(1072, 1920), jitter=0.01)
+    return net, state, clip[0:1], clip[1:2], mvl, mvr
+
+
+def test_crop_grids_kernel_matches_the_oracle_for_all_eight_crops(full_hd):
+    """fs_crop_grids = crop_motion_vector (flow/transform.py:215-261) for the 8 windows of a 1072x1920 frame in one launch:
+    Python-rounded block ranges (45 or 44 rows, 45 or 44 / 45 columns), renormalisation, resize to 44x44."""
+    _, _, _, _, mvl, mvr = full_hd
+    wins = crops.crop_windows(1072, 1920, 713, 713)
+    yx = [(w[0], w[2]) for w in wins]
+    got = ops.crop_grids(cu(mvl) + cu(mvr), (1072, 1920), yx, (713, 713))
+    assert got.shape == (8, 2 * (N - 1), 44, 44, 2)
+    worst = 0.0
+    for c, (y0, x0) in enumerate(yx):
+        ol, orr = crops_oracle.crop_motion_vector([m.clone() for m in mvl], [m.clone() for m in mvr], 1072, 1920, 713, 713, y0, x0)
+        for j, ref in enumerate(ol + orr):
+            worst = max(worst, (got[c, j].cpu() - ref[0]).abs().max().item())
+        one_l, one_r = crops.crop_motion_vector(cu(mvl), cu(mvr), 1072, 1920, 713, 713, y0, x0)
+        assert all(torch.equal(one_l[j][0], got[c, j]) for j in range(N - 1))          # the per-crop entry = the batched launch
+        assert all(torch.equal(one_r[j][0], got[c, N - 1 + j]) for j in range(N - 1))
+    assert note("crop_grids_1072x1920_max_abs", worst) < 2e-6  # coordinates in [-1.1, 1.1]
+
+
+@pytest.mark.parametrize("no_warp", [False, True])
+def test_sliding_crops_1072x1920_pspnet_batched_route_against_oracle(full_hd, no_warp):
+    """The reference's default real-video route (no_cropping=False, flow/base.py:182-209, 269-277) at its real size with the
+    real network: 8 overlapping 713x713 crops of both key frames through ONE batched network call each way, fused tail +
+    softmax + float64 accumulation, count normalisation, argmax.  Against crops_oracle (cv2 resize restated: unpinned) and
+    against the generic one-crop-at-a-time route on the GPU."""
+    net, state, prev, nxt, mvl, mvr = full_hd
+    if no_warp:
+        mvl, mvr = synth.dummy_grids(N)
+    fm = FlowModel(net, feature_based=False, no_warp=no_warp).eval()
+    canvas, mask = crops.compute_output(fm, N, prev.cuda(), nxt.cuda(), cu(mvl), cu(mvr), 713, 713, 5, want_mask=True)
+    assert canvas.dtype == torch.float64 and canvas.shape == (N, 5, 1072, 1920) and mask.shape == (N, 1072, 1920)
+    # generic route (what any non-HIP flow model takes): per-crop FlowModel.predict + fs_softmax_accumulate
+    fn = lambda p, q, ml, mr: fm.predict(p, q, ml, mr, N, None)["pred"]  # noqa: E731
+    canvas_g, mask_g = crops.compute_output(fm, N, prev.cuda(), nxt.cuda(), cu(mvl), cu(mvr), 713, 713, 5, want_mask=True, function=fn)
+    assert torch.equal(canvas, canvas_g) and torch.equal(mask, mask_g)  # same arithmetic per crop, bit for bit
+    # (no memo here: the oracle clones every crop, and a freed clone's address may be reused by the next one)
+    seg = lambda x: pspnet_oracle.decoder(pspnet_oracle.encoder(x, state, 50), state)  # noqa: E731
+    pred = lambda p, q, ml, mr: flow_oracle.predict_segmentation(lambda x: x, seg, p, q, ml, mr, N, no_warp)["pred"]  # noqa: E731
+    ref = crops_oracle.compute_output(pred, N, prev, nxt, mvl, mvr, 713, 713, 5)
+    tag = "nowarp" if no_warp else "warp"
+    assert note(f"crops_1072x1920_{tag}_prob_max_abs", (canvas.cpu() - ref).abs().max().item()) < 2e-4  # probabilities in [0,1]
+    agree = (mask.cpu() == ref.max(1)[1].to(torch.uint8)).float().mean().item()
+    assert note(f"crops_1072x1920_{tag}_mask_disagreement", 1 - agree) < 1 - MASK_MIN
+    # predict_step on this route: masks at (1072,1920) come straight from the canvas pass; and with the key-frame cache
+    p0 = FlowPredictor(fm, 5, (1072, 1920), crop=(713, 713))
+    m0 = p0.predict_window(prev.cuda(), nxt.cuda(), cu(mvl), cu(mvr), to_host=False)
+    assert torch.equal(m0, mask)
+    p1 = FlowPredictor(fm, 5, (1072, 1920), crop=(713, 713), cache_keyframes=True)
+    p1.predict_window(nxt.cuda(), prev.cuda(), cu(mvl), cu(mvr), to_host=False, key_ids=(-5, 0))  # leaves frame 0 = `prev` cached
+    m1 = p1.predict_window(prev.cuda(), nxt.cuda(), cu(mvl), cu(mvr), to_host=False, key_ids=(0, 5))
+    assert p1.key_cache.hits == 1 and torch.equal(m1, mask)
+
+
+def test_canvas_resize_argmax_f64_matches_torch():
+    """flow/base.py:275-276 on the float64 canvas when the frame is not 1072x1920: bilinear (align_corners=True) in double +
+    argmax, fused; and the identity case through fs_canvas_finish."""
+    g = torch.Generator().manual_seed(3)
+    canvas = torch.rand(3, 5, 97, 131, generator=g, dtype=torch.float64)
+    count = torch.randint(1, 4, (97, 131), generator=g).double()
+    ref_c = canvas / count
+    ref = F.interpolate(ref_c, (211, 307), mode="bilinear", align_corners=True).max(1)[1].to(torch.uint8)
+    cd = canvas.cuda()
+    got = ops.canvas_finish(cd, count.cuda(), (211, 307), want_mask=True)
+    assert torch.equal(cd.cpu(), ref_c)
+    assert (got.cpu() == ref).float().mean().item() > 0.9999  # ties between interpolated doubles may break either way
+    cd2 = canvas.cuda()
+    same = ops.canvas_finish(cd2, count.cuda(), (97, 131), want_mask=True)
+    assert torch.equal(same.cpu(), ref_c.max(1)[1].to(torch.uint8))
+
+
+def test_segment_crops_equals_segment_of_cloned_crops(psp):
+    """fs_segment_crops reads the windows in place from the full frames: bit-identical to cloning each crop (flow/base.py:199-200)
+    and segmenting it, for both frames, at ragged offsets."""
+    net, _ = psp
+    fr = synth.make_clip(2, (300, 420), seed=77).cuda()
+    yx = [(0, 0), (3, 17), (300 - 161, 420 - 161), (64, 259)]
+    got = net.segment_crops(fr[0:1], fr[1:2], yx, (161, 161))
+    assert got.shape[0] == 8
+    for f in range(2):
+        for c, (y, x) in enumerate(yx):
+            one = net.segment(fr[f:f + 1, :, y:y + 161, x:x + 161].contiguous())
+            assert torch.equal(got[f * 4 + c:f * 4 + c + 1], one), (f, c)
+    only_a = net.segment_crops(fr[0:1], None, yx, (161, 161))
+    assert torch.equal(only_a, got[:4])
+    with pytest.raises(RuntimeError, match="leaves the"):
+        net.segment_crops(fr[0:1], None, [(200, 0)], (161, 161))
+
+
+def test_two_tensor_batch_equals_concatenation(psp):
+    """fs_segment_forward2 / fs_encoder_forward2 read the two key frames in place: bit-identical to the torch.cat they replace."""
+    net, _ = psp
+    a, b = synth.make_clip(1, 161, seed=1).cuda(), synth.make_clip(2, 161, seed=2).cuda()
+    assert torch.equal(net.segment(a, b), net.segment(torch.cat([a, b], 0)))
+    assert torch.equal(net.encode_frames(a, b), net.encoder(torch.cat([a, b], 0)))
+    assert torch.equal(net.segment(a, b, a), net.segment(torch.cat([a, b, a], 0)))

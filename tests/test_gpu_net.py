@@ -1,12 +1,13 @@
 """GPU parity of the network path (FlowPSPNet / FlowDeepLabv3 mirrors over the C ABI) against the CPU
 oracle and the reference-generated golden fixtures.  fp32 end to end.
 
-Tolerance: decoder logits max-abs error <= 1e-3 x max|logit|; masks >= 99.9 % equal.
-Measured errors are ~1e-5, the asserts use 2e-4 to leave room for summation-order differences."""
+Tolerance stated by SURVEY.md 8d: decoder logits max-abs error <= 1e-3 x max|logit|; masks >= 99.9 % equal.  The asserts
+are far tighter: 5e-5 (3-5x the ~1e-5 measured on MI355X with Winograd F(6,3), gpurun_out/parity_measured.txt) and 99.99 %
+mask agreement, so that a numerical regression of the Winograd / fused-head paths cannot hide under the stated tolerance."""
 import pytest
 import torch
 
-from conftest import load_golden, rel_err
+from conftest import load_golden, note, rel_err
 from flood_uav_video_segmentation_amd import synth
 from flood_uav_video_segmentation_amd.model.deeplabv3 import FlowDeepLabv3
 from flood_uav_video_segmentation_amd.model.pspnet import FlowPSPNet
@@ -14,7 +15,8 @@ from oracle import deeplab_oracle, pspnet_oracle
 
 pytestmark = pytest.mark.gpu
 torch.set_grad_enabled(False)
-LOGIT_TOL = 2e-4
+LOGIT_TOL = 5e-5
+MASK_MIN = 0.9999
 
 
 class HP:
@@ -67,8 +69,8 @@ def test_pspnet_small_against_oracle_and_reference_golden(psp):
     logits = net.decoder(feat)
     assert logits.shape == (2, 5, 9, 9) and logits.is_contiguous()
     ofeat = pspnet_oracle.encoder(clip, state, 50)
-    assert rel_err(feat.cpu(), ofeat) < LOGIT_TOL
-    assert rel_err(logits.cpu(), pspnet_oracle.decoder(ofeat, state)) < LOGIT_TOL
+    assert note("pspnet_65_feat_vs_oracle", rel_err(feat.cpu(), ofeat)) < LOGIT_TOL
+    assert note("pspnet_65_logits_vs_oracle", rel_err(logits.cpu(), pspnet_oracle.decoder(ofeat, state))) < LOGIT_TOL
     assert rel_err(feat.cpu()[:, ::128], z["feat_slice"]) < LOGIT_TOL       # reference itself
     assert rel_err(logits.cpu(), z["logits"]) < LOGIT_TOL                   # reference itself
 
@@ -79,13 +81,13 @@ def test_pspnet_713_single_frame_against_reference_golden(psp):
     prev = synth.make_clip(6, 713, seed=1000)[0:1].cuda()
     feat = net.encoder(prev)
     assert feat.shape == (1, 4096, 90, 90)
-    assert rel_err(feat.cpu()[:, ::256, ::6, ::6], z["feat_slice"]) < LOGIT_TOL
+    assert note("pspnet_713_feat_vs_reference", rel_err(feat.cpu()[:, ::256, ::6, ::6], z["feat_slice"])) < LOGIT_TOL
     assert abs(feat.double().abs().mean().item() / float(z["feat_absmean"]) - 1) < 1e-5
     lo = net.decoder(feat)
-    assert rel_err(lo.cpu(), z["logits_lo"]) < LOGIT_TOL
+    assert note("pspnet_713_logits_lo_vs_reference", rel_err(lo.cpu(), z["logits_lo"])) < LOGIT_TOL
     from flood_uav_video_segmentation_amd import ops
     _, mask = ops.seg_tail(lo, None, [], [], 1, (713, 713), True, want_logits=False, want_mask=True)
-    assert (mask[0].cpu().numpy() == z["mask"]).mean() > 0.999
+    assert note("pspnet_713_single_mask_disagreement", 1 - (mask[0].cpu().numpy() == z["mask"]).mean()) < 1 - MASK_MIN
 
 
 def test_batch_of_two_equals_two_single_frames(psp):
@@ -109,7 +111,7 @@ def test_pspnet101_small_against_oracle():
     net.load_state_dict(state)
     x = synth.make_clip(1, 65, seed=8)
     got = net.decoder(net.encoder(x.cuda())).cpu()
-    assert rel_err(got, pspnet_oracle.decoder(pspnet_oracle.encoder(x, state, 101), state)) < LOGIT_TOL
+    assert note("pspnet101_65_logits_vs_oracle", rel_err(got, pspnet_oracle.decoder(pspnet_oracle.encoder(x, state, 101), state))) < LOGIT_TOL
 
 
 def test_deeplabv3_r101_against_oracle_parity_unpinned():
@@ -122,8 +124,8 @@ def test_deeplabv3_r101_against_oracle_parity_unpinned():
     feat = net.encoder(x.cuda())
     assert feat.shape == (2, 2048, 13, 13)
     ofeat = deeplab_oracle.encoder(x, state, 101)
-    assert rel_err(feat.cpu(), ofeat) < LOGIT_TOL
-    assert rel_err(net.decoder(feat).cpu(), deeplab_oracle.decoder(ofeat, state)) < LOGIT_TOL
+    assert note("deeplab101_97_feat_vs_oracle", rel_err(feat.cpu(), ofeat)) < LOGIT_TOL
+    assert note("deeplab101_97_logits_vs_oracle", rel_err(net.decoder(feat).cpu(), deeplab_oracle.decoder(ofeat, state))) < LOGIT_TOL
     # keys as FlowDeepLabv3's state_dict spells them (encoder.model.* / decoder.*)
     ref_keys = {("encoder.model." + k[9:] if k.startswith("backbone.") else "decoder." + k[11:]): v for k, v in state.items()}
     net2 = FlowDeepLabv3(HP(101, 5)).eval()
@@ -143,7 +145,7 @@ def test_fused_segment_route_equals_decoder_of_encoder(psp, size, b):
     assert fused.shape == two_step.shape and fused.dtype == torch.float32
     assert torch.equal(net.segment(x), fused)  # bit-repeatable from call to call
     assert rel_err(fused.cpu(), two_step.cpu()) < 2e-5
-    assert (fused.max(1)[1] == two_step.max(1)[1]).float().mean().item() > 0.9995
+    assert (fused.max(1)[1] == two_step.max(1)[1]).float().mean().item() > 0.9998
 
 
 def test_full_hd_frame_no_cropping_route(psp):
@@ -172,7 +174,7 @@ def test_single_frame_pspnet_class_configs0(psp):
     x = synth.make_clip(6, 713, seed=1000)[0:1].cuda()
     out = net(x)["pred"]
     assert out.shape == (1, 5, 713, 713)
-    assert (out.max(1)[1].cpu().numpy() == z["mask"]).mean() > 0.999
+    assert (out.max(1)[1].cpu().numpy() == z["mask"]).mean() > MASK_MIN
     lo = torch.from_numpy(z["logits_lo"])
     ref = torch.nn.functional.interpolate(lo, (713, 713), mode="bilinear", align_corners=True)
     assert rel_err(out.cpu(), ref) < LOGIT_TOL
@@ -220,8 +222,9 @@ def test_two_handles_on_two_streams_do_not_interfere(psp):
 
 
 def test_deeplabv3_aspp_on_the_winograd_lattice_path_parity_unpinned():
-    """At 257x257 the feature map is 33x33: the dilation-12 ASPP conv then takes the Winograd lattice decomposition (144
-    phases of 3x3 pixels) while dilation 24 / 36 stay direct -- the mix configs[2] runs at 713x713.  HIP vs oracle."""
+    """At 257x257 the feature map is 33x33: the dilation-12 ASPP conv takes the Winograd lattice decomposition (144 phases of
+    3x3 pixels) while dilation 24 / 36 stay on the direct kernel (their lattices would be 2x2 / 1x1 pixels: the row rule of
+    net.hip run_conv rejects them).  At 713x713 all three go to the lattice path: tests/test_gpu_fullsize.py.  HIP vs oracle."""
     state = synth.make_deeplab_state(50, 5, seed=2)
     net = FlowDeepLabv3(HP(50, 5)).eval()
     net.load_state_dict(state)
@@ -229,4 +232,4 @@ def test_deeplabv3_aspp_on_the_winograd_lattice_path_parity_unpinned():
     got = net.segment(x.cuda()).cpu()
     ref = deeplab_oracle.decoder(deeplab_oracle.encoder(x, state, 50), state)
     assert got.shape == ref.shape == (1, 5, 33, 33)
-    assert rel_err(got, ref) < LOGIT_TOL
+    assert note("deeplab50_257_logits_vs_oracle", rel_err(got, ref)) < LOGIT_TOL

@@ -178,6 +178,17 @@ def test_blend_is_bit_exact():
     assert torch.equal(ops.blend(a.to(DEV), 0.6).cpu(), 0.6 * a)
     odd = torch.randn(1, 1, 3, 7, generator=g)  # numel % 4 != 0 exercises the scalar tail
     assert torch.equal(ops.blend(odd.to(DEV), 0.25, odd.to(DEV), 0.75).cpu(), 0.25 * odd + 0.75 * odd)
+    # operands with EQUAL but non-dense strides (two `x[:, :, ::2]` views): both must be densified, not only the first
+    big_a, big_b = torch.randn(2, 5, 16, 9, generator=g).to(DEV), torch.randn(2, 5, 16, 9, generator=g).to(DEV)
+    va, vb = big_a[:, :, ::2], big_b[:, :, ::2]
+    assert va.stride() == vb.stride() and not va.is_contiguous()
+    assert torch.equal(ops.blend(va, 0.4, vb, 0.6).cpu(), (0.4 * va + 0.6 * vb).cpu())
+    # channels_last `a` with a contiguous `b`: one common layout, values unchanged
+    ca = torch.randn(1, 64, 6, 7, generator=g).to(DEV).contiguous(memory_format=torch.channels_last)
+    cb = torch.randn(1, 64, 6, 7, generator=g).to(DEV)
+    assert torch.equal(ops.blend(ca, 0.4, cb, 0.6).cpu(), (0.4 * ca + 0.6 * cb).cpu())
+    with pytest.raises(RuntimeError, match="shapes differ"):
+        ops.blend(ca, 0.5, cb[:, :32], 0.5)
 
 
 def test_argmax_resize_argmax_and_iou_hist():
@@ -212,6 +223,9 @@ WINO_TOL = 5e-5  # F(4x4,3x3) in fp32: ~7e-6 relative on unit-scale data, F(6x6,
     (1, 3, 5, 256, 32, 4, False),       # image smaller than the dilation lattice step
     (1, 45, 40, 256, 64, 12, True),     # ASPP-style dilations: 144 lattice phases of 4x4 / 3x4 pixels
     (2, 30, 30, 256, 32, 24, False),    # 576 phases, most of them 1x1 or 2x2 pixels
+    (1, 90, 90, 2048, 256, 12, True),   # DeepLabv3 ASPP at 713x713 (BASELINE configs[2]): 144 phases of 8x8 / 7x7 pixels,
+    (1, 90, 90, 2048, 256, 24, True),   #   576 phases of 4x4 / 3x3,
+    (1, 90, 90, 2048, 256, 36, True),   #   1296 phases of 3x3 / 2x2 -- all three take the lattice path in the network
 ])
 @pytest.mark.parametrize("tile_m", [4, 6, 0])
 def test_winograd_conv3x3(case, tile_m):

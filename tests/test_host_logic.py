@@ -65,7 +65,10 @@ def test_flowmodel_attributes_match_the_reference_contract():
             "predict_segmentation": ["frame_prev", "frame_next", "mvs_left", "mvs_right", "n", "profiler"],
             "warp": ["frame", "motion_vectors"]}
     for name, params in want.items():
-        assert list(inspect.signature(getattr(fm, name)).parameters) == params, name
+        sig = inspect.signature(getattr(fm, name)).parameters
+        assert list(sig)[:len(params)] == params, name
+        # anything beyond the reference's positional signature is an optional keyword (key_cache)
+        assert all(sig[k].default is not inspect.Parameter.empty for k in list(sig)[len(params):]), name
 
 
 def test_pretrained_flag_is_refused_loudly():

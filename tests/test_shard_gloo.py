@@ -45,6 +45,50 @@ def test_two_ranks_shard_and_reduce(tmp_path):
         assert r["sec"] == 2.0  # MAX over ranks
 
 
+def _worker_uneven(rank, world_size, port, out_dir, num_clips, num_windows):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world_size), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    r, _, w = shard.init("gloo")
+    clips = shard.clips_for_rank(num_clips, r, w)
+    hist = torch.zeros(3, 5, dtype=torch.int64)
+    for c in clips:
+        hist += c + 1
+    total, nframes, sec = shard.reduce_run(hist, 20 * len(clips), 0.25 * (rank + 1))
+    # frame-window sharding of one long clip: contiguous blocks + the boundary mask every non-first block needs
+    block = shard.window_block(num_windows, r, w)
+    last = torch.full((4, 6), 100 + (block[-1] if len(block) else 0), dtype=torch.uint8)
+    nb = shard.exchange_boundary(last, len(block) > 0)
+    shard.barrier()
+    torch.save({"clips": clips, "hist": total, "frames": nframes, "sec": sec, "block": list(block),
+                "neighbour": None if nb is None else int(nb[0, 0]), "desc": shard.describe()}, os.path.join(out_dir, f"r{rank}.pt"))
+    torch.distributed.destroy_process_group()
+
+
+def test_four_ranks_uneven_clip_counts_and_window_blocks(tmp_path):
+    """7 clips on 4 ranks (2/2/2/1 clips) and 3 windows on 4 ranks (one EMPTY block): sums, counts, MAX time, and the
+    boundary mask each block pairs its first frame with -- the nearest earlier rank that had windows."""
+    mp.spawn(_worker_uneven, args=(4, _free_port(), str(tmp_path), 7, 3), nprocs=4, join=True)
+    rs = [torch.load(tmp_path / f"r{i}.pt") for i in range(4)]
+    assert [r["clips"] for r in rs] == [[0, 4], [1, 5], [2, 6], [3]]
+    for r in rs:
+        assert torch.equal(r["hist"], torch.full((3, 5), sum(range(1, 8)), dtype=torch.int64))
+        assert r["frames"] == 7 * 20 and r["sec"] == 1.0 and r["desc"] == ("gloo", 4)
+    assert [r["block"] for r in rs] == [[], [0], [1], [2]]           # 3*r//4 .. 3*(r+1)//4
+    assert [r["neighbour"] for r in rs] == [None, None, 100, 101]     # rank 1 is the first with windows: nothing before it
+
+
+def test_eight_ranks_64_clips_is_the_baseline_configs4_layout():
+    """BASELINE configs[4]: 64 clips on 8 GPUs = 8 clips each, every clip exactly once (pure index arithmetic)."""
+    seen = []
+    for r in range(8):
+        mine = shard.clips_for_rank(64, r, 8)
+        assert len(mine) == 8
+        seen += mine
+    assert sorted(seen) == list(range(64))
+    blocks = [list(shard.window_block(50, r, 8)) for r in range(8)]
+    assert sum(blocks, []) == list(range(50)) and max(map(len, blocks)) - min(map(len, blocks)) <= 1
+
+
 def test_single_process_is_a_no_op():
     hist, frames, sec = shard.reduce_run(torch.ones(3, 5, dtype=torch.int64), 20, 0.5)
     assert frames == 20 and sec == 0.5 and int(hist.sum()) == 15
@@ -52,3 +96,4 @@ def test_single_process_is_a_no_op():
     assert shard.windows_of_clip(21, 5) == [(0, 5), (5, 10), (10, 15), (15, 20)]
     perfect = torch.tensor([[4, 4, 4, 4, 4], [4, 4, 4, 4, 4], [4, 4, 4, 4, 4]])
     assert abs(shard.miou_from_hist(perfect) - 1.0) < 1e-9
+    assert shard.exchange_boundary(torch.zeros(2, 2, dtype=torch.uint8), True) is None and shard.describe() == ("none", 1)

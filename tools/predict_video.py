@@ -9,7 +9,9 @@ frames in between and writes the colourised masks.
 Directory layout read (flow/dataset.py:222-240): <data-root>/frames/<video-id>/{images/<i>.jpg, grids/<i>.npy, inv_grids/<i>.npy}.
 Checkpoints are loaded with `torch.load(..., weights_only=True)` (a Lightning `state_dict` with the `model_G.model.` prefix, or
 a bare state_dict); `--synthetic-weights` uses the seeded random weights of the test-suite instead (no checkpoint ships with
-the reference).  Multi-GPU: launch with torchrun; each rank takes a contiguous block of windows, metrics are reduced at the end.
+the reference).  Multi-GPU: launch with torchrun; each rank takes a contiguous block of windows, the one temporal-consistency
+pair across each block boundary is scored from the neighbour's last mask (one all_gather at the end), metrics are reduced.
+Consecutive windows share a key frame: it is segmented once (`--no-keyframe-cache` recomputes it, as the reference does).
 """
 import argparse
 import os
@@ -20,7 +22,7 @@ import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from flood_uav_video_segmentation_amd import shard, synth  # noqa: E402
+from flood_uav_video_segmentation_amd import ops, shard, synth  # noqa: E402
 from flood_uav_video_segmentation_amd.flow.dataset import PredictWindows  # noqa: E402
 from flood_uav_video_segmentation_amd.flow.model import FlowModel  # noqa: E402
 from flood_uav_video_segmentation_amd.flow.predict import PALETTE, FlowPredictor, colorize  # noqa: E402
@@ -61,6 +63,7 @@ def main():
     ap.add_argument("--palette", help="colors.txt (dataset/flow/list/colors.txt); default: the 5-class flood palette")
     ap.add_argument("--out", help="directory for <frame>.png (model.save_images); omit to only time and score")
     ap.add_argument("--no-metrics", action="store_true")                     # model.compute_metrics False
+    ap.add_argument("--no-keyframe-cache", action="store_true", help="segment both key frames of every window (reference behaviour)")
     args = ap.parse_args()
     if not args.synthetic_weights and not args.ckpt:
         ap.error("give --ckpt or --synthetic-weights")
@@ -76,7 +79,7 @@ def main():
     load_weights(net, args)
     fm = FlowModel(net, feature_based=args.feature_based, no_warp=args.no_warp).eval()
     pred = FlowPredictor(fm, classes=args.classes, out_size=tuple(args.size), crop=None if args.no_cropping else tuple(args.crop),
-                         compute_metrics=not args.no_metrics)
+                         compute_metrics=not args.no_metrics, cache_keyframes=not args.no_keyframe_cache)
     ds = PredictWindows(args.data_root, args.video_id, frame_delta=args.frame_delta, no_warp=args.no_warp, size=tuple(args.size))
     palette = np.loadtxt(args.palette).astype("uint8") if args.palette else PALETTE
     if args.out and rank == 0:
@@ -84,15 +87,20 @@ def main():
     shard.barrier()
 
     # windows are independent units given their two key frames: each rank takes a contiguous block (SURVEY 8e "frame-window
-    # sharding"), so that the temporal-consistency pairs inside a block are the reference's; the one pair across each block
-    # boundary is not scored
-    mine = range(len(ds) * rank // world, len(ds) * (rank + 1) // world)
+    # sharding"), so that the temporal-consistency pairs inside a block are the reference's; the pair across each block
+    # boundary (this rank's first frame vs the previous block's last) is scored after the loop from the neighbour's mask
+    mine = shard.window_block(len(ds), rank, world)
     frames = 0
+    first_mask = last_mask = None
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for w in mine:
         item = ds[w]
-        masks = pred.predict_window(item["frame_prev"], item["frame_next"], item["mvs_left"], item["mvs_right"], to_host=False)
+        masks = pred.predict_window(item["frame_prev"], item["frame_next"], item["mvs_left"], item["mvs_right"], to_host=False,
+                                    key_ids=item["key_ids"])
+        if first_mask is None:
+            first_mask = masks[0].clone()
+        last_mask = masks[-1]
         frames += masks.shape[0]
         if args.out:
             from PIL import Image
@@ -100,6 +108,12 @@ def main():
             rgb = colorize(masks, palette).cpu().numpy()
             for p in range(rgb.shape[0]):
                 Image.fromarray(rgb[p]).save(os.path.join(args.out, f"{item['frame_id'] + p}.png"))
+    if world > 1 and not args.no_metrics:
+        dev = torch.device("cuda", local_rank)
+        blank = torch.zeros(tuple(args.size), dtype=torch.uint8, device=dev)
+        neighbour = shard.exchange_boundary(last_mask if last_mask is not None else blank, len(mine) > 0, dev)
+        if neighbour is not None:  # flow/base.py:284-291 for p == 0 with last_output = the previous block's final frame
+            pred.hist = ops.iou_hist(first_mask, neighbour, args.classes, 255, pred.hist)
     torch.cuda.synchronize()
     seconds = time.perf_counter() - t0
     hist = pred.hist if pred.hist is not None else torch.zeros(3, args.classes, dtype=torch.int64)
