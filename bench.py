@@ -12,10 +12,17 @@ key frame), per-frame argmax, uint8 masks copied to the host (the reference's ti
 "predict_interference", flow/base.py:269-277, at native 713x713 resolution).  Inputs are resident in
 HBM when the clock starts.  value = frames all ranks produced / max-over-ranks wall time.
 Everything is fp32 (the reference's precision); data and weights are synthetic (seeded).
+
+`variants` (never the headline): the reference-exact 1072x1920 post-processing, the key-frame cache (one new key frame per
+window), two windows in flight, the other BASELINE configs on one GPU (configs[0] per-frame PSPNet, configs[2] DeepLabv3-R101
++ logit warp, configs[3] ViT-S/16 + feature flow) and the reference's default real-video route (8 crops of a 1072x1920 frame).
 """
 import argparse
+import glob
+import hashlib
 import json
 import os
+import re
 import sys
 import time
 
@@ -25,7 +32,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 from flood_uav_video_segmentation_amd import ops, shard, synth  # noqa: E402
-from flood_uav_video_segmentation_amd.flow.model import FlowModel  # noqa: E402
+from flood_uav_video_segmentation_amd.flow.model import FlowModel, KeyframeCache  # noqa: E402
+from flood_uav_video_segmentation_amd.flow.predict import FlowPredictor  # noqa: E402
 from flood_uav_video_segmentation_amd.model.pspnet import FlowPSPNet  # noqa: E402
 
 SIZE = 713
@@ -36,19 +44,70 @@ PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 d
 
 
 class HP:
-    layers, classes, pretrained = 50, CLASSES, False
+    def __init__(self, layers=50):
+        self.layers, self.classes, self.pretrained = layers, CLASSES, False
 
 
-def timed(fn, steps, warmup):
+def build_id():
+    """Identity of the kernels this process runs: sha256 over the library's sources (csrc/*.hip, *.h, Makefile) and the ABI
+    header.  The .so is a pure function of them and of the image's hipcc, and unlike a git head it exists on the GPU box."""
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "flood_uav_video_segmentation_amd", "csrc")
+    files = sorted(glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.h")) + [os.path.join(csrc, "Makefile")])
+    for f in files + [os.path.join(ROOT, "include", "floodseg.h")]:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def newest_pmc_summary():
+    """(path, parsed json) of the newest profiles/rNN_pmc_traffic.json, or (None, None)."""
+    best = None
+    for f in glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")):
+        m = re.search(r"r(\d+)_pmc_traffic\.json$", f)
+        if m and (best is None or int(m.group(1)) > best[0]):
+            best = (int(m.group(1)), f)
+    if best is None:
+        return None, None
+    try:
+        with open(best[1]) as fh:
+            return best[1], json.load(fh)
+    except (OSError, ValueError):
+        return best[1], None
+
+
+def pmc_traffic(dom_kernel):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes of this same command
+    (tools/gpu_pmc_bench.sh; PMC counters cannot be read from inside the process).  Only a summary measured on THIS build
+    (same build_id) is quoted; anything else gives traffic = null with the reason."""
+    path, pmc = newest_pmc_summary()
+    if path is None:
+        return None, "no profiles/r*_pmc_traffic.json committed"
+    rel = os.path.relpath(path, ROOT)
+    if pmc is None:
+        return None, f"{rel} unreadable"
+    meta = pmc.get("meta")
+    if not meta or "build_id" not in meta:
+        return None, f"{rel} does not record the build it was measured on (a previous round's file): stale"
+    if meta["build_id"] != build_id():
+        return None, f"{rel} was measured on build {meta['build_id']} (git {meta.get('git_head', '?')}), this run is build {build_id()}: stale"
+    hits = [k for k in pmc.get("kernels", {}) if f"<{dom_kernel[5:].replace('x', ', ')}," in k]
+    if not hits or "hbm_bytes_per_launch" not in pmc["kernels"][hits[0]]:
+        return None, f"{rel} has no FETCH_SIZE/WRITE_SIZE pair for {dom_kernel}"
+    return round(pmc["kernels"][hits[0]]["hbm_bytes_per_launch"]), (
+        f"(2*FETCH_SIZE + WRITE_SIZE)*1024 B averaged over the kernel's launches, {rel} (same build {meta['build_id']}, git {meta.get('git_head', '?')})")
+
+
+def timed(fn, steps, warmup, dev):
     for i in range(warmup):
         fn(i)
-    shard.barrier()
+    shard.barrier(dev)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(steps):
         fn(i)
     torch.cuda.synchronize()
-    shard.barrier()
+    shard.barrier(dev)
     return time.perf_counter() - t0
 
 
@@ -65,7 +124,7 @@ def host_threads():
 
 
 def cpu_baseline(state, windows_cpu):
-    """The oracle ("port" of the reference CPU PyTorch path) on the host cores, bounded sample."""
+    """The oracle ("port" of the reference CPU PyTorch path) on the host cores: >= 4 windows of the same workload, ~10-25 s."""
     from oracle import flow_oracle, pspnet_oracle
 
     threads = host_threads()
@@ -73,19 +132,20 @@ def cpu_baseline(state, windows_cpu):
     enc = lambda x: pspnet_oracle.encoder(x, state, 50)  # noqa: E731
     dec = lambda f: pspnet_oracle.decoder(f, state)  # noqa: E731
     dl, dr = synth.dummy_grids(N_DELTA)
-    prev, nxt = windows_cpu[0]
     with torch.no_grad():
-        small = prev[:, :, :129, :129]
+        small = windows_cpu[0][0][:, :, :129, :129]
         flow_oracle.predict_segmentation(enc, dec, small, small, dl, dr, N_DELTA, True)  # warm the thread pool
         t0 = time.perf_counter()
         done = 0
-        while done < 2 and time.perf_counter() - t0 < 25.0:
+        while (done < 4 or time.perf_counter() - t0 < 10.0) and time.perf_counter() - t0 < 25.0:
+            prev, nxt = windows_cpu[done % len(windows_cpu)]
             out = flow_oracle.predict_segmentation(enc, dec, prev, nxt, dl, dr, N_DELTA, True)["pred"]
             out.max(1)[1].to(torch.uint8)
             done += 1
         dt = time.perf_counter() - t0
     return {"value": round(done * N_DELTA / dt, 4), "unit": "frames/s", "cores": threads, "kind": "port",
-            "sample": f"{done} window(s) of the same config (PSPNet-R50, no_warp, n=5, 713x713, both key frames) through oracle/ on torch-CPU fp32"}
+            "sample": f"{done} windows ({dt:.1f} s) of the same config (PSPNet-R50, no_warp, n=5, 713x713, both key frames segmented per window) "
+                      "through oracle/ on torch-CPU fp32"}
 
 
 def main():
@@ -94,7 +154,7 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="skip the secondary variants (1072x1920 post-processing, key-frame cache)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary variants")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="multi-rank rehearsal on a 1-GPU box: every rank uses cuda:0 and the reduction runs over gloo")
     args = ap.parse_args()
@@ -106,6 +166,8 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     torch.set_grad_enabled(False)
+    backend, dist_world = shard.describe()
+    rdev = "cpu" if backend != "nccl" else dev  # RCCL reduces on-device tensors; gloo (rehearsal / single process) on the host
 
     # ---- model: weights replicated on every rank (regenerated from the same seed, no broadcast needed)
     state = synth.make_pspnet_state(50, CLASSES, seed=0)
@@ -127,8 +189,7 @@ def main():
         host_masks.copy_(ops.argmax_u8(logits), non_blocking=True)
         torch.cuda.current_stream().synchronize()  # masks are on the host when the step ends
 
-    elapsed = timed(step_native, args.steps, args.warmup)
-    rdev = "cpu" if args.rehearse_on_one_gpu else dev
+    elapsed = timed(step_native, args.steps, args.warmup, dev)
     _, frames_total, elapsed_max = shard.reduce_run(torch.zeros(3, CLASSES, dtype=torch.int64), args.steps * N_DELTA, elapsed, rdev)
     fps = frames_total / elapsed_max
 
@@ -141,6 +202,11 @@ def main():
                                "frame_delta=5, 713x713, one window per step per GPU, both key frames segmented per window, "
                                "argmax uint8 masks copied to host", "frames_per_step_per_gpu": N_DELTA,
                    "parallelism": f"{world} independent clip shard(s), no data-path collective"},
+        # what the launcher really set up: "nccl" IS RCCL on ROCm; a single process has no process group
+        "distributed": {"backend": backend, "rccl_world_size": dist_world if backend == "nccl" else 0, "world_size": dist_world,
+                        "collectives": "end-of-run all_reduce of int64 frame count + float64 seconds (and int64[3,K] histograms in tools/predict_video.py); "
+                                       "none inside the timed loop"},
+        "build_id": build_id(),
         "reference_claim_fps_other_hw": 76.85,
     }
 
@@ -177,16 +243,7 @@ def main():
         dom_name, dom = max(conv.items(), key=lambda kv: kv[1]["ms"])
         ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
         alg_bytes = sum(r[3] for r in rows if r[1] == dom_name) / max(1, dom["launches"])
-        traffic, traffic_note = None, "no PMC summary committed"
-        try:  # HBM bytes per launch from the committed rocprofv3 --pmc passes of this same command (tools/gpu_pmc_bench.sh);
-            # PMC counters cannot be read from inside the process, so this field is filled from profiles/
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
-                pmc = json.load(f)
-            key = [k for k in pmc if f"<{dom_name[5:].replace('x', ', ')}," in k][0]
-            traffic = round(pmc[key]["hbm_bytes_per_launch"])
-            traffic_note = "(2*FETCH_SIZE + WRITE_SIZE)*1024 B averaged over the kernel's launches, profiles/r01_pmc_traffic.json"
-        except Exception:  # noqa: BLE001
-            pass
+        traffic, traffic_note = pmc_traffic(dom_name)
         all_ms = sum(v["ms"] for v in conv.values())
         all_fl = sum(v["flops"] for v in conv.values())
         result["roofline"] = {
@@ -201,67 +258,123 @@ def main():
         }
 
     if not args.no_extras:
-        # (ii) the reference-exact post-processing: bilinear upsample to 1072x1920 + argmax (flow/base.py:275-277), fused
-        def step_post(i):
-            prev, nxt = windows[i % 4]
-            logits = fm.predict(prev, nxt, dl, dr, N_DELTA, None)["pred"]
-            host_post.copy_(ops.resize_argmax_u8(logits, (1072, 1920)), non_blocking=True)
-            torch.cuda.current_stream().synchronize()
-
-        # (iii) key-frame cache: consecutive windows share a key frame, so only ONE frame is segmented per window
-        cache = {}
-
-        def step_cached(i):
-            prev, nxt = windows[i % 4]
-            lo_prev = cache.get("lo")
-            if lo_prev is None or i % 4 == 0:
-                lo_prev = net.segment(prev)
-            lo_next = net.segment(nxt)
-            _, mask = ops.seg_tail(lo_prev, lo_next, dl, dr, N_DELTA, (SIZE, SIZE), True, want_logits=False, want_mask=True)
-            cache["lo"] = lo_next
-            host_masks.copy_(mask, non_blocking=True)
-            torch.cuda.current_stream().synchronize()
-
-        # (iv) two windows in flight: a second library handle (own workspace) on a second stream, two windows per step.
-        # Independent launches of the two streams fill each other's tile prologues/epilogues and launch tails.
-        net2 = FlowPSPNet(HP()).eval()
-        net2.load_state_dict(state)
-        fm2 = FlowModel(net2, feature_based=False, no_warp=True).eval()
-        side = torch.cuda.Stream()
-        host_masks2 = torch.empty((N_DELTA, SIZE, SIZE), dtype=torch.uint8).pin_memory()
-
-        def step_two(i):
-            main = torch.cuda.current_stream()
-            side.wait_stream(main)
-            prev, nxt = windows[(2 * i) % 4]
-            host_masks.copy_(ops.argmax_u8(fm.predict(prev, nxt, dl, dr, N_DELTA, None)["pred"]), non_blocking=True)
-            with torch.cuda.stream(side):
-                prev2, nxt2 = windows[(2 * i + 1) % 4]
-                host_masks2.copy_(ops.argmax_u8(fm2.predict(prev2, nxt2, dl, dr, N_DELTA, None)["pred"]), non_blocking=True)
-            main.synchronize()
-            side.synchronize()
-
-        e_post = timed(step_post, args.steps, 1)
-        e_cache = timed(step_cached, args.steps, 1)
-        e_two = timed(step_two, max(1, args.steps // 2), 1)
-        _, f_post, e_post = shard.reduce_run(torch.zeros(1, dtype=torch.int64), args.steps * N_DELTA, e_post, rdev)
-        _, f_cache, e_cache = shard.reduce_run(torch.zeros(1, dtype=torch.int64), args.steps * N_DELTA, e_cache, rdev)
-        _, f_two, e_two = shard.reduce_run(torch.zeros(1, dtype=torch.int64), max(1, args.steps // 2) * 2 * N_DELTA, e_two, rdev)
-        result["variants"] = {
-            "fps_post1072x1920_reference_exact_timed_region": round(f_post / e_post, 3),
-            "fps_keyframe_cache_one_new_keyframe_per_window": round(f_cache / e_cache, 3),
-            "fps_two_windows_in_flight_two_streams": round(f_two / e_two, 3),
-        }
+        result["variants"] = variants(args, dev, rdev, net, state, fm, windows, dl, dr, host_masks, host_post)
 
     if rank == 0:
         # direct-convolution-equivalent rate (727.44 GFLOP per key frame); the heavy 3x3 convs run as Winograd
-        # F(6x6,3x3) and the head skips the pyramid channels, which together execute ~2.4x fewer FLOPs, so this "effective" figure may exceed the fp32 MFMA peak
+        # F(6x6,3x3) and the head skips the pyramid channels, which together execute ~2.3x fewer FLOPs, so this "effective"
+        # figure may exceed the fp32 MFMA peak -- it is NOT a roofline fraction
         result["effective_tflops_direct_conv_equivalent_per_gpu"] = round(2 * KEYFRAME_GFLOP * 1e-3 * (fps / world) / N_DELTA, 2)
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(state, windows_cpu)
         print(json.dumps(result), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()
+
+
+def variants(args, dev, rdev, net, state, fm, windows, dl, dr, host_masks, host_post):
+    """Secondary, driver-timed figures (each: same barrier + synchronize bracket, max over ranks).  FPS = output frames / s."""
+    out = {}
+    steps = args.steps
+    few = max(1, min(steps, 40))  # the heavier variants: bounded so that the default run stays within minutes
+
+    def run(name, fn, nsteps, frames_per_step, warm=2):
+        e = timed(fn, nsteps, warm, dev)
+        _, f, e = shard.reduce_run(torch.zeros(1, dtype=torch.int64), nsteps * frames_per_step, e, rdev)
+        out[name] = round(f / e, 3)
+
+    # (ii) the reference-exact post-processing: bilinear upsample to 1072x1920 + argmax (flow/base.py:275-277), fused
+    def step_post(i):
+        prev, nxt = windows[i % 4]
+        logits = fm.predict(prev, nxt, dl, dr, N_DELTA, None)["pred"]
+        host_post.copy_(ops.resize_argmax_u8(logits, (1072, 1920)), non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+    run("fps_post1072x1920_reference_exact_timed_region", step_post, steps, N_DELTA)
+
+    # (iii) key-frame cache (product feature: FlowModel.predict(..., key_cache=...)): consecutive windows of a clip share a
+    # key frame, so ONE frame is segmented per window (SURVEY 8d); bit-identical masks (tests/test_gpu_fullsize.py)
+    cache = KeyframeCache()
+
+    def step_cached(i):
+        w = i % 4
+        if w == 0:
+            cache.clear()  # a new clip starts: its first window segments both key frames
+        prev, nxt = windows[w]
+        mask = fm.predict_masks(prev, nxt, dl, dr, N_DELTA, None, key_cache=cache.window(5 * w, 5 * w + 5))
+        host_masks.copy_(mask, non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+    run("fps_keyframe_cache_one_new_keyframe_per_window", step_cached, steps, N_DELTA)
+
+    # (iv) two windows in flight: a second library handle (own workspace) on a second stream, two windows per step
+    net2 = FlowPSPNet(HP()).eval()
+    net2.load_state_dict(state)
+    fm2 = FlowModel(net2, feature_based=False, no_warp=True).eval()
+    side = torch.cuda.Stream()
+    host_masks2 = torch.empty((N_DELTA, SIZE, SIZE), dtype=torch.uint8).pin_memory()
+
+    def step_two(i):
+        main_s = torch.cuda.current_stream()
+        side.wait_stream(main_s)
+        prev, nxt = windows[(2 * i) % 4]
+        host_masks.copy_(ops.argmax_u8(fm.predict(prev, nxt, dl, dr, N_DELTA, None)["pred"]), non_blocking=True)
+        with torch.cuda.stream(side):
+            prev2, nxt2 = windows[(2 * i + 1) % 4]
+            host_masks2.copy_(ops.argmax_u8(fm2.predict(prev2, nxt2, dl, dr, N_DELTA, None)["pred"]), non_blocking=True)
+        main_s.synchronize()
+        side.synchronize()
+    run("fps_two_windows_in_flight_two_streams", step_two, max(1, steps // 2), 2 * N_DELTA)
+    del net2, fm2
+
+    # (v) BASELINE configs[0] on the GPU: single-frame PSPNet inference over a 4-frame clip, one frame per step
+    frames4 = [windows[i][0] for i in range(4)]
+
+    def step_single(i):
+        lo = net.segment(frames4[i % 4])
+        _, mask = ops.seg_tail(lo, None, [], [], 1, (SIZE, SIZE), True, want_logits=False, want_mask=True)
+        host_masks[:1].copy_(mask, non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+    run("fps_config0_pspnet_r50_single_frame", step_single, steps, 1)
+
+    # (vi) the reference's default real-video route (no_cropping=False): 1072x1920 frames, 8 overlapping 713x713 crops of both
+    # key frames batched through the network, fused tail + softmax + float64 canvas, masks at 1072x1920 (flow/base.py:182-209)
+    hd = synth.make_clip(6, (1072, 1920), seed=1200, only=[0, 5]).to(dev)
+    gl, gr = [[g.to(dev) for g in gs] for gs in synth.make_grids(N_DELTA, 67, 120, seed=2100, frame=(1072, 1920), jitter=0.01)]
+    fmw = FlowModel(net, feature_based=False, no_warp=False).eval()
+    pred = FlowPredictor(fmw, CLASSES, (1072, 1920), crop=(SIZE, SIZE), compute_metrics=False)
+
+    def step_crops(i):
+        host_post.copy_(pred.predict_window(hd[0:1], hd[1:2], gl, gr, to_host=False), non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+    run("fps_real_video_route_8crops_1072x1920_warp", step_crops, max(1, few // 2), N_DELTA, warm=1)
+    del pred, hd
+
+    # (vii) BASELINE configs[2]: DeepLabv3-ResNet101 key frames + optical-flow warp of the logits
+    from flood_uav_video_segmentation_amd.model.deeplabv3 import FlowDeepLabv3
+    wl, wr = [[g.to(dev) for g in gs] for gs in synth.make_grids(N_DELTA, 44, 44, seed=2000)]
+    dl3 = FlowDeepLabv3(HP(101)).eval()
+    dl3.load_state_dict(synth.make_deeplab_state(101, CLASSES, 0))
+    fm3 = FlowModel(dl3, feature_based=False, no_warp=False).eval()
+
+    def step_cfg2(i):
+        prev, nxt = windows[i % 4]
+        host_masks.copy_(fm3.predict_masks(prev, nxt, wl, wr, N_DELTA), non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+    run("fps_config2_deeplabv3_r101_logit_warp", step_cfg2, few, N_DELTA)
+    del dl3, fm3
+
+    # (viii) BASELINE configs[3]: Segmenter ViT-S/16 key frames + feature propagation (our extension: the reference has none)
+    from flood_uav_video_segmentation_amd.model.vit import VITSegmentModel
+    vit = VITSegmentModel(CLASSES, 704, patch_size=16, d_model=384, n_layers=12, dec_layers=2).eval()
+    vit.load_state_dict(synth.make_vit_state(CLASSES, 704, 16, 384, 12, 2, seed=0))
+    fmv = FlowModel(vit, feature_based=True, no_warp=False).eval()
+
+    def step_cfg3(i):
+        prev, nxt = windows[i % 4]
+        out_ = fmv.predict(prev, nxt, wl, wr, N_DELTA, None)["pred"]
+        host_masks.copy_(ops.argmax_u8(out_), non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+    run("fps_config3_vit_s16_feature_flow", step_cfg3, few, N_DELTA)
+    return out
 
 
 if __name__ == "__main__":

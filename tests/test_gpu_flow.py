@@ -13,7 +13,7 @@ from oracle import flow_oracle, pspnet_oracle
 pytestmark = pytest.mark.gpu
 torch.set_grad_enabled(False)
 TOL = 2e-5       # toy model: tiny torch convs on the GPU + HIP interpolation kernels
-NET_TOL = 5e-5   # full PSPNet in fp32: 3-5x the ~1e-5 measured (see test_gpu_net.py)
+NET_TOL = 3e-5   # full PSPNet in fp32: 3-5x the 3-8e-6 measured (see test_gpu_net.py)
 MASK_MIN = 0.9999
 
 

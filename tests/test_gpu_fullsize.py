@@ -27,9 +27,9 @@ from oracle import crops_oracle, deeplab_oracle, flow_oracle, pspnet_oracle, vit
 pytestmark = pytest.mark.gpu
 torch.set_grad_enabled(False)
 
-LOGIT_TOL = 5e-5   # conv networks, fp32 with Winograd F(6,3): measured 0.9-1.3e-5 of max|logit|
-MASK_MIN = 0.9999  # per-pixel argmax agreement: measured >= 0.99998
-VIT_TOL = 3e-4     # Segmenter logits = LayerNorm over K = 5 cosine similarities: amplifies the fp32 noise of 14 blocks (measured ~6e-5)
+LOGIT_TOL = 3e-5   # conv networks, fp32 with Winograd F(6,3): measured 4-8e-6 of max|logit| (worst: 8.0e-6, head over the concat)
+MASK_MIN = 0.9999  # per-pixel argmax agreement: measured >= 0.999986
+VIT_TOL = 1.5e-4   # Segmenter logits = LayerNorm over K = 5 cosine similarities: amplifies the fp32 noise of 14 blocks (measured 3.4e-5)
 N = 5
 
 
@@ -119,7 +119,7 @@ def test_config3_vit_s16_per_frame_against_oracle(vit_s16, size):
     tok = net.encoder(x.cuda())
     g = (size + pad) // 16
     ref_tok = vit_oracle.encoder_tokens(F.pad(x, (0, pad, 0, pad)), state, 16, 12, 704)[:, 1:]
-    assert note(f"cfg3_vit_s16_{size}_tokens", rel_err(tok.permute(0, 2, 3, 1).reshape(2, g * g, 384).cpu(), ref_tok)) < 5e-5
+    assert note(f"cfg3_vit_s16_{size}_tokens", rel_err(tok.permute(0, 2, 3, 1).reshape(2, g * g, 384).cpu(), ref_tok)) < 4e-5
     assert note(f"cfg3_vit_s16_{size}_logits", rel_err(got.cpu(), ref)) < VIT_TOL
     agree = (got.max(1)[1].cpu() == ref.max(1)[1]).float().mean().item()
     assert note(f"cfg3_vit_s16_{size}_mask_disagreement", 1 - agree) < 1e-3

@@ -2,7 +2,7 @@
 oracle and the reference-generated golden fixtures.  fp32 end to end.
 
 Tolerance stated by SURVEY.md 8d: decoder logits max-abs error <= 1e-3 x max|logit|; masks >= 99.9 % equal.  The asserts
-are far tighter: 5e-5 (3-5x the ~1e-5 measured on MI355X with Winograd F(6,3), gpurun_out/parity_measured.txt) and 99.99 %
+are far tighter: 3e-5 (3-5x the 3-8e-6 measured on MI355X with Winograd F(6,3), gpurun_out/parity_measured.txt) and 99.99 %
 mask agreement, so that a numerical regression of the Winograd / fused-head paths cannot hide under the stated tolerance."""
 import pytest
 import torch
@@ -15,7 +15,7 @@ from oracle import deeplab_oracle, pspnet_oracle
 
 pytestmark = pytest.mark.gpu
 torch.set_grad_enabled(False)
-LOGIT_TOL = 5e-5
+LOGIT_TOL = 3e-5
 MASK_MIN = 0.9999
 
 

@@ -1,6 +1,7 @@
 """GPU parity of every kernel behind the C ABI against the torch-CPU op it replaces (fp32).
 Tolerances are relative to the reference tensor's max |value| and written per test."""
 import pytest
+from conftest import note
 import torch
 import torch.nn.functional as F
 
@@ -211,6 +212,7 @@ def test_argmax_resize_argmax_and_iou_hist():
 
 
 WINO_TOL = 5e-5  # F(4x4,3x3) in fp32: ~7e-6 relative on unit-scale data, F(6x6,3x3) ~1.5x that; the tolerance leaves room for K = 1024
+WINO_TOL_2048 = 1.5e-4  # the error grows ~sqrt(Cin): Cin = 2048 with F(6,3) forced measures 6.7e-5 (F(4,3), the network's pick there: lower)
 
 
 @pytest.mark.parametrize("case", [
@@ -247,7 +249,7 @@ def test_winograd_conv3x3(case, tile_m):
     view = out[..., 16:]
     check(lib.fs_conv3x3_winograd_nhwc(ptr(xd), cin, ptr(wd), ptr(scd), ptr(shd), ptr(view), cout + 32, b, h, w, cin, cout, dil, int(relu),
                                        tile_m, ptr(ws), stream_ptr()))
-    assert rel(out[..., 16:16 + cout].permute(0, 3, 1, 2), ref) < WINO_TOL
+    assert note(f"winograd_op_{h}x{w}x{cin}_d{dil}_m{tile_m}", rel(out[..., 16:16 + cout].permute(0, 3, 1, 2), ref)) < (WINO_TOL if cin <= 1024 else WINO_TOL_2048)
     assert (out[..., :16] == -7.0).all() and (out[..., 16 + cout:] == -7.0).all()
 
 

@@ -1,6 +1,12 @@
 #!/usr/bin/env python3
 """FPS of every BASELINE.json config on ONE MI355X (secondary numbers for DESIGN.md; bench.py is the headline).
-All fp32, synthetic weights/frames, inputs resident in HBM, uint8 masks copied to the host each step."""
+All fp32, synthetic weights/frames, inputs resident in HBM, uint8 masks copied to the host each step.
+
+    python tools/bench_configs.py                 # all rows
+    python tools/bench_configs.py --only cfg2     # one config (cfg0 cfg1 cfg4 feat cfg2 cfg3 vitb) -- the command that
+                                                  # `rocprofv3 --kernel-trace --stats` wraps for profiles/r02_cfg*_kernel_stats.csv
+"""
+import argparse
 import os
 import sys
 import time
@@ -35,6 +41,11 @@ def timeit(fn, steps=10, warmup=2):
 
 
 def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default="", help="cfg0 | cfg1 | cfg4 | feat | cfg2 | cfg3 | vitb")
+    ap.add_argument("--steps", type=int, default=10)
+    args = ap.parse_args()
+    want = lambda k: not args.only or args.only == k  # noqa: E731
     dev = "cuda"
     host = torch.empty((N, 713, 713), dtype=torch.uint8).pin_memory()
     rows = []
@@ -49,41 +60,52 @@ def main():
             torch.cuda.current_stream().synchronize()
         return step
 
-    psp = FlowPSPNet(HP(50)).eval()
-    psp.load_state_dict(synth.make_pspnet_state(50, 5, 0))
+    psp = None
+    if any(want(k) for k in ("cfg0", "cfg1", "cfg4", "feat")):
+        psp = FlowPSPNet(HP(50)).eval()
+        psp.load_state_dict(synth.make_pspnet_state(50, 5, 0))
 
     def single(i):  # configs[0] semantics on the GPU: one frame per step, PSPNet.forward + argmax
         lo = psp.segment(keys[i % 5:i % 5 + 1])
         _, mask = ops.seg_tail(lo, None, [], [], 1, (713, 713), True, want_logits=False, want_mask=True)
         host[:1].copy_(mask, non_blocking=True)
         torch.cuda.current_stream().synchronize()
-    t = timeit(single)
-    rows.append(("configs[0] PSPNet-R50 single-frame (GPU)", 1 / t, t * 1e3))
-    t = timeit(window(FlowModel(psp, feature_based=False, no_warp=True).eval(), (dl, dr)))
-    rows.append(("configs[1] PSPNet-R50 keyframe + linear interp", N / t, t * 1e3))
-    t = timeit(window(FlowModel(psp, feature_based=False, no_warp=False).eval(), (wl, wr)))
-    rows.append(("configs[4]/1GPU PSPNet-R50 keyframe + logit warp", N / t, t * 1e3))
-    t = timeit(window(FlowModel(psp, feature_based=True, no_warp=False).eval(), (wl, wr)), steps=5)
-    rows.append(("(extra) PSPNet-R50 keyframe + FEATURE warp", N / t, t * 1e3))
+    st = args.steps
+    if want("cfg0"):
+        t = timeit(single, st)
+        rows.append(("configs[0] PSPNet-R50 single-frame (GPU)", 1 / t, t * 1e3))
+    if want("cfg1"):
+        t = timeit(window(FlowModel(psp, feature_based=False, no_warp=True).eval(), (dl, dr)), st)
+        rows.append(("configs[1] PSPNet-R50 keyframe + linear interp", N / t, t * 1e3))
+    if want("cfg4"):
+        t = timeit(window(FlowModel(psp, feature_based=False, no_warp=False).eval(), (wl, wr)), st)
+        rows.append(("configs[4]/1GPU PSPNet-R50 keyframe + logit warp", N / t, t * 1e3))
+    if want("feat"):
+        t = timeit(window(FlowModel(psp, feature_based=True, no_warp=False).eval(), (wl, wr)), steps=max(1, st // 2))
+        rows.append(("(extra) PSPNet-R50 keyframe + FEATURE warp", N / t, t * 1e3))
     del psp
-    dl3 = FlowDeepLabv3(HP(101)).eval()
-    dl3.load_state_dict(synth.make_deeplab_state(101, 5, 0))
-    t = timeit(window(FlowModel(dl3, feature_based=False, no_warp=False).eval(), (wl, wr)))
-    rows.append(("configs[2] DeepLabv3-R101 keyframe + logit warp", N / t, t * 1e3))
-    del dl3
-    vit = VITSegmentModel(5, 704, patch_size=16, d_model=384, n_layers=12, dec_layers=2).eval()
-    vit.load_state_dict(synth.make_vit_state(5, 704, 16, 384, 12, 2, seed=0))
-    t = timeit(window(FlowModel(vit, feature_based=True, no_warp=False).eval(), (wl, wr)))
-    rows.append(("configs[3] Segmenter ViT-S/16 keyframe + feature flow (extension)", N / t, t * 1e3))
-    vitb = VITSegmentModel(5, 704).eval()
-    vitb.load_state_dict(synth.make_vit_state(5, 704, seed=0))
+    if want("cfg2"):
+        dl3 = FlowDeepLabv3(HP(101)).eval()
+        dl3.load_state_dict(synth.make_deeplab_state(101, 5, 0))
+        t = timeit(window(FlowModel(dl3, feature_based=False, no_warp=False).eval(), (wl, wr)), st)
+        rows.append(("configs[2] DeepLabv3-R101 keyframe + logit warp", N / t, t * 1e3))
+        del dl3
+    if want("cfg3"):
+        vit = VITSegmentModel(5, 704, patch_size=16, d_model=384, n_layers=12, dec_layers=2).eval()
+        vit.load_state_dict(synth.make_vit_state(5, 704, 16, 384, 12, 2, seed=0))
+        t = timeit(window(FlowModel(vit, feature_based=True, no_warp=False).eval(), (wl, wr)), st)
+        rows.append(("configs[3] Segmenter ViT-S/16 keyframe + feature flow (extension)", N / t, t * 1e3))
+        del vit
+    if want("vitb"):
+        vitb = VITSegmentModel(5, 704).eval()
+        vitb.load_state_dict(synth.make_vit_state(5, 704, seed=0))
 
-    def vit_single(i):
-        out = vitb(keys[i % 5:i % 5 + 1])["pred"]
-        host[:1].copy_(ops.argmax_u8(out.contiguous()), non_blocking=True)
-        torch.cuda.current_stream().synchronize()
-    t = timeit(vit_single)
-    rows.append(("(extra) Segmenter ViT-B/32 per-frame (as model/vit.py builds it)", 1 / t, t * 1e3))
+        def vit_single(i):
+            out = vitb(keys[i % 5:i % 5 + 1])["pred"]
+            host[:1].copy_(ops.argmax_u8(out.contiguous()), non_blocking=True)
+            torch.cuda.current_stream().synchronize()
+        t = timeit(vit_single, st)
+        rows.append(("(extra) Segmenter ViT-B/32 per-frame (as model/vit.py builds it)", 1 / t, t * 1e3))
     print(f"{'config':68s} {'FPS':>9s} {'ms/step':>9s}")
     for name, fps, ms in rows:
         print(f"{name:68s} {fps:9.1f} {ms:9.3f}")

@@ -1,6 +1,8 @@
 #!/bin/bash
 # HBM traffic of the dominant kernel during bench.py: FETCH_SIZE and WRITE_SIZE in SEPARATE passes (TCC slots),
 # kernel-trace only (no sys/hip/hsa trace domains together with --pmc).  Summary -> gpurun_out/pmc_bench_summary.json
+# (copy it to profiles/rNN_pmc_traffic.json: bench.py quotes it only while its build_id matches the running sources).
+# usage on the GPU box: GIT_HEAD=<short sha> tools/gpu_pmc_bench.sh
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/pmcb
@@ -11,7 +13,9 @@ for C in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum"; do
   timeout -k 10 400 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $d -- python3 $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-extras > $d.log 2>&1; echo "pass $C exit=$?"
 done
 python3 - <<PY
-import csv, glob, collections, json
+import csv, glob, collections, json, os, sys, hashlib
+sys.path.insert(0, "$R")
+import bench
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob("$O/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
@@ -25,7 +29,11 @@ for k, cs in agg.items():
         # rocprofv3 reports KiB; on gfx950 FETCH_SIZE counts 128-B requests as 64 B -> x2 (MI355X_MICROARCH.md, HBM)
         e["hbm_bytes_per_launch"] = (2.0 * e["FETCH_SIZE"]["mean"] + e["WRITE_SIZE"]["mean"]) * 1024.0
     out[k] = e
-json.dump(out, open("$R/gpurun_out/pmc_bench_summary.json", "w"), indent=1)
+so = open("$R/flood_uav_video_segmentation_amd/libfloodseg.so", "rb").read()
+meta = {"build_id": bench.build_id(), "git_head": os.environ.get("GIT_HEAD", "unknown"), "so_sha256": hashlib.sha256(so).hexdigest()[:16],
+        "command": "rocprofv3 --kernel-trace --pmc <C> -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-extras, one pass per counter group",
+        "formula": "hbm_bytes_per_launch = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (rocprofv3 reports KiB; gfx950 counts a 128-B fetch as 64 B)"}
+json.dump({"meta": meta, "kernels": out}, open("$R/gpurun_out/pmc_bench_summary.json", "w"), indent=1)
 for k, e in out.items():
     print(k[:60], {c: (round(v["mean"], 1) if isinstance(v, dict) else round(v / 1e6, 2)) for c, v in e.items()})
 PY
