@@ -767,7 +767,16 @@ int net_decoder(fs_handle h, const float* feat, int B, int fh, int fw, float* ou
     float* pooled = h->small;
     float* reduced = h->small + (size_t)B * 2048;
     FS_TRY(prof_begin(h, "aspp.pool", "adaptive_avgpool", 0, 4.0 * px * 2048.0, s));
-    FS_TRY(launch_adaptive_avgpool(feat, 2048, pooled, B, fh, fw, 2048, 1, s));
+    if (fh % 6 == 0 && fw % 6 == 0) {
+        // one window per image is only B * 64 workgroups with 254 serial pixels per thread (0.14 ms at 90x90): sum 6x6 cells
+        // first (4608 workgroups), then the 36 cell means -- the PSPNet pyramid's two-stage pooling; bins 2 / 3 land in scratch
+        float* cells = h->small + (size_t)B * 4096;
+        float* spare = cells + (size_t)B * 36 * 2048;
+        FS_TRY(launch_adaptive_avgpool(feat, 2048, cells, B, fh, fw, 2048, 6, s));
+        FS_TRY(launch_ppm_pool_combine(cells, pooled, spare, spare + (size_t)B * 4 * 2048, B, 2048, s));
+    } else {
+        FS_TRY(launch_adaptive_avgpool(feat, 2048, pooled, B, fh, fw, 2048, 1, s));
+    }
     FS_TRY(prof_end(h, s));
     FS_TRY(prof_begin(h, h->aspp_pool.name, "rowdot_1x1", 2.0 * B * 2048.0 * 256.0, 4.0 * 2048.0 * 256.0, s));
     FS_TRY(launch_rowdot_1x1(pooled, 2048, h->aspp_pool.w, h->aspp_pool.scale, h->aspp_pool.shift, reduced, 256, B, 2048, 256, 1, s));

@@ -9,19 +9,11 @@
 
 namespace fs {
 
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-// The 2-D transforms keep (m+2)^2 values live per thread; WVI / WVO = channels per thread in the input / output transform
-// (float2 where the register budget allows: F(6,3)'s input transform at 175 VGPRs still gains from 8-byte accesses, its
-// output transform at 214 VGPRs does not).
-template <int WV> struct WVec;
-template <> struct WVec<1> { typedef float type; };
-template <> struct WVec<2> { typedef f32x2 type; };
-
 template <int MT> struct Wino;
 
 // ---------------------------------------------------------------- F(4,3)
 template <> struct Wino<4> {
-    static constexpr int A = 6, WVI = 2, WVO = 2;
+    static constexpr int A = 6;
     template <typename T> __device__ static __forceinline__ void bt(const T d[6], T t[6]) {  // B^T d
         t[0] = 4.f * d[0] - 5.f * d[2] + d[4];
         t[1] = -4.f * (d[1] + d[2]) + d[3] + d[4];
@@ -48,7 +40,7 @@ template <> struct Wino<4> {
 
 // ---------------------------------------------------------------- F(6,3)
 template <> struct Wino<6> {
-    static constexpr int A = 8, WVI = 2, WVO = 1;
+    static constexpr int A = 8;
     template <typename T> __device__ static __forceinline__ void bt(const T d[8], T t[8]) {
         const T a = d[2] - 4.25f * d[4] + d[6], b = d[1] - 4.25f * d[3] + d[5];
         const T c = 0.25f * d[2] - 1.25f * d[4] + d[6], e = 0.5f * d[1] - 2.5f * d[3] + 2.f * d[5];
@@ -121,108 +113,127 @@ int launch_winograd_filter(const float* w_oihw, float* U, int O, int I, int mt, 
     return 0;
 }
 
-// ---- input transform: thread per (tile, channel group); (m+2)^2 coalesced loads (zero outside the image)
+// ---- input / output transforms.  Both are separable (rows, then columns); a workgroup takes ONE tile x 128 channels and splits
+// the two 1-D passes over A x 32 threads through LDS: thread (x, cq) loads column x of the patch for channel quad cq (A
+// float4 loads, 512 contiguous bytes per 32 lanes), transforms it and parks the A results in LDS; after the barrier thread
+// (r, cq) transforms row r and stores A float4 results.  (Round 1 gave a thread a whole (m+2)^2 patch: 64 loads, 175-214
+// VGPRs, and a 90x90x256 map is only 900 waves -- under one per SIMD, every load latency exposed: 15 us for 46 MB.  Split
+// this way the same map is 3600 waves of 8 loads each.)  The arithmetic (B^T d B, A^T m A; which products are formed and in
+// which order) is unchanged.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
 template <int MT>
-__global__ __launch_bounds__(256) void winograd_input_kernel(const float* __restrict__ in, int ld_in, float* __restrict__ V, int B, int H,
-                                                             int W, int CV, int th, int tw, int dil) {
-    constexpr int A = Wino<MT>::A, WV = Wino<MT>::WVI;
-    typedef typename WVec<WV>::type wv_t;
+__global__ __launch_bounds__((MT + 2) * 32) void winograd_input_kernel(const float* __restrict__ in, int ld_in, float* __restrict__ V, int B, int H,
+                                                                       int W, int C4, int th, int tw, int dil) {
+    constexpr int A = Wino<MT>::A;
+    __shared__ f32x4 tmp[A][A][32];  // [r][x][channel quad]
     // dilation d: the conv splits into d*d independent undilated convs on the pixel lattices (py + d*i, px + d*j);
     // tile t = (b, py, px, ty, tx) covers lattice rows m*ty-1 .. m*ty+m of phase (py, px)
     const int64_t T = (int64_t)B * dil * dil * th * tw;
-    const int64_t total = T * CV;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-        const int cv = (int)(i % CV);
-        const int64_t t = i / CV;
+    const int cblocks = (C4 + 31) / 32;
+    const int cq = threadIdx.x & 31, lane_x = threadIdx.x >> 5;  // lane_x: column in pass 1, row in pass 2
+    for (int64_t blk = blockIdx.x; blk < T * cblocks; blk += gridDim.x) {
+        const int cb = (int)(blk % cblocks);
+        const int64_t t = blk / cblocks;
+        const int c4 = cb * 32 + cq;
+        const bool cok = c4 < C4;
         const int tx = (int)(t % tw), ty = (int)((t / tw) % th);
         const int ph = (int)((t / ((int64_t)tw * th)) % (dil * dil)), b = (int)(t / ((int64_t)tw * th * dil * dil));
         const int py = ph / dil, px = ph - py * dil;
         const int y0 = py + dil * (ty * MT - 1), x0 = px + dil * (tx * MT - 1);  // pad = dil <=> lattice pad 1
-        const float* base = in + (size_t)b * H * W * ld_in + cv * WV;
-        wv_t tmp[A][A];  // rows transformed: tmp[r][x] = (B^T d)[r][x]
-#pragma unroll
-        for (int x = 0; x < A; ++x) {
-            wv_t col[A];
-            const int ix = x0 + dil * x;
+        {
+            const int ix = x0 + dil * lane_x;
+            const float* base = in + (size_t)b * H * W * ld_in + (size_t)c4 * 4;
+            f32x4 col[A];
 #pragma unroll
             for (int y = 0; y < A; ++y) {
                 const int iy = y0 + dil * y;
-                const bool ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
-                const size_t off = ok ? ((size_t)iy * W + ix) * ld_in : 0;
-                const wv_t v = *reinterpret_cast<const wv_t*>(base + off);
-                col[y] = ok ? v : wv_t(0.f);
+                const bool ok = cok && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+                col[y] = ok ? *reinterpret_cast<const f32x4*>(base + ((size_t)iy * W + ix) * ld_in) : f32x4(0.f);
             }
-            wv_t tc[A];
+            f32x4 tc[A];
             Wino<MT>::bt(col, tc);
 #pragma unroll
-            for (int r = 0; r < A; ++r) tmp[r][x] = tc[r];
+            for (int r = 0; r < A; ++r) tmp[r][lane_x][cq] = tc[r];
         }
+        __syncthreads();
+        {
+            f32x4 row[A], o[A];
 #pragma unroll
-        for (int r = 0; r < A; ++r) {
-            wv_t o[A];
-            Wino<MT>::bt(tmp[r], o);
+            for (int x = 0; x < A; ++x) row[x] = tmp[lane_x][x][cq];
+            Wino<MT>::bt(row, o);
+            if (cok) {
 #pragma unroll
-            for (int q = 0; q < A; ++q) *reinterpret_cast<wv_t*>(V + ((size_t)(r * A + q) * T + t) * CV * WV + cv * WV) = o[q];
+                for (int q = 0; q < A; ++q) *reinterpret_cast<f32x4*>(V + ((size_t)(lane_x * A + q) * T + t) * C4 * 4 + (size_t)c4 * 4) = o[q];
+            }
         }
+        __syncthreads();  // tmp is reused by the next tile of the grid-stride loop
     }
 }
 
 int launch_winograd_input(const float* in, int ld_in, float* V, int B, int H, int W, int C, int dil, int mt, hipStream_t s) {
     FS_REQUIRE(C % 4 == 0 && ld_in % 4 == 0 && dil >= 1, "winograd_input: C must be a multiple of 4");
     FS_REQUIRE(mt == 4 || mt == 6, "winograd: tile size must be 4 or 6");
+    FS_REQUIRE(((uintptr_t)in & 15) == 0 && ((uintptr_t)V & 15) == 0, "winograd_input: unaligned operand");
     const int th = (cdiv(H, dil) + mt - 1) / mt, tw = (cdiv(W, dil) + mt - 1) / mt;
-    const int wv = mt == 4 ? Wino<4>::WVI : Wino<6>::WVI;
-    const int64_t total = (int64_t)B * dil * dil * th * tw * (C / wv);
-    const dim3 grid((unsigned)std::min<int64_t>(cdiv64(total, 256), 1 << 20));
-    if (mt == 4) hipLaunchKernelGGL(winograd_input_kernel<4>, grid, dim3(256), 0, s, in, ld_in, V, B, H, W, C / wv, th, tw, dil);
-    else hipLaunchKernelGGL(winograd_input_kernel<6>, grid, dim3(256), 0, s, in, ld_in, V, B, H, W, C / wv, th, tw, dil);
+    const int64_t blocks = (int64_t)B * dil * dil * th * tw * cdiv(C / 4, 32);
+    const dim3 grid((unsigned)std::min<int64_t>(blocks, 1 << 20));
+    if (mt == 4) hipLaunchKernelGGL(winograd_input_kernel<4>, grid, dim3(6 * 32), 0, s, in, ld_in, V, B, H, W, C / 4, th, tw, dil);
+    else hipLaunchKernelGGL(winograd_input_kernel<6>, grid, dim3(8 * 32), 0, s, in, ld_in, V, B, H, W, C / 4, th, tw, dil);
     FS_HIP(hipGetLastError());
     return 0;
 }
 
-// ---- output transform + scale/shift + activation: thread per (tile, output-channel group)
+// ---- output transform + scale/shift + activation: pass 1 thread (q, oq) transforms column q of M, pass 2 thread (a, oq), a < m,
+// transforms row a, applies BatchNorm + ReLU and stores its m pixels.
 template <int MT>
-__global__ __launch_bounds__(256) void winograd_output_kernel(const float* __restrict__ M, const float* __restrict__ scale,
-                                                              const float* __restrict__ shift, float* __restrict__ out, int ld_out, int B,
-                                                              int H, int W, int NV, int th, int tw, int relu, int dil) {
-    constexpr int A = Wino<MT>::A, WV = Wino<MT>::WVO;
-    typedef typename WVec<WV>::type wv_t;
+__global__ __launch_bounds__((MT + 2) * 32) void winograd_output_kernel(const float* __restrict__ M, const float* __restrict__ scale,
+                                                                        const float* __restrict__ shift, float* __restrict__ out, int ld_out, int B,
+                                                                        int H, int W, int N4, int th, int tw, int relu, int dil) {
+    constexpr int A = Wino<MT>::A;
+    __shared__ f32x4 tmp[MT][A][32];  // [a][q][channel quad]
     const int64_t T = (int64_t)B * dil * dil * th * tw;
-    const int64_t total = T * NV;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-        const int nv = (int)(i % NV);
-        const int64_t t = i / NV;
+    const int nblocks = (N4 + 31) / 32;
+    const int oq = threadIdx.x & 31, lane_q = threadIdx.x >> 5;
+    for (int64_t blk = blockIdx.x; blk < T * nblocks; blk += gridDim.x) {
+        const int nb = (int)(blk % nblocks);
+        const int64_t t = blk / nblocks;
+        const int n4 = nb * 32 + oq;
+        const bool nok = n4 < N4;
         const int tx = (int)(t % tw), ty = (int)((t / tw) % th);
         const int ph = (int)((t / ((int64_t)tw * th)) % (dil * dil)), b = (int)(t / ((int64_t)tw * th * dil * dil));
         const int py = ph / dil, px = ph - py * dil;
-        wv_t tmp[MT][A];  // tmp[a][q] = (A^T m)[a][q]
+        {
+            f32x4 col[A], y[MT];
 #pragma unroll
-        for (int q = 0; q < A; ++q) {
-            wv_t col[A];
-#pragma unroll
-            for (int r = 0; r < A; ++r) col[r] = *reinterpret_cast<const wv_t*>(M + ((size_t)(r * A + q) * T + t) * NV * WV + nv * WV);
-            wv_t y[MT];
+            for (int r = 0; r < A; ++r)
+                col[r] = nok ? *reinterpret_cast<const f32x4*>(M + ((size_t)(r * A + lane_q) * T + t) * N4 * 4 + (size_t)n4 * 4) : f32x4(0.f);
             Wino<MT>::at(col, y);
 #pragma unroll
-            for (int a = 0; a < MT; ++a) tmp[a][q] = y[a];
+            for (int a = 0; a < MT; ++a) tmp[a][lane_q][oq] = y[a];
         }
-        const wv_t sc = scale ? *reinterpret_cast<const wv_t*>(scale + nv * WV) : wv_t(1.f);
-        const wv_t sh = shift ? *reinterpret_cast<const wv_t*>(shift + nv * WV) : wv_t(0.f);
+        __syncthreads();
+        if (lane_q < MT && nok) {
+            const int a = lane_q;
+            f32x4 row[A], y[MT];
 #pragma unroll
-        for (int a = 0; a < MT; ++a) {
-            wv_t y[MT];
-            Wino<MT>::at(tmp[a], y);
+            for (int q = 0; q < A; ++q) row[q] = tmp[a][q][oq];
+            Wino<MT>::at(row, y);
+            const f32x4 sc = scale ? *reinterpret_cast<const f32x4*>(scale + (size_t)n4 * 4) : f32x4(1.f);
+            const f32x4 sh = shift ? *reinterpret_cast<const f32x4*>(shift + (size_t)n4 * 4) : f32x4(0.f);
             const int oy = py + dil * (ty * MT + a);
-            if (oy >= H) continue;
+            if (oy < H) {
 #pragma unroll
-            for (int c = 0; c < MT; ++c) {
-                const int ox = px + dil * (tx * MT + c);
-                if (ox >= W) continue;
-                wv_t v = y[c] * sc + sh;
-                if (relu) v = __builtin_elementwise_max(v, wv_t(0.f));
-                *reinterpret_cast<wv_t*>(out + ((size_t)(b * H + oy) * W + ox) * ld_out + nv * WV) = v;
+                for (int c = 0; c < MT; ++c) {
+                    const int ox = px + dil * (tx * MT + c);
+                    if (ox >= W) continue;
+                    f32x4 v = y[c] * sc + sh;
+                    if (relu) v = __builtin_elementwise_max(v, f32x4(0.f));
+                    *reinterpret_cast<f32x4*>(out + ((size_t)(b * H + oy) * W + ox) * ld_out + (size_t)n4 * 4) = v;
+                }
             }
         }
+        __syncthreads();
     }
 }
 
@@ -230,14 +241,15 @@ int launch_winograd_output(const float* M, const float* scale, const float* shif
                            int relu, int dil, int mt, hipStream_t s) {
     FS_REQUIRE(N % 4 == 0 && ld_out % 4 == 0 && dil >= 1, "winograd_output: N must be a multiple of 4");
     FS_REQUIRE(mt == 4 || mt == 6, "winograd: tile size must be 4 or 6");
+    FS_REQUIRE(((uintptr_t)M & 15) == 0 && ((uintptr_t)out & 15) == 0 && ((uintptr_t)scale & 15) == 0 && ((uintptr_t)shift & 15) == 0,
+               "winograd_output: unaligned operand");
     const int th = (cdiv(H, dil) + mt - 1) / mt, tw = (cdiv(W, dil) + mt - 1) / mt;
-    const int wv = mt == 4 ? Wino<4>::WVO : Wino<6>::WVO;
-    const int64_t total = (int64_t)B * dil * dil * th * tw * (N / wv);
-    const dim3 grid((unsigned)std::min<int64_t>(cdiv64(total, 256), 1 << 20));
+    const int64_t blocks = (int64_t)B * dil * dil * th * tw * cdiv(N / 4, 32);
+    const dim3 grid((unsigned)std::min<int64_t>(blocks, 1 << 20));
     if (mt == 4)
-        hipLaunchKernelGGL(winograd_output_kernel<4>, grid, dim3(256), 0, s, M, scale, shift, out, ld_out, B, H, W, N / wv, th, tw, relu, dil);
+        hipLaunchKernelGGL(winograd_output_kernel<4>, grid, dim3(6 * 32), 0, s, M, scale, shift, out, ld_out, B, H, W, N / 4, th, tw, relu, dil);
     else
-        hipLaunchKernelGGL(winograd_output_kernel<6>, grid, dim3(256), 0, s, M, scale, shift, out, ld_out, B, H, W, N / wv, th, tw, relu, dil);
+        hipLaunchKernelGGL(winograd_output_kernel<6>, grid, dim3(8 * 32), 0, s, M, scale, shift, out, ld_out, B, H, W, N / 4, th, tw, relu, dil);
     FS_HIP(hipGetLastError());
     return 0;
 }
