@@ -128,7 +128,10 @@ __device__ unsigned long long fs_trace_buf[8 * 65536];
 // well; expcnt left at "no wait"), then the barrier.
 #define FS_DMA_PUBLISH() { __builtin_amdgcn_s_waitcnt(0x0070); __syncthreads(); }
 // WGM x WGN waves per workgroup (2x2 = 256 threads, two workgroups per CU; 4x2 = 512 threads, one per CU).
-template <int BM, int BN, int WGM = 2, int WGN = 2>
+// DUAL = true: concatenated-K GEMM of two 1x1 convs (ConvParams::in2): the K chunks beyond the first conv's come from a second
+// map with its own pixel stride / conv stride.  A separate instantiation (no residual input: the shortcut IS the second
+// operand), so the plain kernel's register budget -- 252 of the 256 VGPRs that let two workgroups share a CU -- is untouched.
+template <int BM, int BN, int WGM = 2, int WGN = 2, bool DUAL = false>
 __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_dma_f32(ConvParams p, int tiles_m, int tiles_n) {
 #if defined(__HIP_DEVICE_COMPILE__)  // the buffer-resource builtins do not exist in the host pass, which only needs the launch stub
     constexpr int BK = 32;
@@ -165,9 +168,10 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_dma_f32(ConvParams 
     const int wm = wv / WGN, wn = wv % WGN, l31 = lane & 31, hh = lane >> 5;
     const int wv_u = __builtin_amdgcn_readfirstlane(wv);
     const int M = p.B * p.Ho * p.Wo;
-    const int K = p.KH * p.KW * p.Cin;
+    const int K = p.KH * p.KW * p.Cin + (DUAL ? p.Cin2 : 0);
     const int cpt = p.Cin >> 5;
-    const int nchunks = p.KH * p.KW * cpt;
+    const int nchunks1 = p.KH * p.KW * cpt;
+    const int nchunks = nchunks1 + (DUAL ? p.Cin2 >> 5 : 0);
 
     const int sc = t & 7, r0 = t >> 3;
     const int swz = sc ^ ((r0 >> 1) & 7);  // logical chunk this lane fetches into LDS slot sc (same key for rows r0+32j)
@@ -208,6 +212,23 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_dma_f32(ConvParams 
             a_mask[j] = v ? mask : 0u;
         }
     }
+    // DUAL: the second operand's descriptor and per-row offsets (pixel (b, oy*stride2, ox*stride2) of the H2 x W2 map)
+    const __amdgpu_buffer_rsrc_t a2_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(DUAL ? p.in2 : p.in), 0, DUAL ? (unsigned)((long long)p.B * p.H2 * p.W2 * p.ld_in2 * 4) : 0u, 0x00020000);
+    unsigned a2_voff[DUAL ? RA : 1];
+    if (DUAL) {
+#pragma unroll
+        for (int j = 0; j < RA; ++j) {
+            const int m = m0 + r0 + RSTEP * j;
+            const int mm = m < M ? m : 0;
+            const int hw = p.Ho * p.Wo;
+            const int b = mm / hw;
+            const int rem = mm - b * hw;
+            const int oy = rem / p.Wo;
+            const int ox = rem - oy * p.Wo;
+            a2_voff[j] = (unsigned)((((b * p.H2 + oy * p.stride2) * p.W2 + ox * p.stride2) * p.ld_in2 + swz * 4) * 4);
+        }
+    }
     unsigned b_voff[RB];
 #pragma unroll
     for (int j = 0; j < RB; ++j) {
@@ -225,15 +246,22 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_dma_f32(ConvParams 
     const int sw = (l31 >> 1) & 7;
 
     int tap_r = 0, tap_s = 0, cc = 0;  // chunk being fetched
+    int fetch = 0;                     // its index along K (DUAL: chunks >= nchunks1 belong to the second operand)
     unsigned b_soff = 0;               // its byte offset along k in the packed filters
 
     // One DMA row (A rows first, then B rows): ROW_ in [0, RA+RB).
 #define FS_DMA_ROW(STG, ROW_)                                                                                     \
     if ((ROW_) < RA) {                                                                                            \
         const int j = (ROW_) < RA ? (ROW_) : 0;                                                                   \
-        const unsigned vo = ((a_mask[j] >> tap_bit) & 1u) ? a_voff[j] : SENT;                                     \
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (__attribute__((address_space(3))) void*)(lds + (STG) * STAGE + (8 * wv_u + RSTEP * j) * BK), \
-                                                 16, vo, a_soff, 0, 0);                                           \
+        if (DUAL && second) {                                                                                     \
+            const unsigned vo = (a_mask[j] & 1u) ? a2_voff[DUAL ? j : 0] : SENT;                                  \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(a2_rsrc, (__attribute__((address_space(3))) void*)(lds + (STG) * STAGE + (8 * wv_u + RSTEP * j) * BK), \
+                                                     16, vo, a_soff, 0, 0);                                       \
+        } else {                                                                                                  \
+            const unsigned vo = ((a_mask[j] >> tap_bit) & 1u) ? a_voff[j] : SENT;                                 \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (__attribute__((address_space(3))) void*)(lds + (STG) * STAGE + (8 * wv_u + RSTEP * j) * BK), \
+                                                     16, vo, a_soff, 0, 0);                                       \
+        }                                                                                                         \
     } else {                                                                                                      \
         const int j = (ROW_) >= RA ? (ROW_) - RA : 0;                                                             \
         __builtin_amdgcn_raw_ptr_buffer_load_lds(b_rsrc, (__attribute__((address_space(3))) void*)(lds + (STG) * STAGE + BM * BK + (8 * wv_u + RSTEP * j) * BK), \
@@ -241,6 +269,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_dma_f32(ConvParams 
     }
 #define FS_DMA_ADVANCE()                                                                                          \
     {                                                                                                             \
+        ++fetch;                                                                                                  \
         if (p.korder == 0) {                                                                                      \
             if (++cc == cpt) { cc = 0; if (++tap_s == p.KW) { tap_s = 0; ++tap_r; } }                             \
         } else {                                                                                                  \
@@ -249,8 +278,10 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_dma_f32(ConvParams 
     }
 #define FS_DMA_ALL(STG)                                                                                           \
     {                                                                                                             \
+        const bool second = DUAL && fetch >= nchunks1;                                                            \
         const int tap_bit = tap_r * p.KW + tap_s;                                                                 \
-        const unsigned a_soff = (unsigned)((((tap_r * p.W + tap_s) * p.dil) * p.ld_in + cc * 32) * 4);            \
+        const unsigned a_soff = second ? (unsigned)((fetch - nchunks1) * 128)                                     \
+                                       : (unsigned)((((tap_r * p.W + tap_s) * p.dil) * p.ld_in + cc * 32) * 4);  \
         _Pragma("unroll") for (int rw = 0; rw < RA + RB; ++rw) { FS_DMA_ROW(STG, rw) }                            \
         b_soff += 128;                                                                                            \
     }
@@ -296,7 +327,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_dma_f32(ConvParams 
         FS_DMA_ALL(1)
         FS_DMA_ADVANCE()
     }
-    if (p.res && nchunks <= 2) igemm_load_residual(rv, p, M, em_base, en_base);
+    if (!DUAL && p.res && nchunks <= 2) igemm_load_residual(rv, p, M, em_base, en_base);
     FS_FRAGS(0, 0, a0, b0)
     for (int kc = 0; kc < nchunks; ++kc) {
         // sub-step 0's fragments were requested under the previous chunk's last MFMAs: start multiplying at once and
@@ -320,7 +351,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_dma_f32(ConvParams 
             FS_DMA_ALL(cur)
             FS_DMA_ADVANCE()
         }
-        if (p.res && kc + 3 == nchunks) igemm_load_residual(rv, p, M, em_base, en_base);  // one and a quarter chunks to land
+        if (!DUAL && p.res && kc + 3 == nchunks) igemm_load_residual(rv, p, M, em_base, en_base);  // one and a quarter chunks to land
         if (kc + 1 < nchunks) FS_FRAGS(cur ^ 1, 0, a0, b0)
         __builtin_amdgcn_sched_barrier(0);
         FS_MMA(a1, b1)
@@ -340,7 +371,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_dma_f32(ConvParams 
 #ifdef FS_TRACE
     if ((p.dbg & 16) && p.ld_out >= 0) return;  // timing experiment: skip the epilogue (the test keeps the main loop alive)
 #endif
-    if (p.res) {
+    if (!DUAL && p.res) {
         if (p.relu == 1) igemm_epilogue<1, true>(acc, rv, sc_n, sh_n, p, M, em_base, en_base);
         else if (p.relu == 2) igemm_epilogue<2, true>(acc, rv, sc_n, sh_n, p, M, em_base, en_base);
         else igemm_epilogue<0, true>(acc, rv, sc_n, sh_n, p, M, em_base, en_base);
@@ -373,7 +404,7 @@ int pick_tile(const ConvParams& p) {
     const double eff[5] = {0, 1.00, 0.92, 0.80, 0.92};
     int best = 1;
     double best_t = 1e300;
-    for (int c = 1; c <= 4; ++c) {
+    for (int c = 1; c <= (p.in2 ? 2 : 4); ++c) {
         const int bm = kTiles[c].bm, bn = kTiles[c].bn;
         if (p.Cout < bn && bn > 64) continue;
         const long tiles = (long)cdiv(M, bm) * cdiv(p.Cout, bn) * (p.groups > 1 ? p.groups : 1);
@@ -393,6 +424,15 @@ const char* conv_igemm_tile_name(const ConvParams& p, int tile) {
 
 int launch_conv_igemm(const ConvParams& p, hipStream_t s, int tile) {
     FS_REQUIRE(p.Cin % 32 == 0, "conv_igemm: Cin=%d must be a multiple of 32", p.Cin);
+    if (p.in2) {
+        FS_REQUIRE(p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0 && p.res == nullptr && p.groups <= 1,
+                   "conv_igemm: a concatenated-K launch takes two 1x1 convs, the first with stride 1, and no residual");
+        FS_REQUIRE(p.Cin2 >= 32 && p.Cin2 % 32 == 0 && p.ld_in2 % 4 == 0 && p.ld_in2 >= p.Cin2 && p.stride2 >= 1 && ((uintptr_t)p.in2 & 15) == 0,
+                   "conv_igemm: bad second operand (Cin2=%d ld=%d stride=%d)", p.Cin2, p.ld_in2, p.stride2);
+        FS_REQUIRE((p.H2 - 1) / p.stride2 + 1 == p.Ho && (p.W2 - 1) / p.stride2 + 1 == p.Wo, "conv_igemm: second operand %dx%d / stride %d does not give %dx%d",
+                   p.H2, p.W2, p.stride2, p.Ho, p.Wo);
+        FS_REQUIRE((int64_t)p.B * p.H2 * p.W2 * p.ld_in2 * 4 < (int64_t)1 << 31, "conv_igemm: second operand must be smaller than 2 GiB");
+    }
     FS_REQUIRE(p.ld_in % 4 == 0 && p.ld_in >= p.Cin, "conv_igemm: bad ld_in=%d (Cin=%d)", p.ld_in, p.Cin);
     FS_REQUIRE(p.ld_out >= p.Cout, "conv_igemm: bad ld_out=%d (Cout=%d)", p.ld_out, p.Cout);
     FS_REQUIRE(((uintptr_t)p.in & 15) == 0 && ((uintptr_t)p.wgt & 15) == 0, "conv_igemm: unaligned operand");
@@ -402,7 +442,7 @@ int launch_conv_igemm(const ConvParams& p, hipStream_t s, int tile) {
     // the DMA kernel addresses both operands with 32-bit byte offsets and uses 0x80000000 as the out-of-range sentinel
     FS_REQUIRE(((int64_t)p.B * p.H * p.W * p.ld_in + ((int64_t)p.pad * p.W + p.pad) * p.ld_in) * 4 < (int64_t)1 << 31,
                "conv_igemm: input tensor must be smaller than 2 GiB");
-    FS_REQUIRE((int64_t)p.Cout * p.KH * p.KW * p.Cin * 4 < (int64_t)1 << 31, "conv_igemm: filter bank must be smaller than 2 GiB");
+    FS_REQUIRE((int64_t)p.Cout * (p.KH * p.KW * p.Cin + (p.in2 ? p.Cin2 : 0)) * 4 < (int64_t)1 << 31, "conv_igemm: filter bank must be smaller than 2 GiB");
     FS_REQUIRE(p.KH * p.KW <= 32, "conv_igemm: at most 32 filter taps");
     // the epilogue stores (and reads the residual) through 32-bit-offset buffer descriptors as well
     FS_REQUIRE((int64_t)p.B * p.Ho * p.Wo * p.ld_out * 4 < (int64_t)1 << 31 && ((uintptr_t)p.out & 3) == 0,
@@ -417,6 +457,13 @@ int launch_conv_igemm(const ConvParams& p, hipStream_t s, int tile) {
     const int groups = p.groups > 1 ? p.groups : 1;
     FS_REQUIRE(groups == 1 || p.res == nullptr, "conv_igemm: grouped GEMM has no residual input");
     const dim3 grid(tm * tn * groups), block(256);
+    if (p.in2) {  // concatenated-K instantiations exist for the two 128-row tiles
+        if (tile == 2) hipLaunchKernelGGL((conv_igemm_dma_f32<128, 64, 2, 2, true>), grid, block, 0, s, p, tm, tn);
+        else if (tile == 1) hipLaunchKernelGGL((conv_igemm_dma_f32<128, 128, 2, 2, true>), grid, block, 0, s, p, tm, tn);
+        else return fail("conv_igemm: concatenated-K launches use tile 1 or 2");
+        FS_HIP(hipGetLastError());
+        return 0;
+    }
     if (tile == 5) {  // 8-wave workgroup, one per CU
         hipLaunchKernelGGL((conv_igemm_dma_f32<256, 128, 4, 2>), grid, dim3(512), 0, s, p, tm, tn);
         FS_HIP(hipGetLastError());

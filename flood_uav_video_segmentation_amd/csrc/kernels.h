@@ -24,6 +24,11 @@ struct ConvParams {
     int B, H, W, Cin;
     int Ho, Wo, Cout;
     int KH, KW, stride, pad, dil;
+    // second input of a concatenated-K GEMM (nullptr = none): a 1x1 conv with stride `stride2` over an H2 x W2 x Cin2 map whose
+    // output geometry is Ho x Wo; its Cin2 weights follow the first conv's K in every filter row.  The bottleneck block with a
+    // projection shortcut runs conv3 and downsample as ONE launch this way (model/resnet.py:86-94); first conv must be 1x1 s1.
+    const float* in2;   int ld_in2;
+    int Cin2, stride2, H2, W2;
     int relu;  // epilogue activation: 0 none, 1 ReLU, 2 GELU (erf)
     int korder;  // weight k order: 0 = (r, s, c) ; 1 = (c/32, r, s, c%32)
     // grouped GEMM (Winograd: one GEMM per transform position): group g uses in + g*g_in, wgt + g*g_wgt, out + g*g_out
@@ -111,6 +116,10 @@ int launch_pack_slice_tap_major(const float* w, float* out, int O, int I, int c0
 size_t ppm_term_scratch_floats(int B, int H, int C);
 int launch_ppm_term_finish(float* T, int ld, const float* const Z[4], const int bins[4], float* scratch, const float* scale,
                            const float* shift, int B, int H, int W, int C, int relu, hipStream_t s);
+// out[o][0..Ka) = sa[o] * wa[o][:], out[o][Ka..Ka+Kb) = sb[o] * wb[o][:]; shift_out[o] = ha[o] + hb[o]: the filter bank and bias of
+// BN_a(conv_a(x)) + BN_b(conv_b(y)) written as one GEMM over the concatenated K (both 1x1)
+int launch_concat_scaled_filters(const float* wa, const float* sa, const float* ha, int Ka, const float* wb, const float* sb, const float* hb,
+                                 int Kb, float* out, float* shift_out, int O, hipStream_t s);
 int launch_nchw_to_nhwc(const float* in, float* out, int ld_out, int B, int C, int HW, hipStream_t s);
 int launch_nhwc_to_nchw(const float* in, int ld_in, float* out, int B, int C, int HW, hipStream_t s);
 

@@ -44,6 +44,10 @@ struct ConvBN {
 struct Bottleneck {
     ConvBN c1, c2, c3, ds;
     bool has_ds = false;
+    // projection block: relu(bn3(conv3(f)) + bn_ds(downsample(x))) (model/resnet.py:86-94) as ONE GEMM over the concatenated K:
+    // filters [Cout][Cin3 + Cin_ds] with the two BatchNorm scales folded into their halves, shift = shift3 + shift_ds
+    ConvBN c3ds;
+    int ds_cin = 0, ds_stride = 1;
 };
 
 // nn.Linear / nn.LayerNorm of the Segmenter (weights kept [out][in] exactly as torch stores them)
@@ -119,6 +123,7 @@ struct fs_net {
     bool use_winograd = true;    // !(flags & FS_OPT_NO_WINOGRAD)
     int wino_force_m = 0;        // winograd_tile: 4 | 6 forces F(4,3) / F(6,3); 0 = the cheaper one for the map at hand
     bool use_fused_head = true;  // !(flags & FS_OPT_NO_FUSED_HEAD)
+    bool use_fused_shortcut = true;  // !(flags & FS_OPT_NO_FUSED_SHORTCUT)
     int device = 0;              // HIP device the handle's memory lives on (current device at fs_create)
 
     // workspace

@@ -294,13 +294,14 @@ int net_create(const fs_config* cfg, fs_handle* out) {
     FS_REQUIRE(cfg->arch == FS_ARCH_SEGMENTER || cfg->layers == 50 || cfg->layers == 101 || cfg->layers == 152,
                "fs_create: layers must be 50, 101 or 152");
     FS_REQUIRE(cfg->classes >= 1 && cfg->classes <= 255, "fs_create: classes out of range");
-    FS_REQUIRE((cfg->flags & ~(FS_OPT_NO_WINOGRAD | FS_OPT_NO_FUSED_HEAD)) == 0, "fs_create: unknown option bits 0x%x", cfg->flags);
+    FS_REQUIRE((cfg->flags & ~(FS_OPT_NO_WINOGRAD | FS_OPT_NO_FUSED_HEAD | FS_OPT_NO_FUSED_SHORTCUT)) == 0, "fs_create: unknown option bits 0x%x", cfg->flags);
     FS_REQUIRE(cfg->winograd_tile == 0 || cfg->winograd_tile == 4 || cfg->winograd_tile == 6, "fs_create: winograd_tile must be 0, 4 or 6");
     fs_net* h = new fs_net();
     h->cfg = *cfg;
     h->use_winograd = !(cfg->flags & FS_OPT_NO_WINOGRAD);
     h->wino_force_m = cfg->winograd_tile;
     h->use_fused_head = !(cfg->flags & FS_OPT_NO_FUSED_HEAD);
+    h->use_fused_shortcut = !(cfg->flags & FS_OPT_NO_FUSED_SHORTCUT);
     if (hipGetDevice(&h->device) != hipSuccess) {
         delete h;
         return fail("fs_create: no HIP device");
@@ -412,8 +413,22 @@ int net_finalize(fs_handle h, hipStream_t s) {
             FS_TRY(make_conv(h, blk.c2, pre + "conv2.weight", pre + "bn2", "", stride, dil, dil, 1, false, s));
             FS_TRY(make_conv(h, blk.c3, pre + "conv3.weight", pre + "bn3", "", 1, 0, 1, 1, false, s));
             blk.has_ds = b == 0;
-            if (blk.has_ds)
+            if (blk.has_ds) {
                 FS_TRY(make_conv(h, blk.ds, pre + "downsample.0.weight", pre + "downsample.1", "", stride, 0, 1, 0, false, s));
+                if (blk.c3.KH == 1 && blk.ds.KH == 1 && blk.c3.Cin % 32 == 0 && blk.ds.Cin % 32 == 0 && blk.c3.scale && blk.ds.scale) {
+                    ConvBN& f = blk.c3ds;
+                    f.name = pre + "conv3+downsample";
+                    f.Cin = blk.c3.Cin;
+                    f.Cout = blk.c3.Cout;
+                    f.relu = 1;
+                    blk.ds_cin = blk.ds.Cin;
+                    blk.ds_stride = blk.ds.stride;
+                    FS_TRY(dev_alloc(h, &f.w, (size_t)f.Cout * (blk.c3.Cin + blk.ds.Cin)));
+                    FS_TRY(dev_alloc(h, &f.shift, (size_t)f.Cout));
+                    FS_TRY(launch_concat_scaled_filters(blk.c3.w, blk.c3.scale, blk.c3.shift, blk.c3.Cin, blk.ds.w, blk.ds.scale, blk.ds.shift,
+                                                        blk.ds.Cin, f.w, f.shift, f.Cout, s));
+                }
+            }
             h->blocks.push_back(blk);
         }
         h->layer_end.push_back((int)h->blocks.size());
@@ -618,7 +633,21 @@ int encoder_core(fs_handle h, const FrameSrc& src, int B, int H, int W, float* o
         const int ld_dst = last && !fused ? h->feat_channels() : Cn;
         ConvBN c3 = blk.c3;
         c3.relu = 1;  // ReLU after the residual add (model/resnet.py:93-94)
-        if (blk.has_ds) {
+        if (blk.has_ds && blk.c3ds.w && h->use_fused_shortcut) {
+            // conv3 and the projection shortcut as one launch over the concatenated K: the shortcut map is never written
+            if (!dst) dst = F3;
+            ConvParams p{};
+            p.in = F2; p.ld_in = blk.c2.Cout; p.wgt = blk.c3ds.w; p.shift = blk.c3ds.shift; p.out = dst; p.ld_out = ld_dst;
+            p.B = B; p.H = oH; p.W = oW; p.Cin = blk.c3ds.Cin; p.Ho = oH; p.Wo = oW; p.Cout = Cn;
+            p.KH = p.KW = 1; p.stride = 1; p.dil = 1; p.relu = 1;
+            p.in2 = X; p.ld_in2 = C; p.Cin2 = blk.ds_cin; p.stride2 = blk.ds_stride; p.H2 = curH; p.W2 = curW;
+            const double M = (double)B * oH * oW;
+            FS_TRY(prof_begin(h, blk.c3ds.name, conv_igemm_tile_name(p), 2.0 * M * Cn * (p.Cin + p.Cin2),
+                              4.0 * (M * p.Cin + (double)B * curH * curW * p.Cin2 + (double)Cn * (p.Cin + p.Cin2) + M * Cn), s));
+            FS_TRY(launch_conv_igemm(p, s));
+            FS_TRY(prof_end(h, s));
+            if (!last) std::swap(X, F3);
+        } else if (blk.has_ds) {
             FS_TRY(run_conv(h, blk.ds, X, C, B, curH, curW, F3, Cn, nullptr, 0, s));
             if (!dst) dst = F3;  // in place over the shortcut
             FS_TRY(run_conv(h, c3, F2, blk.c2.Cout, B, oH, oW, dst, ld_dst, F3, Cn, s));

@@ -80,6 +80,88 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(StemParams p) {
     }
 }
 
+// -------------------------------------------------------------------------------------------
+// The same stem conv on the matrix cores (Cout a multiple of 32, <= 128): an implicit GEMM with M = output pixels,
+// N = Cout, K = KH*KW*3 taps (27 or 147, padded to an even count with zero weights).  One wave = 32 pixels x all channels;
+// v_mfma_f32_32x32x2_f32 takes A[i][k] from lane (i = l&31, h = l>>5) with k = 2*step + h: each lane gathers ITS tap of ITS
+// pixel straight from the NCHW frame (neighbouring pixels share lines: L1/L2 hits), B[k][n] comes from the filter bank in LDS.
+// The VALU version above spends 27 (147) x Cout fmas per pixel on ds_read-fed VALU: 47 us (139 us for the 7x7 stem) at
+// 713x713, B = 2, against an 11 us HBM write; this one needs 28 (148) MFMAs per 32 pixels.
+// -------------------------------------------------------------------------------------------
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int NT /* 32-channel sub-tiles */>
+__global__ __launch_bounds__(256) void stem_conv_mfma_kernel(StemParams p, int ksteps) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int taps = p.KH * p.KW * 3, kpad = 2 * ksteps;
+    float* wl = smem;                                            // [kpad][Cout], rows >= taps are zero
+    int* koff = reinterpret_cast<int*>(smem + kpad * p.Cout);    // [kpad]: element offset of tap k from the patch origin
+    int* kyx = koff + kpad;                                      // [kpad]: ky << 16 | kx
+    const int rowW = p.src.ncrops ? p.src.FW : p.W;
+    const long long plane = p.src.ncrops ? (long long)p.src.FH * p.src.FW : (long long)p.H * p.W;
+    for (int i = threadIdx.x; i < kpad * p.Cout; i += 256) wl[i] = i < taps * p.Cout ? p.wgt[i] : 0.f;
+    for (int k = threadIdx.x; k < kpad; k += 256) {
+        const int kk = k < taps ? k : 0;  // k = (ky*KW + kx)*3 + ci
+        const int ci = kk % 3, kx = (kk / 3) % p.KW, ky = kk / (3 * p.KW);
+        koff[k] = (int)(ci * plane + (long long)ky * rowW + kx);
+        kyx[k] = k < taps ? (ky << 16 | kx) : (0x7fff << 16);  // padding taps: a row index no image has
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 31, h = lane >> 5;
+    const int M = p.B * p.Ho * p.Wo, hw = p.Ho * p.Wo;
+    const int tiles = (M + 31) / 32;
+    for (int tile = blockIdx.x * 4 + wave; tile < tiles; tile += gridDim.x * 4) {
+        const int m = tile * 32 + i;
+        const bool mok = m < M;
+        const int mm = mok ? m : 0;
+        const int b = mm / hw, rem = mm - b * hw;
+        const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+        const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;
+        const float* inb;
+        if (p.src.ncrops) {
+            const int c = b < p.src.ncrops ? b : b - p.src.ncrops;
+            inb = (b < p.src.ncrops ? p.src.in : p.src.in2) + (size_t)p.src.cy[c] * rowW + p.src.cx[c];
+        } else {
+            inb = b < p.src.B1 ? p.src.in + (size_t)b * 3 * plane : p.src.in2 + (size_t)(b - p.src.B1) * 3 * plane;
+        }
+        const float* origin = inb + (long long)iy0 * rowW + ix0;  // may point before the frame: only dereferenced for in-range taps
+        f32x16 acc[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+        // taps in batches of 8 steps: 8 gathers in flight per lane before their MFMAs (kpad is padded to the batch, see launcher)
+        for (int s0 = 0; s0 < ksteps; s0 += 8) {
+            float av[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int k = 2 * (s0 + u) + h;
+                const int yx = kyx[k];
+                const int iy = iy0 + (yx >> 16), ix = ix0 + (yx & 0xffff);
+                const bool ok = mok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+                av[u] = ok ? origin[koff[k]] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int k = 2 * (s0 + u) + h;
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], wl[k * p.Cout + j * 32 + i], acc[j], 0, 0, 0);
+            }
+        }
+        // D layout: col n = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * h: every store instruction writes two 128-B channel runs
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int n = j * 32 + i;
+            const float sc = p.scale[n], sh = p.shift[n];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int mr = tile * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                if (mr < M) p.out[(size_t)mr * p.ld_out + n] = fmaxf(acc[j][e] * sc + sh, 0.f);
+            }
+        }
+    }
+}
+
 int launch_stem_conv(const StemParams& p, hipStream_t s) {
     FS_REQUIRE(p.Cout % 16 == 0 && p.Cout <= 256 && 256 % (p.Cout / 16) == 0, "stem_conv: unsupported Cout=%d", p.Cout);
     FS_REQUIRE(p.ld_out % 4 == 0, "stem_conv: ld_out must be a multiple of 4");
@@ -93,8 +175,25 @@ int launch_stem_conv(const StemParams& p, hipStream_t s) {
         FS_REQUIRE(f.B1 >= 0 && f.B1 <= p.B && (f.B1 == p.B || f.in2) && (f.B1 == 0 || f.in), "stem_conv: bad frame split B1=%d of B=%d", f.B1, p.B);
     }
     const int M = p.B * p.Ho * p.Wo;
+    const int taps = p.KH * p.KW * 3;
+    if (p.Cout % 32 == 0 && p.Cout <= 128 && p.KH < 0x7fff) {  // matrix-core route
+        const int ksteps = cdiv(cdiv(taps, 2), 8) * 8;  // whole batches of 8 MFMA k-steps; the padding taps carry zero weights
+        const size_t lds = (size_t)2 * ksteps * (p.Cout + 2) * sizeof(float);
+        FS_REQUIRE(lds <= 64 * 1024, "stem_conv: filter bank %zu B exceeds LDS budget", lds);
+        FS_REQUIRE((long long)3 * (f.ncrops ? (long long)f.FH * f.FW : (long long)p.H * p.W) < (1ll << 31), "stem_conv: frame too large for 32-bit tap offsets");
+        const int tiles = cdiv(M, 32);
+        const dim3 grid((unsigned)std::min(cdiv(tiles, 4), 256 * 8));
+        switch (p.Cout / 32) {
+            case 1: hipLaunchKernelGGL((stem_conv_mfma_kernel<1>), grid, dim3(256), lds, s, p, ksteps); break;
+            case 2: hipLaunchKernelGGL((stem_conv_mfma_kernel<2>), grid, dim3(256), lds, s, p, ksteps); break;
+            case 3: hipLaunchKernelGGL((stem_conv_mfma_kernel<3>), grid, dim3(256), lds, s, p, ksteps); break;
+            default: hipLaunchKernelGGL((stem_conv_mfma_kernel<4>), grid, dim3(256), lds, s, p, ksteps); break;
+        }
+        FS_HIP(hipGetLastError());
+        return 0;
+    }
     const int groups = p.Cout / 16, ppb = 256 / groups;
-    const size_t lds = (size_t)p.KH * p.KW * 3 * p.Cout * sizeof(float);
+    const size_t lds = (size_t)taps * p.Cout * sizeof(float);
     FS_REQUIRE(lds <= 64 * 1024, "stem_conv: filter bank %zu B exceeds LDS budget", lds);
     hipLaunchKernelGGL((stem_conv_kernel<16>), dim3(cdiv(M, ppb)), dim3(256), lds, s, p);
     FS_HIP(hipGetLastError());
@@ -401,6 +500,28 @@ int launch_pack_oihw_to_hwio(const float* w, float* out, int O, int I, int KH, i
     const int64_t total = (int64_t)O * I * KH * KW;
     hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)std::min<int64_t>(cdiv64(total, 256), 65535)), dim3(256), 0, s, w, out,
                        O, I, KH, KW, 1);
+    FS_HIP(hipGetLastError());
+    return 0;
+}
+
+__global__ __launch_bounds__(256) void concat_scaled_filters_kernel(const float* __restrict__ wa, const float* __restrict__ sa,
+                                                                    const float* __restrict__ ha, int Ka, const float* __restrict__ wb,
+                                                                    const float* __restrict__ sb, const float* __restrict__ hb, int Kb,
+                                                                    float* __restrict__ out, float* __restrict__ shift_out, int O) {
+    const int K = Ka + Kb;
+    const int64_t total = (int64_t)O * K;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int k = (int)(i % K), o = (int)(i / K);
+        out[i] = k < Ka ? sa[o] * wa[(size_t)o * Ka + k] : sb[o] * wb[(size_t)o * Kb + (k - Ka)];
+        if (k == 0) shift_out[o] = ha[o] + hb[o];
+    }
+}
+int launch_concat_scaled_filters(const float* wa, const float* sa, const float* ha, int Ka, const float* wb, const float* sb, const float* hb,
+                                 int Kb, float* out, float* shift_out, int O, hipStream_t s) {
+    FS_REQUIRE(wa && sa && ha && wb && sb && hb && out && shift_out && O >= 1 && Ka >= 1 && Kb >= 1, "concat_scaled_filters: bad arguments");
+    const int64_t total = (int64_t)O * (Ka + Kb);
+    hipLaunchKernelGGL(concat_scaled_filters_kernel, dim3((unsigned)std::min<int64_t>(cdiv64(total, 256), 65535)), dim3(256), 0, s, wa, sa, ha, Ka,
+                       wb, sb, hb, Kb, out, shift_out, O);
     FS_HIP(hipGetLastError());
     return 0;
 }

@@ -56,7 +56,8 @@ typedef struct fs_config {
 
 enum {
     FS_OPT_NO_WINOGRAD = 1,   /* every 3x3 conv on the direct implicit-GEMM kernel                                      */
-    FS_OPT_NO_FUSED_HEAD = 2  /* fs_segment_forward = fs_decoder_forward(fs_encoder_forward(x)) over the 4096-ch concat */
+    FS_OPT_NO_FUSED_HEAD = 2, /* fs_segment_forward = fs_decoder_forward(fs_encoder_forward(x)) over the 4096-ch concat */
+    FS_OPT_NO_FUSED_SHORTCUT = 4 /* projection blocks: downsample and conv3 as two launches instead of one concatenated-K GEMM */
 };
 
 int fs_version(void);

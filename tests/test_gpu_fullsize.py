@@ -207,10 +207,12 @@ def test_model_representation_wraps_a_hip_network(psp):
 
 # ------------------------------------------------------------------------------------------------ A/B options at full size
 @pytest.mark.parametrize("opts", [dict(hip_no_winograd=True), dict(hip_winograd_tile=4), dict(hip_winograd_tile=6),
-                                  dict(hip_no_fused_head=True), dict(hip_no_winograd=True, hip_no_fused_head=True)])
+                                  dict(hip_no_fused_head=True), dict(hip_no_fused_shortcut=True),
+                                  dict(hip_no_winograd=True, hip_no_fused_head=True, hip_no_fused_shortcut=True)])
 def test_every_shipped_option_matches_the_reference_golden_at_713(psp, opts):
     """Each arithmetic-changing route the library ships (direct conv instead of Winograd, F(4,3) / F(6,3) forced, head over
-    the 4096-channel concat instead of the fused pyramid term) against the reference's own 713x713 outputs."""
+    the 4096-channel concat instead of the fused pyramid term, projection shortcut + conv3 as two launches instead of one
+    concatenated-K GEMM) against the reference's own 713x713 outputs."""
     _, state = psp
     net = FlowPSPNet(HP(**opts)).eval()
     net.load_state_dict(state)
@@ -225,6 +227,25 @@ def test_every_shipped_option_matches_the_reference_golden_at_713(psp, opts):
     fm = FlowModel(net, feature_based=False, no_warp=True).eval()
     mask = fm.predict_masks(prev, nxt, cu(dl), cu(dr), N)
     assert note(f"option[{tag}]_713_cfg1_mask_disagreement", 1 - (mask.cpu().numpy() == zp["cfg2_mask"]).mean()) < 1 - MASK_MIN
+
+
+@pytest.mark.parametrize("size,b", [((713, 713), 2), ((129, 161), 3)])
+def test_fused_projection_shortcut_equals_the_two_launch_route(psp, size, b):
+    """relu(bn3(conv3(f)) + bn_ds(downsample(x))) (model/resnet.py:86-94) as ONE GEMM over the concatenated K, BatchNorm scales
+    folded into the filters, against downsample-then-conv3-with-residual: every projection block (stride 1 and the stride-2
+    one of layer2), whole-network outputs within fp32 reassociation noise."""
+    _, state = psp
+    fused = FlowPSPNet(HP()).eval()
+    plain = FlowPSPNet(HP(hip_no_fused_shortcut=True)).eval()
+    fused.load_state_dict(state)
+    plain.load_state_dict(state)
+    x = synth.make_clip(b, size, seed=55).cuda()
+    a, c = fused.segment(x), plain.segment(x)
+    assert note(f"fused_shortcut_vs_two_launches_{size[0]}", rel_err(a.cpu(), c.cpu())) < 1e-5
+    assert (a.max(1)[1] == c.max(1)[1]).float().mean().item() > 0.9998
+    assert torch.equal(fused.segment(x), a)  # bit-repeatable
+    fa, fc = fused.encoder(x), plain.encoder(x)
+    assert rel_err(fa.cpu(), fc.cpu()) < 1e-5
 
 
 # ------------------------------------------------------------------------------------------------ key-frame cache
