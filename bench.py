@@ -76,6 +76,14 @@ def newest_pmc_summary():
         return best[1], None
 
 
+def kernel_symbol(label):
+    """HIP-event label of the library's profile (igemm128x128, igemm128x64cat, ...) -> the kernel symbol rocprofv3 reports."""
+    m = re.match(r"igemm(\d+)x(\d+)(cat)?$", label)
+    bm, bn, cat = int(m.group(1)), int(m.group(2)), bool(m.group(3))
+    waves = "4, 2" if bm == 256 else "2, 2"
+    return f"conv_igemm_dma_f32<{bm}, {bn}, {waves}, {'true' if cat else 'false'}>"
+
+
 def pmc_traffic(dom_kernel):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes of this same command
     (tools/gpu_pmc_bench.sh; PMC counters cannot be read from inside the process).  Only a summary measured on THIS build
@@ -91,7 +99,7 @@ def pmc_traffic(dom_kernel):
         return None, f"{rel} does not record the build it was measured on (a previous round's file): stale"
     if meta["build_id"] != build_id():
         return None, f"{rel} was measured on build {meta['build_id']} (git {meta.get('git_head', '?')}), this run is build {build_id()}: stale"
-    hits = [k for k in pmc.get("kernels", {}) if f"<{dom_kernel[5:].replace('x', ', ')}," in k]
+    hits = [k for k in pmc.get("kernels", {}) if kernel_symbol(dom_kernel) in k]
     if not hits or "hbm_bytes_per_launch" not in pmc["kernels"][hits[0]]:
         return None, f"{rel} has no FETCH_SIZE/WRITE_SIZE pair for {dom_kernel}"
     return round(pmc["kernels"][hits[0]]["hbm_bytes_per_launch"]), (
@@ -247,7 +255,7 @@ def main():
         all_ms = sum(v["ms"] for v in conv.values())
         all_fl = sum(v["flops"] for v in conv.values())
         result["roofline"] = {
-            "bound": "mfma", "kernel": f"conv_igemm_dma_f32<{dom_name[5:].replace('x', ', ')}>", "achieved": round(ach, 2),
+            "bound": "mfma", "kernel": kernel_symbol(dom_name), "achieved": round(ach, 2),
             "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
             "traffic_unit": "B per launch", "traffic_source": traffic_note, "algorithmic_bytes_per_launch": round(alg_bytes),
             "avg_launch_ms": round(dom["ms"] / dom["launches"], 5), "launches_per_step": dom["launches"] // prof_steps,
@@ -324,6 +332,9 @@ def variants(args, dev, rdev, net, state, fm, windows, dl, dr, host_masks, host_
         side.synchronize()
     run("fps_two_windows_in_flight_two_streams", step_two, max(1, steps // 2), 2 * N_DELTA)
     del net2, fm2
+
+    if shard.describe()[1] > 1:
+        return out  # the other BASELINE configs are single-GPU figures: measured by the N = 1 run only
 
     # (v) BASELINE configs[0] on the GPU: single-frame PSPNet inference over a 4-frame clip, one frame per step
     frames4 = [windows[i][0] for i in range(4)]

@@ -419,6 +419,7 @@ int pick_tile(const ConvParams& p) {
 const char* conv_igemm_tile_name(const ConvParams& p, int tile) {
     tile &= 0xff;
     if (tile <= 0 || tile > 5) tile = pick_tile(p);
+    if (p.in2) return tile == 2 ? "igemm128x64cat" : "igemm128x128cat";  // the concatenated-K instantiations are kernels of their own
     return kTiles[tile].name;
 }
 
