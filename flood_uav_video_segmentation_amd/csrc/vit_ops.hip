@@ -159,8 +159,10 @@ constexpr int ATT_NW = 4;    // waves per workgroup = 128 queries per staged K/V
 // CUs, one wave per SIMD, so the softmax VALU work of a wave is never hidden behind another wave's MFMAs.  With
 // nsplit > 1 workgroup (query tile, split) walks only its share of the key tiles and stores the UNNORMALISED O^T plus
 // (running max, running sum) per query; attention_combine_kernel merges the splits.  nsplit == 1 writes `out` directly.
+// __launch_bounds__(.., 3): three waves per SIMD (the compiler fits 154 VGPRs instead of 210, no spills), so that the three
+// workgroups the key split aims at per CU are really co-resident: 96.8 -> 101.9 TFLOP/s on ViT-S/16 (profiles/r02_experiments.txt).
 template <bool SPLIT>
-__global__ __launch_bounds__(64 * ATT_NW) void attention_f32_kernel(const float* __restrict__ qkv, float* __restrict__ out,
+__global__ __launch_bounds__(64 * ATT_NW, 3) void attention_f32_kernel(const float* __restrict__ qkv, float* __restrict__ out,
                                                                      float* __restrict__ part_o, float* __restrict__ part_ml, int N,
                                                                      int heads, float scale, int nsplit) {
     __shared__ __attribute__((aligned(16))) float Ks[ATT_KT * ATT_LDK];
