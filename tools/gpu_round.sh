@@ -1,21 +1,18 @@
 #!/bin/bash
-# One GPU-box round trip: parity tests, smoke, bench, rocprofv3 kernel stats.  Outputs under gpurun_out/.
+# One complete GPU-box round: parity tests (measured errors -> gpurun_out/parity_measured.txt), smoke, the default bench
+# (-> gpurun_out/bench_n1.json), rocprofv3 kernel stats for configs 1/2/3 + layer tables (tools/gpu_profiles.sh) and the
+# PMC traffic passes (tools/gpu_pmc_bench.sh).  usage: GIT_HEAD=<short sha> tools/gpu_round.sh [noprofile]
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out
 mkdir -p $O
 cd $R
-if [ "$1" != "noprofile" ]; then
-timeout -k 10 600 python -m pytest tests -m gpu -q -p no:cacheprovider -x > $O/pytest_gpu.txt 2>&1; echo "pytest exit=$?"; tail -3 $O/pytest_gpu.txt
-timeout -k 10 300 python __graft_entry__.py smoke > $O/smoke.txt 2>&1; echo "smoke exit=$?"; tail -2 $O/smoke.txt
-fi
-timeout -k 10 400 python bench.py > $O/bench.json 2> $O/bench.err; echo "bench exit=$?"; cat $O/bench.json; tail -3 $O/bench.err
-if [ "$1" != "noprofile" ]; then
-cd /tmp && export TMPDIR=/tmp
-rm -rf $O/prof
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extras > $O/prof_bench.json 2> $O/prof.err; echo "rocprof exit=$?"
-find $O/prof -name "*kernel_stats*.csv" | head -3
-f=$(find $O/prof -name "*kernel_stats*.csv" | head -1); [ -n "$f" ] && head -25 "$f"
-# keep the merged output small: the per-dispatch trace is large
-find $O/prof -name "*kernel_trace*.csv" -size +20M -delete
-fi
+rm -f $O/parity_measured.txt
+timeout -k 10 900 python -m pytest tests -m gpu -q -p no:cacheprovider --timeout 900 > $O/pytest_gpu.txt 2>&1; rc=$?; echo "pytest exit=$rc"; tail -3 $O/pytest_gpu.txt
+[ $rc -ne 0 ] && exit $rc
+timeout -k 10 300 python __graft_entry__.py smoke > $O/smoke.txt 2>&1; echo "smoke exit=$?"; tail -1 $O/smoke.txt
+timeout -k 10 600 python bench.py > $O/bench_n1.json 2> $O/bench.err; echo "bench exit=$?"; cut -c1-400 $O/bench_n1.json
+[ "$1" == "noprofile" ] && exit 0
+tools/gpu_profiles.sh && tools/gpu_pmc_bench.sh
+# the bench line once more, now that the PMC summary of THIS build exists (roofline.traffic filled): copy it in place first
+cp $O/pmc_bench_summary.json $R/profiles/_pmc_this_build.json 2>/dev/null
