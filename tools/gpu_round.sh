@@ -14,5 +14,5 @@ timeout -k 10 300 python __graft_entry__.py smoke > $O/smoke.txt 2>&1; echo "smo
 timeout -k 10 600 python bench.py > $O/bench_n1.json 2> $O/bench.err; echo "bench exit=$?"; cut -c1-400 $O/bench_n1.json
 [ "$1" == "noprofile" ] && exit 0
 tools/gpu_profiles.sh && tools/gpu_pmc_bench.sh
-# the bench line once more, now that the PMC summary of THIS build exists (roofline.traffic filled): copy it in place first
-cp $O/pmc_bench_summary.json $R/profiles/_pmc_this_build.json 2>/dev/null
+
+
