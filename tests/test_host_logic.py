@@ -250,3 +250,34 @@ def test_eval_window_label_transform_and_item_layout(tmp_path):
     assert label.dtype == torch.int64 and np.array_equal(label.numpy(), want) and label.max() <= 4
     assert None in p["left_ids"] + p["right_ids"]
     assert ds.default_grid.dtype == torch.float32 and np.array_equal(ds.default_grid.numpy(), get_default_grid().astype(np.float32))
+
+
+def test_bench_quotes_pmc_traffic_only_for_the_running_build(tmp_path, monkeypatch):
+    """roofline.traffic comes from the newest profiles/r*_pmc_traffic.json and only while that file was
+    measured on THIS build (sha256 of the kernel sources); otherwise null + the reason."""
+    import json
+    import os
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+
+    assert bench.kernel_symbol("igemm128x128") == "conv_igemm_dma_f32<128, 128, 2, 2, false>"
+    assert bench.kernel_symbol("igemm128x64cat") == "conv_igemm_dma_f32<128, 64, 2, 2, true>"
+    assert bench.kernel_symbol("igemm256x128") == "conv_igemm_dma_f32<256, 128, 4, 2, false>"
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    monkeypatch.setattr(bench, "build_id", lambda: "abc")
+    assert bench.pmc_traffic("igemm128x128")[0] is None                      # nothing committed
+    key = "void fs::conv_igemm_dma_f32<128, 128, 2, 2, false>(fs::ConvParams, int, int)"
+    (prof / "r01_pmc_traffic.json").write_text(json.dumps({key: {"hbm_bytes_per_launch": 1.0}}))
+    t, why = bench.pmc_traffic("igemm128x128")
+    assert t is None and "stale" in why                                      # a file without build meta (round 1's format)
+    (prof / "r03_pmc_traffic.json").write_text(json.dumps({"meta": {"build_id": "zzz", "git_head": "g"}, "kernels": {key: {"hbm_bytes_per_launch": 2.0}}}))
+    t, why = bench.pmc_traffic("igemm128x128")
+    assert t is None and "zzz" in why and "abc" in why                       # newest file, other build
+    (prof / "r04_pmc_traffic.json").write_text(json.dumps({"meta": {"build_id": "abc", "git_head": "g"}, "kernels": {key: {"hbm_bytes_per_launch": 3.0}}}))
+    t, why = bench.pmc_traffic("igemm128x128")
+    assert t == 3 and "r04_pmc_traffic.json" in why
