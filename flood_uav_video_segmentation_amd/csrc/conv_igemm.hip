@@ -181,7 +181,9 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_dma_f32(ConvParams 
     const long long pad_off = ((long long)p.pad * p.W + p.pad) * p.ld_in;
     const unsigned a_bytes = (unsigned)(((long long)p.B * p.H * p.W * p.ld_in + pad_off) * 4);
     const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(p.in - pad_off), 0, a_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.wgt, 0, (unsigned)((long long)p.Cout * K * 4), 0x00020000);
+    const int ldw = p.ld_wgt ? p.ld_wgt : K;  // filter row stride (> K for a K-slice of wider rows)
+    const __amdgpu_buffer_rsrc_t b_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc((void*)p.wgt, 0, (unsigned)((((long long)p.Cout - 1) * ldw + K) * 4), 0x00020000);
     unsigned a_voff[RA], a_mask[RA];
     if (p.KH * p.KW == 1 && p.stride == 1 && p.pad == 0) {
         // 1x1 stride-1 conv / plain GEMM (most launches): output pixel m IS input pixel m, no coordinate split needed
@@ -233,7 +235,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_dma_f32(ConvParams 
 #pragma unroll
     for (int j = 0; j < RB; ++j) {
         const int n = n0 + r0 + RSTEP * j;
-        b_voff[j] = n < p.Cout ? (unsigned)((n * K + swz * 4) * 4) : SENT;
+        b_voff[j] = n < p.Cout ? (unsigned)((n * ldw + swz * 4) * 4) : SENT;
     }
 
     f32x16 acc[TM][TN];
@@ -443,7 +445,8 @@ int launch_conv_igemm(const ConvParams& p, hipStream_t s, int tile) {
     // the DMA kernel addresses both operands with 32-bit byte offsets and uses 0x80000000 as the out-of-range sentinel
     FS_REQUIRE(((int64_t)p.B * p.H * p.W * p.ld_in + ((int64_t)p.pad * p.W + p.pad) * p.ld_in) * 4 < (int64_t)1 << 31,
                "conv_igemm: input tensor must be smaller than 2 GiB");
-    FS_REQUIRE((int64_t)p.Cout * (p.KH * p.KW * p.Cin + (p.in2 ? p.Cin2 : 0)) * 4 < (int64_t)1 << 31, "conv_igemm: filter bank must be smaller than 2 GiB");
+    FS_REQUIRE((int64_t)p.Cout * std::max(p.ld_wgt, p.KH * p.KW * p.Cin + (p.in2 ? p.Cin2 : 0)) * 4 < (int64_t)1 << 31, "conv_igemm: filter bank must be smaller than 2 GiB");
+    FS_REQUIRE(p.ld_wgt == 0 || (p.ld_wgt >= p.KH * p.KW * p.Cin + (p.in2 ? p.Cin2 : 0) && p.ld_wgt % 4 == 0), "conv_igemm: bad ld_wgt=%d", p.ld_wgt);
     FS_REQUIRE(p.KH * p.KW <= 32, "conv_igemm: at most 32 filter taps");
     // the epilogue stores (and reads the residual) through 32-bit-offset buffer descriptors as well
     FS_REQUIRE((int64_t)p.B * p.Ho * p.Wo * p.ld_out * 4 < (int64_t)1 << 31 && ((uintptr_t)p.out & 3) == 0,

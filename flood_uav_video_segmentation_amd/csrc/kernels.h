@@ -17,6 +17,8 @@ namespace fs {
 struct ConvParams {
     const float* in;    int ld_in;   // NHWC input
     const float* wgt;                // [Cout][KH*KW*Cin], k ordered (r, s, c), c fastest
+    int ld_wgt;                      // floats between two filter rows; 0 = KH*KW*Cin (+ Cin2).  > K: the launch multiplies a K-slice
+                                     // of wider rows (split-K groups of one nn.Linear: group g takes columns g*Cin .. of W[out][in])
     const float* scale;              // [Cout] or nullptr (=1)
     const float* shift;              // [Cout] or nullptr (=0)
     const float* res;   int ld_res;  // residual, NHWC at output resolution, or nullptr
@@ -217,6 +219,8 @@ int launch_layernorm(const float* in, const float* gamma, const float* beta, flo
 size_t attention_scratch_floats(int B, int N, int heads);
 int launch_attention_f32(const float* qkv, float* out, int B, int N, int heads, float scale, float* scratch, hipStream_t s);
 // masks[b][k][i] = LayerNorm_K( <pp[b][i]/|pp|, cc[b][N+k]/|cc|> )  (segm/model/decoder.py:90-100), NCHW out
+// out[r][c] = sum_s part[s][r][c] + bias[c] (+ res[r][c]): merges the split-K partial products of a Linear
+int launch_splitk_combine(const float* part, int nsplit, const float* bias, const float* res, float* out, int rows, int N, hipStream_t s);
 int launch_mask_head(const float* pp, const float* cc, const float* gamma, const float* beta, float* out, int B, int N, int K,
                      int D, hipStream_t s);
 

@@ -526,7 +526,7 @@ size_t net_workspace_bytes(fs_handle h, int B, int H, int W) {
     if (h->cfg.arch == FS_ARCH_SEGMENTER) {
         const int P = h->cfg.patch, D = h->cfg.d_model;
         const size_t T = (size_t)B * (((H + P - 1) / P) * ((W + P - 1) / P) + 1 + h->cfg.classes);
-        return (T * D * 11 + T * 3 * P * P + 64) * sizeof(float);
+        return (T * D * 15 + T * 3 * P * P + 64) * sizeof(float);
     }
     return (4 * encoder_buf_elems(h, B, H, W) + small_elems_for(B)) * sizeof(float);
 }

@@ -43,8 +43,36 @@ int make_block(fs_net* h, VitBlock& b, const std::string& p, int D) {
     return 0;
 }
 
+// A Linear whose 64x64 tiles do not even give every CU two workgroups (ViT-S/16 fc2: 61 x 6 = 366 tiles for 256 CUs, 110 of
+// them with two and the rest with one) while its K is long: cut K into `split` slices -- grouped launch, group g multiplies
+// columns g*K/split .. of the [out][in] weight rows (ConvParams::ld_wgt) into its own partial buffer -- and merge the partials
+// with bias + residual in one small pass.  S/16 fc2 59 -> 4x us (profiles/r02_experiments.txt).  0 = no split.
+int linear_splits(const Linear& l, int rows, int act) {
+    if (act != 0 || l.in < 768) return 0;
+    const long tiles = (long)cdiv(rows, 64) * cdiv(l.out, 64);
+    int split = (int)std::min<long>(4, (768 + tiles / 2) / std::max<long>(tiles, 1));  // aim at ~3 workgroups per CU
+    while (split >= 2 && (l.in % (32 * split) != 0 || l.in / split < 384)) --split;
+    return split >= 2 ? split : 0;
+}
+
 // out[rows][l.out] = act(in[rows][l.in] @ W^T + b (+ res))
-int run_linear(fs_net* h, const Linear& l, const float* in, int rows, float* out, const float* res, int act, hipStream_t s) {
+int run_linear(fs_net* h, const Linear& l, const float* in, int rows, float* out, const float* res, int act, hipStream_t s, float* part = nullptr) {
+    const int split = part ? linear_splits(l, rows, act) : 0;
+    if (split) {
+        ConvParams p{};
+        p.in = in; p.ld_in = l.in; p.wgt = l.w; p.ld_wgt = l.in; p.out = part; p.ld_out = l.out;
+        p.B = 1; p.H = rows; p.W = 1; p.Cin = l.in / split; p.Ho = rows; p.Wo = 1; p.Cout = l.out;
+        p.KH = p.KW = 1; p.stride = 1; p.dil = 1;
+        p.groups = split;
+        p.g_in = l.in / split;
+        p.g_wgt = l.in / split;
+        p.g_out = (long long)rows * l.out;
+        const double flops = 2.0 * rows * (double)l.in * l.out;
+        FS_TRY(prof_begin(h, l.name, conv_igemm_tile_name(p), flops, 4.0 * ((double)rows * (l.in + (split + 1.0) * l.out) + (double)l.in * l.out), s));
+        FS_TRY(launch_conv_igemm(p, s));
+        FS_TRY(launch_splitk_combine(part, split, l.b, res, out, rows, l.out, s));
+        return prof_end(h, s);
+    }
     ConvParams p{};
     p.in = in;
     p.ld_in = l.in;
@@ -80,14 +108,14 @@ int run_norm(fs_net* h, const LNorm& n, const float* in, float* out, int rows, i
 }
 
 struct VitWs {
-    float *X, *Xn, *QKV, *A, *Hd, *patches, *emb, *att;
+    float *X, *Xn, *QKV, *A, *Hd, *patches, *emb, *att, *part;
 };
 
 int vit_workspace(fs_net* h, int B, int tokens, VitWs* ws) {
     const size_t D = (size_t)h->cfg.d_model, T = (size_t)B * tokens;
     const size_t P2 = (size_t)3 * h->cfg.patch * h->cfg.patch;
     const size_t att = attention_scratch_floats(B, tokens, (int)(D / 64));
-    const size_t need = T * D * 3 + T * 3 * D + T * 4 * D + T * P2 + T * D + att + 64;
+    const size_t need = T * D * 3 + T * 3 * D + T * 4 * D + T * P2 + T * D + att + 4 * T * D + 64;  // + split-K partials (<= 4 slices)
     if (need > h->vit_ws_elems) {
         FS_HIP(hipDeviceSynchronize());
         if (h->vit_ws) FS_HIP(hipFree(h->vit_ws));
@@ -104,6 +132,8 @@ int vit_workspace(fs_net* h, int B, int tokens, VitWs* ws) {
     ws->patches = p; p += T * P2;
     ws->emb = p; p += T * D;
     ws->att = att ? p : nullptr;
+    p += att;
+    ws->part = p;
     return 0;
 }
 
@@ -116,10 +146,10 @@ int run_block(fs_net* h, const VitBlock& blk, const VitWs& ws, int B, int tokens
     FS_TRY(prof_begin(h, blk.qkv.name + ".attention", "attention_f32", aflops, 4.0 * rows * 4.0 * D, s));
     FS_TRY(launch_attention_f32(ws.QKV, ws.A, B, tokens, heads, 0.125f, ws.att, s));
     FS_TRY(prof_end(h, s));
-    FS_TRY(run_linear(h, blk.proj, ws.A, rows, ws.X, ws.X, 0, s));          // x = x + proj(attn)
+    FS_TRY(run_linear(h, blk.proj, ws.A, rows, ws.X, ws.X, 0, s, ws.part));  // x = x + proj(attn)
     FS_TRY(run_norm(h, blk.n2, ws.X, ws.Xn, rows, tokens, 0, s));
     FS_TRY(run_linear(h, blk.fc1, ws.Xn, rows, ws.Hd, nullptr, 2, s));       // GELU
-    FS_TRY(run_linear(h, blk.fc2, ws.Hd, rows, ws.X, ws.X, 0, s));           // x = x + mlp(x)
+    FS_TRY(run_linear(h, blk.fc2, ws.Hd, rows, ws.X, ws.X, 0, s, ws.part));  // x = x + mlp(x)
     return 0;
 }
 

@@ -379,6 +379,27 @@ int launch_attention_f32(const float* qkv, float* out, int B, int N, int heads, 
     return 0;
 }
 
+// ------------------------------------------------------------------ split-K merge of a Linear: out = sum_s part[s] + bias (+ res)
+__global__ __launch_bounds__(256) void splitk_combine_kernel(const float* __restrict__ part, int nsplit, const float* __restrict__ bias,
+                                                             const float* __restrict__ res, float* __restrict__ out, int64_t total4, int N4) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
+        f32x4 v = reinterpret_cast<const f32x4*>(part)[i];
+        for (int sidx = 1; sidx < nsplit; ++sidx) v += reinterpret_cast<const f32x4*>(part)[(int64_t)sidx * total4 + i];
+        if (bias) v += reinterpret_cast<const f32x4*>(bias)[i % N4];
+        if (res) v += reinterpret_cast<const f32x4*>(res)[i];
+        reinterpret_cast<f32x4*>(out)[i] = v;
+    }
+}
+
+int launch_splitk_combine(const float* part, int nsplit, const float* bias, const float* res, float* out, int rows, int N, hipStream_t s) {
+    FS_REQUIRE(part && out && nsplit >= 2 && rows >= 1 && N % 4 == 0, "splitk_combine: bad arguments");
+    const int64_t total4 = (int64_t)rows * N / 4;
+    hipLaunchKernelGGL(splitk_combine_kernel, dim3((unsigned)std::min<int64_t>(cdiv64(total4, 256), 4096)), dim3(256), 0, s, part, nsplit, bias, res,
+                       out, total4, N / 4);
+    FS_HIP(hipGetLastError());
+    return 0;
+}
+
 // ------------------------------------------------------------------ mask head: one wave per patch token
 __global__ __launch_bounds__(256) void mask_head_kernel(const float* __restrict__ pp, const float* __restrict__ cc,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
