@@ -53,8 +53,10 @@ int wino_bank(fs_net* h, const ConvBN& c, int mt, hipStream_t s, const float** U
     float*& slot = mt == 6 ? c.wino->U6 : c.wino->U4;
     if (!slot) {
         FS_REQUIRE(c.korder == 1, "winograd: conv '%s' has no chunk-major filter bank", c.name.c_str());
-        FS_TRY(dev_alloc(h, &slot, (size_t)(mt + 2) * (mt + 2) * c.Cout * c.Cin));
-        FS_TRY(launch_winograd_filter(c.w, slot, c.Cout, c.Cin, mt, s, 1));
+        float* bank = nullptr;  // published only once the transform has been enqueued: a failed launch must not leave a half-built bank behind
+        FS_TRY(dev_alloc(h, &bank, (size_t)(mt + 2) * (mt + 2) * c.Cout * c.Cin));
+        FS_TRY(launch_winograd_filter(c.w, bank, c.Cout, c.Cin, mt, s, 1));
+        slot = bank;
     }
     *U = slot;
     return 0;
