@@ -47,17 +47,20 @@ int make_block(fs_net* h, VitBlock& b, const std::string& p, int D) {
 // them with two and the rest with one) while its K is long: cut K into `split` slices -- grouped launch, group g multiplies
 // columns g*K/split .. of the [out][in] weight rows (ConvParams::ld_wgt) into its own partial buffer -- and merge the partials
 // with bias + residual in one small pass.  S/16 fc2 59 -> 4x us (profiles/r02_experiments.txt).  0 = no split.
-int linear_splits(const Linear& l, int rows, int act) {
+int linear_splits(const Linear& l, int rows_per_image, int act) {
+    // decided on ONE image's rows (for the usual batch of two key frames: ~768 workgroups), never on the batch: a frame's
+    // result must not depend on the batch it is computed in (the key-frame cache relies on it)
     if (act != 0 || l.in < 768) return 0;
-    const long tiles = (long)cdiv(rows, 64) * cdiv(l.out, 64);
-    int split = (int)std::min<long>(4, (768 + tiles / 2) / std::max<long>(tiles, 1));  // aim at ~3 workgroups per CU
+    const long tiles = (long)cdiv(rows_per_image, 64) * cdiv(l.out, 64);
+    int split = (int)std::min<long>(4, (384 + tiles / 2) / std::max<long>(tiles, 1));
     while (split >= 2 && (l.in % (32 * split) != 0 || l.in / split < 384)) --split;
     return split >= 2 ? split : 0;
 }
 
 // out[rows][l.out] = act(in[rows][l.in] @ W^T + b (+ res))
-int run_linear(fs_net* h, const Linear& l, const float* in, int rows, float* out, const float* res, int act, hipStream_t s, float* part = nullptr) {
-    const int split = part ? linear_splits(l, rows, act) : 0;
+int run_linear(fs_net* h, const Linear& l, const float* in, int rows, float* out, const float* res, int act, hipStream_t s, float* part = nullptr,
+               int rows_per_image = 0) {
+    const int split = part ? linear_splits(l, rows_per_image ? rows_per_image : rows, act) : 0;
     if (split) {
         ConvParams p{};
         p.in = in; p.ld_in = l.in; p.wgt = l.w; p.ld_wgt = l.in; p.out = part; p.ld_out = l.out;
@@ -146,10 +149,10 @@ int run_block(fs_net* h, const VitBlock& blk, const VitWs& ws, int B, int tokens
     FS_TRY(prof_begin(h, blk.qkv.name + ".attention", "attention_f32", aflops, 4.0 * rows * 4.0 * D, s));
     FS_TRY(launch_attention_f32(ws.QKV, ws.A, B, tokens, heads, 0.125f, ws.att, s));
     FS_TRY(prof_end(h, s));
-    FS_TRY(run_linear(h, blk.proj, ws.A, rows, ws.X, ws.X, 0, s, ws.part));  // x = x + proj(attn)
+    FS_TRY(run_linear(h, blk.proj, ws.A, rows, ws.X, ws.X, 0, s, ws.part, tokens));  // x = x + proj(attn)
     FS_TRY(run_norm(h, blk.n2, ws.X, ws.Xn, rows, tokens, 0, s));
     FS_TRY(run_linear(h, blk.fc1, ws.Xn, rows, ws.Hd, nullptr, 2, s));       // GELU
-    FS_TRY(run_linear(h, blk.fc2, ws.Hd, rows, ws.X, ws.X, 0, s, ws.part));  // x = x + mlp(x)
+    FS_TRY(run_linear(h, blk.fc2, ws.Hd, rows, ws.X, ws.X, 0, s, ws.part, tokens));  // x = x + mlp(x)
     return 0;
 }
 

@@ -344,11 +344,13 @@ __global__ __launch_bounds__(256) void attention_combine_kernel(const float* __r
     *reinterpret_cast<f32x4*>(out + ((size_t)b * N + q) * (heads * ATT_DH) + head * ATT_DH + c4 * 4) = o;
 }
 
-int attention_splits(int B, int N, int heads) {
-    // aim at ~3 workgroups per CU (256 CUs): their waves share a SIMD, so one's softmax overlaps another's MFMAs
-    const int units = cdiv(N, 32 * ATT_NW) * heads * B;
+int attention_splits(int /*B*/, int N, int heads) {
+    // aim at ~3 workgroups per CU (256 CUs) for the usual batch of two key frames: their waves share a SIMD, so one's softmax
+    // overlaps another's MFMAs.  Decided on ONE image's work, never on the batch: the merge order of the key splits is part of
+    // the result, and a frame's output must not depend on the batch it is computed in (the key-frame cache relies on it).
+    const int units = cdiv(N, 32 * ATT_NW) * heads;
     const int ntiles = cdiv(N, ATT_KT);
-    int ns = (768 + units / 2) / units;
+    int ns = (384 + units / 2) / units;
     ns = std::min(ns, std::min(4, ntiles / 2));
     return std::max(ns, 1);
 }

@@ -275,6 +275,21 @@ def test_keyframe_cache_is_bit_identical_over_consecutive_windows(psp, mode):
     assert cache.misses == 2 and torch.equal(again, fm.predict(keys[0:1], keys[1:2], cu(grids[0][0]), cu(grids[0][1]), N, None)["pred"])
 
 
+def test_keyframe_cache_is_bit_identical_for_the_segmenter(vit_s16):
+    """configs[3] with the cache: the ViT tokens of a key frame computed alone (B = 1) are the ones it gets as half of a pair --
+    attention key splits and split-K Linears are decided per image -- so the cached windows equal the uncached ones bit for bit."""
+    net, _ = vit_s16
+    keys = synth.make_clip(11, 704, seed=1000, only=[0, 5, 10]).cuda()
+    fm = FlowModel(net, feature_based=True, no_warp=False).eval()
+    cache = KeyframeCache()
+    for i in range(2):
+        mvl, mvr = (cu(g) for g in synth.make_grids(N, 44, 44, seed=2000 + i, frame=(704, 704)))
+        plain = fm.predict(keys[i:i + 1], keys[i + 1:i + 2], mvl, mvr, N, None)["pred"]
+        cached = fm.predict(keys[i:i + 1], keys[i + 1:i + 2], mvl, mvr, N, None, key_cache=cache.window(5 * i, 5 * i + 5))["pred"]
+        assert torch.equal(plain, cached), f"window {i}"
+    assert (cache.hits, cache.misses) == (1, 1)
+
+
 def test_predictor_with_keyframe_cache_matches_uncached_run(psp):
     """FlowPredictor(cache_keyframes=True) over 3 windows: the same 1072x1920 masks and the same temporal-consistency metric."""
     net, _ = psp

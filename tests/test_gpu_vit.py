@@ -84,3 +84,16 @@ def test_vit_feature_flow_extension_against_oracle_parity_unpinned():
     ref = flow_oracle.predict_feature(enc, dec, clip[0:1], clip[1:2], mvl, mvr, n, False)["pred"]
     assert got.shape == ref.shape == (3, 5, size, size)
     assert rel_err(got.cpu(), ref) < VIT_TOL
+
+
+def test_vit_frame_result_does_not_depend_on_its_batch():
+    """The key-frame cache reuses a frame's tokens computed in another batch (alone, or as either half of a pair): the split
+    counts of the attention keys and of the split-K Linears are decided per image, so B = 1 and B = 2 agree bit for bit."""
+    state = synth.make_vit_state(5, 96, 16, 384, 2, 1, seed=9)
+    net = VITSegmentModel(5, 96, patch_size=16, d_model=384, n_layers=2, dec_layers=1).eval()
+    net.load_state_dict(state)
+    for size in (96, 203, 320):
+        x = synth.make_clip(2, size, seed=size).cuda()
+        both = net.encoder(x)
+        assert torch.equal(both[0:1], net.encoder(x[0:1])) and torch.equal(both[1:2], net.encoder(x[1:2])), size
+        assert torch.equal(net(x)["pred"][1:2], net(x[1:2])["pred"]), size
