@@ -408,3 +408,58 @@ def test_two_tensor_batch_equals_concatenation(psp):
     assert torch.equal(net.segment(a, b), net.segment(torch.cat([a, b], 0)))
     assert torch.equal(net.encode_frames(a, b), net.encoder(torch.cat([a, b], 0)))
     assert torch.equal(net.segment(a, b, a), net.segment(torch.cat([a, b, a], 0)))
+
+
+def test_seg_tail_accumulate_equals_tail_then_softmax_accumulate():
+    """fs_seg_tail_accumulate (tail + softmax + float64 canvas fused) against the two-call route it replaces
+    (fs_seg_tail -> fs_softmax_accumulate), bit for bit: warp and no_warp, two overlapping crops, K = 5 and K = 11."""
+    from flood_uav_video_segmentation_amd import _lib
+    from flood_uav_video_segmentation_amd._lib import check, ptr, stream_ptr
+
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(5)
+    for k, no_warp in ((5, False), (5, True), (11, False)):
+        n, h, w, ch, cw, H, W = 4, 12, 13, 90, 97, 150, 140
+        lo_p, lo_n = torch.randn(1, k, h, w, generator=g).cuda(), torch.randn(1, k, h, w, generator=g).cuda()
+        mvl, mvr = synth.dummy_grids(n) if no_warp else synth.make_grids(n, 6, 7, seed=3, frame=(ch, cw), jitter=0.05)
+        mvl, mvr = cu(mvl), cu(mvr)
+        fused_c = torch.zeros(n, k, H, W, dtype=torch.float64, device="cuda")
+        fused_n = torch.zeros(H, W, dtype=torch.float64, device="cuda")
+        two_c, two_n = torch.zeros_like(fused_c), torch.zeros_like(fused_n)
+        for (y0, x0) in ((0, 0), (60, 43)):
+            ops.seg_tail_accumulate(lo_p, lo_n, mvl, mvr, n, (ch, cw), no_warp, fused_c, fused_n, y0, x0)
+            logits, _ = ops.seg_tail(lo_p, lo_n, mvl, mvr, n, (ch, cw), no_warp, want_logits=True)
+            check(lib.fs_softmax_accumulate(ptr(logits), n, k, ch, cw, ptr(two_c), ptr(two_n), H, W, y0, x0, stream_ptr()))
+        assert torch.equal(fused_c, two_c) and torch.equal(fused_n, two_n)
+        assert float(fused_n.max()) == 2.0 and float(fused_n.min()) == 0.0
+    with pytest.raises(RuntimeError, match="outside the canvas"):
+        ops.seg_tail_accumulate(lo_p, lo_n, mvl, mvr, n, (ch, cw), False, fused_c, fused_n, 100, 100)
+
+
+def test_crop_grids_identity_block_range_and_edge_cases():
+    """A crop whose block range already is (crop // 16)^2 skips the resize (64x64 crop on 16-px blocks at a block-aligned
+    offset): the output is the renormalised cut, exactly; f64 grids are accepted; a crop outside the grid is refused."""
+    mvl, mvr = synth.make_grids(3, 20, 30, seed=8, frame=(320, 480), jitter=0.02)
+    got = ops.crop_grids(cu(mvl) + cu(mvr), (320, 480), [(32, 48), (0, 0)], (64, 64))
+    assert got.shape == (2, 4, 4, 4, 2)
+    for c, (y0, x0) in enumerate(((32, 48), (0, 0))):
+        ref_l, ref_r = crops_oracle.crop_motion_vector([m.clone() for m in mvl], [m.clone() for m in mvr], 320, 480, 64, 64, y0, x0)
+        for j, ref in enumerate(ref_l + ref_r):
+            assert torch.equal(got[c, j].cpu(), ref[0]), (c, j)  # no interpolation involved: the same fp32 op chain as numpy
+    g64 = ops.crop_grids([m.double().cuda() for m in mvl], (320, 480), [(32, 48)], (64, 64))
+    assert torch.equal(g64[0], got[0, :2])
+    with pytest.raises(RuntimeError, match="outside"):
+        ops.crop_grids(cu(mvl), (320, 480), [(300, 0)], (64, 64))
+
+
+def test_segment_crops_deeplab_equals_cloned_crops():
+    """The crop-window read of the stem is shared by every conv network: DeepLabv3 (7x7 stem on the matrix cores) too."""
+    state = synth.make_deeplab_state(50, 5, seed=4)
+    net = FlowDeepLabv3(HP(50)).eval()
+    net.load_state_dict(state)
+    fr = synth.make_clip(2, (260, 330), seed=78).cuda()
+    yx = [(0, 0), (7, 33), (260 - 193, 330 - 193)]
+    got = net.segment_crops(fr[0:1], fr[1:2], yx, (193, 193))
+    for f in range(2):
+        for c, (y, x) in enumerate(yx):
+            assert torch.equal(got[f * 3 + c:f * 3 + c + 1], net.segment(fr[f:f + 1, :, y:y + 193, x:x + 193].contiguous())), (f, c)
