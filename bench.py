@@ -102,8 +102,15 @@ def pmc_traffic(dom_kernel):
     hits = [k for k in pmc.get("kernels", {}) if kernel_symbol(dom_kernel) in k]
     if not hits or "hbm_bytes_per_launch" not in pmc["kernels"][hits[0]]:
         return None, f"{rel} has no FETCH_SIZE/WRITE_SIZE pair for {dom_kernel}"
-    return round(pmc["kernels"][hits[0]]["hbm_bytes_per_launch"]), (
+    e = pmc["kernels"][hits[0]]
+    extra = {k: (round(e[k], 4) if isinstance(e[k], float) else {a: round(b, 4) for a, b in e[k].items()})
+             for k in ("mfma_utilisation", "lds_bank_conflict_share_of_lds_cycles", "wave_time_shares") if k in e}
+    pmc_traffic.extra = extra  # SQ / GRBM counters of the same passes: the hardware's own MFMA-busy share, LDS conflicts, wave time split
+    return round(e["hbm_bytes_per_launch"]), (
         f"(2*FETCH_SIZE + WRITE_SIZE)*1024 B averaged over the kernel's launches, {rel} (same build {meta['build_id']}, git {meta.get('git_head', '?')})")
+
+
+pmc_traffic.extra = {}
 
 
 def timed(fn, steps, warmup, dev):
@@ -260,6 +267,7 @@ def main():
             "traffic_unit": "B per launch", "traffic_source": traffic_note, "algorithmic_bytes_per_launch": round(alg_bytes),
             "avg_launch_ms": round(dom["ms"] / dom["launches"], 5), "launches_per_step": dom["launches"] // prof_steps,
             "gflop_per_launch": round(dom["flops"] / dom["launches"] / 1e9, 3),
+            "pmc": pmc_traffic.extra,
             "all_conv_kernels": {"achieved": round(all_fl / (all_ms * 1e-3) / 1e12, 2), "ms_per_step": round(all_ms / prof_steps, 4),
                                  "gflop_per_step": round(all_fl / prof_steps / 1e9, 2)},
             "per_kernel_ms_per_step": {k: round(v["ms"] / prof_steps, 4) for k, v in sorted(per.items(), key=lambda kv: -kv[1]["ms"])},
