@@ -1,0 +1,58 @@
+"""bench.py's contract, on the GPU box: the JSON line the driver parses (single process) and the N > 1 path under
+torch.distributed.run (two ranks rehearsed on the one GPU over gloo -- RCCL refuses two ranks on one device)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _last_json(stdout):
+    lines = [l for l in stdout.splitlines() if l.startswith("{")]
+    assert lines, stdout[-2000:]
+    return json.loads(lines[-1])
+
+
+def test_bench_json_line_has_the_contract_fields():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--no-extras", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = _last_json(r.stdout)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "distributed", "build_id", "parity"):
+        assert k in j, k
+    assert j["n_gpus"] == 1 and j["steps"] == 3 and j["warmup"] == 1 and j["unit"] == "frames/s" and j["dtype"] == "f32"
+    assert j["scaling"] == "weak" and j["higher_is_better"] is True and j["vs_baseline"] is None and j["data"] == "synthetic"
+    assert "workload" in j["config"] and "model" not in j["config"]
+    assert abs(j["value"] - 5 * 1000.0 / j["ms_per_step"]) < 1e-2 * j["value"]  # 5 frames per window
+    ro = j["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel"):
+        assert k in ro, k
+    assert ro["bound"] == "mfma" and ro["unit"] == "TFLOP/s" and abs(ro["frac"] - ro["achieved"] / ro["peak"]) < 1e-3
+    assert ro["kernel"].startswith("conv_igemm_dma_f32<") and 0.3 < ro["frac"] < 1.0
+    assert ro["traffic"] is None or ro["traffic"] > 0
+    if ro["traffic"] is None:
+        assert "stale" in ro["traffic_source"] or "no " in ro["traffic_source"]  # never a silent number from another build
+    assert j["distributed"] == {"backend": "none", "rccl_world_size": 0, "world_size": 1, "collectives": j["distributed"]["collectives"]}
+    assert j["parity"]["mask_agreement_vs_reference"] > 0.9999 and j["parity"]["miou_delta_pp"] < 0.1
+
+
+def test_bench_two_ranks_rehearsed_on_one_gpu():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port",
+           str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--no-extras", "--no-cpu-baseline",
+           "--rehearse-on-one-gpu"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = _last_json(r.stdout)
+    assert j["n_gpus"] == 2 and j["distributed"]["world_size"] == 2 and j["distributed"]["backend"] == "gloo"
+    assert j["config"]["frames_per_step_per_gpu"] == 5
+    # whole-job value: frames of BOTH ranks over the slower rank's time
+    assert abs(j["value"] - 2 * 5 * 1000.0 / j["ms_per_step"]) < 1e-2 * j["value"]
