@@ -356,16 +356,28 @@ def variants(args, dev, rdev, net, state, fm, windows, dl, dr, host_masks, host_
 
     # (vi) the reference's default real-video route (no_cropping=False): 1072x1920 frames, 8 overlapping 713x713 crops of both
     # key frames batched through the network, fused tail + softmax + float64 canvas, masks at 1072x1920 (flow/base.py:182-209)
-    hd = synth.make_clip(6, (1072, 1920), seed=1200, only=[0, 5]).to(dev)
+    hd = synth.make_clip(16, (1072, 1920), seed=1200, only=[0, 5, 10, 15]).to(dev)
     gl, gr = [[g.to(dev) for g in gs] for gs in synth.make_grids(N_DELTA, 67, 120, seed=2100, frame=(1072, 1920), jitter=0.01)]
     fmw = FlowModel(net, feature_based=False, no_warp=False).eval()
     pred = FlowPredictor(fmw, CLASSES, (1072, 1920), crop=(SIZE, SIZE), compute_metrics=False)
 
     def step_crops(i):
-        host_post.copy_(pred.predict_window(hd[0:1], hd[1:2], gl, gr, to_host=False), non_blocking=True)
+        w = i % 3
+        host_post.copy_(pred.predict_window(hd[w:w + 1], hd[w + 1:w + 2], gl, gr, to_host=False), non_blocking=True)
         torch.cuda.current_stream().synchronize()
     run("fps_real_video_route_8crops_1072x1920_warp", step_crops, max(1, few // 2), N_DELTA, warm=1)
-    del pred, hd
+
+    # ... and as tools/predict_video.py runs it by default: with the key-frame cache (8 new crop inferences per window, not 16)
+    predc = FlowPredictor(fmw, CLASSES, (1072, 1920), crop=(SIZE, SIZE), compute_metrics=False, cache_keyframes=True)
+
+    def step_crops_cached(i):
+        w = i % 3
+        if w == 0:
+            predc.key_cache.clear()  # a new clip: its first window segments both key frames
+        host_post.copy_(predc.predict_window(hd[w:w + 1], hd[w + 1:w + 2], gl, gr, to_host=False, key_ids=(5 * w, 5 * w + 5)), non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+    run("fps_real_video_route_8crops_keyframe_cache", step_crops_cached, max(3, few // 2), N_DELTA, warm=1)
+    del pred, predc, hd
 
     # (vii) BASELINE configs[2]: DeepLabv3-ResNet101 key frames + optical-flow warp of the logits
     from flood_uav_video_segmentation_amd.model.deeplabv3 import FlowDeepLabv3
