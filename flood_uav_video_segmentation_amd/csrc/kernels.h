@@ -93,6 +93,10 @@ int launch_ppm_pool_combine(const float* cell_mean, float* out1, float* out2, fl
 // Used for the pooled PPM / ASPP-pooling branches (M = B*bin*bin <= ~100).
 int launch_rowdot_1x1(const float* in, int ld_in, const float* wgt, const float* scale, const float* shift,
                       float* out, int ld_out, int M, int K, int N, int relu, hipStream_t s);
+// up to four such problems of one (K, N, ld_in, ld_out) in ONE launch (the four pyramid levels: M = B, 4B, 9B, 36B)
+struct RowdotProblem { const float* in; const float* wgt; const float* scale; const float* shift; float* out; int M; };
+struct RowdotBatch { RowdotProblem p[4]; };
+int launch_rowdot_1x1_batch(const RowdotBatch& pb, int nprob, int ld_in, int ld_out, int K, int N, int relu, hipStream_t s);
 
 // Bilinear (align_corners as given) upsample of a tiny [B][hi*wi][C] map into a channel
 // slice of an NHWC buffer (PPM: model/pspnet.py:33, align_corners=True).

@@ -556,6 +556,8 @@ int pyramid_reduce(fs_net* h, const float* feat, int ld_feat, int B, int H, int 
         FS_TRY(launch_ppm_pool_combine(pooled + pool_off[3], pooled + pool_off[0], pooled + pool_off[1], pooled + pool_off[2], B, 2048, s));
         FS_TRY(prof_end(h, s));
     }
+    RowdotBatch pb{};
+    double flops = 0;
     for (int i = 0; i < 4; ++i) {
         const int bin = h->bins[i];
         const int cells = bin * bin;
@@ -565,11 +567,13 @@ int pyramid_reduce(fs_net* h, const float* feat, int ld_feat, int B, int H, int 
             FS_TRY(prof_end(h, s));
         }
         const ConvBN& c = h->ppm[i];
-        FS_TRY(prof_begin(h, c.name, "rowdot_1x1", 2.0 * B * cells * 2048.0 * 512.0, 4.0 * 2048.0 * 512.0, s));
-        FS_TRY(launch_rowdot_1x1(pooled + pool_off[i], 2048, c.w, c.scale, c.shift, reduced + (size_t)i * B * 36 * 512, 512, B * cells, 2048,
-                                 512, 1, s));
-        FS_TRY(prof_end(h, s));
+        pb.p[i] = RowdotProblem{pooled + pool_off[i], c.w, c.scale, c.shift, reduced + (size_t)i * B * 36 * 512, B * cells};
+        flops += 2.0 * B * cells * 2048.0 * 512.0;
     }
+    // the four levels' 1x1 conv + BN + ReLU (model/pspnet.py:23-25) as ONE launch: M = B, 4B, 9B, 36B rows of the same (K, N)
+    FS_TRY(prof_begin(h, "ppm.features.*.1.weight", "rowdot_1x1", flops, 4.0 * 4 * 2048.0 * 512.0, s));
+    FS_TRY(launch_rowdot_1x1_batch(pb, 4, 2048, 512, 2048, 512, 1, s));
+    FS_TRY(prof_end(h, s));
     return 0;
 }
 

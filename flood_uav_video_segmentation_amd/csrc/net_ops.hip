@@ -322,23 +322,24 @@ int launch_ppm_pool_combine(const float* cell_mean, float* out1, float* out2, fl
 // block's row chunk (blockIdx.y): the rows are independent, so chunking them shortens the serial chain per wave.
 // -------------------------------------------------------------------------------------------
 template <int KV /* float4 per lane = K/256 */>
-__global__ __launch_bounds__(256) void rowdot_1x1_kernel(const float* __restrict__ in, int ld_in, const float* __restrict__ wgt,
-                                                         const float* __restrict__ scale, const float* __restrict__ shift,
-                                                         float* __restrict__ out, int ld_out, int M, int K, int N, int relu) {
+__global__ __launch_bounds__(256) void rowdot_1x1_kernel(RowdotBatch pb, int ld_in, int ld_out, int K, int N, int relu) {
+    const RowdotProblem& q = pb.p[blockIdx.z];  // several small problems of one (K, N) in one launch: the four pyramid levels
     const int lane = threadIdx.x & 63;
     const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (n >= N) return;
+    const int M = q.M;
+    const int per = (M + gridDim.y - 1) / gridDim.y;
+    const int m_begin = blockIdx.y * per, m_end = min(M, (int)(blockIdx.y + 1) * per);
+    if (m_begin >= m_end) return;
     f32x4 w[KV];
 #pragma unroll
-    for (int i = 0; i < KV; ++i) w[i] = *reinterpret_cast<const f32x4*>(wgt + (size_t)n * K + (i * 64 + lane) * 4);
-    const float sc = scale ? scale[n] : 1.f, sh = shift ? shift[n] : 0.f;
-    const int per = (M + gridDim.y - 1) / gridDim.y;
-    const int m_end = min(M, (int)(blockIdx.y + 1) * per);
-    for (int m = blockIdx.y * per; m < m_end; ++m) {
+    for (int i = 0; i < KV; ++i) w[i] = *reinterpret_cast<const f32x4*>(q.wgt + (size_t)n * K + (i * 64 + lane) * 4);
+    const float sc = q.scale ? q.scale[n] : 1.f, sh = q.shift ? q.shift[n] : 0.f;
+    for (int m = m_begin; m < m_end; ++m) {
         float acc = 0.f;
 #pragma unroll
         for (int i = 0; i < KV; ++i) {
-            const f32x4 x = *reinterpret_cast<const f32x4*>(in + (size_t)m * ld_in + (i * 64 + lane) * 4);
+            const f32x4 x = *reinterpret_cast<const f32x4*>(q.in + (size_t)m * ld_in + (i * 64 + lane) * 4);
             acc += x[0] * w[i][0] + x[1] * w[i][1] + x[2] * w[i][2] + x[3] * w[i][3];
         }
 #pragma unroll
@@ -346,18 +347,20 @@ __global__ __launch_bounds__(256) void rowdot_1x1_kernel(const float* __restrict
         if (lane == 0) {
             float y = acc * sc + sh;
             if (relu) y = fmaxf(y, 0.f);
-            out[(size_t)m * ld_out + n] = y;
+            q.out[(size_t)m * ld_out + n] = y;
         }
     }
 }
 
-int launch_rowdot_1x1(const float* in, int ld_in, const float* wgt, const float* scale, const float* shift, float* out,
-                      int ld_out, int M, int K, int N, int relu, hipStream_t s) {
+int launch_rowdot_1x1_batch(const RowdotBatch& pb, int nprob, int ld_in, int ld_out, int K, int N, int relu, hipStream_t s) {
     FS_REQUIRE(K % 256 == 0 && K <= 4096, "rowdot_1x1: K=%d must be a multiple of 256 and <= 4096", K);
-    const dim3 grid(cdiv(N, 4), std::max(1, std::min(12, M / 6))), block(256);  // ~6+ rows per wave
+    FS_REQUIRE(nprob >= 1 && nprob <= 4, "rowdot_1x1: 1..4 problems per launch");
+    int mmax = 1;
+    for (int i = 0; i < nprob; ++i) mmax = std::max(mmax, pb.p[i].M);
+    const dim3 grid(cdiv(N, 4), std::max(1, std::min(12, mmax / 6)), nprob), block(256);  // ~6+ rows per wave of the largest problem
 #define FS_ROWDOT(KV)                                                                                             \
     case KV:                                                                                                      \
-        hipLaunchKernelGGL((rowdot_1x1_kernel<KV>), grid, block, 0, s, in, ld_in, wgt, scale, shift, out, ld_out, M, K, N, relu); \
+        hipLaunchKernelGGL((rowdot_1x1_kernel<KV>), grid, block, 0, s, pb, ld_in, ld_out, K, N, relu);            \
         break;
     switch (K / 256) {
         FS_ROWDOT(1) FS_ROWDOT(2) FS_ROWDOT(3) FS_ROWDOT(4) FS_ROWDOT(5) FS_ROWDOT(6) FS_ROWDOT(7) FS_ROWDOT(8)
@@ -367,6 +370,13 @@ int launch_rowdot_1x1(const float* in, int ld_in, const float* wgt, const float*
 #undef FS_ROWDOT
     FS_HIP(hipGetLastError());
     return 0;
+}
+
+int launch_rowdot_1x1(const float* in, int ld_in, const float* wgt, const float* scale, const float* shift, float* out,
+                      int ld_out, int M, int K, int N, int relu, hipStream_t s) {
+    RowdotBatch pb{};
+    pb.p[0] = RowdotProblem{in, wgt, scale, shift, out, M};
+    return launch_rowdot_1x1_batch(pb, 1, ld_in, ld_out, K, N, relu, s);
 }
 
 // -------------------------------------------------------------------------------------------

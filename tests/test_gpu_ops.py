@@ -105,17 +105,20 @@ def test_conv_rejects_bad_shapes():
     assert rc != 0 and b"multiple of 32" in lib.fs_last_error()
 
 
-@pytest.mark.parametrize("k,stride,pad", [(3, 2, 1), (7, 2, 3)])
-def test_stem_conv(k, stride, pad):
+@pytest.mark.parametrize("cout", [64, 128, 96, 16])
+@pytest.mark.parametrize("k,stride,pad", [(3, 2, 1), (7, 2, 3), (3, 1, 1)])
+def test_stem_conv(k, stride, pad, cout):
+    """Cin = 3 stem conv from NCHW: Cout % 32 == 0 (<= 128) runs on the matrix cores (one, two, three or four 32-channel
+    sub-tiles; 27 / 147 taps padded to whole batches of 8 MFMA k-steps with zero weights), Cout = 16 keeps the VALU kernel."""
     lib = _lib.load()
-    g = torch.Generator().manual_seed(k)
+    g = torch.Generator().manual_seed(k * 100 + cout)
     x = torch.randn(2, 3, 65, 71, generator=g)
-    wt = torch.randn(64, 3, k, k, generator=g) * 0.2
-    sc, sh = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g) * 0.1
+    wt = torch.randn(cout, 3, k, k, generator=g) * 0.2
+    sc, sh = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.1
     ref = (F.conv2d(x, wt, None, stride, pad) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)).relu()
-    out = torch.empty((2, ref.shape[2], ref.shape[3], 64), device=DEV)
+    out = torch.empty((2, ref.shape[2], ref.shape[3], cout), device=DEV)
     xd, wd, scd, shd = x.to(DEV), wt.permute(2, 3, 1, 0).contiguous().to(DEV), sc.to(DEV), sh.to(DEV)
-    check(lib.fs_stem_conv_nchw(ptr(xd), ptr(wd), ptr(scd), ptr(shd), ptr(out), 2, 65, 71, 64, k, k, stride, pad, stream_ptr()))
+    check(lib.fs_stem_conv_nchw(ptr(xd), ptr(wd), ptr(scd), ptr(shd), ptr(out), 2, 65, 71, cout, k, k, stride, pad, stream_ptr()))
     assert rel(out.permute(0, 3, 1, 2), ref) < CONV_TOL
 
 
