@@ -163,7 +163,7 @@ __global__ __launch_bounds__(256) void stem_conv_mfma_kernel(StemParams p, int k
 }
 
 int launch_stem_conv(const StemParams& p, hipStream_t s) {
-    FS_REQUIRE(p.Cout % 16 == 0 && p.Cout <= 256 && 256 % (p.Cout / 16) == 0, "stem_conv: unsupported Cout=%d", p.Cout);
+    FS_REQUIRE(p.Cout >= 16 && p.Cout <= 256 && p.Cout % 16 == 0, "stem_conv: unsupported Cout=%d", p.Cout);
     FS_REQUIRE(p.ld_out % 4 == 0, "stem_conv: ld_out must be a multiple of 4");
     const FrameSrc& f = p.src;
     if (f.ncrops) {
@@ -179,19 +179,27 @@ int launch_stem_conv(const StemParams& p, hipStream_t s) {
     if (p.Cout % 32 == 0 && p.Cout <= 128 && p.KH < 0x7fff) {  // matrix-core route
         const int ksteps = cdiv(cdiv(taps, 2), 8) * 8;  // whole batches of 8 MFMA k-steps; the padding taps carry zero weights
         const size_t lds = (size_t)2 * ksteps * (p.Cout + 2) * sizeof(float);
-        FS_REQUIRE(lds <= 64 * 1024, "stem_conv: filter bank %zu B exceeds LDS budget", lds);
+        FS_REQUIRE(lds <= 128 * 1024, "stem_conv: filter bank %zu B exceeds LDS budget", lds);
         FS_REQUIRE((long long)3 * (f.ncrops ? (long long)f.FH * f.FW : (long long)p.H * p.W) < (1ll << 31), "stem_conv: frame too large for 32-bit tap offsets");
         const int tiles = cdiv(M, 32);
         const dim3 grid((unsigned)std::min(cdiv(tiles, 4), 256 * 8));
+#define FS_STEM_LAUNCH(NT_)                                                                                                      \
+    {                                                                                                                            \
+        if (lds > 64 * 1024)  /* 7x7 with > 64 channels: more dynamic LDS than the default cap */                                \
+            FS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_conv_mfma_kernel<NT_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL((stem_conv_mfma_kernel<NT_>), grid, dim3(256), lds, s, p, ksteps);                                    \
+    }
         switch (p.Cout / 32) {
-            case 1: hipLaunchKernelGGL((stem_conv_mfma_kernel<1>), grid, dim3(256), lds, s, p, ksteps); break;
-            case 2: hipLaunchKernelGGL((stem_conv_mfma_kernel<2>), grid, dim3(256), lds, s, p, ksteps); break;
-            case 3: hipLaunchKernelGGL((stem_conv_mfma_kernel<3>), grid, dim3(256), lds, s, p, ksteps); break;
-            default: hipLaunchKernelGGL((stem_conv_mfma_kernel<4>), grid, dim3(256), lds, s, p, ksteps); break;
+            case 1: FS_STEM_LAUNCH(1) break;
+            case 2: FS_STEM_LAUNCH(2) break;
+            case 3: FS_STEM_LAUNCH(3) break;
+            default: FS_STEM_LAUNCH(4) break;
         }
+#undef FS_STEM_LAUNCH
         FS_HIP(hipGetLastError());
         return 0;
     }
+    FS_REQUIRE(256 % (p.Cout / 16) == 0, "stem_conv: the VALU kernel needs Cout / 16 to divide 256 (Cout=%d)", p.Cout);
     const int groups = p.Cout / 16, ppb = 256 / groups;
     const size_t lds = (size_t)taps * p.Cout * sizeof(float);
     FS_REQUIRE(lds <= 64 * 1024, "stem_conv: filter bank %zu B exceeds LDS budget", lds);
