@@ -175,7 +175,9 @@ class FlowModel(nn.Module):
         The reference's size test compares shape[1]/shape[2] with (i_h, i_w) (:102), i.e. channels vs
         height: it is almost always true, so the resize runs whenever warping is enabled -- kept."""
         i_h, i_w = input.shape[2], input.shape[3]
-        rows = []
+        nhwc = ops.is_channels_last_dense(input) and input.shape[1] > 1 and not input.is_contiguous()
+        out = (ops.empty_nhwc(len(index_list), input.shape[1], i_h, i_w, input.device) if nhwc else
+               torch.empty((len(index_list), input.shape[1], i_h, i_w), dtype=torch.float32, device=input.device))
         for i, index in enumerate(index_list):
             cur = input[i:i + 1]
             if not self.no_warp:
@@ -183,13 +185,8 @@ class FlowModel(nn.Module):
                     cur = self.warp(cur, mvs[j][i:i + 1])
                 if cur.shape[1] != i_h or cur.shape[2] != i_w:
                     cur = ops.resize_bilinear(cur, (i_h, i_w), align_corners=True)
-            rows.append(ops.blend(cur, (n_list[i] - index) / n_list[i]))
-        if ops.is_channels_last_dense(rows[0]) and rows[0].shape[1] > 1:
-            out = ops.empty_nhwc(len(rows), rows[0].shape[1], i_h, i_w, input.device)
-            for i, r in enumerate(rows):
-                out[i:i + 1].copy_(r)
-            return out
-        return torch.cat(rows, 0)
+            ops.blend(cur, (n_list[i] - index) / n_list[i], out=out[i:i + 1])  # written in place: no per-sample copy
+        return out
 
     # ------------------------------------------------------------------------------------ inference
     def predict(self, *args, **kwargs):
@@ -223,6 +220,11 @@ class FlowModel(nn.Module):
         with _region(profiler, "predict_encoder"):
             f, f_next = self._key_outputs(self._encode, ("feat", h, w), frame_prev, frame_next, key_cache)
         f_h, f_w = f.shape[2], f.shape[3]
+        # the n maps the decoder sees are produced straight into ONE batch tensor (the reference stacks them with torch.cat, :173-176)
+        nmaps = n if f_next is not None else 1
+        nhwc = ops.is_channels_last_dense(f) and f.shape[1] > 1 and not f.is_contiguous()
+        stack = (ops.empty_nhwc(nmaps, f.shape[1], f_h, f_w, f.device) if nhwc else
+                 torch.empty((nmaps, f.shape[1], f_h, f_w), dtype=torch.float32, device=f.device))
         fwd, bwd = [], []
         if f_next is not None and not self.no_warp:
             with _region(profiler, "predict_warp"):
@@ -238,21 +240,20 @@ class FlowModel(nn.Module):
             # the key-frame feature goes through the 67x120 identity grid, align_corners=True (:154-159)
             if self.default_motion_vector.device != f.device:
                 self.default_motion_vector = self.default_motion_vector.to(device=f.device)
-            f = self._fit(ops.grid_sample(f, self.default_motion_vector, align_corners=True), f_h, f_w)
-        maps = [f]
+            g0 = ops.grid_sample(f, self.default_motion_vector, align_corners=True)
+            if g0.shape[2] != f_h or g0.shape[3] != f_w:
+                f = ops.resize_bilinear(g0, (f_h, f_w), align_corners=True, out=stack[0:1])
+            else:
+                f = ops.blend(g0, 1.0, out=stack[0:1])
+        else:
+            f = ops.blend(f, 1.0, out=stack[0:1])  # 1.0 * x is x: a HIP copy into the batch slot
         if f_next is not None:
             with _region(profiler, "predict_fusion"):
                 for p in range(1, n):
                     if self.no_warp:
-                        maps.append(ops.blend(f, (n - p) / n, f_next, p / n))
+                        ops.blend(f, (n - p) / n, f_next, p / n, out=stack[p:p + 1])
                     else:
-                        maps.append(ops.blend(fwd[p - 1], (n - p) / n, bwd[n - p - 1], p / n))
+                        ops.blend(fwd[p - 1], (n - p) / n, bwd[n - p - 1], p / n, out=stack[p:p + 1])
         with _region(profiler, "predict_decoder"):
-            if ops.is_channels_last_dense(maps[0]) and maps[0].shape[1] > 1:
-                stack = ops.empty_nhwc(len(maps), maps[0].shape[1], f_h, f_w, f.device)
-                for i, m in enumerate(maps):
-                    stack[i:i + 1].copy_(m)
-            else:
-                stack = torch.cat(maps, 0)
             out = self._fit_out(self.model.decoder(stack), h, w)
         return {"pred": out}

@@ -63,32 +63,42 @@ def grid_sample(inp, grid, align_corners=False):
         return out
 
 
-def resize_bilinear(inp, size, align_corners=True):
+def _check_out(out, shape, nhwc, what):
+    """`out=`: a caller-owned destination (e.g. one image slot of a batch tensor) -- must already have the layout the op writes."""
+    if tuple(out.shape) != tuple(shape) or out.dtype != torch.float32:
+        raise RuntimeError(f"{what}: out must be float32 {tuple(shape)}, got {out.dtype} {tuple(out.shape)}")
+    if not (is_channels_last_dense(out) if nhwc else out.is_contiguous()):
+        raise RuntimeError(f"{what}: out must be dense {'channels_last' if nhwc else 'contiguous'}")
+    return out
+
+
+def resize_bilinear(inp, size, align_corners=True, out=None):
     """F.interpolate(inp, size, mode='bilinear', align_corners=...) (flow/model.py:42..228)."""
     lib = _lib.load()
     b, c, hi, wi = inp.shape
     ho, wo = int(size[0]), int(size[1])
-    dev = one_device(inp, what="floodseg.resize_bilinear")
+    dev = one_device(inp, out, what="floodseg.resize_bilinear")
     with torch.cuda.device(dev):
         if b == 0:
             return torch.empty((0, c, ho, wo), dtype=torch.float32, device=dev)
         if c % 4 == 0 and c >= 64 and is_channels_last_dense(inp):
             src = inp if inp.dtype == torch.float32 else inp.float()
-            out = empty_nhwc(b, c, ho, wo, dev)
+            out = empty_nhwc(b, c, ho, wo, dev) if out is None else _check_out(out, (b, c, ho, wo), True, "floodseg.resize_bilinear")
             check(lib.fs_resize_bilinear_nhwc(ptr(src), c, b, c, hi, wi, ptr(out), c, ho, wo, int(align_corners), stream_ptr()))
             return out
         src = _f32c(inp, "input")
-        out = torch.empty((b, c, ho, wo), dtype=torch.float32, device=dev)
+        out = torch.empty((b, c, ho, wo), dtype=torch.float32, device=dev) if out is None else _check_out(out, (b, c, ho, wo), False, "floodseg.resize_bilinear")
         check(lib.fs_resize_bilinear_nchw(ptr(src), b * c, hi, wi, ptr(out), ho, wo, int(align_corners), stream_ptr()))
         return out
 
 
-def blend(a, wa, b=None, wb=0.0):
-    """wa*a + wb*b with the reference's rounding order (flow/model.py:104,168,234-236)."""
+def blend(a, wa, b=None, wb=0.0, out=None):
+    """wa*a + wb*b with the reference's rounding order (flow/model.py:104,168,234-236).  out: optional destination of the
+    layout the result has (channels_last when `a` is, else contiguous), e.g. one image slot of a preallocated batch."""
     lib = _lib.load()
     if b is not None and a.shape != b.shape:
         raise RuntimeError(f"floodseg.blend: shapes differ ({tuple(a.shape)} vs {tuple(b.shape)})")
-    dev = one_device(a, b, what="floodseg.blend")
+    dev = one_device(a, b, out, what="floodseg.blend")
     with torch.cuda.device(dev):
         # the kernel walks both operands as flat arrays: bring BOTH to one dense layout (channels_last kept when `a` has it,
         # so the feature-mode maps are not transposed; any other view -- equal strides or not -- becomes plain contiguous)
@@ -102,7 +112,8 @@ def blend(a, wa, b=None, wb=0.0):
         a = a if a.dtype == torch.float32 else a.float()
         if b is not None and b.dtype != torch.float32:
             b = b.float()
-        out = torch.empty_like(a)
+        out = torch.empty_like(a) if out is None else _check_out(out, a.shape, a.dim() == 4 and is_channels_last_dense(a) and not a.is_contiguous(),
+                                                                 "floodseg.blend")
         if a.numel() == 0:
             return out
         check(lib.fs_blend(ptr(a), float(wa), ptr(b), float(wb), ptr(out), a.numel(), stream_ptr()))

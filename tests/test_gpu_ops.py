@@ -193,6 +193,16 @@ def test_blend_is_bit_exact():
     assert torch.equal(ops.blend(ca, 0.4, cb, 0.6).cpu(), (0.4 * ca + 0.6 * cb).cpu())
     with pytest.raises(RuntimeError, match="shapes differ"):
         ops.blend(ca, 0.5, cb[:, :32], 0.5)
+    # out=: results written straight into one image slot of a preallocated batch (what predict_feature / warp_batch do)
+    batch = ops.empty_nhwc(3, 64, 6, 7, DEV)
+    got = ops.blend(ca, 0.4, cb, 0.6, out=batch[1:2])
+    assert got.data_ptr() == batch[1:2].data_ptr() and torch.equal(batch[1:2], ops.blend(ca, 0.4, cb, 0.6))
+    up = ops.resize_bilinear(ca, (6, 7), out=batch[2:3])
+    assert up.data_ptr() == batch[2:3].data_ptr() and torch.equal(batch[2:3], ca)  # identity resize
+    with pytest.raises(RuntimeError, match="out must be"):
+        ops.blend(ca, 0.4, cb, 0.6, out=torch.empty(1, 64, 6, 7, device=DEV))      # contiguous slot for a channels_last result
+    with pytest.raises(RuntimeError, match="out must be"):
+        ops.blend(big_a, 1.0, out=torch.empty(2, 5, 16, 8, device=DEV))            # wrong shape
 
 
 def test_argmax_resize_argmax_and_iou_hist():
