@@ -54,6 +54,47 @@ def test_conv_igemm(case, tile):
     assert rel(got, ref) < CONV_TOL
 
 
+def test_conv_and_winograd_on_seeded_random_shapes():
+    """30 seeded random geometries (batch, ragged H x W, channel counts that leave partial n-tiles, kernel 1 / 3, stride, dilation,
+    residual, activation) through fs_conv2d_nhwc with the cost model's tile, and -- where eligible -- through the Winograd route,
+    against F.conv2d: a net for indexing slips that the hand-picked cases above may miss."""
+    import random
+
+    rnd = random.Random(20261004)
+    lib = _lib.load()
+    for it in range(30):
+        b = rnd.choice([1, 1, 2, 3])
+        h, w = rnd.randint(1, 61), rnd.randint(1, 61)
+        cin = 32 * rnd.randint(1, 8)
+        cout = rnd.choice([8, 32, 40, 64, 96, 130, 192, 256])
+        k = rnd.choice([1, 3])
+        dil = rnd.choice([1, 1, 2, 4, 7]) if k == 3 else 1
+        stride = rnd.choice([1, 1, 2])
+        pad = dil if k == 3 else 0
+        relu, res = rnd.random() < 0.5, rnd.random() < 0.4
+        g = torch.Generator().manual_seed(it)
+        x = torch.randn(b, cin, h, w, generator=g)
+        wt = torch.randn(cout, cin, k, k, generator=g) * (2.0 / (cin * k * k)) ** 0.5
+        sc, sh = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.1
+        ref = F.conv2d(x, wt, None, stride, pad, dil) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)
+        r = torch.randn(ref.shape, generator=g) if res else None
+        if res:
+            ref = ref + r
+        if relu:
+            ref = ref.relu()
+        got = ops.conv2d_nhwc(x.to(DEV), wt.to(DEV), sc.to(DEV), sh.to(DEV), r.to(DEV) if res else None, stride, pad, dil, relu, 0)
+        assert rel(got, ref) < CONV_TOL, (it, b, h, w, cin, cout, k, stride, dil, relu, res)
+        if k == 3 and stride == 1 and not res and cout % 4 == 0:
+            for tile_m in (4, 6):
+                out = torch.empty((b, h, w, cout), device=DEV)
+                ws = torch.empty(lib.fs_winograd_workspace_floats(b, h, w, cin, cout, dil, tile_m), device=DEV)
+                xd = ops.as_nhwc(x.to(DEV))
+                wd, scd, shd = wt.to(DEV), sc.to(DEV), sh.to(DEV)
+                check(lib.fs_conv3x3_winograd_nhwc(ptr(xd), cin, ptr(wd), ptr(scd), ptr(shd), ptr(out), cout, b, h, w, cin, cout, dil, int(relu),
+                                                   tile_m, ptr(ws), stream_ptr()))
+                assert rel(out.permute(0, 3, 1, 2), ref) < WINO_TOL, (it, tile_m, b, h, w, cin, cout, dil)
+
+
 @pytest.mark.parametrize("dil", [1, 7, 18, 36])
 def test_conv_chunk_major_filters_over_dilations(dil):
     """The layout the network uses for 3x3 convs ([O][I/32][KH][KW][32], tile bit 10) with dilations from 'all taps live' to
