@@ -76,7 +76,7 @@ def exchange_boundary(last_mask, has_windows, device="cpu"):
     Every rank contributes its last uint8 mask [H,W] (zeros + has_windows=False when its block is empty); returns the mask to
     pair this rank's first frame with, or None (rank 0 / no earlier rank had windows / single process).  One all_gather of
     H*W bytes per rank at the end of the run -- not in the per-window loop."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return None
     rank, size = dist.get_rank(), dist.get_world_size()
     mine = torch.as_tensor(last_mask, dtype=torch.uint8, device=device).contiguous()
@@ -99,7 +99,7 @@ def reduce_run(hist, frames, seconds, device="cpu"):
     hist = torch.as_tensor(hist, dtype=torch.int64).to(device).clone()
     cnt = torch.tensor([int(frames)], dtype=torch.int64, device=device)
     sec = torch.tensor([float(seconds)], dtype=torch.float64, device=device)
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_available() and dist.is_initialized():  # also for a world of one: the collective path is the same code
         dist.all_reduce(hist, op=dist.ReduceOp.SUM)
         dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
         dist.all_reduce(sec, op=dist.ReduceOp.MAX)

@@ -56,3 +56,33 @@ def test_bench_two_ranks_rehearsed_on_one_gpu():
     assert j["config"]["frames_per_step_per_gpu"] == 5
     # whole-job value: frames of BOTH ranks over the slower rank's time
     assert abs(j["value"] - 2 * 5 * 1000.0 / j["ms_per_step"]) < 1e-2 * j["value"]
+
+
+def test_rccl_code_path_with_a_world_of_one():
+    """No second GPU on this box, so RCCL cannot be exercised across ranks here -- but the exact calls the N > 1 run makes
+    (init_process_group("nccl"), barrier(device_ids=...), on-device all_reduce SUM / MAX, the boundary all_gather) do run
+    through RCCL with a world of one.  In a child process, so the test runner keeps no process group."""
+    code = """
+import os, sys, torch
+sys.path.insert(0, %r)
+os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=%r)
+import torch.distributed as dist
+from flood_uav_video_segmentation_amd import shard
+torch.cuda.set_device(0)
+dist.init_process_group(backend="nccl", rank=0, world_size=1)
+assert shard.describe() == ("nccl", 1)
+dev = torch.device("cuda", 0)
+shard.barrier(dev)
+hist, frames, sec = shard.reduce_run(torch.arange(15).view(3, 5), 20, 1.5, dev)
+assert hist.tolist() == torch.arange(15).view(3, 5).tolist() and frames == 20 and sec == 1.5
+nb = shard.exchange_boundary(torch.full((8, 8), 7, dtype=torch.uint8, device=dev), True, dev)
+assert nb is None
+shard.barrier(dev)
+dist.destroy_process_group()
+print("rccl-ok")
+"""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = str(s.getsockname()[1])
+    r = subprocess.run([sys.executable, "-c", code % (ROOT, port)], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0 and "rccl-ok" in r.stdout, (r.stdout[-1000:], r.stderr[-3000:])
