@@ -173,12 +173,13 @@ def gen_pspnet():
     save("metrics.npz", inter=ai, union=au, target=at)
 
 
-def gen_vit():
-    """VITSegmentModel (ViT-B/32 as model/vit.py hard-codes it).  timm is absent offline; the reference imports
-    three timm symbols that do not take part in the eval forward (DropPath(0) == Identity, trunc_normal_ and
-    _load_weights are initialisers/loaders), so stand-ins for exactly those names are registered first."""
+def _timm_stand_ins():
+    """timm is absent offline; the reference imports three timm symbols that do not take part in the eval forward
+    (DropPath(0) == Identity, trunc_normal_ and _load_weights are initialisers/loaders): stand-ins for exactly those names."""
     import types
 
+    if "timm" in sys.modules:
+        return
     timm = types.ModuleType("timm")
     timm.models = types.ModuleType("timm.models")
     timm.models.layers = types.ModuleType("timm.models.layers")
@@ -189,6 +190,11 @@ def gen_vit():
     for name, mod in (("timm", timm), ("timm.models", timm.models), ("timm.models.layers", timm.models.layers),
                       ("timm.models.vision_transformer", timm.models.vision_transformer)):
         sys.modules[name] = mod
+
+
+def gen_vit():
+    """VITSegmentModel (ViT-B/32 as model/vit.py hard-codes it)."""
+    _timm_stand_ins()
     import model.vit as ref_vit  # reference
 
     state = synth.make_vit_state(5, 704, seed=0)
@@ -206,8 +212,40 @@ def gen_vit():
          pred713_sub=o713[:, :, ::8, ::8], mask713=o713.max(1)[1].to(torch.uint8)[:, ::2, ::2])
 
 
+def gen_vit_s16():
+    """BASELINE configs[3] names a ViT-S/16; model/vit.py hard-codes B/32 (patch 32, d_model 768), so the S/16 network is
+    assembled from THE REFERENCE'S OWN CLASSES exactly as model/vit.py:24-52 assembles them, with S/16 numbers (patch 16,
+    d_model 384 -> 6 heads, 12 + 2 layers; segm/config.yml:52-59).  Same weights / frames as tests/test_gpu_fullsize.py."""
+    _timm_stand_ins()
+    import segm.model.decoder as ref_dec  # reference
+    import segm.model.segmenter as ref_seg  # reference
+    import segm.model.vit as ref_enc  # reference
+
+    d, patch, size = 384, 16, 704
+    encoder = ref_enc.VisionTransformer(image_size=(size, size), patch_size=patch, n_layers=12, d_model=d, d_ff=4 * d, n_heads=d // 64,
+                                        n_cls=5, dropout=0.1, drop_path_rate=0.0, distilled=False, channels=3)
+    decoder = ref_dec.MaskTransformer(n_cls=5, patch_size=encoder.patch_size, d_encoder=d, n_layers=2, n_heads=d // 64, d_model=d,
+                                      d_ff=4 * d, drop_path_rate=0.0, dropout=0.1)
+    net = ref_seg.Segmenter(encoder, decoder, n_cls=5).eval()
+    state = synth.make_vit_state(5, size, patch, d, 12, 2, seed=3)
+    res = net.load_state_dict(state, strict=False)
+    assert not res.unexpected_keys, res.unexpected_keys
+    assert all(k.startswith("encoder.head") for k in res.missing_keys), res.missing_keys
+    out = {}
+    for sz in (704, 713):
+        x = synth.make_clip(2, sz, seed=310 + sz)[0:1]
+        o = net(x)
+        assert o.shape == (1, 5, sz, sz)
+        print(f"vit-s16 {sz} hist", np.bincount(o.max(1)[1].numpy().ravel(), minlength=5), "range", o.min().item(), o.max().item())
+        out[f"pred{sz}_sub"] = o[:, :, ::8, ::8]
+        out[f"mask{sz}"] = o.max(1)[1].to(torch.uint8)[:, ::2, ::2]
+    save("vit_s16.npz", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["grid", "ops", "toy", "pspnet", "vit"]
+    which = sys.argv[1:] or ["grid", "ops", "toy", "pspnet", "vit", "vit_s16"]
+    if "vit_s16" in which:
+        gen_vit_s16()
     if "vit" in which:
         gen_vit()
     if "grid" in which:

@@ -123,6 +123,10 @@ def test_config3_vit_s16_per_frame_against_oracle(vit_s16, size):
     assert note(f"cfg3_vit_s16_{size}_logits", rel_err(got.cpu(), ref)) < VIT_TOL
     agree = (got.max(1)[1].cpu() == ref.max(1)[1]).float().mean().item()
     assert note(f"cfg3_vit_s16_{size}_mask_disagreement", 1 - agree) < 1e-3
+    # ... and against the reference's own classes assembled with the S/16 numbers (tests/golden/gen_goldens.py::gen_vit_s16)
+    z = load_golden("vit_s16.npz")
+    assert note(f"cfg3_vit_s16_{size}_logits_vs_reference", rel_err(got[0:1, :, ::8, ::8].cpu(), z[f"pred{size}_sub"])) < VIT_TOL
+    assert (got[0:1].max(1)[1].to(torch.uint8)[:, ::2, ::2].cpu().numpy() == z[f"mask{size}"]).mean() > 0.999
 
 
 @pytest.mark.parametrize("size", [704, 713])

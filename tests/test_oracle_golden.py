@@ -163,3 +163,19 @@ def test_vit_b32_matches_reference():
     assert o713.shape == (1, 5, 713, 713)
     assert rel_err(o713[:, :, ::8, ::8], z["pred713_sub"]) < 2e-5
     assert (o713.max(1)[1].to(torch.uint8)[:, ::2, ::2].numpy() == z["mask713"]).mean() > 0.9999
+
+
+@pytest.mark.parametrize("size", [704, 713])
+def test_vit_s16_oracle_matches_the_reference_classes(size):
+    """BASELINE configs[3]'s network (ViT-S/16: patch 16, d_model 384, 12 + 2 layers) assembled from the reference's own segm
+    classes as model/vit.py assembles B/32 (tests/golden/gen_goldens.py::gen_vit_s16): pins oracle/vit_oracle.py at the S/16
+    geometry -- 1937 tokens at 704, 2026 with padding + position-embedding resize at 713."""
+    from oracle import vit_oracle
+
+    z = load_golden("vit_s16.npz")
+    state = synth.make_vit_state(5, 704, 16, 384, 12, 2, seed=3)
+    x = synth.make_clip(2, size, seed=310 + size)[0:1]
+    out = vit_oracle.forward(x, state, 16, 12, 2, 704, 5)["pred"]
+    assert out.shape == (1, 5, size, size)
+    assert rel_err(out[:, :, ::8, ::8], z[f"pred{size}_sub"]) < 2e-5
+    assert (out.max(1)[1].to(torch.uint8)[:, ::2, ::2].numpy() == z[f"mask{size}"]).mean() > 0.9999
