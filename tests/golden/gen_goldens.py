@@ -212,6 +212,28 @@ def gen_vit():
          pred713_sub=o713[:, :, ::8, ::8], mask713=o713.max(1)[1].to(torch.uint8)[:, ::2, ::2])
 
 
+def gen_pspnet_feature():
+    """A2 at the BASELINE size: FlowModel(FlowPSPNet, feature_based=True).predict at 713x713, warp and no_warp
+    (flow/model.py:116-181: C = 4096 feature warps 90x90 -> 44x44, ONE decoder call on [5,4096,90,90]).  Same weights, key frames
+    and grids as the segmentation-mode goldens of gen_pspnet()."""
+    state = synth.make_pspnet_state(50, 5, seed=0)
+    net = build_ref_pspnet(state)
+    clip = synth.make_clip(6, 713, seed=1000)
+    prev, nxt = clip[0:1], clip[5:6]
+    n = 5
+    out = {}
+    for tag, no_warp in (("warp", False), ("nowarp", True)):
+        mvl, mvr = synth.dummy_grids(n) if no_warp else synth.make_grids(n, 44, 44, seed=2000)
+        fm = ref_flow.FlowModel(net, feature_based=True, no_warp=no_warp).eval()
+        o = fm.predict(prev, nxt, mvl, mvr, n, Prof())["pred"]
+        assert o.shape == (n, 5, 713, 713)
+        m = o.max(1)[1].to(torch.uint8)
+        print(f"feature {tag}: hist", np.bincount(m.numpy().ravel(), minlength=5), "range", o.min().item(), o.max().item())
+        out[f"{tag}_logits_sub"] = o[:, :, ::16, ::16]
+        out[f"{tag}_mask_sub"] = m[:, ::2, ::2]
+    save("predict_feature_713.npz", **out)
+
+
 def gen_vit_s16():
     """BASELINE configs[3] names a ViT-S/16; model/vit.py hard-codes B/32 (patch 32, d_model 768), so the S/16 network is
     assembled from THE REFERENCE'S OWN CLASSES exactly as model/vit.py:24-52 assembles them, with S/16 numbers (patch 16,
@@ -243,9 +265,11 @@ def gen_vit_s16():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["grid", "ops", "toy", "pspnet", "vit", "vit_s16"]
+    which = sys.argv[1:] or ["grid", "ops", "toy", "pspnet", "vit", "vit_s16", "pspnet_feature"]
     if "vit_s16" in which:
         gen_vit_s16()
+    if "pspnet_feature" in which:
+        gen_pspnet_feature()
     if "vit" in which:
         gen_vit()
     if "grid" in which:

@@ -174,13 +174,23 @@ def test_vit_two_frame_sizes_interleaved_do_not_share_state(vit_s16):
 # ------------------------------------------------------------------------------------------------ A2 at the BASELINE size
 def test_pspnet_feature_based_713_against_oracle(psp):
     """A2 (flow/model.py:116-181) at 713x713: C = 4096 NHWC warps 90x90 -> 44x44, resizes back to 90x90, the key-frame feature
-    through the 67x120 identity grid, ONE batched decoder call on [5,4096,90,90]."""
+    through the 67x120 identity grid, ONE batched decoder call on [5,4096,90,90].  Against the oracle (all pixels) and against
+    the reference's own output of the same call (tests/golden/predict_feature_713.npz, warp and no_warp)."""
     net, state = psp
     clip = synth.make_clip(6, 713, seed=1000)
     prev, nxt = clip[0:1], clip[5:6]
     mvl, mvr = synth.make_grids(N, 44, 44, seed=2000)
+    z = load_golden("predict_feature_713.npz")
+    dl, dr = synth.dummy_grids(N)
+    got_nw = FlowModel(net, feature_based=True, no_warp=True).eval().predict(prev.cuda(), nxt.cuda(), cu(dl), cu(dr), N, None)["pred"]
+    assert note("a2_pspnet_feature_713_nowarp_logits_vs_reference", rel_err(got_nw[:, :, ::16, ::16].cpu(), z["nowarp_logits_sub"])) < LOGIT_TOL
+    assert (ops.argmax_u8(got_nw)[:, ::2, ::2].cpu().numpy() == z["nowarp_mask_sub"]).mean() > MASK_MIN
+    del got_nw
     fm = FlowModel(net, feature_based=True, no_warp=False).eval()
     got = fm.predict(prev.cuda(), nxt.cuda(), cu(mvl), cu(mvr), N, None)["pred"]
+    assert note("a2_pspnet_feature_713_warp_logits_vs_reference", rel_err(got[:, :, ::16, ::16].cpu(), z["warp_logits_sub"])) < LOGIT_TOL
+    assert note("a2_pspnet_feature_713_warp_mask_disagreement_vs_reference",
+                1 - (ops.argmax_u8(got)[:, ::2, ::2].cpu().numpy() == z["warp_mask_sub"]).mean()) < 1 - MASK_MIN
     enc = memo(lambda x: pspnet_oracle.encoder(x, state, 50))
     dec = lambda f: pspnet_oracle.decoder(f, state)  # noqa: E731
     ref = flow_oracle.predict_feature(enc, dec, prev, nxt, mvl, mvr, N, False)["pred"]

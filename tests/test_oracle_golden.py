@@ -179,3 +179,16 @@ def test_vit_s16_oracle_matches_the_reference_classes(size):
     assert out.shape == (1, 5, size, size)
     assert rel_err(out[:, :, ::8, ::8], z[f"pred{size}_sub"]) < 2e-5
     assert (out.max(1)[1].to(torch.uint8)[:, ::2, ::2].numpy() == z[f"mask{size}"]).mean() > 0.9999
+
+
+def test_feature_mode_713_oracle_matches_reference(keyframes_713):
+    """A2 at the BASELINE size (warp mode): flow_oracle.predict_feature over pspnet_oracle against the reference's own
+    FlowModel(FlowPSPNet, feature_based=True).predict (tests/golden/predict_feature_713.npz).  ~20 s of CPU."""
+    prev, nxt, _ = keyframes_713
+    s = synth.make_pspnet_state(50, 5, seed=0)
+    z = load_golden("predict_feature_713.npz")
+    mvl, mvr = synth.make_grids(5, 44, 44, seed=2000)
+    out = flow_oracle.predict_feature(lambda x: pspnet_oracle.encoder(x, s, 50), lambda f: pspnet_oracle.decoder(f, s), prev, nxt, mvl, mvr, 5,
+                                      False)["pred"]
+    assert rel_err(out[:, :, ::16, ::16], z["warp_logits_sub"]) < 2e-5
+    assert (out.max(1)[1].to(torch.uint8)[:, ::2, ::2].numpy() == z["warp_mask_sub"]).mean() > 0.9999
