@@ -112,8 +112,10 @@ def gen_toy_predict():
     save("toy_predict.npz", **arrays)
 
 
-def build_ref_pspnet(state):
-    net = ref_psp.FlowPSPNet(hparams=HP()).eval()
+def build_ref_pspnet(state, layers=50):
+    hp = HP()
+    hp.layers = layers
+    net = ref_psp.FlowPSPNet(hparams=hp).eval()
     res = net.load_state_dict(state, strict=False)
     assert not res.unexpected_keys, res.unexpected_keys
     bad = [k for k in res.missing_keys if not (k.startswith(("layers.", "encoder.")) or k.endswith("num_batches_tracked"))]
@@ -234,6 +236,18 @@ def gen_pspnet_feature():
     save("predict_feature_713.npz", **out)
 
 
+def gen_pspnet_deep():
+    """FlowPSPNet on ResNet-101 and ResNet-152 (model/pspnet.py:45-50) at 65x65: the deeper plans of the same executor."""
+    out = {}
+    for layers, seed in ((101, 1), (152, 2)):
+        state = synth.make_pspnet_state(layers, 5, seed=seed)
+        net = build_ref_pspnet(state, layers)
+        x = synth.make_clip(1, 65, seed=8)
+        out[f"logits{layers}"] = net.decoder(net.encoder(x))
+        print(f"pspnet{layers} 65: range", out[f"logits{layers}"].min().item(), out[f"logits{layers}"].max().item())
+    save("pspnet_deep_small.npz", **out)
+
+
 def gen_vit_s16():
     """BASELINE configs[3] names a ViT-S/16; model/vit.py hard-codes B/32 (patch 32, d_model 768), so the S/16 network is
     assembled from THE REFERENCE'S OWN CLASSES exactly as model/vit.py:24-52 assembles them, with S/16 numbers (patch 16,
@@ -265,7 +279,9 @@ def gen_vit_s16():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["grid", "ops", "toy", "pspnet", "vit", "vit_s16", "pspnet_feature"]
+    which = sys.argv[1:] or ["grid", "ops", "toy", "pspnet", "vit", "vit_s16", "pspnet_feature", "pspnet_deep"]
+    if "pspnet_deep" in which:
+        gen_pspnet_deep()
     if "vit_s16" in which:
         gen_vit_s16()
     if "pspnet_feature" in which:

@@ -105,13 +105,18 @@ def test_decoder_accepts_nchw_contiguous_features(psp):
     assert torch.equal(net.decoder(f.contiguous()), net.decoder(f))
 
 
-def test_pspnet101_small_against_oracle():
-    state = synth.make_pspnet_state(101, 5, seed=1)
-    net = FlowPSPNet(HP(101, 5)).eval()
+@pytest.mark.parametrize("layers,seed", [(101, 1), (152, 2)])
+def test_pspnet_deep_small_against_oracle_and_reference(layers, seed):
+    """ResNet-101 / ResNet-152 backbones (model/pspnet.py:45-50): the deeper plans of the same executor, against the oracle and
+    against the reference's own output (tests/golden/pspnet_deep_small.npz)."""
+    state = synth.make_pspnet_state(layers, 5, seed=seed)
+    net = FlowPSPNet(HP(layers, 5)).eval()
     net.load_state_dict(state)
     x = synth.make_clip(1, 65, seed=8)
     got = net.decoder(net.encoder(x.cuda())).cpu()
-    assert note("pspnet101_65_logits_vs_oracle", rel_err(got, pspnet_oracle.decoder(pspnet_oracle.encoder(x, state, 101), state))) < LOGIT_TOL
+    assert note(f"pspnet{layers}_65_logits_vs_oracle", rel_err(got, pspnet_oracle.decoder(pspnet_oracle.encoder(x, state, layers), state))) < LOGIT_TOL
+    assert note(f"pspnet{layers}_65_logits_vs_reference", rel_err(got, load_golden("pspnet_deep_small.npz")[f"logits{layers}"])) < LOGIT_TOL
+    assert torch.equal(net.segment(x.cuda()).cpu().max(1)[1], got.max(1)[1]) or rel_err(net.segment(x.cuda()).cpu(), got) < 2e-5
 
 
 def test_deeplabv3_r101_against_oracle_parity_unpinned():

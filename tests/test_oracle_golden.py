@@ -192,3 +192,11 @@ def test_feature_mode_713_oracle_matches_reference(keyframes_713):
                                       False)["pred"]
     assert rel_err(out[:, :, ::16, ::16], z["warp_logits_sub"]) < 2e-5
     assert (out.max(1)[1].to(torch.uint8)[:, ::2, ::2].numpy() == z["warp_mask_sub"]).mean() > 0.9999
+
+
+@pytest.mark.parametrize("layers,seed", [(101, 1), (152, 2)])
+def test_pspnet_deep_oracle_matches_reference(layers, seed):
+    s = synth.make_pspnet_state(layers, 5, seed=seed)
+    x = synth.make_clip(1, 65, seed=8)
+    out = pspnet_oracle.decoder(pspnet_oracle.encoder(x, s, layers), s)
+    assert rel_err(out, load_golden("pspnet_deep_small.npz")[f"logits{layers}"]) < 1e-5
