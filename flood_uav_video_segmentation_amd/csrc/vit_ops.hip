@@ -149,6 +149,9 @@ int launch_layernorm(const float* in, const float* gamma, const float* beta, flo
 //  the B operand, step r consumes key (r&3)+8(r>>2) from lane-half 0 and that key + 4 from lane-half 1,
 //  and the A operand reads V at exactly those two keys.)
 // K tile rows are padded to 68 floats: ds_read_b128 of a 16-lane group then hits 16 distinct 4-bank slots.
+#ifndef FS_ATT_EXP
+#define FS_ATT_EXP 0  // tools/probe_attention.hip only: elimination experiments (1 no exp, 2 no PV MFMAs, 3 no K/V re-staging, 4 no S MFMAs)
+#endif
 constexpr int ATT_DH = 64;
 constexpr int ATT_KT = 64;   // keys per LDS tile
 constexpr int ATT_LDK = 68;
@@ -217,6 +220,7 @@ __global__ __launch_bounds__(64 * ATT_NW, 3) void attention_f32_kernel(const flo
     fetch(kt0);
     for (int kt = kt0; kt < ntiles; ++kt) {
         __syncthreads();  // previous tile fully consumed
+        if (FS_ATT_EXP != 3 || kt == kt0)
 #pragma unroll
         for (int j = 0; j < LPT; ++j) {
             const int idx = t + NT * j;
@@ -227,7 +231,7 @@ __global__ __launch_bounds__(64 * ATT_NW, 3) void attention_f32_kernel(const flo
             *reinterpret_cast<f32x4*>(&Vs[row * ATT_DH + c4 * 4]) = ok ? vreg[j] : z;
         }
         __syncthreads();
-        if (kt + 1 < ntiles) fetch(kt + 1);
+        if (kt + 1 < ntiles && FS_ATT_EXP != 3) fetch(kt + 1);
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
             const int key0 = kt * ATT_KT + kb * 32;
@@ -240,7 +244,8 @@ __global__ __launch_bounds__(64 * ATT_NW, 3) void attention_f32_kernel(const flo
             for (int u = 0; u < 8; ++u) {
                 const f32x4 kf = *reinterpret_cast<const f32x4*>(krow + 4 * u);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) sT = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[e], qreg[4 * u + e], sT, 0, 0, 0);
+                for (int e = 0; e < 4; ++e)
+                    if (FS_ATT_EXP != 4 || (u == 0 && e == 0)) sT = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[e], qreg[4 * u + e], sT, 0, 0, 0);
             }
             // mask keys beyond N, running max over this lane's 16 keys and the other half's 16
             if (key0 + 32 > N) {  // block-uniform: only the last block has keys to mask
@@ -257,7 +262,7 @@ __global__ __launch_bounds__(64 * ATT_NW, 3) void attention_f32_kernel(const flo
             float lsum = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                sT[r] = __builtin_amdgcn_exp2f(sT[r] - m_new);
+                sT[r] = FS_ATT_EXP == 1 ? sT[r] - m_new : __builtin_amdgcn_exp2f(sT[r] - m_new);
                 lsum += sT[r];
             }
             l_run = l_run * alpha + lsum;
@@ -274,6 +279,7 @@ __global__ __launch_bounds__(64 * ATT_NW, 3) void attention_f32_kernel(const flo
                 const int krow_r = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
                 const float v0 = Vs[krow_r * ATT_DH + l31];
                 const float v1 = Vs[krow_r * ATT_DH + 32 + l31];
+                if (FS_ATT_EXP == 2 && r > 0) continue;
                 acc_o[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(v0, sT[r], acc_o[0], 0, 0, 0);
                 acc_o[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(v1, sT[r], acc_o[1], 0, 0, 0);
             }
