@@ -321,6 +321,20 @@ def variants(args, dev, rdev, net, state, fm, windows, dl, dr, host_masks, host_
         torch.cuda.current_stream().synchronize()
     run("fps_keyframe_cache_one_new_keyframe_per_window", step_cached, steps, N_DELTA)
 
+    # (iii-b) the same with one window of look-ahead (FlowPredictor.predict_clip): the new key frames of TWO consecutive windows
+    # go through the network as one batch of two, so the cached run also keeps the efficiency of a full batch.  One step = the
+    # four windows of a 21-frame clip (20 frames), masks of every window copied to the host.
+    clip_items = [{"frame_prev": windows[w][0], "frame_next": windows[w][1], "mvs_left": dl, "mvs_right": dr, "key_ids": (5 * w, 5 * w + 5)}
+                  for w in range(4)]
+    pclip = FlowPredictor(fm, CLASSES, (SIZE, SIZE), compute_metrics=False)
+    host_clip = torch.empty((4 * N_DELTA, SIZE, SIZE), dtype=torch.uint8).pin_memory()
+
+    def step_clip(i):
+        for w, masks in enumerate(pclip.predict_clip(clip_items, to_host=False)):
+            host_clip[w * N_DELTA:(w + 1) * N_DELTA].copy_(masks, non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+    run("fps_keyframe_cache_with_one_window_lookahead_clip_of_4_windows", step_clip, max(1, steps // 4), 4 * N_DELTA)
+
     # (iv) two windows in flight: a second library handle (own workspace) on a second stream, two windows per step
     net2 = FlowPSPNet(HP()).eval()
     net2.load_state_dict(state)

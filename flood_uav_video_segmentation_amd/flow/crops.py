@@ -49,8 +49,25 @@ def crop_windows(new_h, new_w, crop_h, crop_w, stride_rate=2 / 3):
     return out
 
 
+def segment_crop_windows(flow_model, frame_a, frame_b, crop_h, crop_w, crop_batch=8):
+    """Per-crop decoder logits of one or two full frames, all crop windows batched through the network in place:
+    ([ncrops,K,fh,fw] for frame_a, the same for frame_b or None)."""
+    net = flow_model.model
+    _, _, new_h, new_w = frame_a.shape
+    yx = [(s_h, s_w) for (s_h, _, s_w, _) in crop_windows(new_h, new_w, crop_h, crop_w)]
+    parts_a, parts_b = [], []
+    for c0 in range(0, len(yx), crop_batch):
+        sub = yx[c0:c0 + crop_batch]
+        lows = net.segment_crops(frame_a, frame_b, sub, (crop_h, crop_w))
+        parts_a.append(lows[:len(sub)])
+        if frame_b is not None:
+            parts_b.append(lows[len(sub):])
+    cat = lambda ps: ps[0] if len(ps) == 1 else torch.cat(ps, 0)  # noqa: E731
+    return cat(parts_a), (cat(parts_b) if frame_b is not None else None)
+
+
 def compute_output(flow_model, n, frame_prev, frame_next, mvs_left, mvs_right, crop_h, crop_w, classes, profiler=None,
-                   want_mask=False, function=None, key_cache=None, out_size=None, crop_batch=8):
+                   want_mask=False, function=None, key_cache=None, out_size=None, crop_batch=8, lows=None):
     """flow/base.py:182-209: returns the float64 [n,K,H,W] crop-averaged softmax (and, with want_mask, the uint8 argmax of its
     align_corners=True resize to `out_size` -- flow/base.py:275-276; out_size None = the frame size).
 
@@ -62,7 +79,8 @@ def compute_output(flow_model, n, frame_prev, frame_next, mvs_left, mvs_right, c
     network as batches of `crop_batch` windows per frame read in place from the full frames (fs_segment_crops), all crop
     grids come from one launch (fs_crop_grids) and every crop's tail runs fused with softmax + accumulation
     (fs_seg_tail_accumulate): per-crop logits never reach HBM.  key_cache (KeyframeCache.window): the previous key frame's
-    per-crop logits are reused from the last window.  Same arithmetic per crop as the generic route."""
+    per-crop logits are reused from the last window; lows = (lo_prev, lo_next): per-crop logits computed elsewhere
+    (FlowPredictor.predict_clip batches the new key frames of two windows).  Same arithmetic per crop as the generic route."""
     _, _, new_h, new_w = frame_prev.shape
     dev = frame_prev.device
     windows = crop_windows(new_h, new_w, crop_h, crop_w)
@@ -70,27 +88,21 @@ def compute_output(flow_model, n, frame_prev, frame_next, mvs_left, mvs_right, c
         canvas = torch.zeros((n, classes, new_h, new_w), dtype=torch.float64, device=dev)
         count = torch.zeros((new_h, new_w), dtype=torch.float64, device=dev)
     net = getattr(flow_model, "model", None)
-    batched = (function is None and not getattr(flow_model, "feature_based", True) and hasattr(net, "segment_crops")
-               and frame_prev.shape[0] == 1 and frame_next is not None)
+    batched = lows is not None or (function is None and not getattr(flow_model, "feature_based", True) and hasattr(net, "segment_crops")
+                                   and frame_prev.shape[0] == 1 and frame_next is not None)
     if batched:
         yx = [(s_h, s_w) for (s_h, _, s_w, _) in windows]
-        nc = len(yx)
         tag = ("crops", new_h, new_w, crop_h, crop_w)
-        lo_prev = key_cache.prev(tag) if key_cache is not None else None
-        parts_prev, parts_next = [], []
-        for c0 in range(0, nc, crop_batch):
-            sub = yx[c0:c0 + crop_batch]
+        if lows is not None:
+            lo_prev, lo_next = lows
+        else:
+            lo_prev = key_cache.prev(tag) if key_cache is not None else None
             if lo_prev is None:
-                lows = net.segment_crops(frame_prev, frame_next, sub, (crop_h, crop_w))
-                parts_prev.append(lows[:len(sub)])
-                parts_next.append(lows[len(sub):])
+                lo_prev, lo_next = segment_crop_windows(flow_model, frame_prev, frame_next, crop_h, crop_w, crop_batch)
             else:
-                parts_next.append(net.segment_crops(frame_next, None, sub, (crop_h, crop_w)))
-        if lo_prev is None:
-            lo_prev = parts_prev[0] if len(parts_prev) == 1 else torch.cat(parts_prev, 0)
-        lo_next = parts_next[0] if len(parts_next) == 1 else torch.cat(parts_next, 0)
-        if key_cache is not None:
-            key_cache.store_next(tag, lo_next)
+                lo_next, _ = segment_crop_windows(flow_model, frame_next, None, crop_h, crop_w, crop_batch)
+            if key_cache is not None:
+                key_cache.store_next(tag, lo_next)
         no_warp = flow_model.no_warp or not _is_grid_list(mvs_left)
         grids = None
         if not no_warp:

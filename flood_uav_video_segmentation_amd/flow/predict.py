@@ -47,13 +47,68 @@ class FlowPredictor:
             # :273 compute_output, then :275-276 (float64 resize + argmax) fused into the canvas's last pass
             _, masks = crops.compute_output(self.model, n, frame_prev, frame_next, mvs_left, mvs_right, self.crop[0], self.crop[1],
                                             self.classes, profiler, want_mask=True, key_cache=kc, out_size=self.out_size)
+        self._score(masks, n)
+        return masks.cpu().numpy() if to_host else masks                # :277
+
+    def _score(self, masks, n):
         if self.compute_metrics:                                      # :280-295 temporal consistency between consecutive frames
             for p in range(n):
                 prev = masks[p - 1] if p > 0 else self.last_output
                 if prev is not None:
                     self.hist = ops.iou_hist(masks[p], prev, self.classes, self.ignore_index, self.hist)
             self.last_output = masks[n - 1].clone()
-        return masks.cpu().numpy() if to_host else masks                # :277
+
+    def predict_clip(self, items, profiler=None, to_host=True):
+        """A clip's consecutive windows (dicts as PredictWindows yields them: frame_prev, frame_next, mvs_left, mvs_right,
+        key_ids) with the key-frame cache AND one window of look-ahead: the new key frames of TWO consecutive windows go through
+        the network as one batch of two -- in steady state window i's and window i+1's `frame_next` -- so every key frame is
+        segmented once and at the efficiency of a full batch (a lone frame leaves half the chip's tiles empty).  Yields the
+        masks of every window, in order, bit-identical to predict_window on the same windows (a frame's network output does
+        not depend on its batch).  Segmentation mode (whole frame or sliding crops); feature mode takes the per-window cache."""
+        items = list(items)
+        fm = self.model
+        if getattr(fm, "feature_based", True) or not hasattr(fm.model, "segment") or any(it.get("key_ids") is None for it in items):
+            if self.key_cache is None:
+                from .model import KeyframeCache
+                self.key_cache = KeyframeCache()
+            for it in items:
+                yield self.predict_window(it["frame_prev"], it["frame_next"], it["mvs_left"], it["mvs_right"], profiler, to_host, it.get("key_ids"))
+            return
+        store = {}  # frame id -> decoder logits of that key frame ([1,K,fh,fw], or [ncrops,K,fh,fw] on the sliding-crop route)
+
+        def run(frames):  # one or two key frames through the network as ONE batch
+            if self.crop is None:
+                lows = fm._segment(*frames)
+                return [lows[j:j + 1] for j in range(len(frames))]
+            a, b = crops.segment_crop_windows(fm, frames[0], frames[1] if len(frames) > 1 else None, self.crop[0], self.crop[1])
+            return [a] if b is None else [a, b]
+
+        for i in range(0, len(items), 2):
+            group = items[i:i + 2]
+            need = []
+            for it in group:
+                for fid, t in ((it["key_ids"][0], it["frame_prev"]), (it["key_ids"][1], it["frame_next"])):
+                    if fid not in store and all(fid != q for q, _ in need):
+                        need.append((fid, t))
+            for j in range(0, len(need), 2):
+                for (fid, _), lo in zip(need[j:j + 2], run([t for _, t in need[j:j + 2]])):
+                    store[fid] = lo
+            for it in group:
+                assert it["frame_prev"].shape[0] == 1 and len(it["mvs_left"]) == len(it["mvs_right"])   # flow/base.py:263-264
+                n = len(it["mvs_left"]) + 1
+                lo_prev, lo_next = store[it["key_ids"][0]], store[it["key_ids"][1]]
+                h, w = it["frame_prev"].shape[2], it["frame_prev"].shape[3]
+                if self.crop is None:
+                    logits, _ = ops.seg_tail(lo_prev, lo_next, it["mvs_left"], it["mvs_right"], n, (h, w), fm.no_warp, want_logits=True)
+                    masks = ops.resize_argmax_u8(logits, self.out_size)
+                else:
+                    _, masks = crops.compute_output(fm, n, it["frame_prev"], it["frame_next"], it["mvs_left"], it["mvs_right"], self.crop[0],
+                                                    self.crop[1], self.classes, profiler, want_mask=True, out_size=self.out_size,
+                                                    lows=(lo_prev, lo_next))
+                self._score(masks, n)
+                yield masks.cpu().numpy() if to_host else masks
+            keep = group[-1]["key_ids"][1]
+            store = {keep: store[keep]}  # the next group's first `frame_prev`
 
     def temporal_consistency(self):
         """on_predict_end's summary (flow/base.py:330-343): (mIoU, mAcc, accuracy) with the reference's 1e-10 epsilon."""

@@ -500,3 +500,45 @@ def test_full_size_networks_are_bit_repeatable_over_many_launches(psp, vit_s16):
     d0 = dl.segment(x)
     for _ in range(20):
         assert torch.equal(dl.segment(x), d0)
+
+
+@pytest.mark.parametrize("route", ["whole_frame_linear", "whole_frame_warp", "crops"])
+def test_predict_clip_lookahead_batches_new_key_frames_and_is_bit_identical(psp, route):
+    """FlowPredictor.predict_clip: key-frame cache + one window of look-ahead (the new key frames of two consecutive windows as
+    one batch of two).  5 windows (an odd count: the last group has one window), masks and the temporal-consistency
+    histogram equal to the plain per-window run bit for bit; every key frame is segmented exactly once."""
+    net, _ = psp
+    nwin = 5
+    if route == "crops":
+        size, crop, nwin = (300, 420), (161, 161), 3
+        gsz = (size[0] // 16, size[1] // 16)
+    else:
+        size, crop, gsz = (713, 713), None, (44, 44)
+    keys = synth.make_clip(5 * nwin + 1, size, seed=1000, only=[5 * i for i in range(nwin + 1)]).cuda()
+    nw = route == "whole_frame_linear"
+    fm = FlowModel(net, feature_based=False, no_warp=nw).eval()
+    items = []
+    for i in range(nwin):
+        mvl, mvr = synth.dummy_grids(N) if nw else synth.make_grids(N, gsz[0], gsz[1], seed=2000 + i, frame=size, jitter=0.02)
+        items.append({"frame_prev": keys[i:i + 1], "frame_next": keys[i + 1:i + 2], "mvs_left": cu(mvl), "mvs_right": cu(mvr),
+                      "key_ids": (5 * i, 5 * i + 5)})
+    plain = FlowPredictor(fm, 5, (size[0] + 7, size[1] + 9) if crop else (1072, 1920), crop=crop)
+    want = [plain.predict_window(it["frame_prev"], it["frame_next"], it["mvs_left"], it["mvs_right"], to_host=False) for it in items]
+    calls = []
+    real = net._hip_net.segment if crop is None else net._hip_net.segment_crops
+    if crop is None:
+        net._hip_net.segment = lambda *fr: (calls.append(len(fr)), real(*fr))[1]
+    else:
+        net._hip_net.segment_crops = lambda a, b, yx, hw: (calls.append(1 if b is None else 2), real(a, b, yx, hw))[1]
+    try:
+        look = FlowPredictor(fm, 5, plain.out_size, crop=crop)
+        got = list(look.predict_clip(items, to_host=False))
+    finally:
+        if crop is None:
+            net._hip_net.segment = real
+        else:
+            net._hip_net.segment_crops = real
+    assert len(got) == nwin and all(torch.equal(g, w) for g, w in zip(got, want))
+    assert torch.equal(look.hist, plain.hist)
+    assert sum(calls) == nwin + 1  # every key frame once ...
+    assert calls.count(2) >= (nwin + 1) // 2 - (0 if crop is None else 0)  # ... and in pairs
