@@ -541,4 +541,4 @@ def test_predict_clip_lookahead_batches_new_key_frames_and_is_bit_identical(psp,
     assert len(got) == nwin and all(torch.equal(g, w) for g, w in zip(got, want))
     assert torch.equal(look.hist, plain.hist)
     assert sum(calls) == nwin + 1  # every key frame once ...
-    assert calls.count(2) >= (nwin + 1) // 2 - (0 if crop is None else 0)  # ... and in pairs
+    assert calls.count(2) == (nwin + 1) // 2 and calls.count(1) == (nwin + 1) % 2  # ... two at a time
