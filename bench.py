@@ -3,8 +3,15 @@
 (PSPNet-ResNet50, key-frame + linear interpolation, frame_delta = 5), N = 1/2/4/8 MI355X.
 
     python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --gpus N --steps K --warmup W        # N > 1 without a launcher: spawns the N ranks itself (below)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
+
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment: this process touches no GPU -- it starts the N ranks as fresh
+child processes (`python -m torch.distributed.run ... bench.py <same arguments>`, rendezvous on 127.0.0.1), lets rank 0's JSON
+line through on stdout and exits with the children's return code.  Under N > 1 the step walks BASELINE configs[4]: 64 synthetic
+713x713 clips sharded by clip (rank r owns clips r, r+N, ...; 4 key-frame windows per 21-frame clip, flow/dataset.py:64,112-114),
+window after window, cyclically for the K timed steps; no data-path collective.
 
 A step = one key-frame window of the hot path on each rank: FlowModel.predict(prev, next, ...) through
 the C ABI (BOTH key frames segmented, exactly the work the reference does per predict call -- no cached
@@ -23,22 +30,34 @@ import hashlib
 import json
 import os
 import re
+import socket
+import subprocess
 import sys
 import time
-
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from flood_uav_video_segmentation_amd import ops, shard, synth  # noqa: E402
-from flood_uav_video_segmentation_amd.flow.model import FlowModel, KeyframeCache  # noqa: E402
-from flood_uav_video_segmentation_amd.flow.predict import FlowPredictor  # noqa: E402
-from flood_uav_video_segmentation_amd.model.pspnet import FlowPSPNet  # noqa: E402
+# torch and the package are imported by load_runtime(), AFTER main() has decided whether this process is a rank or only the
+# launcher of the ranks: the launcher must never initialise a GPU (and has no use for a minute of imports).
+torch = ops = shard = synth = FlowModel = KeyframeCache = FlowPredictor = FlowPSPNet = None
+
+
+def load_runtime():
+    global torch, ops, shard, synth, FlowModel, KeyframeCache, FlowPredictor, FlowPSPNet
+    import torch as _torch
+    from flood_uav_video_segmentation_amd import ops as _ops, shard as _shard, synth as _synth
+    from flood_uav_video_segmentation_amd.flow.model import FlowModel as _FM, KeyframeCache as _KC
+    from flood_uav_video_segmentation_amd.flow.predict import FlowPredictor as _FP
+    from flood_uav_video_segmentation_amd.model.pspnet import FlowPSPNet as _PSP
+    torch, ops, shard, synth, FlowModel, KeyframeCache, FlowPredictor, FlowPSPNet = _torch, _ops, _shard, _synth, _FM, _KC, _FP, _PSP
+
 
 SIZE = 713
 N_DELTA = 5
 CLASSES = 5
+NUM_CLIPS = 64                   # BASELINE configs[4]: 64 synthetic clips sharded by clip
+CLIP_FRAMES = 21                 # 4 key-frame windows of frame_delta 5 per clip (flow/dataset.py:64)
 KEYFRAME_GFLOP = 727.44          # PSPNet-R50 encoder+decoder at 713^2
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 
@@ -163,6 +182,21 @@ def cpu_baseline(state, windows_cpu):
                       "through oracle/ on torch-CPU fp32"}
 
 
+def spawn_ranks(n):
+    """`bench.py --gpus N` launched directly (no WORLD_SIZE): start the N ranks as FRESH child processes under
+    torch.distributed.run and hand back their return code.  Nothing in this process has touched a GPU, and it does not
+    replace itself (no exec): the children are ordinary subprocesses; rank 0 prints the JSON line on the inherited stdout."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env, cwd=ROOT).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -173,9 +207,15 @@ def main():
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="multi-rank rehearsal on a 1-GPU box: every rank uses cuda:0 and the reduction runs over gloo")
     args = ap.parse_args()
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))  # launcher only: no torch, no GPU in this process
+    load_runtime()
 
     rank, local_rank, world = shard.init("gloo" if args.rehearse_on_one_gpu else None)
-    assert world == args.gpus, f"launched with WORLD_SIZE={world} but --gpus {args.gpus}"
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: launched with WORLD_SIZE={world} but --gpus {args.gpus}")
     if args.rehearse_on_one_gpu:
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -190,16 +230,25 @@ def main():
     net.load_state_dict(state)
     fm = FlowModel(net, feature_based=False, no_warp=True).eval()
 
-    # ---- data: this rank's clip (clip id = rank; seed 1000 + id), its 4 key-frame windows, resident in HBM
-    keys = synth.make_clip(21, SIZE, seed=1000 + rank, only=[0, 5, 10, 15, 20])
-    windows_cpu = [(keys[i:i + 1], keys[i + 1:i + 2]) for i in range(4)]
-    windows = [(a.to(dev), b.to(dev)) for a, b in windows_cpu]
+    # ---- data, resident in HBM.  N = 1: BASELINE configs[1], the 4 key-frame windows of ONE clip (clip 0).  N > 1: BASELINE
+    # configs[4], this rank's shard of the 64 clips (clip c = seed 1000 + c; rank r owns c = r, r+N, ...), 4 windows each.
+    schedule = shard.clip_window_schedule(NUM_CLIPS if world > 1 else 1, CLIP_FRAMES, N_DELTA, rank, world)
+    keys_of = {}
+    for c in sorted({c for c, _, _ in schedule}):
+        keys_of[c] = synth.make_clip(CLIP_FRAMES, SIZE, seed=1000 + c, only=list(range(0, CLIP_FRAMES, N_DELTA)))
+    first = schedule[0][0]
+    windows_cpu = [(keys_of[first][i:i + 1], keys_of[first][i + 1:i + 2]) for i in range(4)] if rank == 0 else []
+    keys_dev = {c: k.to(dev) for c, k in keys_of.items()}
+    windows = [(keys_dev[c][k0 // N_DELTA:k0 // N_DELTA + 1], keys_dev[c][k1 // N_DELTA:k1 // N_DELTA + 1]) for c, k0, k1 in schedule]
+    del keys_of
+    nwin = len(windows)
     dl, dr = [[g.to(dev) for g in gs] for gs in synth.dummy_grids(N_DELTA)]
     host_masks = torch.empty((N_DELTA, SIZE, SIZE), dtype=torch.uint8).pin_memory()
     host_post = torch.empty((N_DELTA, 1072, 1920), dtype=torch.uint8).pin_memory()
+    net.reserve(2, SIZE, SIZE)  # the library's workspace for this geometry, once, before the clock starts (fs_reserve)
 
     def step_native(i):
-        prev, nxt = windows[i % 4]
+        prev, nxt = windows[i % nwin]
         logits = fm.predict(prev, nxt, dl, dr, N_DELTA, None)["pred"]
         host_masks.copy_(ops.argmax_u8(logits), non_blocking=True)
         torch.cuda.current_stream().synchronize()  # masks are on the host when the step ends
@@ -213,9 +262,15 @@ def main():
         "value": round(fps, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed_max / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "BASELINE configs[1]: PSPNet-ResNet50 keyframe + linear interp (no_warp=True, feature_based=False), "
-                               "frame_delta=5, 713x713, one window per step per GPU, both key frames segmented per window, "
-                               "argmax uint8 masks copied to host", "frames_per_step_per_gpu": N_DELTA,
+        "config": {"workload": ("BASELINE configs[1]: PSPNet-ResNet50 keyframe + linear interp (no_warp=True, feature_based=False), "
+                                "frame_delta=5, 713x713, one window per step per GPU, both key frames segmented per window, "
+                                "argmax uint8 masks copied to host") if world == 1 else
+                               (f"BASELINE configs[4]: {NUM_CLIPS} synthetic 713x713 clips sharded by clip over {world} GPUs (rank r owns clips "
+                                f"r, r+{world}, ...: {len(schedule) // 4} clips x 4 key-frame windows on this rank), PSPNet-ResNet50 keyframe + linear "
+                                "interp, frame_delta=5; one window per step per GPU, the timed steps walk the rank's shard window after "
+                                "window (cyclically), both key frames segmented per window, argmax uint8 masks copied to host"),
+                   "frames_per_step_per_gpu": N_DELTA, "clips_total": NUM_CLIPS if world > 1 else 1,
+                   "windows_in_this_ranks_shard": nwin,
                    "parallelism": f"{world} independent clip shard(s), no data-path collective"},
         # what the launcher really set up: "nccl" IS RCCL on ROCm; a single process has no process group
         "distributed": {"backend": backend, "rccl_world_size": dist_world if backend == "nccl" else 0, "world_size": dist_world,
@@ -273,7 +328,7 @@ def main():
             "per_kernel_ms_per_step": {k: round(v["ms"] / prof_steps, 4) for k, v in sorted(per.items(), key=lambda kv: -kv[1]["ms"])},
         }
 
-    if not args.no_extras:
+    if not args.no_extras and world == 1:  # the variants are single-GPU figures: measured by the N = 1 run only
         result["variants"] = variants(args, dev, rdev, net, state, fm, windows, dl, dr, host_masks, host_post)
 
     if rank == 0:
@@ -354,9 +409,6 @@ def variants(args, dev, rdev, net, state, fm, windows, dl, dr, host_masks, host_
         side.synchronize()
     run("fps_two_windows_in_flight_two_streams", step_two, max(1, steps // 2), 2 * N_DELTA)
     del net2, fm2
-
-    if shard.describe()[1] > 1:
-        return out  # the other BASELINE configs are single-GPU figures: measured by the N = 1 run only
 
     # (v) BASELINE configs[0] on the GPU: single-frame PSPNet inference over a 4-frame clip, one frame per step
     frames4 = [windows[i][0] for i in range(4)]

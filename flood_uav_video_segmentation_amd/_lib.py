@@ -42,6 +42,8 @@ _SIGNATURES = {
     "fs_finalize": (c_int, [c_void, c_void]),
     "fs_feature_shape": (c_int, [c_void, c_int, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
     "fs_workspace_bytes": (ctypes.c_size_t, [c_void, c_int, c_int, c_int]),
+    "fs_reserve": (c_int, [c_void, c_int, c_int, c_int, c_void]),
+    "fs_reserved_bytes": (ctypes.c_size_t, [c_void]),
     "fs_encoder_forward": (c_int, [c_void, c_void, c_int, c_int, c_int, c_void, c_void]),
     "fs_decoder_forward": (c_int, [c_void, c_void, c_int, c_int, c_int, c_void, c_void]),
     "fs_segment_forward": (c_int, [c_void, c_void, c_int, c_int, c_int, c_void, c_void]),

@@ -3,13 +3,14 @@
 #include "kernels.h"
 #include "net.h"
 
+#include <algorithm>
 #include <cmath>
 
 #define FS_API extern "C" __attribute__((visibility("default")))
 
 static inline hipStream_t S(fs_stream s) { return reinterpret_cast<hipStream_t>(s); }
 
-FS_API int fs_version(void) { return 200; }
+FS_API int fs_version(void) { return 300; }
 FS_API const char* fs_last_error(void) { return fs::last_error().c_str(); }
 
 FS_API int fs_create(const fs_config* cfg, fs_handle* out) { return fs::net_create(cfg, out); }
@@ -21,6 +22,8 @@ FS_API int fs_load_weight(fs_handle h, const char* name, const float* data, cons
 FS_API int fs_finalize(fs_handle h, fs_stream stream) { return fs::net_finalize(h, S(stream)); }
 FS_API int fs_feature_shape(fs_handle h, int H, int W, int* C, int* fh, int* fw) { return fs::net_feature_shape(h, H, W, C, fh, fw); }
 FS_API size_t fs_workspace_bytes(fs_handle h, int B, int H, int W) { return fs::net_workspace_bytes(h, B, H, W); }
+FS_API int fs_reserve(fs_handle h, int B, int H, int W, fs_stream stream) { return fs::net_reserve(h, B, H, W, S(stream)); }
+FS_API size_t fs_reserved_bytes(fs_handle h) { return fs::net_reserved_bytes(h); }
 FS_API int fs_encoder_forward(fs_handle h, const float* in_nchw, int B, int H, int W, float* out_nhwc, fs_stream stream) {
     return fs::net_encoder(h, fs::frames_plain(in_nchw, nullptr, B), B, H, W, out_nhwc, S(stream));
 }
@@ -184,38 +187,47 @@ FS_API int fs_canvas_resize_argmax(const double* canvas, int n, int K, int Hi, i
 }
 FS_API int fs_crop_grids(const float* const* grids, int ngrids, int Hg, int Wg, int H, int W, int ncrops, const int* crop_y,
                          const int* crop_x, int ch, int cw, float* out, fs_stream stream) {
-    if (!grids || !crop_y || !crop_x || !out || ngrids < 1 || ngrids > 32 || ncrops < 1 || ncrops > 32 || Hg < 1 || Wg < 1 || H < 1 || W < 1 ||
-        ch < 16 || cw < 16)
-        return fs::fail("fs_crop_grids: bad arguments (1..32 grids, 1..32 crops, crop >= 16 px)");
-    fs::CropGridParams p{};
-    for (int j = 0; j < ngrids; ++j) {
+    if (!grids || !crop_y || !crop_x || !out || ngrids < 1 || ncrops < 1 || Hg < 1 || Wg < 1 || H < 1 || W < 1 || ch < 16 || cw < 16)
+        return fs::fail("fs_crop_grids: bad arguments (>= 1 grid, >= 1 crop, crop >= 16 px)");
+    for (int j = 0; j < ngrids; ++j)
         if (!grids[j]) return fs::fail("fs_crop_grids: null grid %d", j);
-        p.grids[j] = grids[j];
-    }
-    p.ngrids = ngrids;
-    p.Hg = Hg;
-    p.Wg = Wg;
-    p.H = H;
-    p.W = W;
-    p.ncrops = ncrops;
-    p.fh = ch / 16;  // flow/transform.py:226-227
-    p.fw = cw / 16;
-    p.out = out;
     // flow/transform.py:223-233 in double, Python's round() = round-half-to-even = nearbyint in the default rounding mode
     const double ppb_h = (double)H / Hg, ppb_w = (double)W / Wg;
-    for (int c = 0; c < ncrops; ++c) {
-        const int bho = (int)std::nearbyint(crop_y[c] / ppb_h), bwo = (int)std::nearbyint(crop_x[c] / ppb_w);
-        const int bh = (int)std::nearbyint((crop_y[c] + ch) / ppb_h) - bho, bw = (int)std::nearbyint((crop_x[c] + cw) / ppb_w) - bwo;
-        p.bho[c] = (short)bho;
-        p.bwo[c] = (short)bwo;
-        p.bh[c] = (short)bh;
-        p.bw[c] = (short)bw;
-        p.off_h[c] = (float)crop_y[c];
-        p.off_w[c] = (float)crop_x[c];
-        p.den_h[c] = (float)(bh * ppb_h);
-        p.den_w[c] = (float)(bw * ppb_w);
+    const int fh = ch / 16, fw = cw / 16;  // flow/transform.py:226-227
+    // one launch takes at most 32 crops x 32 grids (fixed-size kernel arguments): frame_delta = 25 (the reference's default,
+    // flow/base.py:350) has 48 grids per window, a 2160 x 3840 frame 40 crops -- cut into slices, each written in place
+    for (int c0 = 0; c0 < ncrops; c0 += 32) {
+        for (int g0 = 0; g0 < ngrids; g0 += 32) {
+            fs::CropGridParams p{};
+            p.ngrids = std::min(32, ngrids - g0);
+            p.ncrops = std::min(32, ncrops - c0);
+            p.ng_total = ngrids;
+            p.g0 = g0;
+            for (int j = 0; j < p.ngrids; ++j) p.grids[j] = grids[g0 + j];
+            p.Hg = Hg;
+            p.Wg = Wg;
+            p.H = H;
+            p.W = W;
+            p.fh = fh;
+            p.fw = fw;
+            p.out = out + (size_t)c0 * ngrids * fh * fw * 2;
+            for (int c = 0; c < p.ncrops; ++c) {
+                const int y = crop_y[c0 + c], x = crop_x[c0 + c];
+                const int bho = (int)std::nearbyint(y / ppb_h), bwo = (int)std::nearbyint(x / ppb_w);
+                const int bh = (int)std::nearbyint((y + ch) / ppb_h) - bho, bw = (int)std::nearbyint((x + cw) / ppb_w) - bwo;
+                p.bho[c] = (short)bho;
+                p.bwo[c] = (short)bwo;
+                p.bh[c] = (short)bh;
+                p.bw[c] = (short)bw;
+                p.off_h[c] = (float)y;
+                p.off_w[c] = (float)x;
+                p.den_h[c] = (float)(bh * ppb_h);
+                p.den_w[c] = (float)(bw * ppb_w);
+            }
+            if (int rc = fs::launch_crop_grids(p, S(stream))) return rc;
+        }
     }
-    return fs::launch_crop_grids(p, S(stream));
+    return 0;
 }
 
 FS_API int fs_pack_conv_weight(const float* oihw, float* ohwi, int O, int I, int KH, int KW, fs_stream stream) {

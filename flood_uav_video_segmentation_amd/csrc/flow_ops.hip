@@ -530,14 +530,15 @@ __global__ __launch_bounds__(256) void crop_grids_kernel(CropGridParams p) {
             rx = bilerp(at(cy.i0, cx.i0, 0), at(cy.i0, cx.i1, 0), at(cy.i1, cx.i0, 0), at(cy.i1, cx.i1, 0), cy, cx);
             ry = bilerp(at(cy.i0, cx.i0, 1), at(cy.i0, cx.i1, 1), at(cy.i1, cx.i0, 1), at(cy.i1, cx.i1, 1), cy, cx);
         }
-        p.out[(size_t)i * 2 + 0] = rx;
-        p.out[(size_t)i * 2 + 1] = ry;
+        float* o = p.out + ((size_t)(c * p.ng_total + p.g0 + j) * per + px) * 2;  // this call's slice of [crops][all grids][fh][fw][2]
+        o[0] = rx;
+        o[1] = ry;
     }
 }
 
 int launch_crop_grids(const CropGridParams& p, hipStream_t s) {
     FS_REQUIRE(p.ncrops >= 1 && p.ncrops <= 32 && p.ngrids >= 1 && p.ngrids <= 32, "crop_grids: at most 32 crops x 32 grids per call");
-    FS_REQUIRE(p.fh >= 1 && p.fw >= 1 && p.out, "crop_grids: bad output geometry");
+    FS_REQUIRE(p.fh >= 1 && p.fw >= 1 && p.out && p.g0 >= 0 && p.g0 + p.ngrids <= p.ng_total, "crop_grids: bad output geometry");
     for (int c = 0; c < p.ncrops; ++c)
         FS_REQUIRE(p.bho[c] >= 0 && p.bwo[c] >= 0 && p.bh[c] >= 1 && p.bw[c] >= 1 && p.bho[c] + p.bh[c] <= p.Hg && p.bwo[c] + p.bw[c] <= p.Wg,
                    "crop_grids: block range of crop %d outside the %dx%d grid", c, p.Hg, p.Wg);

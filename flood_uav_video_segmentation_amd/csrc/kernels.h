@@ -186,7 +186,8 @@ struct CropGridParams {
     const float* grids[32];  // ngrids device pointers, each [Hg, Wg, 2] fp32
     int ngrids, Hg, Wg;
     int H, W;                // frame size the grids are normalised to
-    int ncrops, fh, fw;      // output grids [ncrops][ngrids][fh][fw][2]
+    int ncrops, fh, fw;      // output grids [ncrops][ng_total][fh][fw][2]; this launch fills grids g0 .. g0+ngrids-1 of its crops
+    int ng_total, g0;        // (a window with more than 32 grids or crops is cut into several launches by fs_crop_grids)
     short bho[32], bwo[32], bh[32], bw[32];          // block range per crop (Python-rounded on the host)
     float off_h[32], off_w[32], den_h[32], den_w[32];  // pixel offset of the crop; bh * pixels-per-block, bw * pixels-per-block
     float* out;

@@ -27,6 +27,10 @@ struct RawTensor {
 struct WinoBank {
     float* U4 = nullptr;  // [36][Cout][Cin]  F(4x4,3x3)
     float* U6 = nullptr;  // [64][Cout][Cin]  F(6x6,3x3)
+    // recorded on the stream the bank was built on, right behind the filter transform; [0] = U4, [1] = U6.  A forward on any
+    // other stream waits for it before its first read (the events belong to the handle: fs_net::bank_events)
+    hipEvent_t ready[2] = {nullptr, nullptr};
+    hipStream_t built_on[2] = {nullptr, nullptr};
 };
 
 // conv + (eval BatchNorm | bias) + optional ReLU, ready to launch
@@ -119,6 +123,10 @@ struct fs_net {
     size_t vit_ws_elems = 0;
     float* wino_ws = nullptr;  // V [36][T][Cin] followed by M [36][T][Cout]
     size_t wino_ws_elems = 0;
+    std::vector<hipEvent_t> bank_events;  // "bank built" events of the Winograd filter banks (WinoBank::ready)
+    size_t bank_elems = 0;                // floats held by those banks
+    size_t pos_elems = 0;                 // floats of pos_cur
+    size_t ws_allocs = 0;                 // workspace / bank allocations made so far (none after fs_reserve, tests/test_gpu_net.py)
     // explicit options of fs_config (include/floodseg.h): nothing is read from the environment
     bool use_winograd = true;    // !(flags & FS_OPT_NO_WINOGRAD)
     int wino_force_m = 0;        // winograd_tile: 4 | 6 forces F(4,3) / F(6,3); 0 = the cheaper one for the map at hand
@@ -151,6 +159,8 @@ int net_load_weight(fs_handle h, const char* name, const float* data, const int6
 int net_finalize(fs_handle h, hipStream_t s);
 int net_feature_shape(fs_handle h, int H, int W, int* C, int* fh, int* fw);
 size_t net_workspace_bytes(fs_handle h, int B, int H, int W);
+int net_reserve(fs_handle h, int B, int H, int W, hipStream_t s);
+size_t net_reserved_bytes(fs_handle h);
 // src: where the B frames live (kernels.h FrameSrc: one tensor, two tensors, or crop windows of two full frames)
 int net_encoder(fs_handle h, const FrameSrc& src, int B, int H, int W, float* out_nhwc, hipStream_t s);
 int net_segment(fs_handle h, const FrameSrc& src, int B, int H, int W, float* out_nchw, hipStream_t s);
@@ -159,6 +169,8 @@ int net_profile_dump(fs_handle h, char* buf, size_t n);
 
 // shared with vit_net.hip
 int dev_alloc(fs_net* h, float** p, size_t elems);
+int ws_grow(fs_net* h, float** p, size_t* have, size_t need, bool zero);
+int vit_reserve(fs_handle h, int B, int H, int W, hipStream_t s);
 int fetch(fs_net* h, const std::string& name, const RawTensor** out);
 int prof_begin(fs_net* h, const std::string& name, const char* kernel, double flops, double bytes, hipStream_t s);
 int prof_end(fs_net* h, hipStream_t s);

@@ -28,6 +28,22 @@ int dev_alloc(fs_net* h, float** p, size_t elems) {
     return 0;
 }
 
+// The ONE place a forward may allocate: grows a library-owned workspace block (never shrinks).  Growing synchronises the
+// device first -- work enqueued earlier may still use the old block -- which is why fs_reserve() exists: it does all the
+// growing for a geometry up front, and no later forward at that geometry (or a smaller one) comes through the `need > have` arm.
+int ws_grow(fs_net* h, float** p, size_t* have, size_t need, bool zero) {
+    if (need <= *have) return 0;
+    FS_HIP(hipDeviceSynchronize());
+    if (*p) FS_HIP(hipFree(*p));
+    *p = nullptr;
+    *have = 0;
+    FS_HIP(hipMalloc(reinterpret_cast<void**>(p), need * sizeof(float)));
+    if (zero) FS_HIP(hipMemset(*p, 0, need * sizeof(float)));
+    *have = need;
+    ++h->ws_allocs;
+    return 0;
+}
+
 int fetch(fs_net* h, const std::string& name, const RawTensor** out) {
     auto it = h->raw.find(name);
     if (it == h->raw.end()) return fail("missing weight '%s'", name.c_str());
@@ -49,14 +65,28 @@ bool wino_eligible(const ConvBN& c, bool hwio) {
 
 // The F(mt x mt, 3x3) filter bank of a Winograd-eligible conv, transformed (in double, rounded once) from the direct kernel's
 // chunk-major bank the first time this tile size is needed.  Stream-ordered: the transform runs on `s` ahead of its first use.
+// A forward on ANOTHER stream than the one the bank was built on waits for the build's event first (fs_reserve builds the
+// banks ahead of time; without it the first forward that needs a bank allocates and builds it -- never under graph capture).
 int wino_bank(fs_net* h, const ConvBN& c, int mt, hipStream_t s, const float** U) {
+    const int k = mt == 6 ? 1 : 0;
     float*& slot = mt == 6 ? c.wino->U6 : c.wino->U4;
     if (!slot) {
         FS_REQUIRE(c.korder == 1, "winograd: conv '%s' has no chunk-major filter bank", c.name.c_str());
         float* bank = nullptr;  // published only once the transform has been enqueued: a failed launch must not leave a half-built bank behind
-        FS_TRY(dev_alloc(h, &bank, (size_t)(mt + 2) * (mt + 2) * c.Cout * c.Cin));
+        const size_t elems = (size_t)(mt + 2) * (mt + 2) * c.Cout * c.Cin;
+        FS_TRY(dev_alloc(h, &bank, elems));
         FS_TRY(launch_winograd_filter(c.w, bank, c.Cout, c.Cin, mt, s, 1));
+        hipEvent_t ev = nullptr;
+        FS_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        FS_HIP(hipEventRecord(ev, s));
+        c.wino->ready[k] = ev;
+        c.wino->built_on[k] = s;
+        h->bank_events.push_back(ev);
+        h->bank_elems += elems;
+        ++h->ws_allocs;
         slot = bank;
+    } else if (c.wino->built_on[k] != s && c.wino->ready[k]) {
+        FS_HIP(hipStreamWaitEvent(s, c.wino->ready[k], 0));
     }
     *U = slot;
     return 0;
@@ -152,13 +182,7 @@ int run_conv_winograd(fs_net* h, const ConvBN& c, const float* in, int ld_in, in
     const float* U = nullptr;
     FS_TRY(wino_bank(h, c, mt, s, &U));
     const size_t v_elems = (size_t)G * T * c.Cin, m_elems = (size_t)G * T * c.Cout;
-    if (v_elems + m_elems > h->wino_ws_elems) {
-        FS_HIP(hipDeviceSynchronize());
-        if (h->wino_ws) FS_HIP(hipFree(h->wino_ws));
-        h->wino_ws = nullptr;
-        FS_HIP(hipMalloc(reinterpret_cast<void**>(&h->wino_ws), (v_elems + m_elems) * sizeof(float)));
-        h->wino_ws_elems = v_elems + m_elems;
-    }
+    FS_TRY(ws_grow(h, &h->wino_ws, &h->wino_ws_elems, v_elems + m_elems, false));
     float* V = h->wino_ws;
     float* Mb = h->wino_ws + v_elems;
     FS_TRY(prof_begin(h, c.name + ".wino_in", "winograd_input", 0, 4.0 * ((double)B * H * W * c.Cin + (double)v_elems), s));
@@ -193,18 +217,31 @@ int run_conv_winograd(fs_net* h, const ConvBN& c, const float* in, int ld_in, in
     return prof_end(h, s);
 }
 
+// Winograd pays when its 36 GEMM rows per 4x4 tile undercut the 9 taps per pixel of the direct conv even after the
+// tile-edge / lattice-phase waste (large dilations on a small map leave mostly-empty tiles): 36*T < 0.8 * 9*M
+bool takes_winograd(const fs_net* h, const ConvBN& c, int B, int H, int W, bool has_res) {
+    if (!(c.wino && h->use_winograd && !has_res)) return false;
+    const int mt = h->wino_force_m ? h->wino_force_m : winograd_pick_m(B, H, W, c.dil);
+    const double wino_rows = (double)(mt + 2) * (mt + 2) * winograd_tiles(B, H, W, c.dil, mt);
+    const double direct_rows = 9.0 * (double)B * c.out_size(H) * c.out_size(W);
+    // dilation <= 4 (the dilated ResNet stages, the heads): 0.8; the ASPP dilations leave the lattices of a 90x90 map
+    // only 8, 4 and 3 pixels wide and the transforms touch every pixel through 2048 channels, so they must save more
+    return wino_rows < (c.dil <= 4 ? 0.8 : 0.7) * direct_rows;
+}
+
+// fs_reserve: the Winograd workspace this conv needs at this geometry (0 = direct kernel), its filter bank built on `s`
+int reserve_conv(fs_net* h, const ConvBN& c, int B, int H, int W, hipStream_t s, size_t* need) {
+    if (!takes_winograd(h, c, B, H, W, false)) return 0;
+    const int mt = h->wino_force_m ? h->wino_force_m : winograd_pick_m(B, H, W, c.dil);
+    const size_t G = (size_t)(mt + 2) * (mt + 2), T = (size_t)winograd_tiles(B, H, W, c.dil, mt);
+    *need = std::max(*need, G * T * ((size_t)c.Cin + (size_t)c.Cout));
+    const float* U = nullptr;
+    return wino_bank(h, c, mt, s, &U);
+}
+
 int run_conv(fs_net* h, const ConvBN& c, const float* in, int ld_in, int B, int H, int W, float* out, int ld_out,
              const float* res, int ld_res, hipStream_t s) {
-    // Winograd pays when its 36 GEMM rows per 4x4 tile undercut the 9 taps per pixel of the direct conv even after the
-    // tile-edge / lattice-phase waste (large dilations on a small map leave mostly-empty tiles): 36*T < 0.8 * 9*M
-    if (c.wino && h->use_winograd && !res) {
-        const int mt = h->wino_force_m ? h->wino_force_m : winograd_pick_m(B, H, W, c.dil);
-        const double wino_rows = (double)(mt + 2) * (mt + 2) * winograd_tiles(B, H, W, c.dil, mt);
-        const double direct_rows = 9.0 * (double)B * c.out_size(H) * c.out_size(W);
-        // dilation <= 4 (the dilated ResNet stages, the heads): 0.8; the ASPP dilations leave the lattices of a 90x90 map
-        // only 8, 4 and 3 pixels wide and the transforms touch every pixel through 2048 channels, so they must save more
-        if (wino_rows < (c.dil <= 4 ? 0.8 : 0.7) * direct_rows) return run_conv_winograd(h, c, in, ld_in, B, H, W, out, ld_out, s);
-    }
+    if (takes_winograd(h, c, B, H, W, res != nullptr)) return run_conv_winograd(h, c, in, ld_in, B, H, W, out, ld_out, s);
     ConvParams p{};
     p.in = in;
     p.ld_in = ld_in;
@@ -239,25 +276,15 @@ int run_conv(fs_net* h, const ConvBN& c, const float* in, int ld_in, int B, int 
 
 int ensure_workspace(fs_net* h, size_t buf_elems, size_t small_elems) {
     if (buf_elems > h->buf_elems) {
-        FS_HIP(hipDeviceSynchronize());
         for (int i = 0; i < 4; ++i) {
-            if (h->buf[i]) FS_HIP(hipFree(h->buf[i]));
-            h->buf[i] = nullptr;
-            FS_HIP(hipMalloc(reinterpret_cast<void**>(&h->buf[i]), buf_elems * sizeof(float)));
+            size_t have = h->buf_elems;
+            FS_TRY(ws_grow(h, &h->buf[i], &have, buf_elems, false));
         }
         h->buf_elems = buf_elems;
     }
-    if (small_elems > h->small_elems) {
-        FS_HIP(hipDeviceSynchronize());
-        if (h->small) FS_HIP(hipFree(h->small));
-        h->small = nullptr;
-        FS_HIP(hipMalloc(reinterpret_cast<void**>(&h->small), small_elems * sizeof(float)));
-        // zeroed once: the fixed-stride pyramid slots have rows no kernel ever writes (levels with fewer than 36 cells) and
-        // the grouped Z GEMM multiplies them like any other row
-        FS_HIP(hipMemset(h->small, 0, small_elems * sizeof(float)));
-        h->small_elems = small_elems;
-    }
-    return 0;
+    // zeroed once: the fixed-stride pyramid slots have rows no kernel ever writes (levels with fewer than 36 cells) and
+    // the grouped Z GEMM multiplies them like any other row
+    return ws_grow(h, &h->small, &h->small_elems, small_elems, true);
 }
 
 struct Geometry {
@@ -335,6 +362,7 @@ int net_destroy(fs_handle h) {
     if (h->seg_feat) (void)hipFree(h->seg_feat);
     if (h->wino_ws) (void)hipFree(h->wino_ws);
     if (h->pos_cur) (void)hipFree(h->pos_cur);
+    for (hipEvent_t e : h->bank_events) (void)hipEventDestroy(e);
     for (auto& r : h->prof) {
         (void)hipEventDestroy(r.e0);
         (void)hipEventDestroy(r.e1);
@@ -533,6 +561,50 @@ size_t net_workspace_bytes(fs_handle h, int B, int H, int W) {
     return (4 * encoder_buf_elems(h, B, H, W) + small_elems_for(B)) * sizeof(float);
 }
 
+// fs_reserve: every library-owned block a forward over B frames of H x W touches -- activation buffers, pooled maps, the
+// internal feature map of the unfused routes, the Winograd V / M workspace of the largest eligible conv -- is grown to its
+// final size now, and the Winograd filter banks this geometry selects are built on `s`.  A later fs_encoder_forward /
+// fs_decoder_forward / fs_segment_forward / fs_segment_crops with the same H x W and at most B frames allocates nothing.
+int net_reserve(fs_handle h, int B, int H, int W, hipStream_t s) {
+    FS_REQUIRE(h && h->finalized, "fs_reserve: network not finalized");
+    FS_TRY(check_device(h, "fs_reserve"));
+    FS_REQUIRE(B >= 1 && H >= 1 && W >= 1, "fs_reserve: bad arguments (B=%d H=%d W=%d)", B, H, W);
+    if (h->cfg.arch == FS_ARCH_SEGMENTER) return vit_reserve(h, B, H, W, s);
+    FS_REQUIRE(H >= 33 && W >= 33, "fs_reserve: frames of at least 33 x 33 (got %d x %d)", H, W);
+    const Geometry g = geometry(h, H, W);
+    const int fh = g.H3, fw = g.W3;
+    const size_t px = (size_t)B * fh * fw;
+    const bool psp = h->cfg.arch == FS_ARCH_PSPNET;
+    size_t buf = encoder_buf_elems(h, B, H, W);
+    buf = std::max(buf, psp ? std::max(px * 512, ppm_term_scratch_floats(B, fh, h->cls_main.Cout)) : px * 1280);
+    FS_TRY(ensure_workspace(h, buf, small_elems_for(B)));
+    if (!psp || !h->use_fused_head) FS_TRY(ws_grow(h, &h->seg_feat, &h->seg_feat_elems, px * (size_t)h->feat_channels(), false));
+    size_t wino = 0;
+    if (h->deep_stem) {
+        FS_TRY(reserve_conv(h, h->stem[1], B, g.H1, g.W1, s, &wino));
+        FS_TRY(reserve_conv(h, h->stem[2], B, g.H1, g.W1, s, &wino));
+    }
+    int curH = g.H2, curW = g.W2;
+    for (const Bottleneck& blk : h->blocks) {
+        FS_TRY(reserve_conv(h, blk.c2, B, curH, curW, s, &wino));
+        curH = blk.c2.out_size(curH);
+        curW = blk.c2.out_size(curW);
+    }
+    if (psp) {
+        FS_TRY(reserve_conv(h, h->use_fused_head ? h->cls_main : h->cls_conv, B, fh, fw, s, &wino));
+        FS_TRY(reserve_conv(h, h->cls_conv, B, fh, fw, s, &wino));  // fs_decoder_forward on its own (feature mode)
+    } else {
+        for (int i = 1; i < 4; ++i) FS_TRY(reserve_conv(h, h->aspp[i], B, fh, fw, s, &wino));
+        FS_TRY(reserve_conv(h, h->head_conv, B, fh, fw, s, &wino));
+    }
+    return ws_grow(h, &h->wino_ws, &h->wino_ws_elems, wino, false);
+}
+
+size_t net_reserved_bytes(fs_handle h) {
+    if (!h) return 0;
+    return (4 * h->buf_elems + h->small_elems + h->seg_feat_elems + h->wino_ws_elems + h->vit_ws_elems + h->pos_elems + h->bank_elems) * sizeof(float);
+}
+
 // ---------------------------------------------------------------------------------------------
 namespace {
 // Pyramid pooling up to the reduced maps (model/pspnet.py:22-26): adaptive average pools (bins 1, 2, 3, 6) of the 2048
@@ -714,13 +786,7 @@ int net_segment(fs_handle h, const FrameSrc& src, int B, int H, int W, float* ou
     if (h->cfg.arch != FS_ARCH_PSPNET || !h->use_fused_head) {
         FS_TRY(net_feature_shape(h, H, W, &C, &fh, &fw));
         const size_t need = h->cfg.arch == FS_ARCH_SEGMENTER ? (size_t)B * (fh * fw + 1) * C : (size_t)B * fh * fw * C;
-        if (need > h->seg_feat_elems) {
-            FS_HIP(hipDeviceSynchronize());
-            if (h->seg_feat) FS_HIP(hipFree(h->seg_feat));
-            h->seg_feat = nullptr;
-            FS_HIP(hipMalloc(reinterpret_cast<void**>(&h->seg_feat), need * sizeof(float)));
-            h->seg_feat_elems = need;
-        }
+        FS_TRY(ws_grow(h, &h->seg_feat, &h->seg_feat_elems, need, false));
         FS_TRY(net_encoder(h, src, B, H, W, h->seg_feat, s));
         return net_decoder(h, h->seg_feat, B, fh, fw, out_nchw, s);
     }

@@ -119,13 +119,7 @@ int vit_workspace(fs_net* h, int B, int tokens, VitWs* ws) {
     const size_t P2 = (size_t)3 * h->cfg.patch * h->cfg.patch;
     const size_t att = attention_scratch_floats(B, tokens, (int)(D / 64));
     const size_t need = T * D * 3 + T * 3 * D + T * 4 * D + T * P2 + T * D + att + 4 * T * D + 64;  // + split-K partials (<= 4 slices)
-    if (need > h->vit_ws_elems) {
-        FS_HIP(hipDeviceSynchronize());
-        if (h->vit_ws) FS_HIP(hipFree(h->vit_ws));
-        h->vit_ws = nullptr;
-        FS_HIP(hipMalloc(reinterpret_cast<void**>(&h->vit_ws), need * sizeof(float)));
-        h->vit_ws_elems = need;
-    }
+    FS_TRY(ws_grow(h, &h->vit_ws, &h->vit_ws_elems, need, false));
     float* p = h->vit_ws;
     ws->X = p; p += T * D;
     ws->Xn = p; p += T * D;
@@ -202,6 +196,32 @@ int vit_feature_shape(fs_handle h, int H, int W, int* C, int* fh, int* fw) {
     return 0;
 }
 
+// position embedding for a gh x gw grid (segm/model/vit.py:122-130, utils.py:22-40: bilinear, align_corners=False); the
+// resized table is kept until another geometry asks (fs_reserve builds it ahead of the first forward)
+static int vit_pos_embed(fs_net* h, int gh, int gw, hipStream_t s, const float** pos) {
+    const int D = h->cfg.d_model, N = gh * gw;
+    *pos = h->pos_embed;
+    if (gh == h->pos_g0 && gw == h->pos_g0) return 0;
+    if (gh != h->pos_gh || gw != h->pos_gw) {
+        FS_TRY(ws_grow(h, &h->pos_cur, &h->pos_elems, (size_t)(1 + N) * D, false));
+        FS_HIP(hipMemcpyAsync(h->pos_cur, h->pos_embed, (size_t)D * sizeof(float), hipMemcpyDeviceToDevice, s));
+        FS_TRY(launch_resize_bilinear_nhwc(h->pos_embed + D, D, 1, D, h->pos_g0, h->pos_g0, h->pos_cur + D, D, gh, gw, 0, s));
+        h->pos_gh = gh;
+        h->pos_gw = gw;
+    }
+    *pos = h->pos_cur;
+    return 0;
+}
+
+int vit_reserve(fs_handle h, int B, int H, int W, hipStream_t s) {
+    const int P = h->cfg.patch;
+    const int gh = (H + P - 1) / P, gw = (W + P - 1) / P;
+    VitWs ws;
+    FS_TRY(vit_workspace(h, B, gh * gw + 1 + h->cfg.classes, &ws));
+    const float* pos = nullptr;
+    return vit_pos_embed(h, gh, gw, s, &pos);
+}
+
 int vit_encoder(fs_handle h, const FrameSrc& src, int B, int H, int W, float* out_tokens, hipStream_t s) {
     FS_REQUIRE(out_tokens && B >= 1 && H >= 1 && W >= 1, "fs_encoder_forward(segmenter): bad arguments");
     FS_REQUIRE(src.ncrops == 0, "fs_segment_crops: the Segmenter has no sliding-crop route (the reference never wires ViT into flow/base.py:182-209)");
@@ -212,21 +232,8 @@ int vit_encoder(fs_handle h, const FrameSrc& src, int B, int H, int W, float* ou
     const int gh = (H + P - 1) / P, gw = (W + P - 1) / P, N = gh * gw;
     VitWs ws;
     FS_TRY(vit_workspace(h, B, N + 1 + h->cfg.classes, &ws));
-    // position embedding for this grid (segm/model/vit.py:122-130, utils.py:22-40: bilinear, align_corners=False)
-    const float* pos = h->pos_embed;
-    if (gh != h->pos_g0 || gw != h->pos_g0) {
-        if (gh != h->pos_gh || gw != h->pos_gw) {
-            FS_HIP(hipDeviceSynchronize());
-            if (h->pos_cur) FS_HIP(hipFree(h->pos_cur));
-            h->pos_cur = nullptr;
-            FS_HIP(hipMalloc(reinterpret_cast<void**>(&h->pos_cur), (size_t)(1 + N) * D * sizeof(float)));
-            FS_HIP(hipMemcpyAsync(h->pos_cur, h->pos_embed, (size_t)D * sizeof(float), hipMemcpyDeviceToDevice, s));
-            FS_TRY(launch_resize_bilinear_nhwc(h->pos_embed + D, D, 1, D, h->pos_g0, h->pos_g0, h->pos_cur + D, D, gh, gw, 0, s));
-            h->pos_gh = gh;
-            h->pos_gw = gw;
-        }
-        pos = h->pos_cur;
-    }
+    const float* pos = nullptr;
+    FS_TRY(vit_pos_embed(h, gh, gw, s, &pos));
     FS_TRY(prof_begin(h, "patchify", "patchify", 0, 8.0 * B * N * 3.0 * P * P, s));
     FS_TRY(launch_patchify(in_nchw, in2, B1, ws.patches, B, H, W, P, gh, gw, s));
     FS_TRY(prof_end(h, s));

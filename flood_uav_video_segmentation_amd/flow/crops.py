@@ -92,7 +92,7 @@ def compute_output(flow_model, n, frame_prev, frame_next, mvs_left, mvs_right, c
                                    and frame_prev.shape[0] == 1 and frame_next is not None)
     if batched:
         yx = [(s_h, s_w) for (s_h, _, s_w, _) in windows]
-        tag = ("crops", new_h, new_w, crop_h, crop_w)
+        tag = ("crops", new_h, new_w, crop_h, crop_w, getattr(getattr(net, "_hip_net", None), "generation", 0))
         if lows is not None:
             lo_prev, lo_next = lows
         else:

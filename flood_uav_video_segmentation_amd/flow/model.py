@@ -46,9 +46,12 @@ class KeyframeCache:
         cache = KeyframeCache()
         fm.predict(prev, nxt, mvl, mvr, n, profiler, key_cache=cache.window(prev_id, next_id))
 
-    What is kept is whatever the mode propagates: decoder logits (segmentation mode), encoder features (feature mode) or the
-    per-crop logits of the sliding-crop route; a tag keeps different modes / geometries apart.  Results are bit-identical to
-    the uncached call: a frame's network output does not depend on the batch it was computed in."""
+    The ids only have to be hashable and to name a frame uniquely for as long as the cache lives: when frame numbers restart
+    per video, use (video, frame) pairs -- or call clear() between videos (FlowPredictor.reset() does).  What is kept is
+    whatever the mode propagates: decoder logits (segmentation mode), encoder features (feature mode) or the per-crop logits of
+    the sliding-crop route; a tag keeps different modes / geometries / weight generations apart (reloading the network's
+    state_dict invalidates the slot).  Results are bit-identical to the uncached call: a frame's network output does not depend
+    on the batch it was computed in."""
 
     def __init__(self):
         self.frame_id, self.tag, self.value = None, None, None
@@ -101,10 +104,17 @@ class FlowModel(nn.Module):
         """decoder(encoder(frames)) as ONE batch -> low-resolution logits [sum(B_i), K, fh, fw].  Networks that offer a
         fused `segment` (the HIP mirrors) are called once; any other module goes through .encoder / .decoder."""
         seg = getattr(self.model, "segment", None)
-        if seg is not None:
-            return seg(*frames)  # separate tensors are read in place (fs_segment_forward2): no torch.cat on the window path
+        if seg is not None and (len(frames) == 1 or hasattr(self.model, "encode_frames")):
+            # the HIP mirrors (they advertise the multi-tensor call with `encode_frames`) read separate tensors in place
+            # (fs_segment_forward2): no torch.cat on the window path.  A user network's segment(x) only ever sees ONE tensor.
+            return seg(*frames)
         x = frames[0] if len(frames) == 1 else torch.cat(frames, 0)
-        return self.model.decoder(self.model.encoder(x))
+        return seg(x) if seg is not None else self.model.decoder(self.model.encoder(x))
+
+    def _tag(self, kind, h, w):
+        """Cache tag of a key frame's output: mode, frame geometry and the generation of the network's weights (the HIP mirrors
+        bump it in load_state_dict), so that a cached output never survives a change of any of them."""
+        return (kind, h, w, getattr(getattr(self.model, "_hip_net", None), "generation", 0))
 
     def _key_outputs(self, fn, tag, frame_prev, frame_next, key_cache):
         """(out_prev, out_next) of `fn` = _segment / _encode for the two key frames of a window.  With a key_cache the
@@ -199,7 +209,7 @@ class FlowModel(nn.Module):
         Returns {"pred": [n,K,h,w]} ([1,K,h,w] when frame_next is None).  key_cache: see KeyframeCache (extension)."""
         h, w = frame_prev.shape[2], frame_prev.shape[3]
         with _region(profiler, "predict_encoder"), _region(profiler, "predict_decoder"):
-            lo_prev, lo_next = self._key_outputs(self._segment, ("seg", h, w), frame_prev, frame_next, key_cache)
+            lo_prev, lo_next = self._key_outputs(self._segment, self._tag("seg", h, w), frame_prev, frame_next, key_cache)
         with _region(profiler, "predict_warp"), _region(profiler, "predict_fusion"):
             logits, _ = ops.seg_tail(lo_prev, lo_next, mvs_left, mvs_right, n, (h, w), self.no_warp, want_logits=True)
         return {"pred": logits}
@@ -209,7 +219,7 @@ class FlowModel(nn.Module):
         (Extension for the native-resolution timed region of bench.py; not a reference method.)"""
         h, w = frame_prev.shape[2], frame_prev.shape[3]
         with _region(profiler, "predict_encoder"), _region(profiler, "predict_decoder"):
-            lo_prev, lo_next = self._key_outputs(self._segment, ("seg", h, w), frame_prev, frame_next, key_cache)
+            lo_prev, lo_next = self._key_outputs(self._segment, self._tag("seg", h, w), frame_prev, frame_next, key_cache)
         with _region(profiler, "predict_fusion"):
             _, mask = ops.seg_tail(lo_prev, lo_next, mvs_left, mvs_right, n, (h, w), self.no_warp, want_logits=False, want_mask=True)
         return mask
@@ -218,7 +228,7 @@ class FlowModel(nn.Module):
         """Propagate encoder FEATURES, decode all n maps in one batch (reference :116-181)."""
         h, w = frame_prev.shape[2], frame_prev.shape[3]
         with _region(profiler, "predict_encoder"):
-            f, f_next = self._key_outputs(self._encode, ("feat", h, w), frame_prev, frame_next, key_cache)
+            f, f_next = self._key_outputs(self._encode, self._tag("feat", h, w), frame_prev, frame_next, key_cache)
         f_h, f_w = f.shape[2], f.shape[3]
         # the n maps the decoder sees are produced straight into ONE batch tensor (the reference stacks them with torch.cat, :173-176)
         nmaps = n if f_next is not None else 1

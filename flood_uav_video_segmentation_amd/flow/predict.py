@@ -34,11 +34,21 @@ class FlowPredictor:
         self.last_output = None  # flow/base.py:247, :295
         self.hist = None         # int64[3,K]: intersection, |pred|, |target| accumulated over the run
 
-    def predict_window(self, frame_prev, frame_next, mvs_left, mvs_right, profiler=None, to_host=True, key_ids=None):
+    def reset(self):
+        """Start a new video: forget the cached key frame and the last mask (the temporal-consistency metric pairs each frame with
+        its predecessor, flow/base.py:247,295 -- which must not be another video's last frame).  The histogram keeps running."""
+        if self.key_cache is not None:
+            self.key_cache.clear()
+        self.last_output = None
+
+    def predict_window(self, frame_prev, frame_next, mvs_left, mvs_right, profiler=None, to_host=True, key_ids=None, key_cache=None):
+        """key_cache: a KeyframeCache to use for this call instead of the predictor's own (predict_clip's fallback passes a
+        cache that lives for the clip only)."""
         assert frame_prev.shape[0] == 1                      # flow/base.py:263
         assert len(mvs_left) == len(mvs_right)               # :264
         n = len(mvs_left) + 1                                # :266 -- the list length encodes n, also for no_warp dummies
-        kc = self.key_cache.window(*key_ids) if (self.key_cache is not None and key_ids is not None) else None
+        cache = key_cache if key_cache is not None else self.key_cache
+        kc = cache.window(*key_ids) if (cache is not None and key_ids is not None) else None
         if self.crop is None:
             extra = {} if kc is None else {"key_cache": kc}
             logits = self.model.predict(frame_prev, frame_next, mvs_left, mvs_right, n, profiler, **extra)["pred"]
@@ -60,60 +70,87 @@ class FlowPredictor:
 
     def predict_clip(self, items, profiler=None, to_host=True):
         """A clip's consecutive windows (dicts as PredictWindows yields them: frame_prev, frame_next, mvs_left, mvs_right,
-        key_ids) with the key-frame cache AND look-ahead: the clip's key frames go through the network two at a time (each
-        exactly once), and a window is emitted as soon as both of its key frames are there -- every key frame at the efficiency
-        of a full batch (a lone frame runs ~10 % slower per frame: half-empty tile rounds).  Yields the
-        masks of every window, in order, bit-identical to predict_window on the same windows (a frame's network output does
-        not depend on its batch).  Segmentation mode (whole frame or sliding crops); feature mode takes the per-window cache."""
-        items = list(items)
+        key_ids) with the key-frame cache AND look-ahead: key frames go through the network two at a time (each exactly once),
+        and a window is emitted as soon as both of its key frames are there -- every key frame at the efficiency of a full batch
+        (a lone frame runs ~10 % slower per frame: half-empty tile rounds).  Yields the masks of every window, in order,
+        bit-identical to predict_window on the same windows (a frame's network output does not depend on its batch).
+
+        `items` is consumed LAZILY: windows are pulled only until two not-yet-segmented key frames are at hand, so at most two
+        windows' frames (and three key frames' low-resolution logits) are alive at once, however long the clip -- a lazily
+        loading iterable such as PredictWindows streams.  Segmentation mode (whole frame or sliding crops); feature mode, a
+        network without a fused `segment`, or a window without key_ids take predict_window with a cache that lives for this
+        clip only (the predictor's own cache, when it has one)."""
+        from collections import deque
+
+        from .model import KeyframeCache, _region
+
         fm = self.model
-        if getattr(fm, "feature_based", True) or not hasattr(fm.model, "segment") or any(it.get("key_ids") is None for it in items):
-            if self.key_cache is None:
-                from .model import KeyframeCache
-                self.key_cache = KeyframeCache()
-            for it in items:
-                yield self.predict_window(it["frame_prev"], it["frame_next"], it["mvs_left"], it["mvs_right"], profiler, to_host, it.get("key_ids"))
-            return
-        store = {}  # frame id -> decoder logits of that key frame ([1,K,fh,fw], or [ncrops,K,fh,fw] on the sliding-crop route)
+        lookahead = not getattr(fm, "feature_based", True) and hasattr(fm.model, "segment") and hasattr(fm.model, "encode_frames")
+        local_cache = self.key_cache if self.key_cache is not None else KeyframeCache()
+        store = {}         # frame id -> decoder logits of that key frame ([1,K,fh,fw]; [ncrops,K,fh,fw] on the sliding-crop route)
+        queue = []         # key frames not segmented yet, in order of first use: (frame id, tensor)
+        pending = deque()  # windows pulled from `items` and not emitted yet
+        last_next = None   # the newest emitted window's next key: the window still to come names it as its previous key
+        it = iter(items)
+        exhausted = False
 
         def run(frames):  # one or two key frames through the network as ONE batch
-            if self.crop is None:
-                lows = fm._segment(*frames)
-                return [lows[j:j + 1] for j in range(len(frames))]
-            a, b = crops.segment_crop_windows(fm, frames[0], frames[1] if len(frames) > 1 else None, self.crop[0], self.crop[1])
-            return [a] if b is None else [a, b]
-
-        # the clip's key frames in order of first use, each once; they go through the network two at a time, and a window is
-        # emitted as soon as both of its key frames are there (in order: windows are consecutive)
-        frames, seen = [], set()
-        for it in items:
-            for fid, t in ((it["key_ids"][0], it["frame_prev"]), (it["key_ids"][1], it["frame_next"])):
-                if fid not in seen:
-                    seen.add(fid)
-                    frames.append((fid, t))
-        emitted = 0
-        for j in range(0, len(frames), 2):
-            pair = frames[j:j + 2]
-            for (fid, _), lo in zip(pair, run([t for _, t in pair])):
-                store[fid] = lo
-            while emitted < len(items) and all(k in store for k in items[emitted]["key_ids"]):
-                it = items[emitted]
-                assert it["frame_prev"].shape[0] == 1 and len(it["mvs_left"]) == len(it["mvs_right"])   # flow/base.py:263-264
-                n = len(it["mvs_left"]) + 1
-                lo_prev, lo_next = store[it["key_ids"][0]], store[it["key_ids"][1]]
-                h, w = it["frame_prev"].shape[2], it["frame_prev"].shape[3]
+            with _region(profiler, "predict_encoder"), _region(profiler, "predict_decoder"):
                 if self.crop is None:
-                    logits, _ = ops.seg_tail(lo_prev, lo_next, it["mvs_left"], it["mvs_right"], n, (h, w), fm.no_warp, want_logits=True)
-                    masks = ops.resize_argmax_u8(logits, self.out_size)
-                else:
-                    _, masks = crops.compute_output(fm, n, it["frame_prev"], it["frame_next"], it["mvs_left"], it["mvs_right"], self.crop[0],
-                                                    self.crop[1], self.classes, profiler, want_mask=True, out_size=self.out_size,
-                                                    lows=(lo_prev, lo_next))
-                self._score(masks, n)
-                emitted += 1
-                yield masks.cpu().numpy() if to_host else masks
-            live = {k for it in items[emitted:] for k in it["key_ids"]}
-            store = {k: v for k, v in store.items() if k in live}  # only what a window still to come needs
+                    lows = fm._segment(*frames)
+                    return [lows[j:j + 1] for j in range(len(frames))]
+                a, b = crops.segment_crop_windows(fm, frames[0], frames[1] if len(frames) > 1 else None, self.crop[0], self.crop[1])
+                return [a] if b is None else [a, b]
+
+        def emit(w):
+            assert w["frame_prev"].shape[0] == 1 and len(w["mvs_left"]) == len(w["mvs_right"])   # flow/base.py:263-264
+            n = len(w["mvs_left"]) + 1
+            lo_prev, lo_next = store[w["key_ids"][0]], store[w["key_ids"][1]]
+            h, wd = w["frame_prev"].shape[2], w["frame_prev"].shape[3]
+            if self.crop is None:
+                with _region(profiler, "predict_warp"), _region(profiler, "predict_fusion"):
+                    logits, _ = ops.seg_tail(lo_prev, lo_next, w["mvs_left"], w["mvs_right"], n, (h, wd), fm.no_warp, want_logits=True)
+                masks = ops.resize_argmax_u8(logits, self.out_size)
+            else:
+                _, masks = crops.compute_output(fm, n, w["frame_prev"], w["frame_next"], w["mvs_left"], w["mvs_right"], self.crop[0],
+                                                self.crop[1], self.classes, profiler, want_mask=True, out_size=self.out_size,
+                                                lows=(lo_prev, lo_next))
+            self._score(masks, n)
+            return masks.cpu().numpy() if to_host else masks
+
+        while True:
+            plain = None  # a window that cannot take the look-ahead route (no key_ids / feature mode / foreign network)
+            while len(queue) < 2 and not exhausted and plain is None:
+                if pending and not queue and all(k in store for k in pending[0]["key_ids"]):
+                    break  # nothing to wait for: emit before pulling more
+                try:
+                    w = next(it)
+                except StopIteration:
+                    exhausted = True
+                    break
+                if not lookahead or w.get("key_ids") is None:
+                    plain = w
+                    break
+                pending.append(w)
+                for fid, t in zip(w["key_ids"], (w["frame_prev"], w["frame_next"])):
+                    if fid not in store and all(fid != q for q, _ in queue):
+                        queue.append((fid, t))
+            # segment what is queued: pairs while there are pairs; a lone frame only when nothing can join it any more
+            while len(queue) >= 2 or (queue and (exhausted or plain is not None)):
+                pair, queue = queue[:2], queue[2:]
+                for (fid, _), lo in zip(pair, run([t for _, t in pair])):
+                    store[fid] = lo
+            while pending and all(k in store for k in pending[0]["key_ids"]):
+                w = pending.popleft()
+                last_next = w["key_ids"][1]
+                yield emit(w)
+            live = {k for w in pending for k in w["key_ids"]} | {last_next}
+            store = {k: v for k, v in store.items() if k in live}  # only what a window still to come can need
+            if plain is not None:
+                yield self.predict_window(plain["frame_prev"], plain["frame_next"], plain["mvs_left"], plain["mvs_right"], profiler, to_host,
+                                          plain.get("key_ids"), key_cache=local_cache)
+            elif exhausted and not pending and not queue:
+                return
 
     def temporal_consistency(self):
         """on_predict_end's summary (flow/base.py:330-343): (mIoU, mAcc, accuracy) with the reference's 1e-10 epsilon."""

@@ -34,6 +34,7 @@ class HipNet:
         self.ready = False
         self._lib = None
         self.device = None  # torch.device the handle's weights and workspace live on (set by load())
+        self.generation = 0  # bumped by every load(): key-frame caches tag their entries with it (flow/model.py)
 
     # -- lifecycle ---------------------------------------------------------------------------
     def _create(self):
@@ -78,6 +79,7 @@ class HipNet:
             check(lib.fs_finalize(self._h, stream_ptr()))
         self.device = device
         self.ready = True
+        self.generation += 1
 
     def close(self):
         if self._h is not None and self._lib is not None:
@@ -105,6 +107,17 @@ class HipNet:
         c, fh, fw = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
         check(self._lib.fs_feature_shape(self._h, h, w, ctypes.byref(c), ctypes.byref(fh), ctypes.byref(fw)))
         return c.value, fh.value, fw.value
+
+    def reserve(self, batch, h, w):
+        """fs_reserve: size the library's workspace (and build the Winograd filter banks) for forwards over at most `batch`
+        frames / crops of h x w, once, so that no later forward at that geometry allocates or synchronises."""
+        self._need_ready()
+        with torch.cuda.device(self.device):
+            check(self._lib.fs_reserve(self._h, int(batch), int(h), int(w), stream_ptr()))
+
+    def reserved_bytes(self):
+        self._need_ready()
+        return int(self._lib.fs_reserved_bytes(self._h))
 
     def _frames(self, frames, what):
         """Validate a batch given as one or two [B_i,3,H,W] tensors (a longer list is concatenated: rare, not the window path)."""
@@ -235,6 +248,10 @@ class HipSegNet(nn.Module):
         self._hip_net = HipNet(self.ARCH, hparams.layers, hparams.classes, **hip_options(hparams))
         self.encoder = HipStage(self._hip_net.encode, "encoder")
         self.decoder = HipStage(self._hip_net.decode, "decoder")
+
+    def reserve(self, batch, h, w):
+        """Pre-size the HIP library's workspace for forwards over at most `batch` frames (or crops) of h x w (fs_reserve)."""
+        self._hip_net.reserve(batch, h, w)
 
     def encode_frames(self, *frames):
         """model.encoder over a batch given as separate tensors (FlowModel: frame_prev, frame_next) -- read in place."""

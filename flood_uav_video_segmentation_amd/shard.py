@@ -44,6 +44,13 @@ def windows_of_clip(num_frames, frame_delta):
     return [(i * frame_delta, (i + 1) * frame_delta) for i in range(num_frames // frame_delta)]
 
 
+def clip_window_schedule(num_clips, num_frames, frame_delta, rank, world_size):
+    """The (clip, key_prev, key_next) windows rank r processes, in order, when `num_clips` clips are sharded by clip
+    (BASELINE configs[4]: 64 clips of 21 frames, frame_delta 5 -> 4 windows per clip): clips r, r+W, ... each walked window by
+    window as FlowData(split='predict') enumerates them.  Over all ranks every (clip, window) appears exactly once."""
+    return [(c, k0, k1) for c in clips_for_rank(num_clips, rank, world_size) for (k0, k1) in windows_of_clip(num_frames, frame_delta)]
+
+
 def window_block(num_windows, rank, world_size):
     """Frame-window sharding of ONE long clip: rank r takes the contiguous block
     [num_windows*r // W, num_windows*(r+1) // W) -- blocks differ by at most one window and may be empty when W > windows."""
@@ -57,8 +64,8 @@ def barrier(device=None):
     all-reduce can never run on another rank's GPU."""
     if dist.is_available() and dist.is_initialized():
         if dist.get_backend() == "nccl":
-            dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
-            dist.barrier(device_ids=[torch.device(dev).index])
+            idx = torch.device(device).index if device is not None else None
+            dist.barrier(device_ids=[idx if idx is not None else torch.cuda.current_device()])  # device="cuda" has no index
         else:
             dist.barrier()
 

@@ -17,7 +17,10 @@
  *   - every pointer named *_dev / in / out is a DEVICE pointer (tensor.data_ptr()); nothing is freed or
  *     retained by the library except its own packed weights and workspace;
  *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream); all work is
- *     enqueued on it, no call synchronises the device except fs_finalize / fs_profile_dump;
+ *     enqueued on it.  fs_finalize, fs_reserve and fs_profile_dump synchronise the device.  A forward synchronises (and
+ *     allocates) only when it has to GROW the library-owned workspace or build a Winograd filter bank for a geometry it has
+ *     not seen: call fs_reserve(handle, B, H, W) once for the largest batch / frame size you will use and no later forward
+ *     allocates, frees or synchronises (required before HIP-graph capture and before using one handle from several streams);
  *   - all functions return 0 on success; on failure a non-zero code, and fs_last_error() holds the text
  *     (the Python shim raises RuntimeError with it -- the reference itself only raises/asserts);
  *   - NCHW tensors are the reference's layout; "NHWC" tensors are pixel-major with an explicit pixel
@@ -74,8 +77,17 @@ int fs_load_weight(fs_handle h, const char* name, const float* data, const int64
 int fs_finalize(fs_handle h, fs_stream stream);
 /* Feature-map geometry produced by fs_encoder_forward for an H x W frame. */
 int fs_feature_shape(fs_handle h, int H, int W, int* C, int* fh, int* fw);
-/* Bytes of library-owned workspace a forward at this geometry needs (allocated lazily). */
+/* Bytes of library-owned activation workspace a forward at this geometry needs (allocated lazily, or by fs_reserve). */
 size_t fs_workspace_bytes(fs_handle h, int B, int H, int W);
+/* Grow every library-owned block that fs_encoder_forward / fs_decoder_forward / fs_segment_forward(2) / fs_segment_crops over
+ * at most B frames (crops) of H x W will touch -- activation buffers, pooled maps, the Winograd V / M workspace, the resized
+ * position table of the Segmenter -- to its final size, and build (on `stream`) the Winograd filter banks this geometry
+ * selects.  Synchronises the device.  After it, a forward at this geometry performs no hipMalloc / hipFree / device sync;
+ * fs_reserved_bytes() is how a caller checks: it does not change across such forwards.  Blocks only ever grow: reserving
+ * several geometries in turn leaves the handle ready for all of them. */
+int fs_reserve(fs_handle h, int B, int H, int W, fs_stream stream);
+/* Bytes of workspace + lazily built filter banks the handle holds right now (packed weights not included). */
+size_t fs_reserved_bytes(fs_handle h);
 
 /* model.encoder(x):  in NCHW [B,3,H,W]  ->  out NHWC [B,fh,fw,C] (ld = C; a channels_last torch tensor)
  * FS_ARCH_SEGMENTER: out = the ViT tokens after the final LayerNorm, cls token dropped, [B, gh*gw, D]
@@ -164,7 +176,7 @@ int fs_canvas_finish(double* canvas, const double* count, int n, int K, int64_t 
  * on compute_output's result), without the [n,K,Ho,Wo] intermediate.  canvas must already be divided by the count. */
 int fs_canvas_resize_argmax(const double* canvas, int n, int K, int Hi, int Wi, uint8_t* mask, int Ho, int Wo, fs_stream stream);
 /* crop_motion_vector (flow/transform.py:215-261) for every crop x every grid of a window in one launch.  grids: host array of
- * `ngrids` device pointers, each fp32 [Hg, Wg, 2] normalised to the H x W frame; crop c is the ch x cw window at
+ * `ngrids` device pointers, each fp32 [Hg, Wg, 2] normalised to the H x W frame (any number: more than 32 grids or crops are cut into several launches); crop c is the ch x cw window at
  * (crop_y[c], crop_x[c]).  out: fp32 [ncrops][ngrids][ch/16][cw/16][2]: block range by Python's round(), coordinates
  * renormalised to the crop, half-pixel bilinear resize (cv2.INTER_LINEAR) to (ch/16) x (cw/16). */
 int fs_crop_grids(const float* const* grids, int ngrids, int Hg, int Wg, int H, int W, int ncrops, const int* crop_y,

@@ -58,6 +58,25 @@ def test_bench_two_ranks_rehearsed_on_one_gpu():
     assert abs(j["value"] - 2 * 5 * 1000.0 / j["ms_per_step"]) < 1e-2 * j["value"]
 
 
+def test_bench_launched_directly_with_gpus_2_spawns_its_own_ranks():
+    """How the driver starts it: plain `python bench.py --gpus N` (no torchrun, no WORLD_SIZE).  The parent spawns the ranks as
+    fresh children (here rehearsed on the one GPU over gloo) and relays rank 0's line; the N > 1 step is the BASELINE configs[4]
+    workload: 64 clips sharded by clip, 32 clips = 128 windows on each of two ranks."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "1", "--no-extras",
+                        "--no-cpu-baseline", "--rehearse-on-one-gpu"], capture_output=True, text=True, timeout=1200, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    j = _last_json(r.stdout)
+    assert j["n_gpus"] == 2 and j["steps"] == 6 and j["distributed"]["world_size"] == 2
+    assert "configs[4]" in j["config"]["workload"] and j["config"]["clips_total"] == 64 and j["config"]["windows_in_this_ranks_shard"] == 128
+    assert j["scaling"] == "weak" and abs(j["value"] - 2 * 5 * 1000.0 / j["ms_per_step"]) < 1e-2 * j["value"]
+    assert j["parity"]["mask_agreement_vs_reference"] > 0.9999  # rank 0's first window is clip 0 / keys (0, 5): the golden fixture's
+    # a launch whose world does not match --gpus is refused with a message, not an assertion error
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], capture_output=True,
+                         text=True, timeout=300, cwd=ROOT, env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"))
+    assert bad.returncode != 0 and "WORLD_SIZE=1 but --gpus 2" in bad.stderr
+
+
 def test_rccl_code_path_with_a_world_of_one():
     """No second GPU on this box, so RCCL cannot be exercised across ranks here -- but the exact calls the N > 1 run makes
     (init_process_group("nccl"), barrier(device_ids=...), on-device all_reduce SUM / MAX, the boundary all_gather) do run

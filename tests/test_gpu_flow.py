@@ -164,6 +164,26 @@ def test_sliding_crop_inference_against_oracle_parity_unpinned():
                                                          (359, 1072, 0, 713), (359, 1072, 476, 1189), (359, 1072, 952, 1665), (359, 1072, 1207, 1920)]
 
 
+def test_sliding_crop_inference_with_the_reference_default_frame_delta_25():
+    """frame_delta = 25 (FlowDataModule's default, flow/base.py:350): 48 grids per window through crop_motion_vector and the
+    warp chains of every crop -- ADVICE r2: the one-launch crop_grids used to refuse more than 32 grids."""
+    from flood_uav_video_segmentation_amd.flow import crops
+    from oracle import crops_oracle
+
+    n, H, W, ch, cw, K = 25, 160, 224, 97, 97, 5
+    clip = synth.make_clip(2, (H, W), seed=51)
+    mvl, mvr = synth.make_grids(n, H // 16, W // 16, seed=52, frame=(H, W), jitter=0.01)
+    fm = FlowModel(toy_model(), feature_based=False, no_warp=False).eval()
+    got = crops.compute_output(fm, n, clip[0:1].cuda(), clip[1:2].cuda(), cu(mvl), cu(mvr), ch, cw, K)
+    w = toy_weights()
+    enc = lambda x: torch.relu(torch.nn.functional.conv2d(x, w["enc_w"], w["enc_b"], 4, 1))  # noqa: E731
+    dec = lambda f: torch.nn.functional.conv2d(f, w["dec_w"], w["dec_b"])  # noqa: E731
+    pred = lambda p, q, ml, mr: flow_oracle.predict_segmentation(enc, dec, p, q, ml, mr, n, False)["pred"]  # noqa: E731
+    ref = crops_oracle.compute_output(pred, n, clip[0:1], clip[1:2], mvl, mvr, ch, cw, K)
+    assert got.shape == ref.shape == (n, K, H, W)
+    assert (got.cpu() - ref).abs().max().item() < 2e-5  # 24-deep warp chains; probabilities in [0,1]
+
+
 def test_motion_vectors_to_grids_last_writer_wins_and_npy_round_trip(tmp_path):
     """the grid producer (the reference script needs cv2 + mvextractor at import: restated, unpinned)."""
     from flood_uav_video_segmentation_amd.flow import grids

@@ -466,6 +466,28 @@ def test_crop_grids_identity_block_range_and_edge_cases():
         ops.crop_grids(cu(mvl), (320, 480), [(300, 0)], (64, 64))
 
 
+def test_crop_grids_more_than_32_grids_and_more_than_32_crops():
+    """frame_delta = 25 is the reference's default (flow/base.py:350): 48 grids per window; a 2160x3840 frame with 713 crops
+    has 40 windows.  fs_crop_grids cuts both into slices of at most 32 per launch, written in place (the single
+    launch used to refuse them)."""
+    n = 25
+    mvl, mvr = synth.make_grids(n, 135, 240, seed=9, frame=(2160, 3840), jitter=0.004)
+    wins = crops.crop_windows(2160, 3840, 713, 713)
+    yx = [(w[0], w[2]) for w in wins]
+    assert len(yx) == 40 and len(mvl) + len(mvr) == 48
+    got = ops.crop_grids(cu(mvl) + cu(mvr), (2160, 3840), yx, (713, 713))
+    assert got.shape == (40, 48, 44, 44, 2)
+    worst = 0.0
+    for c in (0, 7, 31, 32, 39):  # both sides of the crop slice boundary
+        ol, orr = crops_oracle.crop_motion_vector([m.clone() for m in mvl], [m.clone() for m in mvr], 2160, 3840, 713, 713, *yx[c])
+        for j, ref in enumerate(ol + orr):  # all 48 grids: both sides of the grid slice boundary
+            worst = max(worst, (got[c, j].cpu() - ref[0]).abs().max().item())
+    assert note("crop_grids_48grids_40crops_max_abs", worst) < 2e-6
+    # a slice of the problem through its own call = the same values (the slicing changes nothing per element)
+    sub = ops.crop_grids(cu(mvl[:3]), (2160, 3840), yx[30:35], (713, 713))
+    assert torch.equal(sub, got[30:35, :3])
+
+
 def test_segment_crops_deeplab_equals_cloned_crops():
     """The crop-window read of the stem is shared by every conv network: DeepLabv3 (7x7 stem on the matrix cores) too."""
     state = synth.make_deeplab_state(50, 5, seed=4)
@@ -500,6 +522,74 @@ def test_full_size_networks_are_bit_repeatable_over_many_launches(psp, vit_s16):
     d0 = dl.segment(x)
     for _ in range(20):
         assert torch.equal(dl.segment(x), d0)
+
+
+def test_predict_clip_streams_its_input_and_leaves_the_predictor_alone(psp):
+    """predict_clip must consume `items` lazily (at most two windows ahead of what it has emitted: a whole video's
+    key frames must never be resident at once), must not install a permanent key cache on the predictor, and reset() starts a
+    new video (no cached key frame, no last mask carried over)."""
+    net, _ = psp
+    size, nwin = 161, 7
+    keys = synth.make_clip(5 * nwin + 1, size, seed=1001, only=[5 * i for i in range(nwin + 1)]).cuda()
+    fm = FlowModel(net, feature_based=False, no_warp=True).eval()
+    dl, dr = synth.dummy_grids(N)
+    pulled = []
+
+    def stream():
+        for i in range(nwin):
+            pulled.append(i)
+            yield {"frame_prev": keys[i:i + 1], "frame_next": keys[i + 1:i + 2], "mvs_left": cu(dl), "mvs_right": cu(dr), "key_ids": (5 * i, 5 * i + 5)}
+
+    look = FlowPredictor(fm, 5, (size, size))
+    ahead = []
+    got = []
+    for k, m in enumerate(look.predict_clip(stream(), to_host=False)):
+        got.append(m)
+        ahead.append(len(pulled) - (k + 1))
+    assert len(got) == nwin and max(ahead) <= 1, ahead  # never more than one window beyond the one being emitted
+    assert look.key_cache is None
+    plain = FlowPredictor(fm, 5, (size, size))
+    want = [plain.predict_window(keys[i:i + 1], keys[i + 1:i + 2], cu(dl), cu(dr), to_host=False) for i in range(nwin)]
+    assert all(torch.equal(g, w) for g, w in zip(got, want)) and torch.equal(look.hist, plain.hist)
+    # feature mode takes the per-window fallback with a clip-local cache: still no permanent cache on the predictor
+    ff = FlowPredictor(FlowModel(net, feature_based=True, no_warp=True).eval(), 5, (size, size))
+    list(ff.predict_clip(stream(), to_host=False))
+    assert ff.key_cache is None
+    # reset(): a second video whose frame ids restart must not hit the first video's cached key frame
+    cached = FlowPredictor(fm, 5, (size, size), cache_keyframes=True)
+    cached.predict_window(keys[0:1], keys[1:2], cu(dl), cu(dr), to_host=False, key_ids=(0, 5))
+    cached.reset()
+    assert cached.last_output is None
+    other = cached.predict_window(keys[3:4], keys[4:5], cu(dl), cu(dr), to_host=False, key_ids=(5, 10))  # id 5 again, another frame
+    assert cached.key_cache.hits == 0 and torch.equal(other, want[3])
+    # reloading the weights invalidates the slot as well (the tag carries the weight generation)
+    cached.predict_window(keys[4:5], keys[5:6], cu(dl), cu(dr), to_host=False, key_ids=(10, 15))
+    assert cached.key_cache.hits == 1
+    net.load_state_dict(psp[1])
+    cached.predict_window(keys[5:6], keys[6:7], cu(dl), cu(dr), to_host=False, key_ids=(15, 20))
+    assert cached.key_cache.hits == 1
+
+
+def test_a_user_network_with_single_tensor_segment_is_called_with_one_tensor():
+    """FlowModel hands two tensors to `segment` only when the network advertises the multi-tensor call
+    (`encode_frames`, as the HIP mirrors do); any other module's segment(x) sees the concatenated batch."""
+    import torch.nn as nn
+
+    class Net(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.seen = []
+
+        def segment(self, x):
+            self.seen.append(tuple(x.shape))
+            return x[:, :, ::8, ::8].repeat(1, 2, 1, 1)[:, :5].contiguous()
+
+    net = Net()
+    fm = FlowModel(net, feature_based=False, no_warp=True).eval()
+    a, b = torch.rand(1, 3, 64, 64, device="cuda"), torch.rand(1, 3, 64, 64, device="cuda")
+    dl, dr = synth.dummy_grids(3)
+    out = fm.predict(a, b, cu(dl), cu(dr), 3, None)["pred"]
+    assert out.shape == (3, 5, 64, 64) and net.seen == [(2, 3, 64, 64)]
 
 
 @pytest.mark.parametrize("route", ["whole_frame_linear", "whole_frame_warp", "crops"])

@@ -238,3 +238,41 @@ def test_deeplabv3_aspp_on_the_winograd_lattice_path_parity_unpinned():
     ref = deeplab_oracle.decoder(deeplab_oracle.encoder(x, state, 50), state)
     assert got.shape == ref.shape == (1, 5, 33, 33)
     assert note("deeplab50_257_logits_vs_oracle", rel_err(got, ref)) < LOGIT_TOL
+
+
+def test_reserve_then_no_forward_grows_the_workspace():
+    """fs_reserve (include/floodseg.h): after it, forwards at that geometry -- encoder, decoder, fused segment, crops, fewer
+    frames -- leave fs_reserved_bytes unchanged: every allocation site of a forward is the grow arm of one helper (ws_grow,
+    Winograd banks included), so an unchanged byte count means no hipMalloc / hipFree / device sync happened.  A larger geometry
+    grows it; reserving is idempotent."""
+    state = synth.make_pspnet_state(50, 5, seed=0)
+    net = FlowPSPNet(HP(50, 5)).eval()
+    net.load_state_dict(state)
+    hn = net._hip_net
+    assert hn.reserved_bytes() == 0
+    net.reserve(2, 161, 161)
+    r0 = hn.reserved_bytes()
+    assert r0 >= hn._lib.fs_workspace_bytes(hn._h, 2, 161, 161) > 0
+    x = synth.make_clip(2, 161, seed=5).cuda()
+    lo = net.segment(x[0:1], x[1:2])
+    f = net.encoder(x)
+    net.decoder(f)
+    net.segment(x[0:1])
+    net.segment_crops(x[0:1], x[1:2], [(0, 0)], (161, 161))
+    torch.cuda.synchronize()
+    assert hn.reserved_bytes() == r0
+    net.reserve(2, 161, 161)
+    assert hn.reserved_bytes() == r0
+    # same results as a handle that grew lazily
+    ref, _ = (lambda n: (n, n.load_state_dict(state)))(FlowPSPNet(HP(50, 5)).eval())
+    assert torch.equal(ref.segment(x[0:1], x[1:2]), lo)
+    net.segment(synth.make_clip(1, 225, seed=6).cuda())  # unreserved, larger: grows lazily
+    assert hn.reserved_bytes() > r0
+    # DeepLabv3 and the Segmenter reserve as well
+    dl = FlowDeepLabv3(HP(50, 5)).eval()
+    dl.load_state_dict(synth.make_deeplab_state(50, 5, seed=1))
+    dl.reserve(2, 193, 193)
+    r1 = dl._hip_net.reserved_bytes()
+    dl.decoder(dl.encoder(x[:, :, :, :].new_zeros(2, 3, 193, 193)))
+    dl.segment(x.new_zeros(1, 3, 193, 193))
+    assert dl._hip_net.reserved_bytes() == r1

@@ -266,7 +266,11 @@ def test_argmax_resize_argmax_and_iou_hist():
 
 
 WINO_TOL = 5e-5  # F(4x4,3x3) in fp32: ~7e-6 relative on unit-scale data, F(6x6,3x3) ~1.5x that; the tolerance leaves room for K = 1024
-WINO_TOL_2048 = 1.5e-4  # the error grows ~sqrt(Cin): Cin = 2048 with F(6,3) forced measures 6.7e-5 (F(4,3), the network's pick there: lower)
+# The error grows ~sqrt(Cin).  Cin = 2048 with F(6,3) measures 6.7e-5 on a single conv (round 2, gpurun_out/r02_pytest_gpu_1.txt) --
+# and F(6,3) IS what the network runs for the 2048-channel PSPNet head at 713x713 (90x90 = exactly 15x15 tiles of 6x6), so
+# this is the shipped per-conv error of that layer (the "head geometry" case below pins it); end to end the 713^2 logits are within
+# 8e-6 of the reference.  Asserted: ~2x the measured value, far inside SURVEY 8(d)'s 1e-3.
+WINO_TOL_2048 = 1.5e-4
 
 
 @pytest.mark.parametrize("case", [
@@ -282,6 +286,8 @@ WINO_TOL_2048 = 1.5e-4  # the error grows ~sqrt(Cin): Cin = 2048 with F(6,3) for
     (1, 90, 90, 2048, 256, 12, True),   # DeepLabv3 ASPP at 713x713 (BASELINE configs[2]): 144 phases of 8x8 / 7x7 pixels,
     (1, 90, 90, 2048, 256, 24, True),   #   576 phases of 4x4 / 3x3,
     (1, 90, 90, 2048, 256, 36, True),   #   1296 phases of 3x3 / 2x2 -- all three take the lattice path in the network
+    (2, 90, 90, 2048, 512, 1, True),    # THE PSPNet head conv of a 713x713 window (decoder.0 over the backbone channels, B = 2): with
+                                        #   tile_m = 0 the library picks F(6,3) here, as the network does
 ])
 @pytest.mark.parametrize("tile_m", [4, 6, 0])
 def test_winograd_conv3x3(case, tile_m):

@@ -97,3 +97,21 @@ def test_vit_frame_result_does_not_depend_on_its_batch():
         both = net.encoder(x)
         assert torch.equal(both[0:1], net.encoder(x[0:1])) and torch.equal(both[1:2], net.encoder(x[1:2])), size
         assert torch.equal(net(x)["pred"][1:2], net(x[1:2])["pred"]), size
+
+
+def test_vit_reserve_then_no_forward_grows_the_workspace():
+    """fs_reserve on the Segmenter: token workspace and the resized position table for a non-native frame size are there
+    before the first forward; forwards leave fs_reserved_bytes unchanged."""
+    state = synth.make_vit_state(5, 128, 16, 128, 2, 1, seed=2)
+    net = VITSegmentModel(5, 128, patch_size=16, d_model=128, n_layers=2, dec_layers=1).eval()
+    net.load_state_dict(state)
+    net.reserve(2, 150, 150)  # 10 x 10 patches: position table resized from 8 x 8
+    r0 = net._hip_net.reserved_bytes()
+    assert r0 > 0
+    x = synth.make_clip(2, 150, seed=9).cuda()
+    out = net(x)["pred"]
+    net(x[0:1])
+    torch.cuda.synchronize()
+    assert net._hip_net.reserved_bytes() == r0
+    ref = vit_oracle.forward(x.cpu(), state, 16, 2, 1, 128, 5)["pred"]
+    assert rel_err(out.cpu(), ref) < VIT_TOL

@@ -89,6 +89,57 @@ def test_eight_ranks_64_clips_is_the_baseline_configs4_layout():
     assert sum(blocks, []) == list(range(50)) and max(map(len, blocks)) - min(map(len, blocks)) <= 1
 
 
+def test_bench_schedule_covers_every_window_of_the_64_clips_once():
+    """bench.py under N > 1 walks shard.clip_window_schedule(64, 21, 5, rank, N): over the ranks every (clip, window) of BASELINE
+    configs[4] appears exactly once, a rank owns whole clips (4 consecutive windows each), and N = 1 with one clip is configs[1]."""
+    for world in (1, 2, 4, 8, 3):  # 3: uneven shards (22 / 21 / 21 clips)
+        seen = []
+        for r in range(world):
+            mine = shard.clip_window_schedule(64, 21, 5, r, world)
+            assert len(mine) == 4 * len(shard.clips_for_rank(64, r, world))
+            for i in range(0, len(mine), 4):
+                c = mine[i][0]
+                assert c % world == r and [m for m in mine[i:i + 4]] == [(c, 0, 5), (c, 5, 10), (c, 10, 15), (c, 15, 20)]
+            seen += mine
+        assert sorted(seen) == [(c, 5 * w, 5 * w + 5) for c in range(64) for w in range(4)]
+    assert shard.clip_window_schedule(1, 21, 5, 0, 1) == [(0, 0, 5), (0, 5, 10), (0, 10, 15), (0, 15, 20)]
+
+
+def test_bench_launches_its_own_ranks_without_touching_torch(monkeypatch):
+    """`python bench.py --gpus N` with no WORLD_SIZE (how the driver starts it): the parent only builds the
+    torch.distributed.run command for N fresh child ranks and returns their exit code -- it must not import torch (a process that
+    has initialised the GPU must never spawn-and-replace, and the launcher has no business paying the import)."""
+    import importlib
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, subprocess\n"
+        "sys.argv = ['bench.py', '--gpus', '8', '--steps', '7', '--warmup', '2']\n"
+        "calls = []\n"
+        "class R: returncode = 5\n"
+        "subprocess.run = lambda cmd, **kw: (calls.append((cmd, kw)), R())[1]\n"
+        "import os; os.environ.pop('WORLD_SIZE', None)\n"
+        f"sys.path.insert(0, {root!r})\n"
+        "import bench\n"
+        "try:\n"
+        "    bench.main()\n"
+        "except SystemExit as e:\n"
+        "    rc = e.code\n"
+        "cmd, kw = calls[0]\n"
+        "assert rc == 5, rc\n"
+        "assert 'torch' not in sys.modules, 'the launcher imported torch'\n"
+        "assert cmd[1:4] == ['-m', 'torch.distributed.run', '--nnodes=1'] and '--nproc-per-node=8' in cmd\n"
+        "assert cmd[cmd.index('--master-addr') + 1] == '127.0.0.1' and int(cmd[cmd.index('--master-port') + 1]) > 0\n"
+        "assert cmd[-6:] == ['--gpus', '8', '--steps', '7', '--warmup', '2'] and cmd[-7].endswith('bench.py')\n"
+        "assert kw['env']['HSA_ENABLE_IPC_MODE_LEGACY'] == '0'\n"
+        "print('launcher-ok')\n")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120, env=env)
+    assert r.returncode == 0 and "launcher-ok" in r.stdout, (r.stdout, r.stderr[-2000:])
+
+
 def test_single_process_is_a_no_op():
     hist, frames, sec = shard.reduce_run(torch.ones(3, 5, dtype=torch.int64), 20, 0.5)
     assert frames == 20 and sec == 0.5 and int(hist.sum()) == 15

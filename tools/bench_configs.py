@@ -42,7 +42,7 @@ def timeit(fn, steps=10, warmup=2):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="", help="cfg0 | cfg1 | cfg4 | feat | cfg2 | cfg3 | vitb")
+    ap.add_argument("--only", default="", help="cfg0 | cfg1 | cfg4 | feat | crops | crops_cached | cfg2 | cfg3 | vitb")
     ap.add_argument("--steps", type=int, default=10)
     args = ap.parse_args()
     want = lambda k: not args.only or args.only == k  # noqa: E731
@@ -61,7 +61,7 @@ def main():
         return step
 
     psp = None
-    if any(want(k) for k in ("cfg0", "cfg1", "cfg4", "feat")):
+    if any(want(k) for k in ("cfg0", "cfg1", "cfg4", "feat", "crops", "crops_cached")):
         psp = FlowPSPNet(HP(50)).eval()
         psp.load_state_dict(synth.make_pspnet_state(50, 5, 0))
 
@@ -83,6 +83,29 @@ def main():
     if want("feat"):
         t = timeit(window(FlowModel(psp, feature_based=True, no_warp=False).eval(), (wl, wr)), steps=max(1, st // 2))
         rows.append(("(extra) PSPNet-R50 keyframe + FEATURE warp", N / t, t * 1e3))
+    for cached in (False, True):
+        if not want("crops_cached" if cached else "crops"):
+            continue
+        # the reference's default real-video route (flow/base.py:182-209): 1072x1920 frames, 8 overlapping 713x713 crops of both key
+        # frames, warp, float64 canvas, masks at 1072x1920 (bench.py's fps_real_video_route_* variants, on their own for rocprofv3)
+        from flood_uav_video_segmentation_amd.flow.predict import FlowPredictor
+        hd = synth.make_clip(16, (1072, 1920), seed=1200, only=[0, 5, 10, 15]).to(dev)
+        gl, gr = [[g.to(dev) for g in gs] for gs in synth.make_grids(N, 67, 120, seed=2100, frame=(1072, 1920), jitter=0.01)]
+        pred = FlowPredictor(FlowModel(psp, feature_based=False, no_warp=False).eval(), 5, (1072, 1920), crop=(713, 713), compute_metrics=False,
+                             cache_keyframes=cached)
+        psp.reserve(16, 713, 713)
+        host_hd = torch.empty((N, 1072, 1920), dtype=torch.uint8).pin_memory()
+
+        def crops_step(i, pred=pred, cached=cached):
+            w = i % 3
+            if cached and w == 0:
+                pred.reset()
+            host_hd.copy_(pred.predict_window(hd[w:w + 1], hd[w + 1:w + 2], gl, gr, to_host=False, key_ids=(5 * w, 5 * w + 5) if cached else None),
+                          non_blocking=True)
+            torch.cuda.current_stream().synchronize()
+        t = timeit(crops_step, steps=max(3, st))
+        rows.append(("(reference default route) 1072x1920, 8 crops x 2 key frames, warp" + (", key-frame cache" if cached else ""), N / t, t * 1e3))
+        del pred, hd
     del psp
     if want("cfg2"):
         dl3 = FlowDeepLabv3(HP(101)).eval()

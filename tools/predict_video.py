@@ -108,6 +108,8 @@ def main():
             rgb = colorize(masks, palette).cpu().numpy()
             for p in range(rgb.shape[0]):
                 Image.fromarray(rgb[p]).save(os.path.join(args.out, f"{item['frame_id'] + p}.png"))
+    torch.cuda.synchronize()
+    seconds = time.perf_counter() - t0  # this rank's own work: the end-of-run exchange below waits for the slowest rank and is not part of it
     if world > 1 and not args.no_metrics:
         dev = torch.device("cuda", local_rank)
         blank = torch.zeros(tuple(args.size), dtype=torch.uint8, device=dev)
@@ -115,7 +117,6 @@ def main():
         if neighbour is not None:  # flow/base.py:284-291 for p == 0 with last_output = the previous block's final frame
             pred.hist = ops.iou_hist(first_mask, neighbour, args.classes, 255, pred.hist)
     torch.cuda.synchronize()
-    seconds = time.perf_counter() - t0
     hist = pred.hist if pred.hist is not None else torch.zeros(3, args.classes, dtype=torch.int64)
     hist, frames, seconds = shard.reduce_run(hist.cpu() if world == 1 else hist, frames, seconds, "cpu" if world == 1 else torch.device("cuda", local_rank))
     if rank == 0:
