@@ -76,6 +76,8 @@ _SIGNATURES = {
     "fs_conv2d_nhwc": (c_int, [c_void, c_int, c_void, c_void, c_void, c_void, c_int, c_void, c_int] + [c_int] * 12 + [c_void]),
     "fs_winograd_workspace_floats": (ctypes.c_size_t, [c_int] * 7),
     "fs_conv3x3_winograd_nhwc": (c_int, [c_void, c_int, c_void, c_void, c_void, c_void, c_int] + [c_int] * 8 + [c_void, c_void]),
+    "fs_winograd_fused_workspace_floats": (ctypes.c_size_t, [c_int, c_int]),
+    "fs_conv3x3_winograd_fused_nhwc": (c_int, [c_void, c_int, c_void, c_void, c_void, c_void, c_int] + [c_int] * 7 + [c_void, c_void]),
     "fs_stem_conv_nchw": (c_int, [c_void, c_void, c_void, c_void, c_void] + [c_int] * 8 + [c_void]),
     "fs_maxpool3x3s2_nhwc": (c_int, [c_void, c_void, c_int, c_int, c_int, c_int, c_void]),
     "fs_adaptive_avgpool_nhwc": (c_int, [c_void, c_int, c_void, c_int, c_int, c_int, c_int, c_int, c_void]),

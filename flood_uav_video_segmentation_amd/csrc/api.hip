@@ -311,6 +311,16 @@ FS_API int fs_conv3x3_winograd_nhwc(const float* in, int ld_in, const float* wgt
     if (int rc = fs::launch_conv_igemm(p, S(stream))) return rc;
     return fs::launch_winograd_output(Mb, scale, shift, out, ld_out, B, H, W, Cout, relu, dil, mt, S(stream));
 }
+FS_API size_t fs_winograd_fused_workspace_floats(int Cin, int Cout) { return fs::wino_fused_bank_floats(Cin, Cout); }
+FS_API int fs_conv3x3_winograd_fused_nhwc(const float* in, int ld_in, const float* wgt_oihw, const float* scale, const float* shift,
+                                          float* out, int ld_out, int B, int H, int W, int Cin, int Cout, int relu, int variant,
+                                          float* workspace, fs_stream stream) {
+    if (!in || !wgt_oihw || !out || !workspace || B < 1 || H < 1 || W < 1 || variant < 0 || variant > 2 ||
+        !fs::wino_fused_supported(Cin, Cout, 3, 3, 1, 1, 1))
+        return fs::fail("fs_conv3x3_winograd_fused_nhwc: bad arguments (Cin %% 32 == 0, 32 <= Cin <= 256, Cout %% 64 == 0, variant 0..2)");
+    if (int rc = fs::launch_wino4_filter_packed(wgt_oihw, workspace, Cout, Cin, S(stream))) return rc;
+    return fs::launch_wino4_fused(in, ld_in, workspace, scale, shift, out, ld_out, B, H, W, Cin, Cout, relu, S(stream), variant);
+}
 FS_API int fs_stem_conv_nchw(const float* in_nchw, const float* wgt_hwio, const float* scale, const float* shift,
                              float* out_nhwc, int B, int H, int W, int Cout, int KH, int KW, int stride, int pad,
                              fs_stream stream) {

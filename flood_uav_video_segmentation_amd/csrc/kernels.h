@@ -260,4 +260,16 @@ static inline int winograd_pick_m(int /*B*/, int H, int W, int dil) {
     return winograd_gemm_rows(1, H, W, dil, 6) < winograd_gemm_rows(1, H, W, dil, 4) ? 6 : 4;
 }
 
+// ---------------------------------------------------------------------------------
+// Fused Winograd F(4x4,3x3) for 3x3 stride-1 pad-1 convs with few input channels (wino_fused.hip): input transform, the 36
+// position GEMMs and the output transform (+BN, ReLU) in ONE kernel -- only the input and output maps touch HBM.
+// U: packed bank [36][Cin/16][Cout][16] from launch_wino4_filter_packed (w: OIHW, or the chunk-major bank when chunk_major).
+// ---------------------------------------------------------------------------------
+size_t wino_fused_bank_floats(int Cin, int Cout);
+bool wino_fused_supported(int Cin, int Cout, int KH, int KW, int stride, int pad, int dil);
+int launch_wino4_filter_packed(const float* w, float* U, int O, int I, hipStream_t s, int chunk_major = 0);
+// variant: 0 = by tile count, 1 = 32 tiles x 64 channels per workgroup (8 waves), 2 = 16 tiles x 64 channels (4 waves)
+int launch_wino4_fused(const float* in, int ld_in, const float* U, const float* scale, const float* shift, float* out, int ld_out, int B, int H,
+                       int W, int Cin, int Cout, int relu, hipStream_t s, int variant = 0);
+
 }  // namespace fs

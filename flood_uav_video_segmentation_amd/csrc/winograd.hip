@@ -6,74 +6,9 @@
 // exactly 15 x 15 tiles of 6x6; its fp32 error is ~1.5x that of F(4,3) (measured 1.5e-5 vs 1.0e-5 relative on a
 // 512-channel conv; direct: 3e-7).  All kernels are HBM-bound elementwise-style passes over channel groups (NHWC).
 #include "kernels.h"
+#include "winograd.h"
 
 namespace fs {
-
-template <int MT> struct Wino;
-
-// ---------------------------------------------------------------- F(4,3)
-template <> struct Wino<4> {
-    static constexpr int A = 6;
-    template <typename T> __device__ static __forceinline__ void bt(const T d[6], T t[6]) {  // B^T d
-        t[0] = 4.f * d[0] - 5.f * d[2] + d[4];
-        t[1] = -4.f * (d[1] + d[2]) + d[3] + d[4];
-        t[2] = 4.f * (d[1] - d[2]) - d[3] + d[4];
-        t[3] = -2.f * d[1] - d[2] + 2.f * d[3] + d[4];
-        t[4] = 2.f * d[1] - d[2] - 2.f * d[3] + d[4];
-        t[5] = 4.f * d[1] - 5.f * d[3] + d[5];
-    }
-    template <typename T> __device__ static __forceinline__ void at(const T m[6], T y[4]) {  // A^T m
-        y[0] = m[0] + m[1] + m[2] + m[3] + m[4];
-        y[1] = m[1] - m[2] + 2.f * (m[3] - m[4]);
-        y[2] = m[1] + m[2] + 4.f * (m[3] + m[4]);
-        y[3] = m[1] - m[2] + 8.f * (m[3] - m[4]) + m[5];
-    }
-    __device__ static __forceinline__ void g(double g0, double g1, double g2, double u[6]) {  // G g
-        u[0] = g0 / 4;
-        u[1] = -(g0 + g1 + g2) / 6;
-        u[2] = -(g0 - g1 + g2) / 6;
-        u[3] = g0 / 24 + g1 / 12 + g2 / 6;
-        u[4] = g0 / 24 - g1 / 12 + g2 / 6;
-        u[5] = g2;
-    }
-};
-
-// ---------------------------------------------------------------- F(6,3)
-template <> struct Wino<6> {
-    static constexpr int A = 8;
-    template <typename T> __device__ static __forceinline__ void bt(const T d[8], T t[8]) {
-        const T a = d[2] - 4.25f * d[4] + d[6], b = d[1] - 4.25f * d[3] + d[5];
-        const T c = 0.25f * d[2] - 1.25f * d[4] + d[6], e = 0.5f * d[1] - 2.5f * d[3] + 2.f * d[5];
-        const T f = 4.f * d[2] - 5.f * d[4] + d[6], h = 2.f * d[1] - 2.5f * d[3] + 0.5f * d[5];
-        t[0] = d[0] - d[6] + 5.25f * (d[4] - d[2]);
-        t[1] = a + b;
-        t[2] = a - b;
-        t[3] = c + e;
-        t[4] = c - e;
-        t[5] = f + h;
-        t[6] = f - h;
-        t[7] = d[7] - d[1] + 5.25f * (d[3] - d[5]);
-    }
-    template <typename T> __device__ static __forceinline__ void at(const T m[8], T y[6]) {
-        const T s1 = m[1] + m[2], d1 = m[1] - m[2], s2 = m[3] + m[4], d2 = m[3] - m[4], s3 = m[5] + m[6], d3 = m[5] - m[6];
-        y[0] = m[0] + s1 + s2 + s3;
-        y[1] = d1 + 2.f * d2 + 0.5f * d3;
-        y[2] = s1 + 4.f * s2 + 0.25f * s3;
-        y[3] = d1 + 8.f * d2 + 0.125f * d3;
-        y[4] = s1 + 16.f * s2 + 0.0625f * s3;
-        y[5] = d1 + 32.f * d2 + 0.03125f * d3 + m[7];
-    }
-    __device__ static __forceinline__ void g(double g0, double g1, double g2, double u[8]) {
-        u[0] = g0;
-        u[1] = -2.0 / 9 * (g0 + g1 + g2);
-        u[2] = -2.0 / 9 * (g0 - g1 + g2);
-        u[3] = g0 / 90 + g1 / 45 + 2 * g2 / 45;
-        u[4] = g0 / 90 - g1 / 45 + 2 * g2 / 45;
-        u[5] = 32 * g0 / 45 + 16 * g1 / 45 + 8 * g2 / 45;
-        u[6] = 32 * g0 / 45 - 16 * g1 / 45 + 8 * g2 / 45;
-        u[7] = g2;
-    }
-};
 
 // ---- filter transform U = G g G^T, once at load, in double (rounded once to fp32): thread per (o, c)
 template <int MT>

@@ -199,6 +199,16 @@ size_t fs_winograd_workspace_floats(int B, int H, int W, int Cin, int Cout, int 
 int fs_conv3x3_winograd_nhwc(const float* in, int ld_in, const float* wgt_oihw, const float* scale, const float* shift, float* out,
                              int ld_out, int B, int H, int W, int Cin, int Cout, int dil, int relu, int tile_m, float* workspace,
                              fs_stream stream);
+/* 3x3 stride-1 pad-1 conv with FEW input channels (32 <= Cin <= 256, Cin % 32 == 0, Cout % 64 == 0) as ONE fused Winograd
+ * F(4x4,3x3) kernel: input transform, the 36 position GEMMs on the fp32 matrix cores and the output transform (+ scale/shift,
+ * ReLU) without the Winograd-domain tensors ever reaching HBM.  The network uses it for the deep stem's 64-channel convs and
+ * conv2 of layer1 / layer2 (model/resnet.py:110-116, 67-69).  workspace: fs_winograd_fused_workspace_floats(Cin, Cout) floats
+ * (the packed filter bank, rebuilt by every call of this test entry; the network builds it once at fs_finalize).
+ * variant: 0 = by tile count, 1 = 32 tiles x 64 channels per workgroup, 2 = 16 tiles x 64 channels. */
+size_t fs_winograd_fused_workspace_floats(int Cin, int Cout);
+int fs_conv3x3_winograd_fused_nhwc(const float* in, int ld_in, const float* wgt_oihw, const float* scale, const float* shift, float* out,
+                                   int ld_out, int B, int H, int W, int Cin, int Cout, int relu, int variant, float* workspace,
+                                   fs_stream stream);
 /* wgt_hwio: [KH][KW][3][Cout] (weight.permute(2,3,1,0)) */
 int fs_stem_conv_nchw(const float* in_nchw, const float* wgt_hwio, const float* scale, const float* shift, float* out_nhwc,
                       int B, int H, int W, int Cout, int KH, int KW, int stride, int pad, fs_stream stream);

@@ -266,7 +266,7 @@ def test_reserve_then_no_forward_grows_the_workspace():
     # same results as a handle that grew lazily
     ref, _ = (lambda n: (n, n.load_state_dict(state)))(FlowPSPNet(HP(50, 5)).eval())
     assert torch.equal(ref.segment(x[0:1], x[1:2]), lo)
-    net.segment(synth.make_clip(1, 225, seed=6).cuda())  # unreserved, larger: grows lazily
+    net.segment(synth.make_clip(2, 321, seed=6).cuda())  # unreserved, larger: grows lazily
     assert hn.reserved_bytes() > r0
     # DeepLabv3 and the Segmenter reserve as well
     dl = FlowDeepLabv3(HP(50, 5)).eval()

@@ -313,6 +313,49 @@ def test_winograd_conv3x3(case, tile_m):
     assert (out[..., :16] == -7.0).all() and (out[..., 16 + cout:] == -7.0).all()
 
 
+WINO_FUSED_TOL = 3e-5  # F(4x4,3x3) in fp32 at Cin <= 256: measured <= 1e-5 (gpurun_out/parity_measured.txt)
+
+
+@pytest.mark.parametrize("case", [
+    # b, h, w, cin, cout, relu
+    (1, 16, 16, 64, 64, True),
+    (2, 23, 29, 64, 128, False),     # ragged: last tile row / column partly outside the map
+    (1, 5, 3, 32, 64, True),         # smaller than two tiles
+    (2, 45, 45, 128, 128, True),     # layer2 conv2 geometry at 353^2
+    (1, 9, 9, 256, 64, False),
+    (1, 179, 179, 64, 64, True),     # layer1 conv2 of a 713x713 frame
+    (1, 357, 357, 64, 128, True),    # the deep stem's layer0.6 of a 713x713 frame
+])
+@pytest.mark.parametrize("variant", [0, 1, 2])
+def test_winograd_fused_conv3x3(case, variant):
+    """The one-kernel Winograd F(4x4,3x3) (wino_fused.hip: transforms and the 36 position GEMMs fused, nothing but the input and
+    output maps in HBM) vs torch conv2d + scale/shift (+ReLU): both workgroup shapes, ragged maps, a channel slice of a wider
+    output buffer, batch > 1; and bit-repeatable from run to run."""
+    lib = _lib.load()
+    b, h, w, cin, cout, relu = case
+    g = torch.Generator().manual_seed(h * 100 + cin + cout)
+    x = torch.randn(b, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (cin * 9)) ** 0.5
+    sc, sh = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.1
+    ref = F.conv2d(x, wt, None, 1, 1, 1) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)
+    if relu:
+        ref = ref.relu()
+    xd = ops.as_nhwc(x.to(DEV))
+    ws = torch.empty(lib.fs_winograd_fused_workspace_floats(cin, cout), device=DEV)
+    wd, scd, shd = wt.to(DEV), sc.to(DEV), sh.to(DEV)
+    outs = []
+    for _ in range(2):
+        out = torch.full((b, h, w, cout + 32), -7.0, device=DEV)
+        view = out[..., 16:]
+        check(lib.fs_conv3x3_winograd_fused_nhwc(ptr(xd), cin, ptr(wd), ptr(scd), ptr(shd), ptr(view), cout + 32, b, h, w, cin, cout, int(relu),
+                                                 variant, ptr(ws), stream_ptr()))
+        outs.append(out)
+    out = outs[0]
+    assert note(f"winograd_fused_{h}x{w}x{cin}x{cout}_v{variant}", rel(out[..., 16:16 + cout].permute(0, 3, 1, 2), ref)) < WINO_FUSED_TOL
+    assert (out[..., :16] == -7.0).all() and (out[..., 16 + cout:] == -7.0).all()
+    assert torch.equal(outs[0], outs[1])
+
+
 @pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5])
 @pytest.mark.parametrize("shape", [
     # b, h, w, cin, cout, k, pad, res  -- the layer shapes of a 713x713 window, where every CU holds 2-5 workgroups at once
