@@ -30,6 +30,7 @@ ARCH_SEGMENTER = 2
 OPT_NO_WINOGRAD = 1      # FS_OPT_NO_WINOGRAD
 OPT_NO_FUSED_HEAD = 2    # FS_OPT_NO_FUSED_HEAD
 OPT_NO_FUSED_SHORTCUT = 4  # FS_OPT_NO_FUSED_SHORTCUT
+OPT_NO_FUSED_WINOGRAD = 8  # FS_OPT_NO_FUSED_WINOGRAD
 CONV_CHUNK_MAJOR = 0x400  # FS_CONV_CHUNK_MAJOR
 
 # name -> (restype, argtypes); must list every symbol of include/floodseg.h

@@ -42,6 +42,7 @@ struct ConvBN {
     int Cin = 0, Cout = 0, KH = 1, KW = 1, stride = 1, pad = 0, dil = 1, relu = 0;
     int korder = 0;  // 1: filters packed chunk-major (3x3 convs)
     std::shared_ptr<WinoBank> wino;  // non-null: 3x3 stride-1 conv with pad == dil and Cin >= 256 (Winograd-eligible)
+    float* wf = nullptr;  // non-null: packed F(4,3) bank [36][Cin/16][Cout][16] of the one-kernel Winograd (wino_fused.hip): 3x3 s1 p1, Cin <= 128
     int out_size(int in) const { return (in + 2 * pad - dil * (KH - 1) - 1) / stride + 1; }
 };
 
@@ -132,6 +133,7 @@ struct fs_net {
     int wino_force_m = 0;        // winograd_tile: 4 | 6 forces F(4,3) / F(6,3); 0 = the cheaper one for the map at hand
     bool use_fused_head = true;  // !(flags & FS_OPT_NO_FUSED_HEAD)
     bool use_fused_shortcut = true;  // !(flags & FS_OPT_NO_FUSED_SHORTCUT)
+    bool use_fused_winograd = true;  // !(flags & FS_OPT_NO_FUSED_WINOGRAD)
     int device = 0;              // HIP device the handle's memory lives on (current device at fs_create)
 
     // workspace

@@ -117,6 +117,11 @@ int make_conv(fs_net* h, ConvBN& c, const std::string& wname, const std::string&
         FS_TRY(launch_pack_oihw_to_ohwi(w->d, c.w, c.Cout, c.Cin, c.KH, c.KW, s));
     }
     if (wino_eligible(c, hwio)) c.wino = std::make_shared<WinoBank>();  // the banks themselves: wino_bank(), on first use
+    if (!hwio && c.korder == 1 && c.Cin <= 128 && wino_fused_supported(c.Cin, c.Cout, c.KH, c.KW, c.stride, c.pad, c.dil)) {
+        // few input channels (deep stem, conv2 of layer1 / layer2): the one-kernel Winograd's packed bank, at most 2.4 MB, built now
+        FS_TRY(dev_alloc(h, &c.wf, wino_fused_bank_floats(c.Cin, c.Cout)));
+        FS_TRY(launch_wino4_filter_packed(c.w, c.wf, c.Cout, c.Cin, s, 1));
+    }
     if (!bn.empty()) {
         const RawTensor *g, *b, *m, *v;
         FS_TRY(fetch(h, bn + ".weight", &g));
@@ -239,9 +244,22 @@ int reserve_conv(fs_net* h, const ConvBN& c, int B, int H, int W, hipStream_t s,
     return wino_bank(h, c, mt, s, &U);
 }
 
+// The one-kernel Winograd (wino_fused.hip) takes a 3x3 s1 p1 conv with Cin <= 128 when ONE image gives it enough 4x4 tiles to
+// spread over the chip (decided per image, never on the batch: a frame's result must not depend on the batch it is computed in)
+bool takes_fused_winograd(const fs_net* h, const ConvBN& c, int H, int W, bool has_res) {
+    return c.wf && h->use_fused_winograd && !has_res && (long)cdiv(H, 4) * cdiv(W, 4) >= 1500;
+}
+
 int run_conv(fs_net* h, const ConvBN& c, const float* in, int ld_in, int B, int H, int W, float* out, int ld_out,
              const float* res, int ld_res, hipStream_t s) {
     if (takes_winograd(h, c, B, H, W, res != nullptr)) return run_conv_winograd(h, c, in, ld_in, B, H, W, out, ld_out, s);
+    if (takes_fused_winograd(h, c, H, W, res != nullptr)) {
+        const double tiles = (double)B * cdiv(H, 4) * cdiv(W, 4);
+        FS_TRY(prof_begin(h, c.name, "wino_fused", 2.0 * 36.0 * tiles * c.Cin * c.Cout,
+                          4.0 * ((double)B * H * W * (c.Cin + c.Cout) + 36.0 * c.Cin * c.Cout), s));
+        FS_TRY(launch_wino4_fused(in, ld_in, c.wf, c.scale, c.shift, out, ld_out, B, H, W, c.Cin, c.Cout, c.relu, s));
+        return prof_end(h, s);
+    }
     ConvParams p{};
     p.in = in;
     p.ld_in = ld_in;
@@ -323,7 +341,8 @@ int net_create(const fs_config* cfg, fs_handle* out) {
     FS_REQUIRE(cfg->arch == FS_ARCH_SEGMENTER || cfg->layers == 50 || cfg->layers == 101 || cfg->layers == 152,
                "fs_create: layers must be 50, 101 or 152");
     FS_REQUIRE(cfg->classes >= 1 && cfg->classes <= 255, "fs_create: classes out of range");
-    FS_REQUIRE((cfg->flags & ~(FS_OPT_NO_WINOGRAD | FS_OPT_NO_FUSED_HEAD | FS_OPT_NO_FUSED_SHORTCUT)) == 0, "fs_create: unknown option bits 0x%x", cfg->flags);
+    FS_REQUIRE((cfg->flags & ~(FS_OPT_NO_WINOGRAD | FS_OPT_NO_FUSED_HEAD | FS_OPT_NO_FUSED_SHORTCUT | FS_OPT_NO_FUSED_WINOGRAD)) == 0,
+               "fs_create: unknown option bits 0x%x", cfg->flags);
     FS_REQUIRE(cfg->winograd_tile == 0 || cfg->winograd_tile == 4 || cfg->winograd_tile == 6, "fs_create: winograd_tile must be 0, 4 or 6");
     fs_net* h = new fs_net();
     h->cfg = *cfg;
@@ -331,6 +350,7 @@ int net_create(const fs_config* cfg, fs_handle* out) {
     h->wino_force_m = cfg->winograd_tile;
     h->use_fused_head = !(cfg->flags & FS_OPT_NO_FUSED_HEAD);
     h->use_fused_shortcut = !(cfg->flags & FS_OPT_NO_FUSED_SHORTCUT);
+    h->use_fused_winograd = !(cfg->flags & (FS_OPT_NO_FUSED_WINOGRAD | FS_OPT_NO_WINOGRAD));
     if (hipGetDevice(&h->device) != hipSuccess) {
         delete h;
         return fail("fs_create: no HIP device");

@@ -60,7 +60,9 @@ typedef struct fs_config {
 enum {
     FS_OPT_NO_WINOGRAD = 1,   /* every 3x3 conv on the direct implicit-GEMM kernel                                      */
     FS_OPT_NO_FUSED_HEAD = 2, /* fs_segment_forward = fs_decoder_forward(fs_encoder_forward(x)) over the 4096-ch concat */
-    FS_OPT_NO_FUSED_SHORTCUT = 4 /* projection blocks: downsample and conv3 as two launches instead of one concatenated-K GEMM */
+    FS_OPT_NO_FUSED_SHORTCUT = 4, /* projection blocks: downsample and conv3 as two launches instead of one concatenated-K GEMM */
+    FS_OPT_NO_FUSED_WINOGRAD = 8 /* the 3x3 convs with Cin <= 128 (deep stem, conv2 of layer1) on the direct kernel instead of the
+                                    one-kernel Winograd F(4x4,3x3) (implied by FS_OPT_NO_WINOGRAD)                             */
 };
 
 int fs_version(void);

@@ -221,12 +221,13 @@ def test_model_representation_wraps_a_hip_network(psp):
 
 # ------------------------------------------------------------------------------------------------ A/B options at full size
 @pytest.mark.parametrize("opts", [dict(hip_no_winograd=True), dict(hip_winograd_tile=4), dict(hip_winograd_tile=6),
-                                  dict(hip_no_fused_head=True), dict(hip_no_fused_shortcut=True),
+                                  dict(hip_no_fused_head=True), dict(hip_no_fused_shortcut=True), dict(hip_no_fused_winograd=True),
                                   dict(hip_no_winograd=True, hip_no_fused_head=True, hip_no_fused_shortcut=True)])
 def test_every_shipped_option_matches_the_reference_golden_at_713(psp, opts):
     """Each arithmetic-changing route the library ships (direct conv instead of Winograd, F(4,3) / F(6,3) forced, head over
     the 4096-channel concat instead of the fused pyramid term, projection shortcut + conv3 as two launches instead of one
-    concatenated-K GEMM) against the reference's own 713x713 outputs."""
+    concatenated-K GEMM, the small-Cin 3x3 convs on the direct kernel instead of the one-kernel Winograd) against the
+    reference's own 713x713 outputs."""
     _, state = psp
     net = FlowPSPNet(HP(**opts)).eval()
     net.load_state_dict(state)
