@@ -315,9 +315,9 @@ FS_API size_t fs_winograd_fused_workspace_floats(int Cin, int Cout) { return fs:
 FS_API int fs_conv3x3_winograd_fused_nhwc(const float* in, int ld_in, const float* wgt_oihw, const float* scale, const float* shift,
                                           float* out, int ld_out, int B, int H, int W, int Cin, int Cout, int relu, int variant,
                                           float* workspace, fs_stream stream) {
-    if (!in || !wgt_oihw || !out || !workspace || B < 1 || H < 1 || W < 1 || variant < 0 || variant > 2 ||
+    if (!in || !wgt_oihw || !out || !workspace || B < 1 || H < 1 || W < 1 || variant < 0 || variant > 3 ||
         !fs::wino_fused_supported(Cin, Cout, 3, 3, 1, 1, 1))
-        return fs::fail("fs_conv3x3_winograd_fused_nhwc: bad arguments (Cin %% 32 == 0, 32 <= Cin <= 256, Cout %% 64 == 0, variant 0..2)");
+        return fs::fail("fs_conv3x3_winograd_fused_nhwc: bad arguments (Cin %% 32 == 0, 32 <= Cin <= 256, Cout %% 64 == 0, variant 0..3)");
     if (int rc = fs::launch_wino4_filter_packed(wgt_oihw, workspace, Cout, Cin, S(stream))) return rc;
     return fs::launch_wino4_fused(in, ld_in, workspace, scale, shift, out, ld_out, B, H, W, Cin, Cout, relu, S(stream), variant);
 }

@@ -268,7 +268,8 @@ static inline int winograd_pick_m(int /*B*/, int H, int W, int dil) {
 size_t wino_fused_bank_floats(int Cin, int Cout);
 bool wino_fused_supported(int Cin, int Cout, int KH, int KW, int stride, int pad, int dil);
 int launch_wino4_filter_packed(const float* w, float* U, int O, int I, hipStream_t s, int chunk_major = 0);
-// variant: 0 = by tile count, 1 = 32 tiles x 64 channels per workgroup (8 waves), 2 = 16 tiles x 64 channels (4 waves)
+// variant: 0 = by workgroup count, 1 = 32 tiles x 64 channels per workgroup (8 waves), 2 = 16 tiles x 64 channels (4 waves, two
+// workgroups per CU), 3 = 16 x 64 warp-specialised (4 MFMA waves + 4 transform waves); bit-identical results
 int launch_wino4_fused(const float* in, int ld_in, const float* U, const float* scale, const float* shift, float* out, int ld_out, int B, int H,
                        int W, int Cin, int Cout, int relu, hipStream_t s, int variant = 0);
 

@@ -247,7 +247,7 @@ int reserve_conv(fs_net* h, const ConvBN& c, int B, int H, int W, hipStream_t s,
 // The one-kernel Winograd (wino_fused.hip) takes a 3x3 s1 p1 conv with Cin <= 128 when ONE image gives it enough 4x4 tiles to
 // spread over the chip (decided per image, never on the batch: a frame's result must not depend on the batch it is computed in)
 bool takes_fused_winograd(const fs_net* h, const ConvBN& c, int H, int W, bool has_res) {
-    return c.wf && h->use_fused_winograd && !has_res && (long)cdiv(H, 4) * cdiv(W, 4) >= 1500;
+    return c.wf && h->use_fused_winograd && !has_res && (long)cdiv(H, 4) * cdiv(W, 4) >= 500;
 }
 
 int run_conv(fs_net* h, const ConvBN& c, const float* in, int ld_in, int B, int H, int W, float* out, int ld_out,

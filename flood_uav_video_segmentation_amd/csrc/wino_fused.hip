@@ -73,6 +73,51 @@ struct WinoFusedParams {
     int th, tw, T;       // tiles per column / row of one image, total tiles
 };
 
+#if defined(__HIP_DEVICE_COMPILE__)
+// Epilogue of both kernel forms: lane (n = lane & 15, q = lane >> 4) holds, for r = 0..3, all 36 positions of (tile tile0 + r,
+// channel n).  A^T m A in registers, BatchNorm + ReLU, 16 stores per tile.  Pixel (y, x) of a tile is at byte offset
+// base + (y * W + x) * ld * 4, the second term uniform (the store's scalar offset); the four tiles of a lane are consecutive, so
+// one division pair finds the first and the others follow by carry.  16 lanes = 16 consecutive channels of one pixel per store.
+__device__ __forceinline__ void wino4_epilogue(const f32x4 (&acc)[36], const WinoFusedParams& p, int tile, int n) {
+    const float sc = p.scale ? p.scale[n] : 1.f, sh = p.shift ? p.shift[n] : 0.f;
+    const __amdgpu_buffer_rsrc_t o_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.out, 0, (unsigned)((long long)p.B * p.H * p.W * p.ld_out * 4), 0x00020000);
+    int tx = tile % p.tw, ty = (tile / p.tw) % p.th, b = tile / (p.tw * p.th);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const bool tv = tile < p.T;
+        const unsigned base = (unsigned)((((b * p.H + 4 * ty) * p.W + 4 * tx) * p.ld_out + n) * 4);
+        float half[4][6];
+#pragma unroll
+        for (int x = 0; x < 6; ++x) {
+            float col[6], y4[4];
+#pragma unroll
+            for (int y = 0; y < 6; ++y) col[y] = acc[y * 6 + x][r];
+            Wino<4>::at(col, y4);
+#pragma unroll
+            for (int y = 0; y < 4; ++y) half[y][x] = y4[y];
+        }
+        const int ny = tv ? p.H - 4 * ty : 0, nx = p.W - 4 * tx;  // valid rows / columns of this tile (>= 4 inside the image)
+#pragma unroll
+        for (int y = 0; y < 4; ++y) {
+            float o4[4];
+            Wino<4>::at(half[y], o4);
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+                float v = o4[x] * sc + sh;
+                if (p.relu) v = fmaxf(v, 0.f);
+                const unsigned vo = (y < ny && x < nx) ? base : 0x80000000u;
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), o_rsrc, vo, (unsigned)((y * p.W + x) * p.ld_out * 4), 0);
+            }
+        }
+        ++tile;
+        if (++tx == p.tw) {
+            tx = 0;
+            if (++ty == p.th) { ty = 0; ++b; }
+        }
+    }
+}
+#endif
+
 template <int WM, int WN>
 __global__ __launch_bounds__(64 * WM * WN, 2) void wino4_fused_kernel(WinoFusedParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -181,42 +226,189 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void wino4_fused_kernel(WinoFusedP
         multiply(s, s & 1);
     }
 
-    // ---- epilogue: lane (n = lane & 15, q = lane >> 4) holds, for r = 0..3, all 36 positions of (tile wm*16 + 4q + r, channel n)
-    const int n = n0 + wn * 16 + m16;
-    const float sc = p.scale ? p.scale[n] : 1.f, sh = p.shift ? p.shift[n] : 0.f;
-    const __amdgpu_buffer_rsrc_t o_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.out, 0, (unsigned)((long long)p.B * p.H * p.W * p.ld_out * 4), 0x00020000);
+    wino4_epilogue(acc, p, tb * NT + wm * 16 + 4 * q4, n0 + wn * 16 + m16);
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Warp-specialised form (variant 3): the same arithmetic, but the two jobs have their own waves.  A workgroup = 16 tiles x 64
+// output channels = 8 waves: waves 0-3 ("M") hold the 36 accumulators of 16 channels each and do nothing but MFMAs, their V
+// fragment reads and their filter loads, PD position pairs ahead; waves 4-7 ("T") load and transform the patches (one (tile,
+// channel) per thread and stage) TWO stages ahead into a ring of three LDS stage images.  Why: a wave's vector-memory
+// operations complete in order (vmcnt), so in a wave that does both jobs every wait for a filter fragment also waits for the
+// patch loads issued before it -- the patch latency lands in the MFMA stream (measured: 44 of 123 us).  With the roles in
+// different waves the M waves never wait for anything but their own filter stream, the T waves have a whole stage of slack
+// per transform, and the SIMD issues T's VALU work in the shadow of M's MFMAs (one M wave and one T wave per SIMD).
+// One barrier per stage (16 input channels).
+#ifdef FS_TRACE
+// tools/probe_wino_trace.hip only: per-workgroup stamps (shader clock).  [0..15]: M wave 0 -- start, first barrier passed, end of
+// stage 0..7 (as many as there are), [14] epilogue done; [16..31]: T wave 4 -- start, after transform 0, 1, then after each loop transform
+__device__ unsigned long long fs_wino_trace[32 * 16384];
+#define FS_WT(slot) { if (lane == 0 && blockIdx.x < 16384) fs_wino_trace[32 * blockIdx.x + (slot)] = __builtin_readcyclecounter(); }
+#else
+#define FS_WT(slot) {}
+#endif
+
+// WM x WN = M waves per workgroup (4): wave (wm, wn) owns tiles 16 wm .. 16 wm + 15 and channels 16 wn .. 16 wn + 15 of the
+// workgroup's 16 WM tiles x 16 WN channels.  Shipped: 1 x 4.  (2 x 2 -- two waves sharing each filter stream through the L1,
+// half the L2 traffic -- was built and measured: the T waves then transform two patches per thread and become the critical
+// path, 100 us against 83 on layer0.3; with the loads pipelined it spills.  Workgroup timelines, tools/probe_wino_trace.hip:
+// an M stage takes 5.1 k cycles for 4.6 k of MFMA issue when the T waves are idle and 6.3-7.4 k while they transform -- the
+// fp32 MFMA runs at the vector rate and the T waves' VALU work does not hide under it.)
+// PD: filter prefetch distance in position pairs; must divide 18 (a pair's slot is pair % PD in every stage).
+template <int WM, int WN, int PD>
+__global__ __launch_bounds__(512, 2) void wino4_ws_kernel(WinoFusedParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    static_assert(WM * WN == 4 && 18 % PD == 0, "four M waves; PD must divide 18");
+    constexpr int NT = 16 * WM, NC = 16 * WN;
+    constexpr int NB = WM == 1 ? 3 : 2;  // LDS stage images in the ring (36 KiB x WM each): the T waves run NB - 1 stages ahead
+    constexpr int SUB = 36 * NT * 16;    // floats of one stage image V[xi][tile][16 ch]
+    __shared__ __attribute__((aligned(1024))) float lds[NB * SUB];
+    constexpr unsigned BAD = 0x40000000u;
+
+    const int t = threadIdx.x, lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int ncb = p.Cout / NC;
+    const int cb = blockIdx.x % ncb, tb = blockIdx.x / ncb;
+    const int n0 = cb * NC;
+    const int nstages = p.Cin >> 4;
+
+    if (wv >= 4) {
+        // ================================================================ T waves: patches -> V, WM (tile, channel) items per thread
+        const int tt = t - 256;
+        const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, (unsigned)((long long)p.B * p.H * p.W * p.ld_in * 4), 0x00020000);
+        unsigned row0[WM], col0[WM], rmask[WM], cmask[WM];  // patch origin (bytes) and which of its 6 rows / columns are inside the image
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int tile = tb * NT + wm * 16 + 4 * q4 + r;
-        const bool tv = tile < p.T;
-        const int tt = tv ? tile : 0;
-        const int tx = tt % p.tw, ty = (tt / p.tw) % p.th, b = tt / (p.tw * p.th);
-        float half[4][6];  // A^T m: rows
+        for (int it = 0; it < WM; ++it) {
+            const int tile = tb * NT + it * 16 + (tt >> 4);
+            const bool tv = tile < p.T;
+            const int tq = tv ? tile : 0;
+            const int tx = tq % p.tw, ty = (tq / p.tw) % p.th, b = tq / (p.tw * p.th);
+            const int y0 = 4 * ty - 1, x0 = 4 * tx - 1;
+            row0[it] = (unsigned)(((b * p.H + y0) * p.W) * p.ld_in * 4);
+            col0[it] = (unsigned)((x0 * p.ld_in + (tt & 15)) * 4);
+            rmask[it] = cmask[it] = 0;
 #pragma unroll
-        for (int x = 0; x < 6; ++x) {
-            float col[6], y4[4];
-#pragma unroll
-            for (int y = 0; y < 6; ++y) col[y] = acc[y * 6 + x][r];
-            Wino<4>::at(col, y4);
-#pragma unroll
-            for (int y = 0; y < 4; ++y) half[y][x] = y4[y];
-        }
-#pragma unroll
-        for (int y = 0; y < 4; ++y) {
-            float o4[4];
-            Wino<4>::at(half[y], o4);
-            const int oy = 4 * ty + y;
-            const bool rowok = tv && oy < p.H;
-#pragma unroll
-            for (int x = 0; x < 4; ++x) {
-                const int ox = 4 * tx + x;
-                float v = o4[x] * sc + sh;
-                if (p.relu) v = fmaxf(v, 0.f);
-                const unsigned vo = (rowok && ox < p.W) ? (unsigned)((((b * p.H + oy) * p.W + ox) * p.ld_out + n) * 4) : 0x80000000u;
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), o_rsrc, vo, 0, 0);
+            for (int k = 0; k < 6; ++k) {
+                if (tv && (unsigned)(y0 + k) < (unsigned)p.H) rmask[it] |= 1u << k;
+                if ((unsigned)(x0 + k) < (unsigned)p.W) cmask[it] |= 1u << k;
             }
         }
+        const unsigned rstride = (unsigned)(p.W * p.ld_in * 4), cstride = (unsigned)(p.ld_in * 4);
+        // The patches of the NEXT stage are requested before the current one is transformed (two register sets): a transform
+        // never waits for its own loads, only for ones issued a whole transform earlier.
+        float d[2][WM][6][6];
+        auto patch_load = [&](int stage, int set) {
+            const unsigned soff = (unsigned)(stage * 64);
+#pragma unroll
+            for (int it = 0; it < WM; ++it)
+#pragma unroll
+                for (int y = 0; y < 6; ++y) {
+                    const unsigned ro = row0[it] + (unsigned)y * rstride + (((rmask[it] >> y) & 1u) ? 0u : BAD);
+#pragma unroll
+                    for (int x = 0; x < 6; ++x) {
+                        const unsigned co = col0[it] + (unsigned)x * cstride + (((cmask[it] >> x) & 1u) ? 0u : BAD);
+                        d[set][it][y][x] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(in_rsrc, ro + co, soff, 0));
+                    }
+                }
+        };
+        auto transform = [&](int stage, int set) {
+#pragma unroll
+            for (int it = 0; it < WM; ++it) {
+#pragma unroll
+                for (int x = 0; x < 6; ++x) {  // B^T along y
+                    float col[6], tc[6];
+#pragma unroll
+                    for (int y = 0; y < 6; ++y) col[y] = d[set][it][y][x];
+                    Wino<4>::bt(col, tc);
+#pragma unroll
+                    for (int y = 0; y < 6; ++y) d[set][it][y][x] = tc[y];
+                }
+                float* dst = lds + (stage % NB) * SUB + it * 256 + tt;
+#pragma unroll
+                for (int y = 0; y < 6; ++y) {  // ... then along x
+                    float o[6];
+                    Wino<4>::bt(d[set][it][y], o);
+#pragma unroll
+                    for (int x = 0; x < 6; ++x) dst[(y * 6 + x) * (NT * 16)] = o[x];
+                }
+            }
+        };
+        // stage j is transformed from register set j & 1; loop bodies are written out for both parities (static register indices)
+        auto produce = [&](int j) {
+            if (j & 1) {
+                if (j + 1 < nstages) patch_load(j + 1, 0);
+                transform(j, 1);
+            } else {
+                if (j + 1 < nstages) patch_load(j + 1, 1);
+                transform(j, 0);
+            }
+        };
+        if (wv == 4) FS_WT(16)
+        patch_load(0, 0);
+        produce(0);
+        if (wv == 4) FS_WT(17)
+        int done = 1;  // stages transformed so far
+        for (int s = 0; s < nstages; ++s) {
+            __syncthreads();  // barrier s: stage s is complete, the M waves are done with stage s - 1 -> its image may be overwritten
+            for (; done < nstages && done < s + NB; ++done) produce(done);
+            if (wv == 4 && s < 12) FS_WT(18 + s)
+        }
+        return;
     }
+
+    // ================================================================ M waves: 36 positions x 16 tiles x 16 channels each
+    const int wn = wv % WN, wm = wv / WN;
+    const int m16 = lane & 15, q4 = lane >> 4;
+    const __amdgpu_buffer_rsrc_t u_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.U, 0, (unsigned)((long long)36 * p.Cin * p.Cout * 4), 0x00020000);
+    const unsigned b_voff = (unsigned)(((n0 + wn * 16 + m16) * 16 + 4 * q4) * 4);
+    const unsigned u_chunk = (unsigned)p.Cout * 64u;          // bytes of one 16-channel slab [Cout][16]
+    const unsigned u_pos = (unsigned)(p.Cin >> 4) * u_chunk;  // bytes of one Winograd position
+    const int a_off = (wm * 16 + m16) * 16 + 4 * q4;
+
+    f32x4 acc[36];
+#pragma unroll
+    for (int g = 0; g < 36; ++g) acc[g] = f32x4(0.f);
+    f32x4 bq[PD][2];
+    auto load_b = [&](int stage, int pair, int slot) {
+        const unsigned so = (unsigned)stage * u_chunk + (unsigned)(2 * pair) * u_pos;
+        bq[slot][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(u_rsrc, b_voff, so, 0));
+        bq[slot][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(u_rsrc, b_voff, so + u_pos, 0));
+    };
+#pragma unroll
+    for (int k = 0; k < PD; ++k) load_b(0, k, k);
+    if (wv == 0) FS_WT(0)
+
+    for (int s = 0; s < nstages; ++s) {
+        __syncthreads();
+        if (wv == 0 && s == 0) FS_WT(1)
+        const float* vsrc = lds + (s % NB) * SUB + a_off;
+        const bool more = s + 1 < nstages;
+        f32x4 aq[2][2];
+        aq[0][0] = *reinterpret_cast<const f32x4*>(vsrc);
+        aq[0][1] = *reinterpret_cast<const f32x4*>(vsrc + NT * 16);
+#pragma unroll
+        for (int k = 0; k < 18; ++k) {
+            if (k + 1 < 18) {
+                aq[(k + 1) & 1][0] = *reinterpret_cast<const f32x4*>(vsrc + (2 * k + 2) * (NT * 16));
+                aq[(k + 1) & 1][1] = *reinterpret_cast<const f32x4*>(vsrc + (2 * k + 3) * (NT * 16));
+            }
+            // two accumulator chains alternate: the next MFMA of a chain may issue 40 cycles after the previous one, the pipe takes one per 32
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                acc[2 * k] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[k & 1][0][e], bq[k % PD][0][e], acc[2 * k], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                acc[2 * k + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[k & 1][1][e], bq[k % PD][1][e], acc[2 * k + 1], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (k + PD < 18) load_b(s, k + PD, k % PD);
+            else if (more) load_b(s + 1, k + PD - 18, k % PD);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (wv == 0 && s < 12) FS_WT(2 + s)
+    }
+
+    wino4_epilogue(acc, p, tb * NT + wm * 16 + 4 * q4, n0 + wn * 16 + m16);
+    if (wv == 0) FS_WT(14)
 #endif
 }
 
@@ -240,8 +432,13 @@ int launch_wino4_fused(const float* in, int ld_in, const float* U, const float* 
     p.th = cdiv(H, 4); p.tw = cdiv(W, 4);
     p.T = B * p.th * p.tw;
     const int ncb = Cout / 64;
-    if (variant == 0) variant = (int64_t)cdiv(p.T, 32) * ncb >= 384 ? 1 : 2;  // enough 32-tile blocks to fill the chip 1.5x over?
-    if (variant == 1) hipLaunchKernelGGL((wino4_fused_kernel<2, 4>), dim3(cdiv(p.T, 32) * ncb), dim3(512), 0, s, p);
+    // Measured on MI355X (profiles/r03_wino_fused.txt): the 16-tile form with two workgroups per CU (2) wins when the launch is
+    // several rounds of workgroups deep (stem convs: 81 / 141 us against 91 / 164), the warp-specialised form (3) when a CU gets
+    // one workgroup or none (layer1 / layer2 conv2: 27 / 39 us against 32 / 50).  All forms give bit-identical results (same
+    // products, same order), so the choice may depend on the batch.
+    if (variant == 0) variant = (int64_t)cdiv(p.T, 16) * ncb > 512 ? 2 : 3;
+    if (variant == 3) hipLaunchKernelGGL((wino4_ws_kernel<1, 4, 6>), dim3(cdiv(p.T, 16) * ncb), dim3(512), 0, s, p);
+    else if (variant == 1) hipLaunchKernelGGL((wino4_fused_kernel<2, 4>), dim3(cdiv(p.T, 32) * ncb), dim3(512), 0, s, p);
     else hipLaunchKernelGGL((wino4_fused_kernel<1, 4>), dim3(cdiv(p.T, 16) * ncb), dim3(256), 0, s, p);
     FS_HIP(hipGetLastError());
     return 0;

@@ -206,7 +206,8 @@ int fs_conv3x3_winograd_nhwc(const float* in, int ld_in, const float* wgt_oihw, 
  * ReLU) without the Winograd-domain tensors ever reaching HBM.  The network uses it for the deep stem's 64-channel convs and
  * conv2 of layer1 / layer2 (model/resnet.py:110-116, 67-69).  workspace: fs_winograd_fused_workspace_floats(Cin, Cout) floats
  * (the packed filter bank, rebuilt by every call of this test entry; the network builds it once at fs_finalize).
- * variant: 0 = by tile count, 1 = 32 tiles x 64 channels per workgroup, 2 = 16 tiles x 64 channels. */
+ * variant: 0 = by workgroup count, 1 = 32 tiles x 64 channels per workgroup, 2 = 16 tiles x 64 channels (two workgroups per CU),
+ * 3 = 16 x 64 warp-specialised (four MFMA waves + four transform waves); all give bit-identical results. */
 size_t fs_winograd_fused_workspace_floats(int Cin, int Cout);
 int fs_conv3x3_winograd_fused_nhwc(const float* in, int ld_in, const float* wgt_oihw, const float* scale, const float* shift, float* out,
                                    int ld_out, int B, int H, int W, int Cin, int Cout, int relu, int variant, float* workspace,

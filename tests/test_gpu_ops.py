@@ -326,7 +326,7 @@ WINO_FUSED_TOL = 3e-5  # F(4x4,3x3) in fp32 at Cin <= 256: measured <= 1e-5 (gpu
     (1, 179, 179, 64, 64, True),     # layer1 conv2 of a 713x713 frame
     (1, 357, 357, 64, 128, True),    # the deep stem's layer0.6 of a 713x713 frame
 ])
-@pytest.mark.parametrize("variant", [0, 1, 2])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3])
 def test_winograd_fused_conv3x3(case, variant):
     """The one-kernel Winograd F(4x4,3x3) (wino_fused.hip: transforms and the 36 position GEMMs fused, nothing but the input and
     output maps in HBM) vs torch conv2d + scale/shift (+ReLU): both workgroup shapes, ragged maps, a channel slice of a wider
@@ -354,6 +354,11 @@ def test_winograd_fused_conv3x3(case, variant):
     assert note(f"winograd_fused_{h}x{w}x{cin}x{cout}_v{variant}", rel(out[..., 16:16 + cout].permute(0, 3, 1, 2), ref)) < WINO_FUSED_TOL
     assert (out[..., :16] == -7.0).all() and (out[..., 16 + cout:] == -7.0).all()
     assert torch.equal(outs[0], outs[1])
+    if variant:  # every workgroup shape forms the same products in the same order: bit-identical (the network picks by batch size)
+        base = torch.full((b, h, w, cout + 32), -7.0, device=DEV)
+        check(lib.fs_conv3x3_winograd_fused_nhwc(ptr(xd), cin, ptr(wd), ptr(scd), ptr(shd), ptr(base[..., 16:]), cout + 32, b, h, w, cin, cout,
+                                                 int(relu), 2 if variant != 2 else 3, ptr(ws), stream_ptr()))
+        assert torch.equal(base, out)
 
 
 @pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5])

@@ -36,7 +36,7 @@ def timed(fn, iters):
 def main():
     iters = int(sys.argv[1]) if len(sys.argv) > 1 else 20
     lib = _lib.load()
-    print(f"{'shape':24s} {'direct us':>10s} {'TF/s':>7s} | {'fused v1 us':>11s} {'fused v2 us':>11s} {'best eff. TF/s':>14s} {'MFMA TF/s':>10s}")
+    print(f"{'shape':24s} {'direct us':>10s} {'TF/s':>7s} | {'fused v1 us':>11s} {'fused v2 us':>11s} {'fused v3 us':>11s} {'best eff. TF/s':>14s} {'MFMA TF/s':>10s}")
     for name, (b, h, w, cin, cout) in SHAPES.items():
         x = torch.randn(b, h, w, cin, device="cuda")
         wt = torch.randn(cout, cin, 3, 3, device="cuda") * 0.05
@@ -51,14 +51,14 @@ def main():
             check(lib.fs_conv2d_nhwc(ptr(x), cin, ptr(wp), ptr(sc), ptr(sh), None, 0, ptr(out), cout, b, h, w, cin, cout, 3, 3, 1, 1, 1, 1, 0, stream_ptr()))
         td = timed(direct, iters)
         tf = []
-        for v in (1, 2):
+        for v in (1, 2, 3):
             def fused(v=v):
                 check(lib.fs_conv3x3_winograd_fused_nhwc(ptr(x), cin, ptr(wt), ptr(sc), ptr(sh), ptr(out), cout, b, h, w, cin, cout, 1, v, ptr(ws), stream_ptr()))
             tf.append(timed(fused, iters))  # includes the (small) filter transform launch of the test entry
         best = min(tf)
         tiles = b * ((h + 3) // 4) * ((w + 3) // 4)
         mfma = 2.0 * 36 * tiles * cin * cout
-        print(f"{name:24s} {td * 1e3:10.1f} {flops / td / 1e9:7.1f} | {tf[0] * 1e3:11.1f} {tf[1] * 1e3:11.1f} {flops / best / 1e9:14.1f} {mfma / best / 1e9:10.1f}")
+        print(f"{name:24s} {td * 1e3:10.1f} {flops / td / 1e9:7.1f} | {tf[0] * 1e3:11.1f} {tf[1] * 1e3:11.1f} {tf[2] * 1e3:11.1f} {flops / best / 1e9:14.1f} {mfma / best / 1e9:10.1f}")
 
 
 if __name__ == "__main__":
