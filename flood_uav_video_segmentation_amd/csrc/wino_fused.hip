@@ -28,6 +28,26 @@ namespace fs {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// F(4,3) B^T d and A^T m on scalars, every multiply-add an explicit fma: all kernel forms then execute the same operations in the
+// same order whatever the optimiser would have contracted -- their results are bit-identical (tests/test_gpu_ops.py), which
+// lets the launcher pick the form by batch size without a frame's result depending on its batch.
+__device__ __forceinline__ void wf_bt(const float d[6], float t[6]) {
+    const float s12 = d[1] + d[2], d12 = d[1] - d[2], s34 = d[3] + d[4], d43 = d[4] - d[3], d42 = d[4] - d[2], d31 = d[3] - d[1];
+    t[0] = __builtin_fmaf(4.f, d[0], __builtin_fmaf(-5.f, d[2], d[4]));
+    t[1] = __builtin_fmaf(-4.f, s12, s34);
+    t[2] = __builtin_fmaf(4.f, d12, d43);
+    t[3] = __builtin_fmaf(2.f, d31, d42);
+    t[4] = __builtin_fmaf(-2.f, d31, d42);
+    t[5] = __builtin_fmaf(4.f, d[1], __builtin_fmaf(-5.f, d[3], d[5]));
+}
+__device__ __forceinline__ void wf_at(const float m[6], float y[4]) {
+    const float s12 = m[1] + m[2], d12 = m[1] - m[2], s34 = m[3] + m[4], d34 = m[3] - m[4];
+    y[0] = (m[0] + s12) + s34;
+    y[1] = __builtin_fmaf(2.f, d34, d12);
+    y[2] = __builtin_fmaf(4.f, s34, s12);
+    y[3] = __builtin_fmaf(8.f, d34, d12) + m[5];
+}
+
 // ---- packed filter bank: U[xi][I/16][O][16] = (G g G^T)[xi] of filter (o, c), in double, rounded once.  Thread per (o, c).
 __global__ __launch_bounds__(256) void wino4_filter_packed_kernel(const float* __restrict__ w, float* __restrict__ U, int O, int I, int chunk_major) {
     const int64_t total = (int64_t)O * I;
@@ -92,7 +112,7 @@ __device__ __forceinline__ void wino4_epilogue(const f32x4 (&acc)[36], const Win
             float col[6], y4[4];
 #pragma unroll
             for (int y = 0; y < 6; ++y) col[y] = acc[y * 6 + x][r];
-            Wino<4>::at(col, y4);
+            wf_at(col, y4);
 #pragma unroll
             for (int y = 0; y < 4; ++y) half[y][x] = y4[y];
         }
@@ -100,10 +120,10 @@ __device__ __forceinline__ void wino4_epilogue(const f32x4 (&acc)[36], const Win
 #pragma unroll
         for (int y = 0; y < 4; ++y) {
             float o4[4];
-            Wino<4>::at(half[y], o4);
+            wf_at(half[y], o4);
 #pragma unroll
             for (int x = 0; x < 4; ++x) {
-                float v = o4[x] * sc + sh;
+                float v = __builtin_fmaf(o4[x], sc, sh);
                 if (p.relu) v = fmaxf(v, 0.f);
                 const unsigned vo = (y < ny && x < nx) ? base : 0x80000000u;
                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), o_rsrc, vo, (unsigned)((y * p.W + x) * p.ld_out * 4), 0);
@@ -182,7 +202,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void wino4_fused_kernel(WinoFusedP
                     float col[6], tc[6];
 #pragma unroll
                     for (int y = 0; y < 6; ++y) col[y] = d[y][x];
-                    Wino<4>::bt(col, tc);
+                    wf_bt(col, tc);
 #pragma unroll
                     for (int y = 0; y < 6; ++y) r[y][x] = tc[y];
                 }
@@ -190,7 +210,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void wino4_fused_kernel(WinoFusedP
 #pragma unroll
                 for (int y = 0; y < 6; ++y) {  // ... then along x
                     float o[6];
-                    Wino<4>::bt(r[y], o);
+                    wf_bt(r[y], o);
 #pragma unroll
                     for (int x = 0; x < 6; ++x) dst[(y * 6 + x) * (NT * 16)] = o[x];
                 }
@@ -319,7 +339,7 @@ __global__ __launch_bounds__(512, 2) void wino4_ws_kernel(WinoFusedParams p) {
                     float col[6], tc[6];
 #pragma unroll
                     for (int y = 0; y < 6; ++y) col[y] = d[set][it][y][x];
-                    Wino<4>::bt(col, tc);
+                    wf_bt(col, tc);
 #pragma unroll
                     for (int y = 0; y < 6; ++y) d[set][it][y][x] = tc[y];
                 }
@@ -327,7 +347,7 @@ __global__ __launch_bounds__(512, 2) void wino4_ws_kernel(WinoFusedParams p) {
 #pragma unroll
                 for (int y = 0; y < 6; ++y) {  // ... then along x
                     float o[6];
-                    Wino<4>::bt(d[set][it][y], o);
+                    wf_bt(d[set][it][y], o);
 #pragma unroll
                     for (int x = 0; x < 6; ++x) dst[(y * 6 + x) * (NT * 16)] = o[x];
                 }
