@@ -66,6 +66,8 @@ _SIGNATURES = {
     "fs_canvas_resize_argmax": (c_int, [c_void, c_int, c_int, c_int, c_int, c_void, c_int, c_int, c_void]),
     "fs_crop_grids": (c_int, [ctypes.POINTER(c_void), c_int, c_int, c_int, c_int, c_int, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int),
                               c_int, c_int, c_void, c_void]),
+    "fs_crops_fuse": (c_int, [c_void, c_void, c_void, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int)] + [c_int] * 9 + [c_void, c_void, c_int, c_int,
+                              c_void, c_void]),
     "fs_argmax_u8": (c_int, [c_void, c_int, c_int, c_i64, c_void, c_void]),
     "fs_resize_argmax_u8": (c_int, [c_void, c_int, c_int, c_int, c_int, c_void, c_int, c_int, c_void]),
     "fs_iou_hist": (c_int, [c_void, c_void, c_i64, c_int, c_int, c_void, c_void]),

@@ -230,6 +230,27 @@ FS_API int fs_crop_grids(const float* const* grids, int ngrids, int Hg, int Wg, 
     return 0;
 }
 
+FS_API int fs_crops_fuse(const float* lo_prev, const float* lo_next, const float* crop_grids, int ncrops, const int* crop_y, const int* crop_x,
+                         int K, int h, int w, int Hg, int Wg, int ch, int cw, int n, int no_warp, double* canvas, uint8_t* mask, int H, int W,
+                         float* scratch, fs_stream stream) {
+    if (!lo_prev || !crop_y || !crop_x || ncrops < 1 || ncrops > 64 || h < 1 || w < 1 || ch < 1 || cw < 1 || H < 1 || W < 1 || H > 32767 || W > 32767)
+        return fs::fail("fs_crops_fuse: bad arguments (1..64 crops, frame at most 32767 px)");
+    fs::CropsFuseParams p{};
+    p.lo_prev = lo_prev;
+    p.lo_next = lo_next;
+    p.nc = ncrops;
+    for (int c = 0; c < ncrops; ++c) {
+        p.cy[c] = (short)crop_y[c];
+        p.cx[c] = (short)crop_x[c];
+    }
+    p.K = K; p.h = h; p.w = w; p.Hg = Hg; p.Wg = Wg; p.ch = ch; p.cw = cw; p.n = n; p.no_warp = no_warp;
+    p.canvas = canvas;
+    p.mask = mask;
+    p.H = H;
+    p.W = W;
+    return fs::launch_crops_fuse(p, crop_grids, scratch, S(stream));
+}
+
 FS_API int fs_pack_conv_weight(const float* oihw, float* ohwi, int O, int I, int KH, int KW, fs_stream stream) {
     if (!oihw || !ohwi || O < 1 || I < 1 || KH < 1 || KW < 1) return fs::fail("fs_pack_conv_weight: bad arguments");
     return fs::launch_pack_oihw_to_ohwi(oihw, ohwi, O, I, KH, KW, S(stream));

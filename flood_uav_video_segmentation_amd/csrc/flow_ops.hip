@@ -357,6 +357,181 @@ int launch_seg_tail(const SegTailParams& p, hipStream_t s) {
     return 0;
 }
 
+// ------------------------------------------------------------------ sliding crops, all crops of a window in one pass
+// compute_output (flow/base.py:182-209) after the network: per crop the warp chains at grid resolution (one launch per step for
+// ALL crops: blockIdx.z = crop), then ONE launch over the pixels of the full frame: every canvas pixel is produced once from the
+// <= 4 crops that cover it, in the reference's crop order -- tail (upsample / warp / blend) -> fp32 softmax over K -> float64
+// sum -> / count -> (optional) argmax.  The same operations in the same order as fs_seg_tail_accumulate per crop followed by
+// fs_canvas_finish, hence bit-identical to them, without the 8 x 203 MB float64 read-modify-writes of the canvas (and without
+// the canvas at all when only the masks are wanted).
+__global__ __launch_bounds__(256) void seg_warp_step_crops_kernel(const float* __restrict__ lo_prev, const float* __restrict__ lo_next,
+                                                                  const float* __restrict__ grids, float* __restrict__ scratch, int step, int n,
+                                                                  int K, int h, int w, int H, int W, int Hg, int Wg, float sy, float sx) {
+    const int dir = blockIdx.y, c = blockIdx.z;
+    const int G = Hg * Wg;
+    const size_t map = (size_t)K * G;
+    const float* lo = (dir ? lo_next : lo_prev) + (size_t)c * K * h * w;
+    float* base = scratch + (size_t)c * 2 * (n - 1) * map + (size_t)dir * (n - 1) * map;  // [crop][dir][step][K][Hg][Wg]
+    const float* src = step ? base + (size_t)(step - 1) * map : nullptr;
+    float* dst = base + (size_t)step * map;
+    const float* grid = grids + ((size_t)c * 2 * (n - 1) + (size_t)dir * (n - 1) + step) * G * 2;
+    const int first = step == 0;
+    for (int g = blockIdx.x * 256 + threadIdx.x; g < G; g += gridDim.x * 256) {
+        const float gx = grid[g * 2 + 0], gy = grid[g * 2 + 1];
+        const int Hs = first ? H : Hg, Ws = first ? W : Wg;
+        const GsTaps t = gs_taps(gx, gy, Ws, Hs, 0);
+        const int x1 = t.x1ok ? t.x0 + 1 : t.x0, y1 = t.y1ok ? t.y0 + 1 : t.y0;
+        for (int k = 0; k < K; ++k) {
+            float vnw, vne, vsw, vse;
+            if (first) {
+                const float* pl = lo + (size_t)k * h * w;
+                vnw = up_at(pl, h, w, t.y0, t.x0, sy, sx);
+                vne = t.x1ok ? up_at(pl, h, w, t.y0, x1, sy, sx) : 0.f;
+                vsw = t.y1ok ? up_at(pl, h, w, y1, t.x0, sy, sx) : 0.f;
+                vse = (t.x1ok && t.y1ok) ? up_at(pl, h, w, y1, x1, sy, sx) : 0.f;
+            } else {
+                const float* pl = src + (size_t)k * G;
+                vnw = pl[t.y0 * Ws + t.x0];
+                vne = t.x1ok ? pl[t.y0 * Ws + x1] : 0.f;
+                vsw = t.y1ok ? pl[y1 * Ws + t.x0] : 0.f;
+                vse = (t.x1ok && t.y1ok) ? pl[y1 * Ws + x1] : 0.f;
+            }
+            dst[(size_t)k * G + g] = gs_combine(vnw, vne, vsw, vse, t);
+        }
+    }
+}
+
+template <int KMAX, int FN>
+__global__ __launch_bounds__(256) void crops_fuse_kernel(CropsFuseParams p) {
+    const int64_t HW = (int64_t)p.H * p.W;
+    const int K = p.K, n = p.n, G = p.Hg * p.Wg;
+    const size_t lo_stride = (size_t)K * p.h * p.w, map = (size_t)K * G;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < HW; i += (int64_t)gridDim.x * 256) {
+        const int X = (int)(i % p.W), Y = (int)(i / p.W);
+        for (int f0 = 0; f0 < n; f0 += FN) {  // FN frames at a time: FN * K float64 sums per pixel stay in registers
+            double acc[FN][KMAX];
+#pragma unroll
+            for (int f = 0; f < FN; ++f)
+#pragma unroll
+                for (int k = 0; k < KMAX; ++k) acc[f][k] = 0.0;
+            int cnt = 0;
+            for (int c = 0; c < p.nc; ++c) {  // the reference's crop order (flow/base.py:192-205): the float64 sums depend on it
+                const int y = Y - p.cy[c], x = X - p.cx[c];
+                if ((unsigned)y >= (unsigned)p.ch || (unsigned)x >= (unsigned)p.cw) continue;
+                ++cnt;
+                const float* lp = p.lo_prev + (size_t)c * lo_stride;
+                const float* ln = p.lo_next ? p.lo_next + (size_t)c * lo_stride : nullptr;
+                const float* sc = p.scratch + (size_t)c * 2 * (n - 1) * map;
+                float a[KMAX], b[KMAX];
+                const LinCoord cy = lin_coord(y, p.h, p.sy_lo, 1), cx = lin_coord(x, p.w, p.sx_lo, 1);
+#pragma unroll
+                for (int k = 0; k < KMAX; ++k) {
+                    if (k < K) {
+                        const float* pl = lp + (size_t)k * p.h * p.w;
+                        a[k] = bilerp(pl[cy.i0 * p.w + cx.i0], pl[cy.i0 * p.w + cx.i1], pl[cy.i1 * p.w + cx.i0], pl[cy.i1 * p.w + cx.i1], cy, cx);
+                        if (ln && p.no_warp) {
+                            const float* pn = ln + (size_t)k * p.h * p.w;
+                            b[k] = bilerp(pn[cy.i0 * p.w + cx.i0], pn[cy.i0 * p.w + cx.i1], pn[cy.i1 * p.w + cx.i0], pn[cy.i1 * p.w + cx.i1], cy, cx);
+                        }
+                    }
+                }
+                LinCoord gy_c, gx_c;
+                if (!p.no_warp) {
+                    gy_c = lin_coord(y, p.Hg, p.sy_g, 1);
+                    gx_c = lin_coord(x, p.Wg, p.sx_g, 1);
+                }
+#pragma unroll
+                for (int ff = 0; ff < FN; ++ff) {
+                    const int f = f0 + ff;
+                    if (f >= n) break;
+                    float v[KMAX];
+                    const float wa = (float)((double)(n - f) / (double)n);
+                    const float wb = (float)((double)f / (double)n);
+#pragma unroll
+                    for (int k = 0; k < KMAX; ++k) {
+                        if (k < K) {
+                            if (f == 0) {
+                                v[k] = a[k];
+                            } else {
+                                float va, vb;
+                                if (p.no_warp) {
+                                    va = a[k];
+                                    vb = b[k];
+                                } else {
+                                    const float* pf = sc + ((size_t)(f - 1) * K + k) * G;
+                                    const float* pb = sc + ((size_t)(n - 1) * K + (size_t)(n - f - 1) * K + k) * G;
+                                    va = bilerp(pf[gy_c.i0 * p.Wg + gx_c.i0], pf[gy_c.i0 * p.Wg + gx_c.i1], pf[gy_c.i1 * p.Wg + gx_c.i0],
+                                                pf[gy_c.i1 * p.Wg + gx_c.i1], gy_c, gx_c);
+                                    vb = bilerp(pb[gy_c.i0 * p.Wg + gx_c.i0], pb[gy_c.i0 * p.Wg + gx_c.i1], pb[gy_c.i1 * p.Wg + gx_c.i0],
+                                                pb[gy_c.i1 * p.Wg + gx_c.i1], gy_c, gx_c);
+                                }
+                                v[k] = __fadd_rn(__fmul_rn(wa, va), __fmul_rn(wb, vb));
+                            }
+                        }
+                    }
+                    float mx = v[0];
+#pragma unroll
+                    for (int k = 1; k < KMAX; ++k)
+                        if (k < K) mx = fmaxf(mx, v[k]);
+                    float sum = 0.f;
+#pragma unroll
+                    for (int k = 0; k < KMAX; ++k)
+                        if (k < K) sum += expf(v[k] - mx);
+#pragma unroll
+                    for (int k = 0; k < KMAX; ++k)
+                        if (k < K) acc[ff][k] += (double)(expf(v[k] - mx) / sum);
+                }
+            }
+            const double count = (double)cnt;
+#pragma unroll
+            for (int ff = 0; ff < FN; ++ff) {
+                const int f = f0 + ff;
+                if (f >= n) break;
+                double best = -1.0;
+                int arg = 0;
+#pragma unroll
+                for (int k = 0; k < KMAX; ++k) {
+                    if (k < K) {
+                        const double val = acc[ff][k] / count;  // flow/base.py:208
+                        if (p.canvas) p.canvas[((size_t)f * K + k) * HW + i] = val;
+                        if (val > best) { best = val; arg = k; }
+                    }
+                }
+                if (p.mask) p.mask[(size_t)f * HW + i] = (uint8_t)arg;
+            }
+        }
+    }
+}
+
+int launch_crops_fuse(CropsFuseParams p, const float* grids, float* scratch, hipStream_t s) {
+    FS_REQUIRE(p.K >= 1 && p.K <= 8, "crops_fuse: K=%d out of range (1..8)", p.K);
+    FS_REQUIRE(p.nc >= 1 && p.nc <= 64 && p.n >= 1, "crops_fuse: 1..64 crops, n >= 1");
+    FS_REQUIRE(p.canvas || p.mask, "crops_fuse: no output requested");
+    for (int c = 0; c < p.nc; ++c)
+        FS_REQUIRE(p.cy[c] >= 0 && p.cx[c] >= 0 && p.cy[c] + p.ch <= p.H && p.cx[c] + p.cw <= p.W, "crops_fuse: crop %d outside the canvas", c);
+    p.sy_lo = resize_scale(p.h, p.ch, 1);
+    p.sx_lo = resize_scale(p.w, p.cw, 1);
+    p.sy_g = p.sx_g = 0.f;
+    p.scratch = scratch;
+    const bool warp = p.lo_next && !p.no_warp && p.n > 1;
+    if (!p.lo_next) p.n = 1;
+    if (warp) {
+        FS_REQUIRE(scratch && grids, "crops_fuse: warp mode needs the crop grids and scratch");
+        p.sy_g = resize_scale(p.Hg, p.ch, 1);
+        p.sx_g = resize_scale(p.Wg, p.cw, 1);
+        const int G = p.Hg * p.Wg;
+        for (int j = 0; j < p.n - 1; ++j)
+            hipLaunchKernelGGL(seg_warp_step_crops_kernel, dim3(cdiv(G, 256), 2, p.nc), dim3(256), 0, s, p.lo_prev, p.lo_next, grids, scratch, j, p.n,
+                               p.K, p.h, p.w, p.ch, p.cw, p.Hg, p.Wg, p.sy_lo, p.sx_lo);
+    } else {
+        p.no_warp = 1;
+    }
+    const int64_t HW = (int64_t)p.H * p.W;
+    hipLaunchKernelGGL((crops_fuse_kernel<8, 5>), dim3((unsigned)std::min<int64_t>(cdiv64(HW, 256), 16384)), dim3(256), 0, s, p);
+    FS_HIP(hipGetLastError());
+    return 0;
+}
+
 // ------------------------------------------------------------------ argmax / fused resize+argmax
 __global__ __launch_bounds__(256) void argmax_u8_kernel(const float* __restrict__ in, int B, int K, int64_t HW,
                                                         uint8_t* __restrict__ out) {

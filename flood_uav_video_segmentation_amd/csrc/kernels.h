@@ -168,6 +168,22 @@ struct SegTailParams {
 };
 int launch_seg_tail(const SegTailParams& p, hipStream_t s);
 
+// Sliding crops in one pass (flow/base.py:182-209 after the network): every pixel of the full frame from the crops covering it.
+struct CropsFuseParams {
+    const float* lo_prev;   // [nc, K, h, w] per-crop decoder logits of the previous key frame
+    const float* lo_next;   // the same for the next key frame, or nullptr (single frame)
+    const float* scratch;   // warp mode: [nc][2][n-1][K][Hg][Wg] warped maps (filled by the launcher)
+    int nc;
+    short cy[64], cx[64];   // crop offsets, in the reference's crop order
+    int K, h, w, Hg, Wg, ch, cw, n, no_warp;
+    double* canvas;         // [n, K, H, W] crop-averaged softmax (already divided by the count) or nullptr
+    uint8_t* mask;          // [n, H, W] its argmax or nullptr
+    int H, W;
+    float sy_lo, sx_lo, sy_g, sx_g;
+};
+// grids: [nc][2(n-1)][Hg][Wg][2] (fs_crop_grids' output) in warp mode; scratch: nc * 2(n-1) * K * Hg * Wg floats
+int launch_crops_fuse(CropsFuseParams p, const float* grids, float* scratch, hipStream_t s);
+
 // argmax over channel dim of NCHW logits -> uint8 (first max wins; flow/base.py:276).
 int launch_argmax_u8(const float* in, int B, int K, int64_t HW, uint8_t* out, hipStream_t s);
 // argmax of the align_corners=True bilinear upsample of NCHW logits, without materialising it

@@ -66,8 +66,13 @@ def segment_crop_windows(flow_model, frame_a, frame_b, crop_h, crop_w, crop_batc
     return cat(parts_a), (cat(parts_b) if frame_b is not None else None)
 
 
+def _blank_canvas(n, classes, h, w, dev):
+    with torch.cuda.device(dev):
+        return (torch.zeros((n, classes, h, w), dtype=torch.float64, device=dev), torch.zeros((h, w), dtype=torch.float64, device=dev))
+
+
 def compute_output(flow_model, n, frame_prev, frame_next, mvs_left, mvs_right, crop_h, crop_w, classes, profiler=None,
-                   want_mask=False, function=None, key_cache=None, out_size=None, crop_batch=8, lows=None):
+                   want_mask=False, function=None, key_cache=None, out_size=None, crop_batch=8, lows=None, want_canvas=True):
     """flow/base.py:182-209: returns the float64 [n,K,H,W] crop-averaged softmax (and, with want_mask, the uint8 argmax of its
     align_corners=True resize to `out_size` -- flow/base.py:275-276; out_size None = the frame size).
 
@@ -80,13 +85,14 @@ def compute_output(flow_model, n, frame_prev, frame_next, mvs_left, mvs_right, c
     grids come from one launch (fs_crop_grids) and every crop's tail runs fused with softmax + accumulation
     (fs_seg_tail_accumulate): per-crop logits never reach HBM.  key_cache (KeyframeCache.window): the previous key frame's
     per-crop logits are reused from the last window; lows = (lo_prev, lo_next): per-crop logits computed elsewhere
-    (FlowPredictor.predict_clip batches the new key frames of two windows).  Same arithmetic per crop as the generic route."""
+    (FlowPredictor.predict_clip batches the new key frames of two windows).  Same arithmetic per crop as the generic route.
+    With K <= 8 and at most 64 crops the whole post-network part is ONE pass over the frame (fs_crops_fuse): every canvas
+    pixel is written once from the crops covering it, in crop order -- bit-identical to the per-crop accumulation, without its
+    float64 read-modify-writes; want_canvas=False (predict_step only needs the masks) then skips the canvas altogether and
+    returns (None, mask)."""
     _, _, new_h, new_w = frame_prev.shape
     dev = frame_prev.device
     windows = crop_windows(new_h, new_w, crop_h, crop_w)
-    with torch.cuda.device(dev):
-        canvas = torch.zeros((n, classes, new_h, new_w), dtype=torch.float64, device=dev)
-        count = torch.zeros((new_h, new_w), dtype=torch.float64, device=dev)
     net = getattr(flow_model, "model", None)
     batched = lows is not None or (function is None and not getattr(flow_model, "feature_based", True) and hasattr(net, "segment_crops")
                                    and frame_prev.shape[0] == 1 and frame_next is not None)
@@ -107,12 +113,21 @@ def compute_output(flow_model, n, frame_prev, frame_next, mvs_left, mvs_right, c
         grids = None
         if not no_warp:
             grids = ops.crop_grids(list(mvs_left) + list(mvs_right), (new_h, new_w), yx, (crop_h, crop_w))  # [nc, 2(n-1), fh, fw, 2]
+        if classes <= 8 and len(yx) <= 64:
+            same = out_size is None or (int(out_size[0]), int(out_size[1])) == (new_h, new_w)
+            canvas, mask = ops.crops_fuse(lo_prev, lo_next, grids, yx, (crop_h, crop_w), n, no_warp, (new_h, new_w),
+                                          want_canvas=want_canvas or (want_mask and not same), want_mask=want_mask and same)
+            if want_mask and not same:
+                mask = ops.canvas_resize_argmax(canvas, out_size)
+            return (canvas if want_canvas else None, mask) if want_mask else canvas
+        canvas, count = _blank_canvas(n, classes, new_h, new_w, dev)
         for c, (y0, x0) in enumerate(yx):
             gl = [grids[c, j][None] for j in range(n - 1)] if grids is not None else mvs_left
             gr = [grids[c, n - 1 + j][None] for j in range(n - 1)] if grids is not None else mvs_right
             ops.seg_tail_accumulate(lo_prev[c:c + 1], lo_next[c:c + 1], gl, gr, n, (crop_h, crop_w), no_warp, canvas, count, y0, x0)
     else:
         lib = _lib.load()
+        canvas, count = _blank_canvas(n, classes, new_h, new_w, dev)
         for (s_h, e_h, s_w, e_w) in windows:
             prev_c = frame_prev[:, :, s_h:e_h, s_w:e_w].contiguous()
             next_c = frame_next[:, :, s_h:e_h, s_w:e_w].contiguous()

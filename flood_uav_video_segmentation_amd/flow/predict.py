@@ -56,7 +56,7 @@ class FlowPredictor:
         else:
             # :273 compute_output, then :275-276 (float64 resize + argmax) fused into the canvas's last pass
             _, masks = crops.compute_output(self.model, n, frame_prev, frame_next, mvs_left, mvs_right, self.crop[0], self.crop[1],
-                                            self.classes, profiler, want_mask=True, key_cache=kc, out_size=self.out_size)
+                                            self.classes, profiler, want_mask=True, key_cache=kc, out_size=self.out_size, want_canvas=False)
         self._score(masks, n)
         return masks.cpu().numpy() if to_host else masks                # :277
 
@@ -114,7 +114,7 @@ class FlowPredictor:
             else:
                 _, masks = crops.compute_output(fm, n, w["frame_prev"], w["frame_next"], w["mvs_left"], w["mvs_right"], self.crop[0],
                                                 self.crop[1], self.classes, profiler, want_mask=True, out_size=self.out_size,
-                                                lows=(lo_prev, lo_next))
+                                                lows=(lo_prev, lo_next), want_canvas=False)
             self._score(masks, n)
             return masks.cpu().numpy() if to_host else masks
 

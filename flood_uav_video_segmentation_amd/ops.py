@@ -222,6 +222,41 @@ def crop_grids(grids, frame_hw, crop_yx, crop_hw):
     return out
 
 
+def crops_fuse(lo_prev, lo_next, grids, crop_yx, crop_hw, n, no_warp, frame_hw, want_canvas=True, want_mask=False):
+    """compute_output after the network for ALL crops of a window in one pass (fs_crops_fuse): lo_prev / lo_next = per-crop
+    decoder logits [nc,K,h,w]; grids = crop_grids' output [nc, 2(n-1), fh, fw, 2] or None (no_warp).  Returns (float64 canvas
+    [n,K,H,W] already divided by the crop count, or None; uint8 argmax [n,H,W] or None) -- each pixel written once."""
+    lib = _lib.load()
+    dev = one_device(lo_prev, lo_next, grids, what="floodseg.crops_fuse")
+    with torch.cuda.device(dev):
+        lo_prev = _f32c(lo_prev, "lo_prev")
+        nc, k, h, w = lo_prev.shape
+        if nc != len(crop_yx):
+            raise RuntimeError(f"floodseg.crops_fuse: {nc} crops of logits but {len(crop_yx)} crop windows")
+        frames = n if lo_next is not None else 1
+        hh, ww = int(frame_hw[0]), int(frame_hw[1])
+        warp = lo_next is not None and not no_warp and n > 1
+        hg = wg = 1
+        scratch = None
+        if lo_next is not None:
+            lo_next = _f32c(lo_next, "lo_next")
+            if lo_next.shape != lo_prev.shape:
+                raise RuntimeError("floodseg.crops_fuse: lo_prev / lo_next shapes differ")
+        if warp:
+            grids = _f32c(grids, "grids")
+            if grids.dim() != 5 or grids.shape[0] != nc or grids.shape[1] != 2 * (n - 1) or grids.shape[4] != 2:
+                raise RuntimeError(f"floodseg.crops_fuse: grids must be [nc, 2(n-1), Hg, Wg, 2], got {tuple(grids.shape)}")
+            hg, wg = grids.shape[2], grids.shape[3]
+            scratch = torch.empty(nc * 2 * (n - 1) * k * hg * wg, dtype=torch.float32, device=dev)
+        canvas = torch.empty((frames, k, hh, ww), dtype=torch.float64, device=dev) if want_canvas else None
+        mask = torch.empty((frames, hh, ww), dtype=torch.uint8, device=dev) if want_mask else None
+        ys = (ctypes.c_int * nc)(*[int(y) for y, _ in crop_yx])
+        xs = (ctypes.c_int * nc)(*[int(x) for _, x in crop_yx])
+        check(lib.fs_crops_fuse(ptr(lo_prev), ptr(lo_next), ptr(grids) if warp else None, nc, ys, xs, k, h, w, hg, wg, int(crop_hw[0]),
+                                int(crop_hw[1]), int(n), int(not warp), ptr(canvas), ptr(mask), hh, ww, ptr(scratch), stream_ptr()))
+    return canvas, mask
+
+
 def canvas_finish(canvas, count, out_size=None, want_mask=False):
     """canvas /= count in place (flow/base.py:208); optionally the uint8 argmax of its align_corners=True bilinear resize to
     `out_size` evaluated in float64 (flow/base.py:275-276) -- the identity resize when out_size is the canvas size."""
@@ -235,6 +270,17 @@ def canvas_finish(canvas, count, out_size=None, want_mask=False):
         if want_mask and not same:
             mask = torch.empty((n, int(out_size[0]), int(out_size[1])), dtype=torch.uint8, device=dev)
             check(lib.fs_canvas_resize_argmax(ptr(canvas), n, k, h, w, ptr(mask), int(out_size[0]), int(out_size[1]), stream_ptr()))
+    return mask
+
+
+def canvas_resize_argmax(canvas, out_size):
+    """uint8 argmax of the align_corners=True bilinear resize (in float64) of a crop-averaged canvas (flow/base.py:275-276)."""
+    lib = _lib.load()
+    dev = one_device(canvas, what="floodseg.canvas_resize_argmax")
+    n, k, h, w = canvas.shape
+    with torch.cuda.device(dev):
+        mask = torch.empty((n, int(out_size[0]), int(out_size[1])), dtype=torch.uint8, device=dev)
+        check(lib.fs_canvas_resize_argmax(ptr(canvas), n, k, h, w, ptr(mask), int(out_size[0]), int(out_size[1]), stream_ptr()))
     return mask
 
 

@@ -184,6 +184,17 @@ int fs_canvas_resize_argmax(const double* canvas, int n, int K, int Hi, int Wi, 
 int fs_crop_grids(const float* const* grids, int ngrids, int Hg, int Wg, int H, int W, int ncrops, const int* crop_y,
                   const int* crop_x, int ch, int cw, float* out, fs_stream stream);
 
+/* compute_output after the network (flow/base.py:182-209, 226-234) for ALL crops of a window in one pass: lo_prev / lo_next =
+ * per-crop decoder logits [ncrops,K,h,w] (lo_next NULL: single frame), crop_grids = fs_crop_grids' output
+ * [ncrops][2(n-1)][Hg][Wg][2] (ignored when no_warp), crop (y, x) offsets in the reference's crop order.  Every pixel of the
+ * H x W frame is written ONCE: per covering crop the predict_segmentation tail and the fp32 softmax over K, summed in float64 in
+ * crop order, divided by the number of covering crops -> canvas[n,K,H,W] (float64, may be NULL) and / or its argmax mask[n,H,W]
+ * (may be NULL).  Bit-identical to fs_seg_tail_accumulate per crop + fs_canvas_finish.  K <= 8, at most 64 crops;
+ * scratch: ncrops * 2(n-1) * K * Hg * Wg floats (warp mode). */
+int fs_crops_fuse(const float* lo_prev, const float* lo_next, const float* crop_grids, int ncrops, const int* crop_y, const int* crop_x,
+                  int K, int h, int w, int Hg, int Wg, int ch, int cw, int n, int no_warp, double* canvas, uint8_t* mask, int H, int W,
+                  float* scratch, fs_stream stream);
+
 /* ---- building blocks (exposed for op-level parity tests and for other host code) ---------------- */
 int fs_pack_conv_weight(const float* oihw, float* ohwi, int O, int I, int KH, int KW, fs_stream stream);
 /* Conv2d (+ per-channel scale/shift, + residual, + ReLU (relu = 1) / GELU (2)) on the fp32 matrix cores; Cin % 32 == 0.

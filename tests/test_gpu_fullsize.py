@@ -451,6 +451,35 @@ def test_seg_tail_accumulate_equals_tail_then_softmax_accumulate():
         ops.seg_tail_accumulate(lo_p, lo_n, mvl, mvr, n, (ch, cw), False, fused_c, fused_n, 100, 100)
 
 
+def test_crops_fuse_single_pass_equals_per_crop_accumulation():
+    """fs_crops_fuse (every canvas pixel written once from the crops covering it, in crop order) against the route it replaces
+    -- fs_seg_tail_accumulate per crop, then fs_canvas_finish -- bit for bit: warp and no_warp, n = 7 (two register chunks of
+    frames), four overlapping crops incl. one pixel covered by all four, K = 5; the masks-only mode gives the same masks."""
+    g = torch.Generator().manual_seed(11)
+    k, n, h, w, ch, cw, H, W = 5, 7, 12, 13, 90, 97, 150, 160
+    yx = [(0, 0), (0, 63), (60, 0), (60, 63)]
+    lo_p, lo_n = torch.randn(4, k, h, w, generator=g).cuda(), torch.randn(4, k, h, w, generator=g).cuda()
+    for no_warp in (False, True):
+        grids = None
+        if not no_warp:
+            mvl, mvr = synth.make_grids(n, 10, 10, seed=3, frame=(H, W), jitter=0.03)
+            grids = ops.crop_grids(cu(mvl) + cu(mvr), (H, W), yx, (ch, cw))
+        ref_c = torch.zeros(n, k, H, W, dtype=torch.float64, device="cuda")
+        ref_n = torch.zeros(H, W, dtype=torch.float64, device="cuda")
+        for c, (y0, x0) in enumerate(yx):
+            gl = [grids[c, j][None] for j in range(n - 1)] if grids is not None else cu(synth.dummy_grids(n)[0])
+            gr = [grids[c, n - 1 + j][None] for j in range(n - 1)] if grids is not None else cu(synth.dummy_grids(n)[1])
+            ops.seg_tail_accumulate(lo_p[c:c + 1], lo_n[c:c + 1], gl, gr, n, (ch, cw), no_warp, ref_c, ref_n, y0, x0)
+        assert float(ref_n.max()) == 4.0 and float(ref_n.min()) == 1.0
+        ref_m = ops.canvas_finish(ref_c, ref_n, None, want_mask=True)
+        canvas, mask = ops.crops_fuse(lo_p, lo_n, grids, yx, (ch, cw), n, no_warp, (H, W), want_canvas=True, want_mask=True)
+        assert torch.equal(canvas, ref_c) and torch.equal(mask, ref_m)
+        none, only = ops.crops_fuse(lo_p, lo_n, grids, yx, (ch, cw), n, no_warp, (H, W), want_canvas=False, want_mask=True)
+        assert none is None and torch.equal(only, ref_m)
+    with pytest.raises(RuntimeError, match="outside the canvas"):
+        ops.crops_fuse(lo_p, lo_n, None, [(0, 0), (0, 63), (60, 0), (100, 63)], (ch, cw), n, True, (H, W))
+
+
 def test_crop_grids_identity_block_range_and_edge_cases():
     """A crop whose block range already is (crop // 16)^2 skips the resize (64x64 crop on 16-px blocks at a block-aligned
     offset): the output is the renormalised cut, exactly; f64 grids are accepted; a crop outside the grid is refused."""
