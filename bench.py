@@ -15,7 +15,8 @@ window after window, cyclically for the K timed steps; no data-path collective (
 
 A step = one key-frame window of the hot path on each rank: FlowModel.predict(prev, next, ...) through
 the C ABI (BOTH key frames segmented, exactly the work the reference does per predict call -- no cached
-key frame), per-frame argmax, uint8 masks copied to the host (the reference's timed region
+key frame) returning the fp32 logits of all 5 frames, per-frame argmax (emitted by the same fused tail that writes the logits),
+uint8 masks copied to the host (the reference's timed region
 "predict_interference", flow/base.py:269-277, at native 713x713 resolution).  Inputs are resident in
 HBM when the clock starts.  value = frames all ranks produced / max-over-ranks wall time.
 Everything is fp32 (the reference's precision); data and weights are synthetic (seeded).
@@ -249,8 +250,8 @@ def main():
 
     def step_native(i):
         prev, nxt = windows[i % nwin]
-        logits = fm.predict(prev, nxt, dl, dr, N_DELTA, None)["pred"]
-        host_masks.copy_(ops.argmax_u8(logits), non_blocking=True)
+        out = fm.predict(prev, nxt, dl, dr, N_DELTA, None, with_mask=True)  # logits [5,K,713,713] AND their argmax, from one fused tail
+        host_masks.copy_(out["mask"], non_blocking=True)
         torch.cuda.current_stream().synchronize()  # masks are on the host when the step ends
 
     elapsed = timed(step_native, args.steps, args.warmup, dev)

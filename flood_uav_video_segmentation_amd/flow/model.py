@@ -204,15 +204,18 @@ class FlowModel(nn.Module):
             return self.predict_feature(*args, **kwargs)
         return self.predict_segmentation(*args, **kwargs)
 
-    def predict_segmentation(self, frame_prev, frame_next, mvs_left, mvs_right, n, profiler=None, key_cache=None):
+    def predict_segmentation(self, frame_prev, frame_next, mvs_left, mvs_right, n, profiler=None, key_cache=None, with_mask=False):
         """Segment the key frames, propagate the LOGITS (reference :184-241).
-        Returns {"pred": [n,K,h,w]} ([1,K,h,w] when frame_next is None).  key_cache: see KeyframeCache (extension)."""
+        Returns {"pred": [n,K,h,w]} ([1,K,h,w] when frame_next is None).  key_cache: see KeyframeCache (extension).
+        with_mask=True (extension): the fused tail also emits the per-frame argmax it has in registers anyway -- an extra
+        "mask" entry, uint8 [n,h,w] = pred.max(1)[1] (flow/base.py:276) -- so that a caller who wants both does not re-read
+        the logits for it."""
         h, w = frame_prev.shape[2], frame_prev.shape[3]
         with _region(profiler, "predict_encoder"), _region(profiler, "predict_decoder"):
             lo_prev, lo_next = self._key_outputs(self._segment, self._tag("seg", h, w), frame_prev, frame_next, key_cache)
         with _region(profiler, "predict_warp"), _region(profiler, "predict_fusion"):
-            logits, _ = ops.seg_tail(lo_prev, lo_next, mvs_left, mvs_right, n, (h, w), self.no_warp, want_logits=True)
-        return {"pred": logits}
+            logits, mask = ops.seg_tail(lo_prev, lo_next, mvs_left, mvs_right, n, (h, w), self.no_warp, want_logits=True, want_mask=with_mask)
+        return {"pred": logits, "mask": mask} if with_mask else {"pred": logits}
 
     def predict_masks(self, frame_prev, frame_next, mvs_left, mvs_right, n, profiler=None, key_cache=None):
         """Same pipeline, but the fused tail emits the per-frame argmax directly: uint8 [n,h,w].
@@ -224,8 +227,8 @@ class FlowModel(nn.Module):
             _, mask = ops.seg_tail(lo_prev, lo_next, mvs_left, mvs_right, n, (h, w), self.no_warp, want_logits=False, want_mask=True)
         return mask
 
-    def predict_feature(self, frame_prev, frame_next, mvs_left, mvs_right, n, profiler=None, key_cache=None):
-        """Propagate encoder FEATURES, decode all n maps in one batch (reference :116-181)."""
+    def predict_feature(self, frame_prev, frame_next, mvs_left, mvs_right, n, profiler=None, key_cache=None, with_mask=False):
+        """Propagate encoder FEATURES, decode all n maps in one batch (reference :116-181).  with_mask: as in predict_segmentation."""
         h, w = frame_prev.shape[2], frame_prev.shape[3]
         with _region(profiler, "predict_encoder"):
             f, f_next = self._key_outputs(self._encode, self._tag("feat", h, w), frame_prev, frame_next, key_cache)
@@ -266,4 +269,4 @@ class FlowModel(nn.Module):
                         ops.blend(fwd[p - 1], (n - p) / n, bwd[n - p - 1], p / n, out=stack[p:p + 1])
         with _region(profiler, "predict_decoder"):
             out = self._fit_out(self.model.decoder(stack), h, w)
-        return {"pred": out}
+        return {"pred": out, "mask": ops.argmax_u8(out)} if with_mask else {"pred": out}

@@ -50,6 +50,8 @@ def test_predict_toy_model_matches_reference(n, fb, nw, profiler):
     assert rel_err(out.cpu(), z[f"predict_n{n}_fb{int(fb)}_nw{int(nw)}"]) < TOL
     assert torch.equal(prev, keep)  # inputs are never mutated
     assert {"predict_encoder", "predict_decoder"} <= set(profiler.names)
+    both = fm.predict(prev, nxt, cu(mvl), cu(mvr), n, None, with_mask=True)  # extension: the tail's argmax next to the logits
+    assert torch.equal(both["pred"], out) and torch.equal(both["mask"], ops.argmax_u8(out))
 
 
 def test_predict_single_frame_and_f64_grids(profiler):
