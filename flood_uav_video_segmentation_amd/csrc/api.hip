@@ -326,9 +326,8 @@ FS_API int fs_conv3x3_winograd_nhwc(const float* in, int ld_in, const float* wgt
     p.stride = 1;
     p.dil = 1;
     p.groups = (int)G;
-    p.g_in = (long long)T * Cin;
     p.g_wgt = (long long)Cout * Cin;
-    p.g_out = (long long)T * Cout;
+    fs::winograd_gemm_params(p, mt, (int)T, Cin, Cout);
     if (int rc = fs::launch_conv_igemm(p, S(stream))) return rc;
     return fs::launch_winograd_output(Mb, scale, shift, out, ld_out, B, H, W, Cout, relu, dil, mt, S(stream));
 }

@@ -263,6 +263,17 @@ int launch_winograd_input(const float* in, int ld_in, float* V /*[(m+2)^2][T][C]
                           hipStream_t s);
 int launch_winograd_output(const float* M /*[(m+2)^2][T][N]*/, const float* scale, const float* shift, float* out, int ld_out, int B,
                            int H, int W, int N, int relu, int dil, int mt, hipStream_t s);
+// element (position xi, tile t, channel c) of V (C = Cin) / M (C = Cout) lives at xi * s_pos + t * s_tile + c
+struct WinoLayout { bool tile_major; long long s_pos, s_tile; };
+WinoLayout winograd_layout(int mt, long long T, int C);
+// the grouped GEMM between the transforms: group g = position g, rows = tiles (fills the V / M addressing of a ConvParams)
+static inline void winograd_gemm_params(ConvParams& p, int mt, int T, int Cin, int Cout) {
+    const WinoLayout a = winograd_layout(mt, T, Cin), o = winograd_layout(mt, T, Cout);
+    p.ld_in = (int)a.s_tile;
+    p.g_in = a.s_pos;
+    p.ld_out = (int)o.s_tile;
+    p.g_out = o.s_pos;
+}
 static inline int winograd_tiles(int B, int H, int W, int dil, int mt) {
     return B * dil * dil * ((cdiv(H, dil) + mt - 1) / mt) * ((cdiv(W, dil) + mt - 1) / mt);
 }

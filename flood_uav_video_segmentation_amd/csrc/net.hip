@@ -210,9 +210,8 @@ int run_conv_winograd(fs_net* h, const ConvBN& c, const float* in, int ld_in, in
     p.stride = 1;
     p.dil = 1;
     p.groups = G;
-    p.g_in = (long long)T * c.Cin;
     p.g_wgt = (long long)c.Cout * c.Cin;
-    p.g_out = (long long)T * c.Cout;
+    winograd_gemm_params(p, mt, T, c.Cin, c.Cout);  // V / M are tile-major when that fits a buffer descriptor (winograd.hip)
     const double flops = 2.0 * G * (double)T * c.Cin * c.Cout;
     FS_TRY(prof_begin(h, c.name + ".wino_gemm", conv_igemm_tile_name(p), flops, 4.0 * ((double)v_elems + (double)G * c.Cout * c.Cin + (double)m_elems), s));
     FS_TRY(launch_conv_igemm(p, s));

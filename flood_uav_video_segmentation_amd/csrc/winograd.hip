@@ -59,7 +59,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 template <int MT>
 __global__ __launch_bounds__((MT + 2) * 32) void winograd_input_kernel(const float* __restrict__ in, int ld_in, float* __restrict__ V, int B, int H,
-                                                                       int W, int C4, int th, int tw, int dil) {
+                                                                       int W, int C4, int th, int tw, int dil, long long s_pos, long long s_tile) {
     constexpr int A = Wino<MT>::A;
     __shared__ f32x4 tmp[A][A][32];  // [r][x][channel quad]
     // dilation d: the conv splits into d*d independent undilated convs on the pixel lattices (py + d*i, px + d*j);
@@ -99,11 +99,24 @@ __global__ __launch_bounds__((MT + 2) * 32) void winograd_input_kernel(const flo
             Wino<MT>::bt(row, o);
             if (cok) {
 #pragma unroll
-                for (int q = 0; q < A; ++q) *reinterpret_cast<f32x4*>(V + ((size_t)(lane_x * A + q) * T + t) * C4 * 4 + (size_t)c4 * 4) = o[q];
+                for (int q = 0; q < A; ++q) *reinterpret_cast<f32x4*>(V + (size_t)(lane_x * A + q) * s_pos + (size_t)t * s_tile + (size_t)c4 * 4) = o[q];
             }
         }
         __syncthreads();  // tmp is reused by the next tile of the grid-stride loop
     }
+}
+
+// Layout of the Winograd-domain tensors V [positions x tiles x C] and M [positions x tiles x N].  Tile-major ([tile][position][c]:
+// one tile's 36 / 64 positions are one contiguous record, so a transform workgroup writes / reads ONE 16-64 KB region instead of
+// 64 chunks of 512 B scattered 0.5 MB apart -- the grouped GEMM addresses group g as rows of pixel stride G*C starting at g*C)
+// whenever the strided view stays below the 2 GiB a buffer descriptor can address; position-major otherwise.
+WinoLayout winograd_layout(int mt, long long T, int C) {
+    const long long G = (long long)(mt + 2) * (mt + 2);
+    WinoLayout l;
+    l.tile_major = T * G * C * 4 < ((long long)1 << 31);
+    l.s_pos = l.tile_major ? C : T * C;
+    l.s_tile = l.tile_major ? G * C : C;
+    return l;
 }
 
 int launch_winograd_input(const float* in, int ld_in, float* V, int B, int H, int W, int C, int dil, int mt, hipStream_t s) {
@@ -113,8 +126,9 @@ int launch_winograd_input(const float* in, int ld_in, float* V, int B, int H, in
     const int th = (cdiv(H, dil) + mt - 1) / mt, tw = (cdiv(W, dil) + mt - 1) / mt;
     const int64_t blocks = (int64_t)B * dil * dil * th * tw * cdiv(C / 4, 32);
     const dim3 grid((unsigned)std::min<int64_t>(blocks, 1 << 20));
-    if (mt == 4) hipLaunchKernelGGL(winograd_input_kernel<4>, grid, dim3(6 * 32), 0, s, in, ld_in, V, B, H, W, C / 4, th, tw, dil);
-    else hipLaunchKernelGGL(winograd_input_kernel<6>, grid, dim3(8 * 32), 0, s, in, ld_in, V, B, H, W, C / 4, th, tw, dil);
+    const WinoLayout lay = winograd_layout(mt, (long long)B * dil * dil * th * tw, C);
+    if (mt == 4) hipLaunchKernelGGL(winograd_input_kernel<4>, grid, dim3(6 * 32), 0, s, in, ld_in, V, B, H, W, C / 4, th, tw, dil, lay.s_pos, lay.s_tile);
+    else hipLaunchKernelGGL(winograd_input_kernel<6>, grid, dim3(8 * 32), 0, s, in, ld_in, V, B, H, W, C / 4, th, tw, dil, lay.s_pos, lay.s_tile);
     FS_HIP(hipGetLastError());
     return 0;
 }
@@ -124,7 +138,8 @@ int launch_winograd_input(const float* in, int ld_in, float* V, int B, int H, in
 template <int MT>
 __global__ __launch_bounds__((MT + 2) * 32) void winograd_output_kernel(const float* __restrict__ M, const float* __restrict__ scale,
                                                                         const float* __restrict__ shift, float* __restrict__ out, int ld_out, int B,
-                                                                        int H, int W, int N4, int th, int tw, int relu, int dil) {
+                                                                        int H, int W, int N4, int th, int tw, int relu, int dil, long long s_pos,
+                                                                        long long s_tile) {
     constexpr int A = Wino<MT>::A;
     __shared__ f32x4 tmp[MT][A][32];  // [a][q][channel quad]
     const int64_t T = (int64_t)B * dil * dil * th * tw;
@@ -142,7 +157,7 @@ __global__ __launch_bounds__((MT + 2) * 32) void winograd_output_kernel(const fl
             f32x4 col[A], y[MT];
 #pragma unroll
             for (int r = 0; r < A; ++r)
-                col[r] = nok ? *reinterpret_cast<const f32x4*>(M + ((size_t)(r * A + lane_q) * T + t) * N4 * 4 + (size_t)n4 * 4) : f32x4(0.f);
+                col[r] = nok ? *reinterpret_cast<const f32x4*>(M + (size_t)(r * A + lane_q) * s_pos + (size_t)t * s_tile + (size_t)n4 * 4) : f32x4(0.f);
             Wino<MT>::at(col, y);
 #pragma unroll
             for (int a = 0; a < MT; ++a) tmp[a][lane_q][oq] = y[a];
@@ -181,10 +196,13 @@ int launch_winograd_output(const float* M, const float* scale, const float* shif
     const int th = (cdiv(H, dil) + mt - 1) / mt, tw = (cdiv(W, dil) + mt - 1) / mt;
     const int64_t blocks = (int64_t)B * dil * dil * th * tw * cdiv(N / 4, 32);
     const dim3 grid((unsigned)std::min<int64_t>(blocks, 1 << 20));
+    const WinoLayout lay = winograd_layout(mt, (long long)B * dil * dil * th * tw, N);
     if (mt == 4)
-        hipLaunchKernelGGL(winograd_output_kernel<4>, grid, dim3(6 * 32), 0, s, M, scale, shift, out, ld_out, B, H, W, N / 4, th, tw, relu, dil);
+        hipLaunchKernelGGL(winograd_output_kernel<4>, grid, dim3(6 * 32), 0, s, M, scale, shift, out, ld_out, B, H, W, N / 4, th, tw, relu, dil,
+                           lay.s_pos, lay.s_tile);
     else
-        hipLaunchKernelGGL(winograd_output_kernel<6>, grid, dim3(8 * 32), 0, s, M, scale, shift, out, ld_out, B, H, W, N / 4, th, tw, relu, dil);
+        hipLaunchKernelGGL(winograd_output_kernel<6>, grid, dim3(8 * 32), 0, s, M, scale, shift, out, ld_out, B, H, W, N / 4, th, tw, relu, dil,
+                           lay.s_pos, lay.s_tile);
     FS_HIP(hipGetLastError());
     return 0;
 }
