@@ -84,3 +84,15 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
         assert "no CPU fallback" in str(e)
     else:
         raise AssertionError("loading a missing library must raise")
+
+
+def test_header_is_plain_c():
+    """include/floodseg.h is the drop-in boundary for a C / cgo / JNI / ctypes caller: it must compile as C99 on its own."""
+    import subprocess
+    import tempfile
+
+    with tempfile.NamedTemporaryFile("w", suffix=".c", delete=False) as f:
+        f.write('#include "floodseg.h"\nint main(void) { fs_config c; int (*v)(void) = fs_version; (void)c; (void)v; return 0; }\n')
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), f.name], capture_output=True, text=True)
+    os.unlink(f.name)
+    assert r.returncode == 0, r.stderr
