@@ -310,8 +310,8 @@ def main():
             d["ms"] += ms
             d["flops"] += flops
             d["launches"] += 1
-        conv = {k: v for k, v in per.items() if k.startswith("igemm") or k == "wino_fused"}  # every launch that runs on the matrix cores
-        dom_name, dom = max(((k, v) for k, v in conv.items() if k.startswith("igemm")), key=lambda kv: kv[1]["ms"])
+        conv = {k: v for k, v in per.items() if k.startswith("igemm")}  # the implicit-GEMM launches (direct convs, Winograd position GEMMs, Linears)
+        dom_name, dom = max(conv.items(), key=lambda kv: kv[1]["ms"])
         ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
         alg_bytes = sum(r[3] for r in rows if r[1] == dom_name) / max(1, dom["launches"])
         traffic, traffic_note = pmc_traffic(dom_name)
@@ -328,6 +328,15 @@ def main():
                                  "gflop_per_step": round(all_fl / prof_steps / 1e9, 2)},
             "per_kernel_ms_per_step": {k: round(v["ms"] / prof_steps, 4) for k, v in sorted(per.items(), key=lambda kv: -kv[1]["ms"])},
         }
+        if "wino_fused" in per:
+            # the one-kernel Winograd F(4x4,3x3) launches (deep stem, conv2 of layer1 / layer2): FLOPs EXECUTED on the matrix cores
+            # (36 products per 16 outputs) and the direct-conv rate they stand for (x4) -- the latter is not a roofline fraction
+            wf = per["wino_fused"]
+            wf_tf = wf["flops"] / (wf["ms"] * 1e-3) / 1e12
+            result["roofline"]["fused_winograd_kernels"] = {
+                "achieved_executed": round(wf_tf, 2), "frac_of_mfma_peak": round(wf_tf / PEAK_F32_MFMA_TFLOPS, 4), "ms_per_step": round(wf["ms"] / prof_steps, 4),
+                "launches_per_step": wf["launches"] // prof_steps, "gflop_executed_per_step": round(wf["flops"] / prof_steps / 1e9, 2),
+                "direct_conv_equivalent_tflops": round(4 * wf_tf, 1)}
 
     if not args.no_extras and world == 1:  # the variants are single-GPU figures: measured by the N = 1 run only
         result["variants"] = variants(args, dev, rdev, net, state, fm, windows, dl, dr, host_masks, host_post)

@@ -245,14 +245,18 @@ int reserve_conv(fs_net* h, const ConvBN& c, int B, int H, int W, hipStream_t s,
 
 // The one-kernel Winograd (wino_fused.hip) takes a 3x3 s1 p1 conv with Cin <= 128 when ONE image gives it enough 4x4 tiles to
 // spread over the chip (decided per image, never on the batch: a frame's result must not depend on the batch it is computed in)
-bool takes_fused_winograd(const fs_net* h, const ConvBN& c, int H, int W, bool has_res) {
-    return c.wf && h->use_fused_winograd && !has_res && (long)cdiv(H, 4) * cdiv(W, 4) >= 500;
+bool takes_fused_winograd(const fs_net* h, const ConvBN& c, int B, int H, int W, int ld_in, int ld_out, bool has_res) {
+    // the kernel addresses its input with 30-bit and its output with 31-bit byte offsets (wino_fused.hip): maps beyond that
+    // (batches of more than ~30 frames at 713^2) stay on the direct kernel -- a size limit, not a batch-dependent result: both
+    // routes are within the parity tolerance of each other, and the key-frame cache never mixes such batches with small ones
+    const bool fits = (int64_t)B * H * W * ld_in * 4 < ((int64_t)1 << 30) && (int64_t)B * H * W * ld_out * 4 < ((int64_t)1 << 31);
+    return c.wf && h->use_fused_winograd && !has_res && fits && (long)cdiv(H, 4) * cdiv(W, 4) >= 500;
 }
 
 int run_conv(fs_net* h, const ConvBN& c, const float* in, int ld_in, int B, int H, int W, float* out, int ld_out,
              const float* res, int ld_res, hipStream_t s) {
     if (takes_winograd(h, c, B, H, W, res != nullptr)) return run_conv_winograd(h, c, in, ld_in, B, H, W, out, ld_out, s);
-    if (takes_fused_winograd(h, c, H, W, res != nullptr)) {
+    if (takes_fused_winograd(h, c, B, H, W, ld_in, ld_out, res != nullptr)) {
         const double tiles = (double)B * cdiv(H, 4) * cdiv(W, 4);
         FS_TRY(prof_begin(h, c.name, "wino_fused", 2.0 * 36.0 * tiles * c.Cin * c.Cout,
                           4.0 * ((double)B * H * W * (c.Cin + c.Cout) + 36.0 * c.Cin * c.Cout), s));
