@@ -155,6 +155,9 @@ int launch_layernorm(const float* in, const float* gamma, const float* beta, flo
 constexpr int ATT_DH = 64;
 constexpr int ATT_KT = 64;   // keys per LDS tile
 constexpr int ATT_LDK = 68;
+#ifndef ATT_USE_DMA
+#define ATT_USE_DMA 1  // 0: the register-staged kernel (A/B builds)
+#endif
 constexpr int ATT_NW = 4;    // waves per workgroup = 128 queries per staged K/V tile.  Measured on ViT-S/16 (N = 1937): 2 waves
                              // (64 queries, 4 workgroups/CU) 36 TFLOP/s -- the K/V staging per query doubles; 4 waves 52+
 
@@ -321,6 +324,168 @@ __global__ __launch_bounds__(64 * ATT_NW, 3) void attention_f32_kernel(const flo
     }
 }
 
+// ------------------------------------------------------------------ the same kernel with K / V staged global -> LDS DIRECTLY
+// (round 3).  The register-staged form above spends, per 64 keys and thread, 8 global loads into 32 VGPRs, 8 ds_write_b128 and
+// two barriers on moving K and V (measured: ~7 % of the launch, tools/probe_attention.hip).  Here a stage is 32 keys, K and V
+// of the NEXT stage are requested with buffer_load_dwordx4 ... lds (four 1-KiB pieces per wave, no VGPRs) right behind the barrier
+// that publishes the current one, and land under its 64 MFMAs; two LDS stage buffers, one barrier per 32 keys.  A piece is
+// lane-linear in LDS (4 rows x 256 B), so rows cannot be padded: the K image is XOR-swizzled instead -- 16-B chunk j of key row r
+// lives at chunk j ^ (r & 15), applied to the per-lane SOURCE offset -- which keeps the fragment reads (ds_read_b128 of one
+// column chunk across 16 different rows) conflict-free; V is read along rows (32 consecutive floats) and stays linear.  Keys
+// beyond N are zero-filled by the descriptor's range check (sentinel offset) and masked to -inf as before.  Same arithmetic,
+// same order: bit-identical to the register-staged kernel.  Measured (ViT-S/16, B = 2, 14 launches): 1.7225 ms against 1.7297 ms --
+// no gain: with three workgroups per CU the staging was already hidden behind the neighbours' MFMAs; what it frees is 32 VGPRs
+// (122 instead of 154).  A fourth workgroup per CU with a 5-way key split (960 workgroups) was measured too: 1.85 ms, worse (more
+// partials to merge, same pipe).  Kept as the shipped form (ATT_USE_DMA 0 builds the register-staged one for A/B).
+template <bool SPLIT>
+__global__ __launch_bounds__(64 * ATT_NW, 3) void attention_dma_kernel(const float* __restrict__ qkv, float* __restrict__ out,
+                                                                     float* __restrict__ part_o, float* __restrict__ part_ml, int N,
+                                                                     int heads, float scale, int nsplit) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int ST = 32;  // keys per stage
+    __shared__ __attribute__((aligned(1024))) float Ks[2][ST * ATT_DH];
+    __shared__ __attribute__((aligned(1024))) float Vs[2][ST * ATT_DH];
+    const int D = heads * ATT_DH, ld = 3 * D;
+    const int b = blockIdx.z, head = blockIdx.y;
+    const int t = threadIdx.x, lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int l31 = lane & 31, hh = lane >> 5;
+    const int qtiles = SPLIT ? gridDim.x / nsplit : gridDim.x;
+    const int qt = SPLIT ? blockIdx.x % qtiles : blockIdx.x, split = SPLIT ? blockIdx.x / qtiles : 0;
+    const int q = qt * (32 * ATT_NW) + wv * 32 + l31;
+    const int qc = min(q, N - 1);
+    const float* base = qkv + (size_t)b * N * ld + head * ATT_DH;
+
+    const float scale2 = scale * 1.44269504088896340736f;
+    float qreg[32];
+    {
+        const f32x4* qp = reinterpret_cast<const f32x4*>(base + (size_t)qc * ld + 32 * hh);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const f32x4 v = qp[u];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) qreg[4 * u + e] = v[e] * scale2;
+        }
+    }
+    f32x16 acc_o[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc_o[i][e] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+
+    // this workgroup's keys: the same 64-key tile ranges as the register-staged kernel, walked 32 keys at a time
+    const int ntiles_all = (N + ATT_KT - 1) / ATT_KT;
+    const int kt0 = SPLIT ? (ntiles_all * split) / nsplit : 0;
+    const int kt1 = SPLIT ? (ntiles_all * (split + 1)) / nsplit : ntiles_all;
+    const int s0 = 2 * kt0, s1 = min(2 * kt1, (N + ST - 1) / ST);
+
+    // DMA pieces of this wave: rows 8 wv + 4 j + (lane >> 4), j = 0, 1; physical chunk lane & 15
+    constexpr unsigned SENT = 0x80000000u;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (unsigned)(((long long)(N - 1) * ld + 3 * D - head * ATT_DH) * 4), 0x00020000);
+    const int prow = lane >> 4, pch = lane & 15;
+    auto issue = [&](int stage, int buf) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int row = 8 * wv + 4 * j + prow;
+            const int key = stage * ST + row;
+            const unsigned ro = key < N ? (unsigned)(key * ld) * 4u : SENT;
+            const unsigned kvo = ro == SENT ? SENT : ro + (unsigned)((D + 4 * (pch ^ (row & 15))) * 4);
+            const unsigned vvo = ro == SENT ? SENT : ro + (unsigned)((2 * D + 4 * pch) * 4);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(&Ks[buf][(8 * wv + 4 * j) * ATT_DH]), 16, kvo, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(&Vs[buf][(8 * wv + 4 * j) * ATT_DH]), 16, vvo, 0, 0, 0);
+        }
+    };
+    const int xk = (l31 & 15) ^ (8 * hh);  // physical chunk of logical chunk 8 hh + u in row l31 = xk ^ u
+
+    if (s0 < s1) issue(s0, 0);
+    for (int s = s0; s < s1; ++s) {
+        const int buf = (s - s0) & 1;
+        // this wave's pieces of stage s have landed (vmcnt), everybody's have (barrier), and everybody is done reading the other buffer
+        __builtin_amdgcn_s_waitcnt(0x0070);
+        __syncthreads();
+        if (s + 1 < s1) issue(s + 1, buf ^ 1);
+        const int key0 = s * ST;
+        f32x16 sT;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) sT[e] = 0.f;
+        const float* krow = &Ks[buf][l31 * ATT_DH];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const f32x4 kf = *reinterpret_cast<const f32x4*>(krow + 4 * (xk ^ u));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) sT = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[e], qreg[4 * u + e], sT, 0, 0, 0);
+        }
+        if (key0 + 32 > N) {  // block-uniform: only the last stage has keys to mask
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (key0 + (r & 3) + 8 * (r >> 2) + 4 * hh >= N) sT[r] = -INFINITY;
+        }
+        float mloc = sT[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mloc = fmaxf(mloc, sT[r]);
+        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+        const float m_new = fmaxf(m_run, mloc);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        float lsum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            sT[r] = __builtin_amdgcn_exp2f(sT[r] - m_new);
+            lsum += sT[r];
+        }
+        l_run = l_run * alpha + lsum;
+        m_run = m_new;
+        if (__any(alpha != 1.f)) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc_o[i][e] *= alpha;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int krow_r = (r & 3) + 8 * (r >> 2) + 4 * hh;
+            const float v0 = Vs[buf][krow_r * ATT_DH + l31];
+            const float v1 = Vs[buf][krow_r * ATT_DH + 32 + l31];
+            acc_o[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(v0, sT[r], acc_o[0], 0, 0, 0);
+            acc_o[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(v1, sT[r], acc_o[1], 0, 0, 0);
+        }
+    }
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    if (SPLIT) {
+        if (q < N) {
+            const size_t row = ((size_t)(b * heads + head) * nsplit + split) * N + q;
+            float* op = part_o + row * ATT_DH;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = acc_o[i][4 * g + e];
+                    *reinterpret_cast<f32x4*>(op + i * 32 + 8 * g + 4 * hh) = v;
+                }
+            if (hh == 0) {
+                part_ml[2 * row] = m_run;
+                part_ml[2 * row + 1] = l_tot;
+            }
+        }
+        return;
+    }
+    const float inv = 1.f / l_tot;
+    if (q < N) {
+        float* op = out + ((size_t)b * N + q) * D + head * ATT_DH;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc_o[i][4 * g + e] * inv;
+                *reinterpret_cast<f32x4*>(op + i * 32 + 8 * g + 4 * hh) = v;
+            }
+    }
+#endif
+}
+
 // merge the key splits of one query: O = sum_s e^(m_s - M) O_s / sum_s e^(m_s - M) l_s ; thread = (query row, float4 of dh)
 __global__ __launch_bounds__(256) void attention_combine_kernel(const float* __restrict__ part_o, const float* __restrict__ part_ml,
                                                                 float* __restrict__ out, int B, int N, int heads, int nsplit) {
@@ -370,15 +535,20 @@ int launch_attention_f32(const float* qkv, float* out, int B, int N, int heads, 
     FS_REQUIRE(B >= 1 && N >= 1 && heads >= 1, "attention: bad shape");
     const int qtiles = cdiv(N, 32 * ATT_NW);
     const int ns = scratch ? attention_splits(B, N, heads) : 1;
+    // the 32-bit byte offsets of the direct-to-LDS form cover one image's [N][3D] rows; beyond 2 GiB (never in practice) the
+    // register-staged kernel takes over
+    const bool dma = ATT_USE_DMA && (int64_t)N * 3 * heads * ATT_DH * 4 < ((int64_t)1 << 31) && ((uintptr_t)qkv & 15) == 0;
     if (ns == 1) {
-        hipLaunchKernelGGL(attention_f32_kernel<false>, dim3(qtiles, heads, B), dim3(64 * ATT_NW), 0, s, qkv, out, nullptr, nullptr, N, heads,
+        if (dma) hipLaunchKernelGGL(attention_dma_kernel<false>, dim3(qtiles, heads, B), dim3(64 * ATT_NW), 0, s, qkv, out, nullptr, nullptr, N, heads, scale, 1);
+        else hipLaunchKernelGGL(attention_f32_kernel<false>, dim3(qtiles, heads, B), dim3(64 * ATT_NW), 0, s, qkv, out, nullptr, nullptr, N, heads,
                            scale, 1);
         FS_HIP(hipGetLastError());
         return 0;
     }
     float* part_o = scratch;
     float* part_ml = scratch + (size_t)B * heads * ns * N * ATT_DH;
-    hipLaunchKernelGGL(attention_f32_kernel<true>, dim3(qtiles * ns, heads, B), dim3(64 * ATT_NW), 0, s, qkv, out, part_o, part_ml, N, heads,
+    if (dma) hipLaunchKernelGGL(attention_dma_kernel<true>, dim3(qtiles * ns, heads, B), dim3(64 * ATT_NW), 0, s, qkv, out, part_o, part_ml, N, heads, scale, ns);
+    else hipLaunchKernelGGL(attention_f32_kernel<true>, dim3(qtiles * ns, heads, B), dim3(64 * ATT_NW), 0, s, qkv, out, part_o, part_ml, N, heads,
                        scale, ns);
     FS_HIP(hipGetLastError());
     const int64_t total = (int64_t)B * heads * N * 16;
