@@ -337,6 +337,14 @@ def main():
                 "achieved_executed": round(wf_tf, 2), "frac_of_mfma_peak": round(wf_tf / PEAK_F32_MFMA_TFLOPS, 4), "ms_per_step": round(wf["ms"] / prof_steps, 4),
                 "launches_per_step": wf["launches"] // prof_steps, "gflop_executed_per_step": round(wf["flops"] / prof_steps / 1e9, 2),
                 "direct_conv_equivalent_tflops": round(4 * wf_tf, 1)}
+            _, pmc = newest_pmc_summary()
+            if pmc and pmc.get("meta", {}).get("build_id") == build_id():  # the same --pmc passes, same build only
+                for kname, e in pmc.get("kernels", {}).items():
+                    if "wino4_" in kname:
+                        tag = "warp_specialised" if "wino4_ws" in kname else "two_workgroups_per_cu"
+                        result["roofline"]["fused_winograd_kernels"]["pmc_" + tag] = {
+                            k: (round(e[k], 4) if isinstance(e[k], float) else {a: round(b, 4) for a, b in e[k].items()})
+                            for k in ("mfma_utilisation", "l2_hit_rate", "lds_bank_conflict_share_of_lds_cycles", "hbm_bytes_per_launch", "wave_time_shares") if k in e}
 
     if not args.no_extras and world == 1:  # the variants are single-GPU figures: measured by the N = 1 run only
         result["variants"] = variants(args, dev, rdev, net, state, fm, windows, dl, dr, host_masks, host_post)

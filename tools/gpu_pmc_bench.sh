@@ -23,9 +23,11 @@ for f in glob.glob("$O/**/*counter_collection.csv", recursive=True):
         agg[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 out = {}
 for k, cs in agg.items():
-    if not k.startswith("void fs::conv_igemm"):
+    if not (k.startswith("void fs::conv_igemm") or "wino4_" in k):  # the matrix-core kernels: implicit GEMM and the one-kernel Winograd
         continue
     e = {c: {"launches": len(v), "mean": sum(v) / len(v), "sum": sum(v)} for c, v in cs.items()}
+    if "TCC_HIT_sum" in e and e["TCC_HIT_sum"]["sum"] + e.get("TCC_MISS_sum", {"sum": 0})["sum"] > 0:
+        e["l2_hit_rate"] = e["TCC_HIT_sum"]["sum"] / (e["TCC_HIT_sum"]["sum"] + e["TCC_MISS_sum"]["sum"])
     if "FETCH_SIZE" in e and "WRITE_SIZE" in e:
         # rocprofv3 reports KiB; on gfx950 FETCH_SIZE counts 128-B requests as 64 B -> x2 (MI355X_MICROARCH.md, HBM)
         e["hbm_bytes_per_launch"] = (2.0 * e["FETCH_SIZE"]["mean"] + e["WRITE_SIZE"]["mean"]) * 1024.0
@@ -50,6 +52,6 @@ meta = {"build_id": bench.build_id(), "git_head": os.environ.get("GIT_HEAD", "un
                    "SQ_ACTIVE_INST_ANY over SQ_WAVE_CYCLES"}
 json.dump({"meta": meta, "kernels": out}, open("$R/gpurun_out/pmc_bench_summary.json", "w"), indent=1)
 for k, e in out.items():
-    print(k[:60], {c: (round(v["mean"], 1) if isinstance(v, dict) and "mean" in v else v) for c, v in e.items() if c in ("hbm_bytes_per_launch", "wave_time_shares", "lds_bank_conflict_share_of_lds_cycles", "mfma_busy_cycles_per_launch", "mfma_utilisation")})
+    print(k[:60], {c: (round(v["mean"], 1) if isinstance(v, dict) and "mean" in v else v) for c, v in e.items() if c in ("hbm_bytes_per_launch", "wave_time_shares", "lds_bank_conflict_share_of_lds_cycles", "mfma_busy_cycles_per_launch", "mfma_utilisation", "l2_hit_rate")})
 PY
 find $O -name "*kernel_trace.csv" -delete
