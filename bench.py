@@ -234,6 +234,10 @@ def main():
     # ---- data, resident in HBM.  N = 1: BASELINE configs[1], the 4 key-frame windows of ONE clip (clip 0).  N > 1: BASELINE
     # configs[4], this rank's shard of the 64 clips (clip c = seed 1000 + c; rank r owns c = r, r+N, ...), 4 windows each.
     schedule = shard.clip_window_schedule(NUM_CLIPS if world > 1 else 1, CLIP_FRAMES, N_DELTA, rank, world)
+    shard_windows = len(schedule)
+    # only the windows the run will visit are generated and kept resident (step i takes window i mod len): a short run on a big
+    # shard does not spend a minute synthesising clips it never touches
+    schedule = schedule[:max(4, min(shard_windows, max(args.steps, args.warmup, 5)))]
     keys_of = {}
     for c in sorted({c for c, _, _ in schedule}):
         keys_of[c] = synth.make_clip(CLIP_FRAMES, SIZE, seed=1000 + c, only=list(range(0, CLIP_FRAMES, N_DELTA)))
@@ -267,11 +271,11 @@ def main():
                                 "frame_delta=5, 713x713, one window per step per GPU, both key frames segmented per window, "
                                 "argmax uint8 masks copied to host") if world == 1 else
                                (f"BASELINE configs[4]: {NUM_CLIPS} synthetic 713x713 clips sharded by clip over {world} GPUs (rank r owns clips "
-                                f"r, r+{world}, ...: {len(schedule) // 4} clips x 4 key-frame windows on this rank), PSPNet-ResNet50 keyframe + linear "
+                                f"r, r+{world}, ...: {shard_windows // 4} clips x 4 key-frame windows on this rank), PSPNet-ResNet50 keyframe + linear "
                                 "interp, frame_delta=5; one window per step per GPU, the timed steps walk the rank's shard window after "
                                 "window (cyclically), both key frames segmented per window, argmax uint8 masks copied to host"),
                    "frames_per_step_per_gpu": N_DELTA, "clips_total": NUM_CLIPS if world > 1 else 1,
-                   "windows_in_this_ranks_shard": nwin,
+                   "windows_in_this_ranks_shard": shard_windows, "windows_resident_and_visited": nwin,
                    "parallelism": f"{world} independent clip shard(s), no data-path collective"},
         # what the launcher really set up: "nccl" IS RCCL on ROCm; a single process has no process group
         "distributed": {"backend": backend, "rccl_world_size": dist_world if backend == "nccl" else 0, "world_size": dist_world,

@@ -31,6 +31,17 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // F(4,3) B^T d and A^T m on scalars, every multiply-add an explicit fma: all kernel forms then execute the same operations in the
 // same order whatever the optimiser would have contracted -- their results are bit-identical (tests/test_gpu_ops.py), which
 // lets the launcher pick the form by batch size without a frame's result depending on its batch.
+// LDS image of one stage: V[position][tile][16 channels], 64 B per (position, tile) row.  The MFMA A fragment of lane (m, q) is the
+// 16-B chunk q of tile row m; ds_read_b128 is served in four groups of 16 lanes ({0-3,12-15,20-27}, ...) and rows 4 apart share
+// their banks (4 x 64 B = the 64-bank width), so with a linear image every group had 2-4 lanes on the same banks (rocprofv3:
+// SQ_LDS_BANK_CONFLICT = 40 % of the LDS cycles of the first version).  Chunk c of tile row m is therefore stored at chunk
+// c ^ g(m >> 2), g = {0, 2, 3, 1}: within every lane group the four rows of one residue m % 4 then land on four different chunks.
+// Returns the float offset of channel k (0..15) of tile row m inside a position's plane.
+__device__ __forceinline__ int wf_voff(int m, int k) {
+    const int g = (0x78 >> ((m >> 1) & 6)) & 3;  // {0, 2, 3, 1}[(m >> 2) & 3], two bits each, packed in 0b01'11'10'00
+    return m * 16 + 4 * ((k >> 2) ^ g) + (k & 3);
+}
+
 __device__ __forceinline__ void wf_bt(const float d[6], float t[6]) {
     const float s12 = d[1] + d[2], d12 = d[1] - d[2], s34 = d[3] + d[4], d43 = d[4] - d[3], d42 = d[4] - d[2], d31 = d[3] - d[1];
     t[0] = __builtin_fmaf(4.f, d[0], __builtin_fmaf(-5.f, d[2], d[4]));
@@ -155,6 +166,9 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void wino4_fused_kernel(WinoFusedP
     const int n0 = cb * NC;
     const int nstages = p.Cin >> 4;
 
+#ifdef FS_WF_STAGGER  // experiment: de-phase the two workgroups of a CU (dispatch order puts bid and bid + 256 on the same CU)
+    if ((blockIdx.x >> 8) & 1) __builtin_amdgcn_s_sleep(FS_WF_STAGGER);
+#endif
     // ---- transform role: ITEMS x (tile, channel) per sub-chunk; the tile is fixed for the whole kernel
     const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, (unsigned)((long long)p.B * p.H * p.W * p.ld_in * 4), 0x00020000);
     unsigned rowoff[ITEMS][6], coloff[ITEMS][6];
@@ -179,7 +193,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void wino4_fused_kernel(WinoFusedP
     const unsigned b_voff = (unsigned)(((n0 + wn * 16 + m16) * 16 + 4 * q4) * 4);
     const unsigned u_chunk = (unsigned)p.Cout * 64u;              // bytes of one 16-channel slab [Cout][16]
     const unsigned u_pos = (unsigned)(p.Cin >> 4) * u_chunk;      // bytes of one Winograd position
-    const int a_off = (wm * 16 + m16) * 16 + 4 * q4;              // floats, inside one V[xi] plane
+    const int a_off = wf_voff(wm * 16 + m16, 4 * q4);              // floats, inside one V[xi] plane
 
     f32x4 acc[36];
 #pragma unroll
@@ -206,7 +220,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void wino4_fused_kernel(WinoFusedP
 #pragma unroll
                     for (int y = 0; y < 6; ++y) r[y][x] = tc[y];
                 }
-                float* dst = lds + buf * SUB + t + it * NTHR;
+                float* dst = lds + buf * SUB + wf_voff((t + it * NTHR) >> 4, t & 15);
 #pragma unroll
                 for (int y = 0; y < 6; ++y) {  // ... then along x
                     float o[6];
@@ -343,7 +357,7 @@ __global__ __launch_bounds__(512, 2) void wino4_ws_kernel(WinoFusedParams p) {
 #pragma unroll
                     for (int y = 0; y < 6; ++y) d[set][it][y][x] = tc[y];
                 }
-                float* dst = lds + (stage % NB) * SUB + it * 256 + tt;
+                float* dst = lds + (stage % NB) * SUB + wf_voff(it * 16 + (tt >> 4), tt & 15);
 #pragma unroll
                 for (int y = 0; y < 6; ++y) {  // ... then along x
                     float o[6];
@@ -383,7 +397,7 @@ __global__ __launch_bounds__(512, 2) void wino4_ws_kernel(WinoFusedParams p) {
     const unsigned b_voff = (unsigned)(((n0 + wn * 16 + m16) * 16 + 4 * q4) * 4);
     const unsigned u_chunk = (unsigned)p.Cout * 64u;          // bytes of one 16-channel slab [Cout][16]
     const unsigned u_pos = (unsigned)(p.Cin >> 4) * u_chunk;  // bytes of one Winograd position
-    const int a_off = (wm * 16 + m16) * 16 + 4 * q4;
+    const int a_off = wf_voff(wm * 16 + m16, 4 * q4);
 
     f32x4 acc[36];
 #pragma unroll

@@ -69,6 +69,7 @@ def test_bench_launched_directly_with_gpus_2_spawns_its_own_ranks():
     j = _last_json(r.stdout)
     assert j["n_gpus"] == 2 and j["steps"] == 6 and j["distributed"]["world_size"] == 2
     assert "configs[4]" in j["config"]["workload"] and j["config"]["clips_total"] == 64 and j["config"]["windows_in_this_ranks_shard"] == 128
+    assert j["config"]["windows_resident_and_visited"] == 6  # only what the 6 steps visit is synthesised
     assert j["scaling"] == "weak" and abs(j["value"] - 2 * 5 * 1000.0 / j["ms_per_step"]) < 1e-2 * j["value"]
     assert j["parity"]["mask_agreement_vs_reference"] > 0.9999  # rank 0's first window is clip 0 / keys (0, 5): the golden fixture's
     # a launch whose world does not match --gpus is refused with a message, not an assertion error
