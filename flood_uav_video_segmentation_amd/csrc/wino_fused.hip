@@ -166,9 +166,6 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void wino4_fused_kernel(WinoFusedP
     const int n0 = cb * NC;
     const int nstages = p.Cin >> 4;
 
-#ifdef FS_WF_STAGGER  // experiment: de-phase the two workgroups of a CU (dispatch order puts bid and bid + 256 on the same CU)
-    if ((blockIdx.x >> 8) & 1) __builtin_amdgcn_s_sleep(FS_WF_STAGGER);
-#endif
     // ---- transform role: ITEMS x (tile, channel) per sub-chunk; the tile is fixed for the whole kernel
     const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, (unsigned)((long long)p.B * p.H * p.W * p.ld_in * 4), 0x00020000);
     unsigned rowoff[ITEMS][6], coloff[ITEMS][6];
