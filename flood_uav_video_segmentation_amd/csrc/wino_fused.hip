@@ -280,121 +280,128 @@ __device__ unsigned long long fs_wino_trace[32 * 16384];
 #define FS_WT(slot) {}
 #endif
 
-// WM x WN = M waves per workgroup (4): wave (wm, wn) owns tiles 16 wm .. 16 wm + 15 and channels 16 wn .. 16 wn + 15 of the
-// workgroup's 16 WM tiles x 16 WN channels.  Shipped: 1 x 4.  (2 x 2 -- two waves sharing each filter stream through the L1,
-// half the L2 traffic -- was built and measured: the T waves then transform two patches per thread and become the critical
-// path, 100 us against 83 on layer0.3; with the loads pipelined it spills.  Workgroup timelines, tools/probe_wino_trace.hip:
-// an M stage takes 5.1 k cycles for 4.6 k of MFMA issue when the T waves are idle and 6.3-7.4 k while they transform -- the
-// fp32 MFMA runs at the vector rate and the T waves' VALU work does not hide under it.)
+// The kernel is PERSISTENT: one workgroup per CU walks the (tile block, channel block) pairs blk, blk + gridDim.x, ... (the grid is
+// a multiple of the channel blocks, so a workgroup keeps its channel block and its filter stream), and the T waves' run-ahead
+// crosses the block boundary: while the M waves transform and store the outputs of block i (no MFMA work: ~6 k cycles), the T
+// waves already load and transform the first two stages of block i + 1, whose first-touch latency (~7 k cycles) was the other
+// exposed piece of a one-block workgroup.  Stages are counted globally (S = block * stages + stage) for the LDS ring and the
+// barrier schedule; both roles execute exactly `total` barriers.  Measured: layer0.3 91 -> 86 us, layer0.6 164 -> 150 us (the
+// two-workgroup form above still wins there, 80 / 140 us); in the steady state an M stage takes 7-10 k cycles with every CU streaming
+// -- the T waves' transform (7-9 k cycles per stage; s_setprio on them changes nothing) and the M waves' MFMAs do not overlap.
+// (Built and measured before settling on four M waves x 16 channels: two waves sharing each filter stream through the L1 -- half
+// the L2 traffic -- make the T waves transform two patches per thread and become the critical path, 100 us against 83 on
+// layer0.3; with the loads pipelined it spills.  Workgroup timelines, tools/probe_wino_trace.hip: an M stage takes 5.1 k cycles
+// for 4.6 k of MFMA issue when the T waves are idle and 6.3-7.4 k while they transform -- the fp32 MFMA runs at the vector rate
+// and the T waves' VALU work does not hide under it.)
 // PD: filter prefetch distance in position pairs; must divide 18 (a pair's slot is pair % PD in every stage).
-template <int WM, int WN, int PD>
+template <int PD>
 __global__ __launch_bounds__(512, 2) void wino4_ws_kernel(WinoFusedParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    static_assert(WM * WN == 4 && 18 % PD == 0, "four M waves; PD must divide 18");
-    constexpr int NT = 16 * WM, NC = 16 * WN;
-    constexpr int NB = WM == 1 ? 3 : 2;  // LDS stage images in the ring (36 KiB x WM each): the T waves run NB - 1 stages ahead
-    constexpr int SUB = 36 * NT * 16;    // floats of one stage image V[xi][tile][16 ch]
+    static_assert(18 % PD == 0, "PD must divide 18");
+    constexpr int NT = 16, NC = 64, NB = 3;  // LDS stage images in the ring (36 KiB each): the T waves run NB - 1 stages ahead
+    constexpr int SUB = 36 * NT * 16;        // floats of one stage image V[xi][tile][16 ch]
     __shared__ __attribute__((aligned(1024))) float lds[NB * SUB];
     constexpr unsigned BAD = 0x40000000u;
 
     const int t = threadIdx.x, lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6);
     const int ncb = p.Cout / NC;
-    const int cb = blockIdx.x % ncb, tb = blockIdx.x / ncb;
-    const int n0 = cb * NC;
+    const int nblk = ((p.T + NT - 1) / NT) * ncb, G = gridDim.x;  // G % ncb == 0 (launcher)
+    const int n0 = ((int)blockIdx.x % ncb) * NC;
     const int nstages = p.Cin >> 4;
+    const int total = ((nblk - (int)blockIdx.x + G - 1) / G) * nstages;  // global stages of this workgroup
 
     if (wv >= 4) {
-        // ================================================================ T waves: patches -> V, WM (tile, channel) items per thread
+        // ================================================================ T waves: patches -> V, one (tile, channel) per thread and stage
         const int tt = t - 256;
         const __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, (unsigned)((long long)p.B * p.H * p.W * p.ld_in * 4), 0x00020000);
-        unsigned row0[WM], col0[WM], rmask[WM], cmask[WM];  // patch origin (bytes) and which of its 6 rows / columns are inside the image
-#pragma unroll
-        for (int it = 0; it < WM; ++it) {
-            const int tile = tb * NT + it * 16 + (tt >> 4);
+        // byte offsets of the 36 patch elements of this thread's (tile, channel) in the current block (BAD added for rows / columns
+        // outside the image): computed once per block -- the T waves have registers to spare, and every VALU instruction they issue
+        // is one the M wave of the same SIMD cannot overlap (the fp32 MFMA and the VALU share the vector ALUs)
+        unsigned voff[6][6];
+        auto setup_block = [&](int blk) {
+            const int tile = (blk / ncb) * NT + (tt >> 4);
             const bool tv = tile < p.T;
             const int tq = tv ? tile : 0;
             const int tx = tq % p.tw, ty = (tq / p.tw) % p.th, b = tq / (p.tw * p.th);
             const int y0 = 4 * ty - 1, x0 = 4 * tx - 1;
-            row0[it] = (unsigned)(((b * p.H + y0) * p.W) * p.ld_in * 4);
-            col0[it] = (unsigned)((x0 * p.ld_in + (tt & 15)) * 4);
-            rmask[it] = cmask[it] = 0;
 #pragma unroll
-            for (int k = 0; k < 6; ++k) {
-                if (tv && (unsigned)(y0 + k) < (unsigned)p.H) rmask[it] |= 1u << k;
-                if ((unsigned)(x0 + k) < (unsigned)p.W) cmask[it] |= 1u << k;
-            }
-        }
-        const unsigned rstride = (unsigned)(p.W * p.ld_in * 4), cstride = (unsigned)(p.ld_in * 4);
-        // The patches of the NEXT stage are requested before the current one is transformed (two register sets): a transform
-        // never waits for its own loads, only for ones issued a whole transform earlier.
-        float d[2][WM][6][6];
-        auto patch_load = [&](int stage, int set) {
-            const unsigned soff = (unsigned)(stage * 64);
+            for (int y = 0; y < 6; ++y) {
+                const unsigned ro = (tv && (unsigned)(y0 + y) < (unsigned)p.H) ? (unsigned)(((b * p.H + y0 + y) * p.W) * p.ld_in * 4) : BAD;
 #pragma unroll
-            for (int it = 0; it < WM; ++it)
-#pragma unroll
-                for (int y = 0; y < 6; ++y) {
-                    const unsigned ro = row0[it] + (unsigned)y * rstride + (((rmask[it] >> y) & 1u) ? 0u : BAD);
-#pragma unroll
-                    for (int x = 0; x < 6; ++x) {
-                        const unsigned co = col0[it] + (unsigned)x * cstride + (((cmask[it] >> x) & 1u) ? 0u : BAD);
-                        d[set][it][y][x] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(in_rsrc, ro + co, soff, 0));
-                    }
-                }
-        };
-        auto transform = [&](int stage, int set) {
-#pragma unroll
-            for (int it = 0; it < WM; ++it) {
-#pragma unroll
-                for (int x = 0; x < 6; ++x) {  // B^T along y
-                    float col[6], tc[6];
-#pragma unroll
-                    for (int y = 0; y < 6; ++y) col[y] = d[set][it][y][x];
-                    wf_bt(col, tc);
-#pragma unroll
-                    for (int y = 0; y < 6; ++y) d[set][it][y][x] = tc[y];
-                }
-                float* dst = lds + (stage % NB) * SUB + wf_voff(it * 16 + (tt >> 4), tt & 15);
-#pragma unroll
-                for (int y = 0; y < 6; ++y) {  // ... then along x
-                    float o[6];
-                    wf_bt(d[set][it][y], o);
-#pragma unroll
-                    for (int x = 0; x < 6; ++x) dst[(y * 6 + x) * (NT * 16)] = o[x];
-                }
+                for (int x = 0; x < 6; ++x)
+                    voff[y][x] = ro + (((unsigned)(x0 + x) < (unsigned)p.W) ? (unsigned)(((x0 + x) * p.ld_in + (tt & 15)) * 4) : BAD);
             }
         };
-        // stage j is transformed from register set j & 1; loop bodies are written out for both parities (static register indices)
-        auto produce = [&](int j) {
-            if (j & 1) {
-                if (j + 1 < nstages) patch_load(j + 1, 0);
-                transform(j, 1);
+        // The patch of the NEXT stage is requested before the current one is transformed (two register sets): a transform never
+        // waits for its own loads, only for ones issued a whole transform earlier.  Loads are issued in global stage order, so the
+        // (block, stage) of the next load is a pair of counters.
+        float d[2][6][6];
+        int ld_stage = 0, ld_blk = blockIdx.x;
+        auto patch_load = [&](int set) {
+            if (ld_stage == 0) setup_block(ld_blk);
+            const unsigned soff = (unsigned)(ld_stage * 64);
+#pragma unroll
+            for (int y = 0; y < 6; ++y)
+#pragma unroll
+                for (int x = 0; x < 6; ++x) d[set][y][x] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(in_rsrc, voff[y][x], soff, 0));
+            if (++ld_stage == nstages) {
+                ld_stage = 0;
+                ld_blk += G;
+            }
+        };
+        const int v_off = wf_voff(tt >> 4, tt & 15);
+        auto transform = [&](int ring, int set) {
+#pragma unroll
+            for (int x = 0; x < 6; ++x) {  // B^T along y
+                float col[6], tc[6];
+#pragma unroll
+                for (int y = 0; y < 6; ++y) col[y] = d[set][y][x];
+                wf_bt(col, tc);
+#pragma unroll
+                for (int y = 0; y < 6; ++y) d[set][y][x] = tc[y];
+            }
+            float* dst = lds + ring * SUB + v_off;
+#pragma unroll
+            for (int y = 0; y < 6; ++y) {  // ... then along x
+                float o[6];
+                wf_bt(d[set][y], o);
+#pragma unroll
+                for (int x = 0; x < 6; ++x) dst[(y * 6 + x) * (NT * 16)] = o[x];
+            }
+        };
+        // global stage j is transformed from register set j & 1 into ring image j % NB; both parities written out (static register indices)
+        int done = 0, ring = 0;
+        auto produce = [&]() {
+            if (done & 1) {
+                if (done + 1 < total) patch_load(0);
+                transform(ring, 1);
             } else {
-                if (j + 1 < nstages) patch_load(j + 1, 1);
-                transform(j, 0);
+                if (done + 1 < total) patch_load(1);
+                transform(ring, 0);
             }
+            ++done;
+            if (++ring == NB) ring = 0;
         };
         if (wv == 4) FS_WT(16)
-        patch_load(0, 0);
-        produce(0);
+        patch_load(0);
+        produce();
         if (wv == 4) FS_WT(17)
-        int done = 1;  // stages transformed so far
-        for (int s = 0; s < nstages; ++s) {
-            __syncthreads();  // barrier s: stage s is complete, the M waves are done with stage s - 1 -> its image may be overwritten
-            for (; done < nstages && done < s + NB; ++done) produce(done);
-            if (wv == 4 && s < 12) FS_WT(18 + s)
+        for (int S = 0; S < total; ++S) {
+            __syncthreads();  // barrier S: global stage S is complete, the M waves are done with stage S - 1 -> its image may be overwritten
+            while (done < total && done < S + NB) produce();
+            if (wv == 4 && S < 12) FS_WT(18 + S)
         }
         return;
     }
 
     // ================================================================ M waves: 36 positions x 16 tiles x 16 channels each
-    const int wn = wv % WN, wm = wv / WN;
+    const int wn = wv;
     const int m16 = lane & 15, q4 = lane >> 4;
     const __amdgpu_buffer_rsrc_t u_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.U, 0, (unsigned)((long long)36 * p.Cin * p.Cout * 4), 0x00020000);
     const unsigned b_voff = (unsigned)(((n0 + wn * 16 + m16) * 16 + 4 * q4) * 4);
     const unsigned u_chunk = (unsigned)p.Cout * 64u;          // bytes of one 16-channel slab [Cout][16]
     const unsigned u_pos = (unsigned)(p.Cin >> 4) * u_chunk;  // bytes of one Winograd position
-    const int a_off = wf_voff(wm * 16 + m16, 4 * q4);
+    const int a_off = wf_voff(m16, 4 * q4);
 
     f32x4 acc[36];
 #pragma unroll
@@ -409,11 +416,13 @@ __global__ __launch_bounds__(512, 2) void wino4_ws_kernel(WinoFusedParams p) {
     for (int k = 0; k < PD; ++k) load_b(0, k, k);
     if (wv == 0) FS_WT(0)
 
-    for (int s = 0; s < nstages; ++s) {
+    int blk = blockIdx.x, ms = 0, ring = 0;  // block being multiplied, stage inside it, ring image of the global stage
+    for (int S = 0; S < total; ++S) {
         __syncthreads();
-        if (wv == 0 && s == 0) FS_WT(1)
-        const float* vsrc = lds + (s % NB) * SUB + a_off;
-        const bool more = s + 1 < nstages;
+        if (wv == 0 && S == 0) FS_WT(1)
+        const float* vsrc = lds + ring * SUB + a_off;
+        const bool more = S + 1 < total;
+        const int ns = ms + 1 == nstages ? 0 : ms + 1;  // the stage after this one: the next block starts at its stage 0 (same filters)
         f32x4 aq[2][2];
         aq[0][0] = *reinterpret_cast<const f32x4*>(vsrc);
         aq[0][1] = *reinterpret_cast<const f32x4*>(vsrc + NT * 16);
@@ -431,15 +440,21 @@ __global__ __launch_bounds__(512, 2) void wino4_ws_kernel(WinoFusedParams p) {
                 acc[2 * k + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[k & 1][1][e], bq[k % PD][1][e], acc[2 * k + 1], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if (k + PD < 18) load_b(s, k + PD, k % PD);
-            else if (more) load_b(s + 1, k + PD - 18, k % PD);
+            if (k + PD < 18) load_b(ms, k + PD, k % PD);
+            else if (more) load_b(ns, k + PD - 18, k % PD);
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (wv == 0 && s < 12) FS_WT(2 + s)
+        if (wv == 0 && S < 12) FS_WT(2 + S)
+        if (++ring == NB) ring = 0;
+        if (++ms == nstages) {  // block complete: outputs, then the next block's accumulators start from zero
+            wino4_epilogue(acc, p, (blk / ncb) * NT + 4 * q4, n0 + wn * 16 + m16);
+            if (wv == 0 && blk == (int)blockIdx.x) FS_WT(14)
+#pragma unroll
+            for (int g = 0; g < 36; ++g) acc[g] = f32x4(0.f);
+            ms = 0;
+            blk += G;
+        }
     }
-
-    wino4_epilogue(acc, p, tb * NT + wm * 16 + 4 * q4, n0 + wn * 16 + m16);
-    if (wv == 0) FS_WT(14)
 #endif
 }
 
@@ -468,7 +483,10 @@ int launch_wino4_fused(const float* in, int ld_in, const float* U, const float* 
     // one workgroup or none (layer1 / layer2 conv2: 27 / 39 us against 32 / 50).  All forms give bit-identical results (same
     // products, same order), so the choice may depend on the batch.
     if (variant == 0) variant = (int64_t)cdiv(p.T, 16) * ncb > 512 ? 2 : 3;
-    if (variant == 3) hipLaunchKernelGGL((wino4_ws_kernel<1, 4, 6>), dim3(cdiv(p.T, 16) * ncb), dim3(512), 0, s, p);
+    if (variant == 3) {  // persistent: one workgroup per CU, a multiple of the channel blocks
+        const int nblk = cdiv(p.T, 16) * ncb;
+        hipLaunchKernelGGL((wino4_ws_kernel<6>), dim3(std::min(nblk, 256 - 256 % ncb)), dim3(512), 0, s, p);
+    }
     else if (variant == 1) hipLaunchKernelGGL((wino4_fused_kernel<2, 4>), dim3(cdiv(p.T, 32) * ncb), dim3(512), 0, s, p);
     else hipLaunchKernelGGL((wino4_fused_kernel<1, 4>), dim3(cdiv(p.T, 16) * ncb), dim3(256), 0, s, p);
     FS_HIP(hipGetLastError());

@@ -51,8 +51,8 @@ int main(int argc, char** argv) {
     hipDeviceSynchronize();
     float ms = 0;
     hipEventElapsedTime(&ms, e0, e1);
-    const int tiles = B * ((H + 3) / 4) * ((W + 3) / 4), nwg = (tiles + 15) / 16 * (Cout / 64), nst = Cin / 16;
-    printf("shape B=%d %dx%d Cin=%d Cout=%d variant %d: %.1f us per launch, %d workgroups, %.1f TFLOP/s on the matrix cores\n", B, H, W, Cin, Cout, variant,
+    const int tiles = B * ((H + 3) / 4) * ((W + 3) / 4), nblk = (tiles + 15) / 16 * (Cout / 64), nwg = variant == 3 ? std::min(nblk, 256) : nblk, nst = Cin / 16;
+    printf("shape B=%d %dx%d Cin=%d Cout=%d variant %d: %.1f us per launch, %d workgroups (stamps: the FIRST block of each), %.1f TFLOP/s on the matrix cores\n", B, H, W, Cin, Cout, variant,
            ms / iters * 1e3, nwg, 2.0 * 36 * tiles * Cin * Cout / (ms / iters * 1e-3) / 1e12);
     if (variant < 3) return 0;
     std::vector<unsigned long long> tr((size_t)32 * 16384);
