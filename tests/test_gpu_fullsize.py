@@ -478,6 +478,12 @@ def test_crops_fuse_single_pass_equals_per_crop_accumulation():
         assert none is None and torch.equal(only, ref_m)
     with pytest.raises(RuntimeError, match="outside the canvas"):
         ops.crops_fuse(lo_p, lo_n, None, [(0, 0), (0, 63), (60, 0), (100, 63)], (ch, cw), n, True, (H, W))
+    # single frame (lo_next None: flow/base.py's compute_output on one key frame), one crop covering the whole canvas, K = 8
+    lo1 = torch.randn(1, 8, h, w, generator=g).cuda()
+    c1, m1 = ops.crops_fuse(lo1, None, None, [(0, 0)], (ch, cw), 1, True, (ch, cw), want_canvas=True, want_mask=True)
+    ref1 = torch.softmax(F.interpolate(lo1.cpu(), (ch, cw), mode="bilinear", align_corners=True), 1).double()
+    assert c1.shape == (1, 8, ch, cw) and (c1.cpu() - ref1).abs().max().item() < 1e-6
+    assert (m1.cpu() == ref1.max(1)[1].to(torch.uint8)).float().mean().item() > 0.9999
 
 
 def test_crop_grids_identity_block_range_and_edge_cases():

@@ -325,6 +325,8 @@ WINO_FUSED_TOL = 3e-5  # F(4x4,3x3) in fp32 at Cin <= 256: measured <= 1e-5 (gpu
     (1, 9, 9, 256, 64, False),
     (1, 179, 179, 64, 64, True),     # layer1 conv2 of a 713x713 frame
     (1, 357, 357, 64, 128, True),    # the deep stem's layer0.6 of a 713x713 frame
+    (1, 20, 20, 96, 64, False),      # six K stages (not a power of two)
+    (2, 70, 66, 32, 192, True),      # three channel blocks: the persistent form's grid must stay a multiple of 3 (630 blocks on 255 workgroups)
 ])
 @pytest.mark.parametrize("variant", [0, 1, 2, 3])
 def test_winograd_fused_conv3x3(case, variant):
