@@ -276,3 +276,35 @@ def test_reserve_then_no_forward_grows_the_workspace():
     dl.decoder(dl.encoder(x[:, :, :, :].new_zeros(2, 3, 193, 193)))
     dl.segment(x.new_zeros(1, 3, 193, 193))
     assert dl._hip_net.reserved_bytes() == r1
+
+
+def test_first_forward_after_reserve_is_hip_graph_capturable():
+    """fs_reserve's contract from the caller's side: on a FRESH handle, reserve, then capture the very first forward (both key
+    frames + the fused tail) into a HIP graph -- a capture fails on any hipMalloc / hipFree / device synchronisation, so this is
+    the strongest check that nothing of the kind is left in a reserved forward (lazily built Winograd banks included) -- and the
+    replay gives the eager result bit for bit."""
+    from flood_uav_video_segmentation_amd import ops
+
+    state = synth.make_pspnet_state(50, 5, seed=0)
+    net = FlowPSPNet(HP(50, 5)).eval()
+    net.load_state_dict(state)
+    keys = synth.make_clip(2, 193, seed=12).cuda()
+    dl, dr = [[g.cuda() for g in gs] for gs in synth.dummy_grids(5)]
+    net.reserve(2, 193, 193)
+
+    def window():
+        lows = net.segment(keys[0:1], keys[1:2])
+        return ops.seg_tail(lows[0:1], lows[1:2], dl, dr, 5, (193, 193), True, want_logits=True, want_mask=True)
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(g, stream=side):  # NO warm-up forward before the capture: the reserve alone must suffice
+            logits, mask = window()
+    torch.cuda.synchronize()
+    g.replay()
+    torch.cuda.synchronize()
+    got_l, got_m = logits.clone(), mask.clone()
+    ref_l, ref_m = window()
+    assert torch.equal(got_l, ref_l) and torch.equal(got_m, ref_m)
