@@ -32,11 +32,13 @@ def test_conv_kernel_waits_for_its_lds_dma_before_every_barrier(tmp_path):
     an explicit s_waitcnt; this test checks the ISA: every s_barrier of every instantiation is preceded by vmcnt(0)."""
     dis = _device_disassembly(str(tmp_path))
     kernels = re.split(r"\n(?=[0-9a-f]+ <[^>]+>:)", dis)
-    checked = 0
+    checked = attention = 0
     for k in kernels:
         head = k.split("\n", 1)[0]
-        if "conv_igemm_dma_f32" not in head:
+        # round 3: the attention kernel stages K / V the same way (attention_dma_kernel) and is held to the same rule
+        if "conv_igemm_dma_f32" not in head and "attention_dma_kernel" not in head:
             continue
+        attention += "attention_dma_kernel" in head
         lines = [l.split("\t", 1)[-1].strip() if "\t" in l else l.strip() for l in k.splitlines()[1:]]
         ops = [re.sub(r"\s*//.*", "", l) for l in lines if l]
         barriers = [i for i, o in enumerate(ops) if o.startswith("s_barrier")]
@@ -47,4 +49,5 @@ def test_conv_kernel_waits_for_its_lds_dma_before_every_barrier(tmp_path):
             assert any("lgkmcnt(0)" in o for o in window), f"{head}: s_barrier without a preceding s_waitcnt lgkmcnt(0): {ops[max(0, i - 4):i + 1]}"
         assert any("buffer_load_dwordx4" in o and "lds" in o for o in ops), f"{head}: the direct-to-LDS loads are gone"
         checked += 1
-    assert checked >= 5, f"expected the five tile instantiations, found {checked}"
+    assert checked - attention >= 5, f"expected the five tile instantiations, found {checked - attention}"
+    assert attention == 2, f"expected both attention_dma_kernel instantiations (split / no split), found {attention}"
