@@ -242,6 +242,9 @@ int launch_attention_f32(const float* qkv, float* out, int B, int N, int heads, 
 // masks[b][k][i] = LayerNorm_K( <pp[b][i]/|pp|, cc[b][N+k]/|cc|> )  (segm/model/decoder.py:90-100), NCHW out
 // out[r][c] = sum_s part[s][r][c] + bias[c] (+ res[r][c]): merges the split-K partial products of a Linear
 int launch_splitk_combine(const float* part, int nsplit, const float* bias, const float* res, float* out, int rows, int N, hipStream_t s);
+// the same merge + nn.LayerNorm(N) of the merged rows into ln_out, one pass (fc2 of block i feeding norm1 of block i + 1)
+int launch_splitk_combine_ln(const float* part, int nsplit, const float* bias, const float* res, float* out, const float* gamma, const float* beta,
+                             float* ln_out, int rows, int N, hipStream_t s);
 int launch_mask_head(const float* pp, const float* cc, const float* gamma, const float* beta, float* out, int B, int N, int K,
                      int D, hipStream_t s);
 

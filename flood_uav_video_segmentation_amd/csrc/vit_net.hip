@@ -58,9 +58,12 @@ int linear_splits(const Linear& l, int rows_per_image, int act) {
 }
 
 // out[rows][l.out] = act(in[rows][l.in] @ W^T + b (+ res))
+// ln / ln_out: when the Linear is split-K, the merge pass also writes LayerNorm(ln)(out) into ln_out (the next block's norm1) and
+// *ln_done is set; otherwise the caller runs that LayerNorm itself.
 int run_linear(fs_net* h, const Linear& l, const float* in, int rows, float* out, const float* res, int act, hipStream_t s, float* part = nullptr,
-               int rows_per_image = 0) {
+               int rows_per_image = 0, const LNorm* ln = nullptr, float* ln_out = nullptr, bool* ln_done = nullptr) {
     const int split = part ? linear_splits(l, rows_per_image ? rows_per_image : rows, act) : 0;
+    if (ln_done) *ln_done = false;
     if (split) {
         ConvParams p{};
         p.in = in; p.ld_in = l.in; p.wgt = l.w; p.ld_wgt = l.in; p.out = part; p.ld_out = l.out;
@@ -73,7 +76,12 @@ int run_linear(fs_net* h, const Linear& l, const float* in, int rows, float* out
         const double flops = 2.0 * rows * (double)l.in * l.out;
         FS_TRY(prof_begin(h, l.name, conv_igemm_tile_name(p), flops, 4.0 * ((double)rows * (l.in + (split + 1.0) * l.out) + (double)l.in * l.out), s));
         FS_TRY(launch_conv_igemm(p, s));
-        FS_TRY(launch_splitk_combine(part, split, l.b, res, out, rows, l.out, s));
+        if (ln && ln_out && ln->D == l.out) {
+            FS_TRY(launch_splitk_combine_ln(part, split, l.b, res, out, ln->g, ln->b, ln_out, rows, l.out, s));
+            if (ln_done) *ln_done = true;
+        } else {
+            FS_TRY(launch_splitk_combine(part, split, l.b, res, out, rows, l.out, s));
+        }
         return prof_end(h, s);
     }
     ConvParams p{};
@@ -134,10 +142,13 @@ int vit_workspace(fs_net* h, int B, int tokens, VitWs* ws) {
     return 0;
 }
 
-// pre-LN transformer block, in place on X (blocks.py:89-95)
-int run_block(fs_net* h, const VitBlock& blk, const VitWs& ws, int B, int tokens, hipStream_t s) {
+// pre-LN transformer block, in place on X (blocks.py:89-95).  n1_done: ws.Xn already holds norm1(X) (written by the previous block's
+// fc2 merge pass); next_n1: the following block's norm1, computed by this block's fc2 merge when that Linear is split-K
+// (*next_done tells the caller).
+int run_block(fs_net* h, const VitBlock& blk, const VitWs& ws, int B, int tokens, hipStream_t s, bool n1_done = false, const LNorm* next_n1 = nullptr,
+              bool* next_done = nullptr) {
     const int D = h->cfg.d_model, heads = D / 64, rows = B * tokens;
-    FS_TRY(run_norm(h, blk.n1, ws.X, ws.Xn, rows, tokens, 0, s));
+    if (!n1_done) FS_TRY(run_norm(h, blk.n1, ws.X, ws.Xn, rows, tokens, 0, s));
     FS_TRY(run_linear(h, blk.qkv, ws.Xn, rows, ws.QKV, nullptr, 0, s));
     const double aflops = 4.0 * B * heads * (double)tokens * tokens * 64;
     FS_TRY(prof_begin(h, blk.qkv.name + ".attention", "attention_f32", aflops, 4.0 * rows * 4.0 * D, s));
@@ -146,7 +157,18 @@ int run_block(fs_net* h, const VitBlock& blk, const VitWs& ws, int B, int tokens
     FS_TRY(run_linear(h, blk.proj, ws.A, rows, ws.X, ws.X, 0, s, ws.part, tokens));  // x = x + proj(attn)
     FS_TRY(run_norm(h, blk.n2, ws.X, ws.Xn, rows, tokens, 0, s));
     FS_TRY(run_linear(h, blk.fc1, ws.Xn, rows, ws.Hd, nullptr, 2, s));       // GELU
-    FS_TRY(run_linear(h, blk.fc2, ws.Hd, rows, ws.X, ws.X, 0, s, ws.part, tokens));  // x = x + mlp(x)
+    FS_TRY(run_linear(h, blk.fc2, ws.Hd, rows, ws.X, ws.X, 0, s, ws.part, tokens, next_n1, ws.Xn, next_done));  // x = x + mlp(x) (+ the next norm1)
+    return 0;
+}
+
+// a stack of blocks on X: each block's fc2 merge also produces the next block's norm1 where it can
+int run_blocks(fs_net* h, const std::vector<VitBlock>& blocks, const VitWs& ws, int B, int tokens, hipStream_t s) {
+    bool have_n1 = false;
+    for (size_t i = 0; i < blocks.size(); ++i) {
+        bool next = false;
+        FS_TRY(run_block(h, blocks[i], ws, B, tokens, s, have_n1, i + 1 < blocks.size() ? &blocks[i + 1].n1 : nullptr, &next));
+        have_n1 = next;
+    }
     return 0;
 }
 
@@ -239,7 +261,7 @@ int vit_encoder(fs_handle h, const FrameSrc& src, int B, int H, int W, float* ou
     FS_TRY(prof_end(h, s));
     FS_TRY(run_linear(h, h->patch_embed, ws.patches, B * N, ws.emb, nullptr, 0, s));
     FS_TRY(launch_vit_assemble(ws.emb, h->cls_token, pos, ws.X, B, N, D, s));
-    for (const VitBlock& blk : h->enc_blocks) FS_TRY(run_block(h, blk, ws, B, N + 1, s));
+    FS_TRY(run_blocks(h, h->enc_blocks, ws, B, N + 1, s));
     return run_norm(h, h->enc_norm, ws.X, out_tokens, B * (N + 1), N + 1, 1, s);  // final norm, cls token dropped
 }
 
@@ -250,7 +272,7 @@ int vit_decoder(fs_handle h, const float* tokens, int B, int gh, int gw, float* 
     FS_TRY(vit_workspace(h, B, N + 1 + K, &ws));
     FS_TRY(run_linear(h, h->proj_dec, tokens, B * N, ws.emb, nullptr, 0, s));
     FS_TRY(launch_dec_assemble(ws.emb, h->cls_emb, ws.X, B, N, K, D, s));
-    for (const VitBlock& blk : h->dec_blocks) FS_TRY(run_block(h, blk, ws, B, T, s));
+    FS_TRY(run_blocks(h, h->dec_blocks, ws, B, T, s));
     FS_TRY(run_norm(h, h->dec_norm, ws.X, ws.Xn, B * T, T, 0, s));
     FS_TRY(run_linear(h, h->proj_patch, ws.Xn, B * T, ws.A, nullptr, 0, s));     // all rows; only the patch rows are read
     FS_TRY(run_linear(h, h->proj_classes, ws.Xn, B * T, ws.QKV, nullptr, 0, s)); // all rows; only the class rows are read

@@ -578,6 +578,73 @@ int launch_splitk_combine(const float* part, int nsplit, const float* bias, cons
     return 0;
 }
 
+// The same merge followed by the next block's LayerNorm in one pass (blocks.py:89-95: x = x + mlp(norm2(x)) of block i is the input
+// of norm1 of block i + 1): one wave per row, D <= 1024; the merged row goes to `out`, its LayerNorm to `ln_out`.  The row never
+// returns from HBM between the two, and a launch disappears per block.  Same operations in the same order as splitk_combine_kernel
+// followed by layernorm_kernel, hence bit-identical to the two launches.
+__global__ __launch_bounds__(256) void splitk_combine_ln_kernel(const float* __restrict__ part, int nsplit, const float* __restrict__ bias,
+                                                                const float* __restrict__ res, float* __restrict__ out, const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta, float* __restrict__ ln_out, int rows, int D4) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int64_t total4 = (int64_t)rows * D4;
+    f32x4 v[4];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = lane + 64 * i;
+        v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (c < D4) {
+            const int64_t idx = (int64_t)row * D4 + c;
+            f32x4 a = reinterpret_cast<const f32x4*>(part)[idx];
+            for (int sidx = 1; sidx < nsplit; ++sidx) a += reinterpret_cast<const f32x4*>(part)[(int64_t)sidx * total4 + idx];
+            if (bias) a += reinterpret_cast<const f32x4*>(bias)[c];
+            if (res) a += reinterpret_cast<const f32x4*>(res)[idx];
+            reinterpret_cast<f32x4*>(out)[idx] = a;
+            v[i] = a;
+        }
+        sum += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
+    const float mean = sum / (float)(D4 * 4);
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (lane + 64 * i < D4) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float d = v[i][e] - mean;
+                sq += d * d;
+            }
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) sq += __shfl_xor(sq, off, 64);
+    const float rstd = 1.f / sqrtf(sq / (float)(D4 * 4) + 1e-5f);
+    f32x4* y = reinterpret_cast<f32x4*>(ln_out) + (size_t)row * D4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = lane + 64 * i;
+        if (c < D4) {
+            const f32x4 g = reinterpret_cast<const f32x4*>(gamma)[c], bt = reinterpret_cast<const f32x4*>(beta)[c];
+            f32x4 r;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) r[e] = (v[i][e] - mean) * rstd * g[e] + bt[e];
+            y[c] = r;
+        }
+    }
+}
+
+int launch_splitk_combine_ln(const float* part, int nsplit, const float* bias, const float* res, float* out, const float* gamma, const float* beta,
+                             float* ln_out, int rows, int N, hipStream_t s) {
+    FS_REQUIRE(part && out && ln_out && gamma && beta && nsplit >= 2 && rows >= 1 && N % 4 == 0 && N <= 1024, "splitk_combine_ln: bad arguments");
+    hipLaunchKernelGGL(splitk_combine_ln_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, s, part, nsplit, bias, res, out, gamma, beta, ln_out, rows, N / 4);
+    FS_HIP(hipGetLastError());
+    return 0;
+}
+
 // ------------------------------------------------------------------ mask head: one wave per patch token
 __global__ __launch_bounds__(256) void mask_head_kernel(const float* __restrict__ pp, const float* __restrict__ cc,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
