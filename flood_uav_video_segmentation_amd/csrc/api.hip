@@ -255,15 +255,17 @@ FS_API int fs_pack_conv_weight(const float* oihw, float* ohwi, int O, int I, int
     if (!oihw || !ohwi || O < 1 || I < 1 || KH < 1 || KW < 1) return fs::fail("fs_pack_conv_weight: bad arguments");
     return fs::launch_pack_oihw_to_ohwi(oihw, ohwi, O, I, KH, KW, S(stream));
 }
-FS_API int fs_conv2d_nhwc(const float* in, int ld_in, const float* wgt_ohwi, const float* scale, const float* shift,
-                          const float* res, int ld_res, float* out, int ld_out, int B, int H, int W, int Cin, int Cout, int KH,
-                          int KW, int stride, int pad, int dil, int relu, int tile, fs_stream stream) {
-    if (!in || !wgt_ohwi || !out || B < 1 || H < 1 || W < 1 || stride < 1 || dil < 1 || pad < 0)
+static int conv2d_entry(const float* in, int ld_in, const float* wgt_ohwi, const void* wgt3, const float* scale, const float* shift,
+                        const float* res, int ld_res, float* out, int ld_out, int B, int H, int W, int Cin, int Cout, int KH,
+                        int KW, int stride, int pad, int dil, int relu, int tile, fs_stream stream) {
+    if (!in || (!wgt_ohwi && !wgt3) || !out || B < 1 || H < 1 || W < 1 || stride < 1 || dil < 1 || pad < 0)
         return fs::fail("fs_conv2d_nhwc: bad arguments");
     fs::ConvParams p{};
     p.in = in;
     p.ld_in = ld_in;
     p.wgt = wgt_ohwi;
+    p.wgt3 = wgt3;
+    p.plane_bytes = (unsigned)((size_t)Cout * KH * KW * Cin * 2);
     p.scale = scale;
     p.shift = shift;
     p.res = res;
@@ -289,6 +291,20 @@ FS_API int fs_conv2d_nhwc(const float* in, int ld_in, const float* wgt_ohwi, con
         return fs::fail("fs_conv2d_nhwc: tile must be 0..5, optionally | FS_CONV_CHUNK_MAJOR (got 0x%x)", tile);
     p.korder = (tile & FS_CONV_CHUNK_MAJOR) ? 1 : 0;
     return fs::launch_conv_igemm(p, S(stream), tile & ~FS_CONV_CHUNK_MAJOR);
+}
+FS_API int fs_conv2d_nhwc(const float* in, int ld_in, const float* wgt_ohwi, const float* scale, const float* shift,
+                          const float* res, int ld_res, float* out, int ld_out, int B, int H, int W, int Cin, int Cout, int KH,
+                          int KW, int stride, int pad, int dil, int relu, int tile, fs_stream stream) {
+    return conv2d_entry(in, ld_in, wgt_ohwi, nullptr, scale, shift, res, ld_res, out, ld_out, B, H, W, Cin, Cout, KH, KW, stride, pad, dil, relu,
+                        tile, stream);
+}
+FS_API int fs_split_bf16x3(const float* w, int64_t n, void* planes, fs_stream stream) { return fs::launch_split_bf16x3(w, n, planes, S(stream)); }
+FS_API int fs_conv2d_nhwc_split(const float* in, int ld_in, const void* wgt_planes, const float* scale, const float* shift,
+                                const float* res, int ld_res, float* out, int ld_out, int B, int H, int W, int Cin, int Cout, int KH,
+                                int KW, int stride, int pad, int dil, int relu, int tile, fs_stream stream) {
+    if (!wgt_planes) return fs::fail("fs_conv2d_nhwc_split: bad arguments");
+    return conv2d_entry(in, ld_in, nullptr, wgt_planes, scale, shift, res, ld_res, out, ld_out, B, H, W, Cin, Cout, KH, KW, stride, pad, dil,
+                        relu, tile, stream);
 }
 FS_API size_t fs_winograd_workspace_floats(int B, int H, int W, int Cin, int Cout, int dil, int tile_m) {
     if (B < 1 || H < 1 || W < 1 || dil < 1 || !(tile_m == 0 || tile_m == 4 || tile_m == 6)) return 0;

@@ -31,6 +31,10 @@ namespace fs {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // ---------------------------------------------------------------------------------------------------------
 // conv_igemm_dma_f32: the tiles go global -> LDS DIRECTLY
@@ -109,6 +113,16 @@ __device__ __forceinline__ void igemm_epilogue(const f32x16 (&acc)[TM][TN], cons
 }
 #endif
 
+// (x0, x1) -> the packed bf16 pairs (h, m, l) with x = h + m + l exactly: v_cvt_pk_bf16_f32 rounds to nearest even, the residues
+// x - h and x - h - m are exact in fp32 (they fit in 16 / 8 significant bits).
+__device__ __forceinline__ void split3_pair(float x0, float x1, unsigned& hu, unsigned& mu, unsigned& lu) {
+    hu = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){x0, x1}, bf16x2));
+    const float r0 = x0 - __builtin_bit_cast(float, hu << 16), r1 = x1 - __builtin_bit_cast(float, hu & 0xffff0000u);
+    mu = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){r0, r1}, bf16x2));
+    const float q0 = r0 - __builtin_bit_cast(float, mu << 16), q1 = r1 - __builtin_bit_cast(float, mu & 0xffff0000u);
+    lu = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){q0, q1}, bf16x2));
+}
+
 #ifdef FS_TRACE
 // tools/probe_conv_trace.hip only (never in libfloodseg.so): per-workgroup timeline, 8 x u64 per workgroup:
 // [0] start, [1] first stage landed, [2] main loop done, [3] epilogue done (shader clock, s_memtime),
@@ -131,7 +145,7 @@ __device__ unsigned long long fs_trace_buf[8 * 65536];
 // DUAL = true: concatenated-K GEMM of two 1x1 convs (ConvParams::in2): the K chunks beyond the first conv's come from a second
 // map with its own pixel stride / conv stride.  A separate instantiation (no residual input: the shortcut IS the second
 // operand), so the plain kernel's register budget -- 252 of the 256 VGPRs that let two workgroups share a CU -- is untouched.
-template <int BM, int BN, int WGM = 2, int WGN = 2, bool DUAL = false>
+template <int BM, int BN, int WGM = 2, int WGN = 2, bool DUAL = false, bool SPLIT = false>
 __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_dma_f32(ConvParams p, int tiles_m, int tiles_n) {
 #if defined(__HIP_DEVICE_COMPILE__)  // the buffer-resource builtins do not exist in the host pass, which only needs the launch stub
     constexpr int BK = 32;
@@ -139,9 +153,13 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_dma_f32(ConvParams 
     constexpr int RSTEP = NT / 8;        // tile rows staged per DMA pass (8 lanes per 128-B row)
     constexpr int WM = BM / WGM, WN = BN / WGN;
     constexpr int TM = WM / 32, TN = WN / 32;
-    constexpr int RA = BM / RSTEP, RB = BN / RSTEP;
+    // SPLIT: a filter row of a chunk is 3 planes x 32 bf16 = 3 x 64 B; one DMA wave-instruction covers 16 rows of one plane
+    constexpr int BPL = BN * 16;  // floats of LDS per filter plane and stage
+    constexpr int RA = BM / RSTEP, RB = SPLIT ? 3 * (BN / 16) / (NT / 64) : BN / RSTEP;
+    constexpr int RB1 = SPLIT ? (BN / 16) / (NT / 64) : RB;  // of them per plane
+    static_assert(!SPLIT || (BN / 16) % (NT / 64) == 0, "split filters: every wave stages whole 16-row groups");
     constexpr int PM = 8;  // m-tiles per raster panel (panels sized to the ~64 tiles co-resident on an XCD: same time, +3 % L2 misses)
-    constexpr int STAGE = (BM + BN) * BK;
+    constexpr int STAGE = BM * BK + (SPLIT ? 3 * BPL : BN * BK);
     __shared__ __attribute__((aligned(1024))) float lds[2 * STAGE];
     FS_TRACE_DECL
 
@@ -162,6 +180,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_dma_f32(ConvParams 
     const int m0 = (panel * PM + within % prow) * BM, n0 = (within / prow) * BN;
     p.in += (long long)grp * p.g_in;
     p.wgt += (long long)grp * p.g_wgt;
+    if (SPLIT) p.wgt3 = (const char*)p.wgt3 + (long long)grp * p.g_wgt * 2;  // the group's rows inside every plane
     p.out += (long long)grp * p.g_out;
 
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
@@ -183,7 +202,8 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_dma_f32(ConvParams 
     const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(p.in - pad_off), 0, a_bytes, 0x00020000);
     const int ldw = p.ld_wgt ? p.ld_wgt : K;  // filter row stride (> K for a K-slice of wider rows)
     const __amdgpu_buffer_rsrc_t b_rsrc =
-        __builtin_amdgcn_make_buffer_rsrc((void*)p.wgt, 0, (unsigned)((((long long)p.Cout - 1) * ldw + K) * 4), 0x00020000);
+        SPLIT ? __builtin_amdgcn_make_buffer_rsrc((void*)p.wgt3, 0, 2u * p.plane_bytes + (unsigned)((((long long)p.Cout - 1) * ldw + K) * 2), 0x00020000)
+              : __builtin_amdgcn_make_buffer_rsrc((void*)p.wgt, 0, (unsigned)((((long long)p.Cout - 1) * ldw + K) * 4), 0x00020000);
     unsigned a_voff[RA], a_mask[RA];
     if (p.KH * p.KW == 1 && p.stride == 1 && p.pad == 0) {
         // 1x1 stride-1 conv / plain GEMM (most launches): output pixel m IS input pixel m, no coordinate split needed
@@ -231,11 +251,22 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_dma_f32(ConvParams 
             a2_voff[j] = (unsigned)((((b * p.H2 + oy * p.stride2) * p.W2 + ox * p.stride2) * p.ld_in2 + swz * 4) * 4);
         }
     }
-    unsigned b_voff[RB];
+    unsigned b_voff[RB1];
+    if (SPLIT) {
+        // lane -> (row, 16-B slot) of a 16-row x 64-B group; the slot holds piece slot ^ ((row >> 2) & 3) of the row's 32 bf16, which
+        // makes the fragment reads (16 consecutive rows, one piece) hit 16 different 16-B columns of the 256-B bank row
 #pragma unroll
-    for (int j = 0; j < RB; ++j) {
-        const int n = n0 + r0 + RSTEP * j;
-        b_voff[j] = n < p.Cout ? (unsigned)((n * ldw + swz * 4) * 4) : SENT;
+        for (int j = 0; j < RB1; ++j) {
+            const int row = 16 * (wv + (NT / 64) * j) + (lane >> 2);
+            const int n = n0 + row;
+            b_voff[j] = n < p.Cout ? (unsigned)(n * ldw * 2 + (((lane & 3) ^ ((row >> 2) & 3)) * 16)) : SENT;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < RB1; ++j) {
+            const int n = n0 + r0 + RSTEP * j;
+            b_voff[j] = n < p.Cout ? (unsigned)((n * ldw + swz * 4) * 4) : SENT;
+        }
     }
 
     f32x16 acc[TM][TN];
@@ -264,6 +295,11 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_dma_f32(ConvParams 
             __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (__attribute__((address_space(3))) void*)(lds + (STG) * STAGE + (8 * wv_u + RSTEP * j) * BK), \
                                                      16, vo, a_soff, 0, 0);                                       \
         }                                                                                                         \
+    } else if (SPLIT) {                                                                                           \
+        const int jj = (ROW_) >= RA ? (ROW_) - RA : 0;                                                            \
+        const int pl = jj / RB1, j = jj % RB1;                                                                    \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(b_rsrc, (__attribute__((address_space(3))) void*)(lds + (STG) * STAGE + BM * BK + pl * BPL + (wv_u + (NT / 64) * j) * 256), \
+                                                 16, b_voff[j], b_soff + (unsigned)pl * p.plane_bytes, 0, 0);     \
     } else {                                                                                                      \
         const int j = (ROW_) >= RA ? (ROW_) - RA : 0;                                                             \
         __builtin_amdgcn_raw_ptr_buffer_load_lds(b_rsrc, (__attribute__((address_space(3))) void*)(lds + (STG) * STAGE + BM * BK + (8 * wv_u + RSTEP * j) * BK), \
@@ -285,7 +321,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_dma_f32(ConvParams 
         const unsigned a_soff = second ? (unsigned)((fetch - nchunks1) * 128)                                     \
                                        : (unsigned)((((tap_r * p.W + tap_s) * p.dil) * p.ld_in + cc * 32) * 4);  \
         _Pragma("unroll") for (int rw = 0; rw < RA + RB; ++rw) { FS_DMA_ROW(STG, rw) }                            \
-        b_soff += 128;                                                                                            \
+        b_soff += SPLIT ? 64 : 128;                                                                               \
     }
 
 #define FS_FRAGS(STG, S_, A_, B_)                                                                                 \
@@ -329,6 +365,103 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_dma_f32(ConvParams 
         FS_DMA_ALL(1)
         FS_DMA_ADVANCE()
     }
+    if constexpr (SPLIT) {
+        // Split operands: every fp32 value x is the exact sum h + m + l of three bf16 terms (h = bf16(x), m = bf16(x - h),
+        // l = bf16(x - h - m), round to nearest even; 3 x 8 significant bits with signed residues cover the 24 of fp32).  The filters
+        // arrive split (three planes); the pixels are split here, in registers, right after the fragment read.  Of the nine cross
+        // products the six of order <= 2^-16 go to the bf16 matrix pipe (v_mfma_f32_32x32x16_bf16: exact products, fp32 accumulate):
+        //   x * w = hh + (hm + mh) + (mm + hl + lh) + [ml + lm + ll <= 2^-23 |x w|, dropped: below the rounding of one fp32 add]
+        // A chunk of 32 k = two MFMA steps of 16 k; lane (i, hh) owns k = 16 s + 8 hh .. + 7 of row i in both operands.
+        bf16x8 A3[TM][3], B3[TN][3], A3n[TM][3], B3n[TN][3];
+        f32x4 araw[TM][2];
+        u32x4 ah[TM][3];
+#define FS_READ3(STG, S_, RAW_, B_)                                                                               \
+    {                                                                                                             \
+        const float* a_src = lds + (STG) * STAGE;                                                                 \
+        const float* b_src = a_src + BM * BK;                                                                     \
+        const int c0 = (4 * (S_) + 2 * hh) ^ sw;                                                                  \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                                          \
+            RAW_[i][0] = *reinterpret_cast<const f32x4*>(&a_src[(wm * WM + i * 32 + l31) * BK + 4 * c0]);         \
+            RAW_[i][1] = *reinterpret_cast<const f32x4*>(&a_src[(wm * WM + i * 32 + l31) * BK + 4 * (c0 ^ 1)]);   \
+        }                                                                                                         \
+        const int bslot = (2 * (S_) + hh) ^ ((l31 >> 2) & 3);                                                     \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                            \
+            _Pragma("unroll") for (int pl = 0; pl < 3; ++pl)                                                      \
+                B_[j][pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(&b_src[pl * BPL + (wn * WN + j * 32 + l31) * 16 + 4 * bslot])); \
+    }
+        // One MFMA step: 6 TM TN MFMAs (32 cycles each on the SIMD's matrix pipe, 8 of them holding the issue port) with the split
+        // of the NEXT step's pixels threaded through them in program order -- every slot is fenced (sched_barrier), because the
+        // compiler otherwise issues the MFMAs back to back and the ~36 TM VALU instructions of the split after them.  Units of the
+        // split: level 0 of every pair (cvt_pk, two unpacks, subtract), then level 1 of every pair, one unit per slot from slot S0 on
+        // (the fragment reads land under the first slots); a pair's final cvt_pk rides in the slot after its level 1.
+        constexpr int NS = 6 * TM * TN, NP = 4 * TM, NU = 3 * NP, S0 = NS >= 24 ? 4 : NS / 6;
+        float rq[NP][2];
+#define FS_STEP3(A_, B_, RAW_, AN_)                                                                               \
+    _Pragma("unroll") for (int k = 0; k < NS; ++k) {                                                              \
+        constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};                                     \
+        const int term = k / (TM * TN), i_ = (k % (TM * TN)) / TN, j_ = k % TN;                                   \
+        acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_[i_][PA[term]], B_[j_][PB[term]], acc[i_][j_], 0, 0, 0); \
+        _Pragma("unroll") for (int u = 0; u < NU; ++u) {                                                          \
+            const int lvl = u / NP, pr = u % NP, pi = pr / 4, pe = pr % 4;                                        \
+            const int v_ = lvl < 2 ? u : NP + pr;  /* level unit (of the pair's level 1 for a final) */            \
+            const int sl = S0 + (2 * NP <= NS - S0 ? v_ : v_ * (NS - S0) / (2 * NP));                             \
+            if ((lvl < 2 ? sl : (sl + 1 < NS ? sl + 1 : NS - 1)) != k) continue;                                  \
+            const float x0 = lvl == 0 ? RAW_[pi][pe >> 1][2 * (pe & 1)] : rq[pr][0];                              \
+            const float x1 = lvl == 0 ? RAW_[pi][pe >> 1][2 * (pe & 1) + 1] : rq[pr][1];                          \
+            unsigned pk = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){x0, x1}, bf16x2));         \
+            asm volatile("" : "+v"(pk));  /* anchors the unit in THIS slot: the optimiser would sink it to its use */ \
+            ah[pi][lvl][pe] = pk;                                                                                 \
+            if (lvl < 2) {                                                                                        \
+                rq[pr][0] = x0 - __builtin_bit_cast(float, pk << 16);                                             \
+                rq[pr][1] = x1 - __builtin_bit_cast(float, pk & 0xffff0000u);                                     \
+            }                                                                                                     \
+        }                                                                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                                                        \
+    }                                                                                                             \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                                \
+        _Pragma("unroll") for (int pl = 0; pl < 3; ++pl) AN_[i][pl] = __builtin_bit_cast(bf16x8, ah[i][pl]);
+        FS_READ3(0, 0, araw, B3)
+        {
+            bf16x8 Z[TM][3];  // prologue: split step 0's pixels (no MFMA to hide under yet)
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                const int lvl = u / NP, pr = u % NP, pi = pr / 4, pe = pr % 4;
+                const float x0 = lvl == 0 ? araw[pi][pe >> 1][2 * (pe & 1)] : rq[pr][0];
+                const float x1 = lvl == 0 ? araw[pi][pe >> 1][2 * (pe & 1) + 1] : rq[pr][1];
+                const unsigned pk = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){x0, x1}, bf16x2));
+                ah[pi][lvl][pe] = pk;
+                if (lvl < 2) {
+                    rq[pr][0] = x0 - __builtin_bit_cast(float, pk << 16);
+                    rq[pr][1] = x1 - __builtin_bit_cast(float, pk & 0xffff0000u);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) A3[i][pl] = __builtin_bit_cast(bf16x8, ah[i][pl]);
+            (void)Z;
+        }
+        for (int kc = 0; kc < nchunks; ++kc) {
+            FS_READ3(cur, 1, araw, B3n)
+            __builtin_amdgcn_sched_barrier(0);
+            FS_STEP3(A3, B3, araw, A3n)
+            __builtin_amdgcn_sched_barrier(0);
+            FS_TRACE_SYNC()  // every wave's reads of stage `cur` are done, chunk kc + 1 has landed
+            if (kc + 2 < nchunks) {
+                FS_DMA_ALL(cur)
+                FS_DMA_ADVANCE()
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            FS_READ3(cur ^ 1, 0, araw, B3)  // (after the last chunk: a stale stage, read and never used)
+            __builtin_amdgcn_sched_barrier(0);
+            FS_STEP3(A3n, B3n, araw, A3)
+            __builtin_amdgcn_sched_barrier(0);
+            cur ^= 1;
+        }
+        if (!DUAL && p.res) igemm_load_residual(rv, p, M, em_base, en_base);
+#undef FS_READ3
+#undef FS_STEP3
+    } else {
     if (!DUAL && p.res && nchunks <= 2) igemm_load_residual(rv, p, M, em_base, en_base);
     FS_FRAGS(0, 0, a0, b0)
     for (int kc = 0; kc < nchunks; ++kc) {
@@ -359,6 +492,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_dma_f32(ConvParams 
         FS_MMA(a1, b1)
         __builtin_amdgcn_sched_barrier(0);
         cur ^= 1;
+    }
     }
 #ifdef FS_TRACE
     tr_loop = __builtin_readcyclecounter();
@@ -406,7 +540,7 @@ int pick_tile(const ConvParams& p) {
     const double eff[5] = {0, 1.00, 0.92, 0.80, 0.92};
     int best = 1;
     double best_t = 1e300;
-    for (int c = 1; c <= (p.in2 ? 2 : 4); ++c) {
+    for (int c = 1; c <= (p.in2 ? 2 : p.wgt3 ? 3 : 4); ++c) {
         const int bm = kTiles[c].bm, bn = kTiles[c].bn;
         if (p.Cout < bn && bn > 64) continue;
         const long tiles = (long)cdiv(M, bm) * cdiv(p.Cout, bn) * (p.groups > 1 ? p.groups : 1);
@@ -421,8 +555,34 @@ int pick_tile(const ConvParams& p) {
 const char* conv_igemm_tile_name(const ConvParams& p, int tile) {
     tile &= 0xff;
     if (tile <= 0 || tile > 5) tile = pick_tile(p);
+    if (p.in2 && p.wgt3) return tile == 2 ? "split128x64cat" : "split128x128cat";
     if (p.in2) return tile == 2 ? "igemm128x64cat" : "igemm128x128cat";  // the concatenated-K instantiations are kernels of their own
+    if (p.wgt3) return tile == 1 ? "split128x128" : tile == 2 ? "split128x64" : "split64x64";
     return kTiles[tile].name;
+}
+
+namespace {
+// filter rows of the split bank are bf16: 16-B DMA pieces need a row stride that is a multiple of 8 elements
+bool ldw_ok(const ConvParams& p) { return (p.ld_wgt ? p.ld_wgt : p.KH * p.KW * p.Cin + (p.in2 ? p.Cin2 : 0)) % 8 == 0; }
+
+__global__ void split_bf16x3_kernel(const float* __restrict__ w, long long n, __bf16* __restrict__ planes) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float x = w[i];
+    const __bf16 h = (__bf16)x;
+    const float r = x - (float)h;
+    const __bf16 m = (__bf16)r;
+    planes[i] = h;
+    planes[n + i] = m;
+    planes[2 * n + i] = (__bf16)(r - (float)m);
+}
+}  // namespace
+
+int launch_split_bf16x3(const float* w, long long n, void* planes, hipStream_t s) {
+    FS_REQUIRE(w && planes && n > 0 && n % 8 == 0, "split_bf16x3: bad arguments (n=%lld)", n);
+    hipLaunchKernelGGL(split_bf16x3_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, w, n, (__bf16*)planes);
+    FS_HIP(hipGetLastError());
+    return 0;
 }
 
 int launch_conv_igemm(const ConvParams& p, hipStream_t s, int tile) {
@@ -461,10 +621,32 @@ int launch_conv_igemm(const ConvParams& p, hipStream_t s, int tile) {
     const int groups = p.groups > 1 ? p.groups : 1;
     FS_REQUIRE(groups == 1 || p.res == nullptr, "conv_igemm: grouped GEMM has no residual input");
     const dim3 grid(tm * tn * groups), block(256);
+    if (p.wgt3) {
+        FS_REQUIRE(((uintptr_t)p.wgt3 & 15) == 0 && p.plane_bytes % 16 == 0 && (int64_t)3 * p.plane_bytes < (int64_t)1 << 31 && ldw_ok(p),
+                   "conv_igemm: bad split filter bank (plane_bytes=%u)", p.plane_bytes);
+        FS_REQUIRE((int64_t)groups * p.g_wgt * 2 <= (int64_t)p.plane_bytes, "conv_igemm: the groups' filters (%d x %lld) exceed a plane of the split bank", groups, p.g_wgt);
+    }
+    if (p.in2 && p.wgt3) {
+        if (tile == 2) hipLaunchKernelGGL((conv_igemm_dma_f32<128, 64, 4, 1, true, true>), grid, block, 0, s, p, tm, tn);
+        else if (tile == 1) hipLaunchKernelGGL((conv_igemm_dma_f32<128, 128, 2, 2, true, true>), grid, block, 0, s, p, tm, tn);
+        else return fail("conv_igemm: concatenated-K launches use tile 1 or 2");
+        FS_HIP(hipGetLastError());
+        return 0;
+    }
     if (p.in2) {  // concatenated-K instantiations exist for the two 128-row tiles
         if (tile == 2) hipLaunchKernelGGL((conv_igemm_dma_f32<128, 64, 2, 2, true>), grid, block, 0, s, p, tm, tn);
         else if (tile == 1) hipLaunchKernelGGL((conv_igemm_dma_f32<128, 128, 2, 2, true>), grid, block, 0, s, p, tm, tn);
         else return fail("conv_igemm: concatenated-K launches use tile 1 or 2");
+        FS_HIP(hipGetLastError());
+        return 0;
+    }
+    if (p.wgt3) {  // split-operand route: same tiles, bf16 matrix pipe
+        switch (tile) {
+            case 1: hipLaunchKernelGGL((conv_igemm_dma_f32<128, 128, 2, 2, false, true>), grid, block, 0, s, p, tm, tn); break;
+            case 2: hipLaunchKernelGGL((conv_igemm_dma_f32<128, 64, 4, 1, false, true>), grid, block, 0, s, p, tm, tn); break;
+            case 3: hipLaunchKernelGGL((conv_igemm_dma_f32<64, 64, 2, 2, false, true>), grid, block, 0, s, p, tm, tn); break;
+            default: return fail("conv_igemm: the split-operand route has tiles 1, 2 and 3");
+        }
         FS_HIP(hipGetLastError());
         return 0;
     }

@@ -36,6 +36,11 @@ struct ConvParams {
     // grouped GEMM (Winograd: one GEMM per transform position): group g uses in + g*g_in, wgt + g*g_wgt, out + g*g_out
     int groups;  // 0 or 1 = plain
     long long g_in, g_wgt, g_out;  // strides in floats
+    // Split-operand route (conv_igemm_dma_f32<..., SPLIT = true>): the SAME filters as `wgt`, each fp32 value written as the exact sum
+    // of three bf16 terms (round-to-nearest residues), stored as three planes [3][rows][ld_wgt or K] of bf16 (split_bf16x3).
+    // nullptr = the fp32-MFMA kernel.  plane_bytes = bytes of one plane.
+    const void* wgt3;
+    unsigned plane_bytes;
 #ifdef FS_TRACE  // tools/probe_conv_trace.hip builds only -- the field does not exist in libfloodseg.so
     int dbg;     // timing experiments (results are wrong when != 0): 2 = one block per CU, 16 = skip the epilogue,
                  // 32 | n << 8 = start workgroups bid+256.. n*1024 cycles late
@@ -44,6 +49,8 @@ struct ConvParams {
 // tile: 0 = heuristic, 1 = 128x128, 2 = 128x64, 3 = 64x64, 4 = 64x128
 int launch_conv_igemm(const ConvParams& p, hipStream_t s, int tile = 0);
 const char* conv_igemm_tile_name(const ConvParams& p, int tile = 0);
+// planes[t][i] (t = 0, 1, 2; bf16) with w[i] == planes[0][i] + planes[1][i] + planes[2][i] exactly (ConvParams::wgt3)
+int launch_split_bf16x3(const float* w, long long n, void* planes, hipStream_t s);
 
 // ---------------------------------------------------------------------------------
 // Stem convolution with Cin = 3 read straight from the caller's NCHW frame

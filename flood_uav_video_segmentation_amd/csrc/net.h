@@ -134,6 +134,9 @@ struct fs_net {
     bool use_fused_head = true;  // !(flags & FS_OPT_NO_FUSED_HEAD)
     bool use_fused_shortcut = true;  // !(flags & FS_OPT_NO_FUSED_SHORTCUT)
     bool use_fused_winograd = true;  // !(flags & FS_OPT_NO_FUSED_WINOGRAD)
+    bool use_split = true;           // !(flags & FS_OPT_NO_SPLIT_BF16): the implicit-GEMM launches take the split-operand kernel
+    // fp32 filter bank -> its three bf16 planes (split_bf16x3), keyed by the bank's first float; value = (planes, floats in the bank)
+    std::map<const float*, std::pair<void*, size_t>> split_banks;
     int device = 0;              // HIP device the handle's memory lives on (current device at fs_create)
 
     // workspace
@@ -172,6 +175,10 @@ int net_profile_dump(fs_handle h, char* buf, size_t n);
 // shared with vit_net.hip
 int dev_alloc(fs_net* h, float** p, size_t elems);
 int ws_grow(fs_net* h, float** p, size_t* have, size_t need, bool zero);
+// split-operand route: split_attach builds (on `s`, right behind the kernel that wrote the bank) and registers the three bf16 planes
+// of a GEMM filter bank; split_use points a launch at them when its `wgt` lies inside a registered bank (no-op otherwise)
+int split_attach(fs_net* h, const float* bank, size_t elems, hipStream_t s);
+void split_use(const fs_net* h, ConvParams& p);
 int vit_reserve(fs_handle h, int B, int H, int W, hipStream_t s);
 int fetch(fs_net* h, const std::string& name, const RawTensor** out);
 int prof_begin(fs_net* h, const std::string& name, const char* kernel, double flops, double bytes, hipStream_t s);

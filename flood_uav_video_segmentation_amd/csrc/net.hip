@@ -44,6 +44,28 @@ int ws_grow(fs_net* h, float** p, size_t* have, size_t need, bool zero) {
     return 0;
 }
 
+int split_attach(fs_net* h, const float* bank, size_t elems, hipStream_t s) {
+    if (!h->use_split || elems % 8 != 0 || h->split_banks.count(bank)) return 0;
+    float* planes = nullptr;
+    FS_TRY(dev_alloc(h, &planes, (3 * elems + 1) / 2));  // 3 planes of bf16
+    FS_TRY(launch_split_bf16x3(bank, (long long)elems, planes, s));
+    h->split_banks[bank] = {planes, elems};
+    return 0;
+}
+
+void split_use(const fs_net* h, ConvParams& p) {
+    p.wgt3 = nullptr;
+    if (!h->use_split || p.Cin % 32 != 0 || h->split_banks.empty()) return;
+    auto it = h->split_banks.upper_bound(p.wgt);
+    if (it == h->split_banks.begin()) return;
+    --it;
+    const size_t off = (size_t)(p.wgt - it->first), elems = it->second.second;
+    const int K = p.KH * p.KW * p.Cin + (p.in2 ? p.Cin2 : 0);
+    if (off >= elems || off % 8 != 0 || (p.ld_wgt ? p.ld_wgt : K) % 8 != 0 || elems * 6 >= ((size_t)1 << 31)) return;
+    p.wgt3 = (const char*)it->second.first + off * 2;
+    p.plane_bytes = (unsigned)(elems * 2);
+}
+
 int fetch(fs_net* h, const std::string& name, const RawTensor** out) {
     auto it = h->raw.find(name);
     if (it == h->raw.end()) return fail("missing weight '%s'", name.c_str());
@@ -76,13 +98,14 @@ int wino_bank(fs_net* h, const ConvBN& c, int mt, hipStream_t s, const float** U
         const size_t elems = (size_t)(mt + 2) * (mt + 2) * c.Cout * c.Cin;
         FS_TRY(dev_alloc(h, &bank, elems));
         FS_TRY(launch_winograd_filter(c.w, bank, c.Cout, c.Cin, mt, s, 1));
+        FS_TRY(split_attach(h, bank, elems, s));
         hipEvent_t ev = nullptr;
         FS_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
         FS_HIP(hipEventRecord(ev, s));
         c.wino->ready[k] = ev;
         c.wino->built_on[k] = s;
         h->bank_events.push_back(ev);
-        h->bank_elems += elems;
+        h->bank_elems += elems + (h->use_split ? (3 * elems + 1) / 2 : 0);
         ++h->ws_allocs;
         slot = bank;
     } else if (c.wino->built_on[k] != s && c.wino->ready[k]) {
@@ -116,6 +139,7 @@ int make_conv(fs_net* h, ConvBN& c, const std::string& wname, const std::string&
     } else {
         FS_TRY(launch_pack_oihw_to_ohwi(w->d, c.w, c.Cout, c.Cin, c.KH, c.KW, s));
     }
+    if (!hwio && c.Cin % 32 == 0) FS_TRY(split_attach(h, c.w, (size_t)w->numel(), s));
     if (wino_eligible(c, hwio)) c.wino = std::make_shared<WinoBank>();  // the banks themselves: wino_bank(), on first use
     if (!hwio && c.korder == 1 && c.Cin <= 128 && wino_fused_supported(c.Cin, c.Cout, c.KH, c.KW, c.stride, c.pad, c.dil)) {
         // few input channels (deep stem, conv2 of layer1 / layer2): the one-kernel Winograd's packed bank, at most 2.4 MB, built now
@@ -212,6 +236,7 @@ int run_conv_winograd(fs_net* h, const ConvBN& c, const float* in, int ld_in, in
     p.groups = G;
     p.g_wgt = (long long)c.Cout * c.Cin;
     winograd_gemm_params(p, mt, T, c.Cin, c.Cout);  // V / M are tile-major when that fits a buffer descriptor (winograd.hip)
+    split_use(h, p);
     const double flops = 2.0 * G * (double)T * c.Cin * c.Cout;
     FS_TRY(prof_begin(h, c.name + ".wino_gemm", conv_igemm_tile_name(p), flops, 4.0 * ((double)v_elems + (double)G * c.Cout * c.Cin + (double)m_elems), s));
     FS_TRY(launch_conv_igemm(p, s));
@@ -287,6 +312,7 @@ int run_conv(fs_net* h, const ConvBN& c, const float* in, int ld_in, int B, int 
     p.dil = c.dil;
     p.relu = c.relu;
     p.korder = c.korder;
+    split_use(h, p);
     const double M = (double)B * p.Ho * p.Wo;
     const double flops = 2.0 * M * c.Cout * c.KH * c.KW * c.Cin;
     const double bytes = 4.0 * ((double)B * H * W * c.Cin + (double)c.Cout * c.KH * c.KW * c.Cin + M * c.Cout * (res ? 2 : 1));
@@ -344,7 +370,7 @@ int net_create(const fs_config* cfg, fs_handle* out) {
     FS_REQUIRE(cfg->arch == FS_ARCH_SEGMENTER || cfg->layers == 50 || cfg->layers == 101 || cfg->layers == 152,
                "fs_create: layers must be 50, 101 or 152");
     FS_REQUIRE(cfg->classes >= 1 && cfg->classes <= 255, "fs_create: classes out of range");
-    FS_REQUIRE((cfg->flags & ~(FS_OPT_NO_WINOGRAD | FS_OPT_NO_FUSED_HEAD | FS_OPT_NO_FUSED_SHORTCUT | FS_OPT_NO_FUSED_WINOGRAD)) == 0,
+    FS_REQUIRE((cfg->flags & ~(FS_OPT_NO_WINOGRAD | FS_OPT_NO_FUSED_HEAD | FS_OPT_NO_FUSED_SHORTCUT | FS_OPT_NO_FUSED_WINOGRAD | FS_OPT_NO_SPLIT_BF16)) == 0,
                "fs_create: unknown option bits 0x%x", cfg->flags);
     FS_REQUIRE(cfg->winograd_tile == 0 || cfg->winograd_tile == 4 || cfg->winograd_tile == 6, "fs_create: winograd_tile must be 0, 4 or 6");
     fs_net* h = new fs_net();
@@ -354,6 +380,7 @@ int net_create(const fs_config* cfg, fs_handle* out) {
     h->use_fused_head = !(cfg->flags & FS_OPT_NO_FUSED_HEAD);
     h->use_fused_shortcut = !(cfg->flags & FS_OPT_NO_FUSED_SHORTCUT);
     h->use_fused_winograd = !(cfg->flags & (FS_OPT_NO_FUSED_WINOGRAD | FS_OPT_NO_WINOGRAD));
+    h->use_split = !(cfg->flags & FS_OPT_NO_SPLIT_BF16);
     if (hipGetDevice(&h->device) != hipSuccess) {
         delete h;
         return fail("fs_create: no HIP device");
@@ -480,6 +507,7 @@ int net_finalize(fs_handle h, hipStream_t s) {
                     FS_TRY(dev_alloc(h, &f.shift, (size_t)f.Cout));
                     FS_TRY(launch_concat_scaled_filters(blk.c3.w, blk.c3.scale, blk.c3.shift, blk.c3.Cin, blk.ds.w, blk.ds.scale, blk.ds.shift,
                                                         blk.ds.Cin, f.w, f.shift, f.Cout, s));
+                    FS_TRY(split_attach(h, f.w, (size_t)f.Cout * (blk.c3.Cin + blk.ds.Cin), s));
                 }
             }
             h->blocks.push_back(blk);
@@ -514,6 +542,7 @@ int net_finalize(fs_handle h, hipStream_t s) {
             FS_REQUIRE(h->cls_conv.korder == 1, "decoder.0: chunk-major bank expected");
             FS_HIP(hipMemcpy2DAsync(m.w, (size_t)2048 * 9 * sizeof(float), h->cls_conv.w, (size_t)4096 * 9 * sizeof(float),
                                     (size_t)2048 * 9 * sizeof(float), (size_t)O, hipMemcpyDeviceToDevice, s));
+            FS_TRY(split_attach(h, m.w, (size_t)O * 2048 * 9, s));
             float* zw = nullptr;  // the four [9*O][512] matrices back to back: groups of one grouped GEMM
             FS_TRY(dev_alloc(h, &zw, (size_t)4 * 9 * O * 512));
             for (int i = 0; i < 4; ++i) {
@@ -524,6 +553,7 @@ int net_finalize(fs_handle h, hipStream_t s) {
                 z.w = zw + (size_t)i * 9 * O * 512;
                 FS_TRY(launch_pack_slice_tap_major(w->d, z.w, O, 4096, 2048 + 512 * i, 512, 9, s));
             }
+            FS_TRY(split_attach(h, zw, (size_t)4 * 9 * O * 512, s));
         }
         const RawTensor *w, *b;
         FS_TRY(fetch(h, "decoder.4.weight", &w));
@@ -742,6 +772,7 @@ int encoder_core(fs_handle h, const FrameSrc& src, int B, int H, int W, float* o
             p.B = B; p.H = oH; p.W = oW; p.Cin = blk.c3ds.Cin; p.Ho = oH; p.Wo = oW; p.Cout = Cn;
             p.KH = p.KW = 1; p.stride = 1; p.dil = 1; p.relu = 1;
             p.in2 = X; p.ld_in2 = C; p.Cin2 = blk.ds_cin; p.stride2 = blk.ds_stride; p.H2 = curH; p.W2 = curW;
+            split_use(h, p);
             const double M = (double)B * oH * oW;
             FS_TRY(prof_begin(h, blk.c3ds.name, conv_igemm_tile_name(p), 2.0 * M * Cn * (p.Cin + p.Cin2),
                               4.0 * (M * p.Cin + (double)B * curH * curW * p.Cin2 + (double)Cn * (p.Cin + p.Cin2) + M * Cn), s));
@@ -850,6 +881,7 @@ int net_segment(fs_handle h, const FrameSrc& src, int B, int H, int W, float* ou
         p.g_in = (long long)rows * 512;
         p.g_wgt = (long long)z.Cout * 512;
         p.g_out = (long long)rows * z.Cout;
+        split_use(h, p);
         FS_TRY(prof_begin(h, "decoder.0.weight[:, ppm]", conv_igemm_tile_name(p), 2.0 * B * 50 * 512.0 * z.Cout,
                           4.0 * (4.0 * z.Cout * 512 + B * 50.0 * (512 + z.Cout)), ps));
         FS_TRY(launch_conv_igemm(p, ps));

@@ -17,13 +17,14 @@ int copy_param(fs_net* h, const std::string& name, int64_t expect, float** dst) 
     return 0;
 }
 
-int make_linear(fs_net* h, Linear& l, const std::string& prefix, int in, int out, bool bias) {
+int make_linear(fs_net* h, Linear& l, const std::string& prefix, int in, int out, bool bias, hipStream_t s) {
     l.name = prefix;
     l.in = in;
     l.out = out;
     FS_TRY(copy_param(h, prefix + ".weight", (int64_t)in * out, &l.w));
     if (bias) FS_TRY(copy_param(h, prefix + ".bias", out, &l.b));
-    return 0;
+    FS_HIP(hipDeviceSynchronize());  // the copy above ran on the null stream; `s` need not be ordered behind it
+    return split_attach(h, l.w, (size_t)in * out, s);
 }
 
 int make_norm(fs_net* h, LNorm& n, const std::string& prefix, int D) {
@@ -33,13 +34,13 @@ int make_norm(fs_net* h, LNorm& n, const std::string& prefix, int D) {
     return 0;
 }
 
-int make_block(fs_net* h, VitBlock& b, const std::string& p, int D) {
+int make_block(fs_net* h, VitBlock& b, const std::string& p, int D, hipStream_t s) {
     FS_TRY(make_norm(h, b.n1, p + "norm1", D));
     FS_TRY(make_norm(h, b.n2, p + "norm2", D));
-    FS_TRY(make_linear(h, b.qkv, p + "attn.qkv", D, 3 * D, true));
-    FS_TRY(make_linear(h, b.proj, p + "attn.proj", D, D, true));
-    FS_TRY(make_linear(h, b.fc1, p + "mlp.fc1", D, 4 * D, true));
-    FS_TRY(make_linear(h, b.fc2, p + "mlp.fc2", 4 * D, D, true));
+    FS_TRY(make_linear(h, b.qkv, p + "attn.qkv", D, 3 * D, true, s));
+    FS_TRY(make_linear(h, b.proj, p + "attn.proj", D, D, true, s));
+    FS_TRY(make_linear(h, b.fc1, p + "mlp.fc1", D, 4 * D, true, s));
+    FS_TRY(make_linear(h, b.fc2, p + "mlp.fc2", 4 * D, D, true, s));
     return 0;
 }
 
@@ -73,6 +74,7 @@ int run_linear(fs_net* h, const Linear& l, const float* in, int rows, float* out
         p.g_in = l.in / split;
         p.g_wgt = l.in / split;
         p.g_out = (long long)rows * l.out;
+        split_use(h, p);
         const double flops = 2.0 * rows * (double)l.in * l.out;
         FS_TRY(prof_begin(h, l.name, conv_igemm_tile_name(p), flops, 4.0 * ((double)rows * (l.in + (split + 1.0) * l.out) + (double)l.in * l.out), s));
         FS_TRY(launch_conv_igemm(p, s));
@@ -106,6 +108,7 @@ int run_linear(fs_net* h, const Linear& l, const float* in, int rows, float* out
     p.pad = 0;
     p.dil = 1;
     p.relu = act;
+    split_use(h, p);
     const double flops = 2.0 * rows * (double)l.in * l.out;
     FS_TRY(prof_begin(h, l.name, conv_igemm_tile_name(p), flops, 4.0 * ((double)rows * (l.in + l.out) + (double)l.in * l.out), s));
     FS_TRY(launch_conv_igemm(p, s));
@@ -182,15 +185,15 @@ int vit_finalize(fs_handle h, hipStream_t s) {
     FS_REQUIRE(c.image_size % P == 0 && c.image_size >= P, "segmenter: image_size %d not divisible by patch %d", c.image_size, P);
     FS_REQUIRE(c.n_layers >= 1 && c.dec_layers >= 1, "segmenter: layer counts must be positive");
     h->pos_g0 = c.image_size / P;
-    FS_TRY(make_linear(h, h->patch_embed, "encoder.patch_embed.proj", 3 * P * P, D, true));
+    FS_TRY(make_linear(h, h->patch_embed, "encoder.patch_embed.proj", 3 * P * P, D, true, s));
     FS_TRY(copy_param(h, "encoder.cls_token", D, &h->cls_token));
     FS_TRY(copy_param(h, "encoder.pos_embed", (int64_t)(1 + h->pos_g0 * h->pos_g0) * D, &h->pos_embed));
     h->enc_blocks.resize((size_t)c.n_layers);
-    for (int i = 0; i < c.n_layers; ++i) FS_TRY(make_block(h, h->enc_blocks[(size_t)i], "encoder.blocks." + std::to_string(i) + ".", D));
+    for (int i = 0; i < c.n_layers; ++i) FS_TRY(make_block(h, h->enc_blocks[(size_t)i], "encoder.blocks." + std::to_string(i) + ".", D, s));
     FS_TRY(make_norm(h, h->enc_norm, "encoder.norm", D));
     h->dec_blocks.resize((size_t)c.dec_layers);
-    for (int i = 0; i < c.dec_layers; ++i) FS_TRY(make_block(h, h->dec_blocks[(size_t)i], "decoder.blocks." + std::to_string(i) + ".", D));
-    FS_TRY(make_linear(h, h->proj_dec, "decoder.proj_dec", D, D, true));
+    for (int i = 0; i < c.dec_layers; ++i) FS_TRY(make_block(h, h->dec_blocks[(size_t)i], "decoder.blocks." + std::to_string(i) + ".", D, s));
+    FS_TRY(make_linear(h, h->proj_dec, "decoder.proj_dec", D, D, true, s));
     FS_TRY(make_norm(h, h->dec_norm, "decoder.decoder_norm", D));
     FS_TRY(make_norm(h, h->mask_norm, "decoder.mask_norm", K));
     FS_TRY(copy_param(h, "decoder.cls_emb", (int64_t)K * D, &h->cls_emb));
@@ -205,6 +208,7 @@ int vit_finalize(fs_handle h, hipStream_t s) {
         l.in = l.out = D;
         FS_TRY(dev_alloc(h, &l.w, (size_t)D * D));
         FS_TRY(launch_nchw_to_nhwc(t->d, l.w, D, 1, D, D, s));  // [in][out] -> [out][in]
+        FS_TRY(split_attach(h, l.w, (size_t)D * D, s));
     }
     FS_HIP(hipStreamSynchronize(s));
     return 0;

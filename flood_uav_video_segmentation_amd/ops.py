@@ -328,8 +328,9 @@ def iou_hist(pred_u8, target_u8, classes, ignore_index=255, hist=None):
 
 
 # ------------------------------------------------------------------------------------------ building blocks
-def conv2d_nhwc(x, weight, scale=None, shift=None, residual=None, stride=1, pad=0, dil=1, relu=False, tile=0, out=None):
-    """Conv2d on the fp32 matrix cores; x logical NCHW (stored NHWC), weight OIHW. Test/bring-up helper."""
+def conv2d_nhwc(x, weight, scale=None, shift=None, residual=None, stride=1, pad=0, dil=1, relu=False, tile=0, out=None, split=False):
+    """Conv2d on the matrix cores; x logical NCHW (stored NHWC), weight OIHW. Test/bring-up helper.  split=True: the split-operand
+    kernel (three bf16 terms per fp32 value, bf16 MFMA, fp32 accumulate: fs_conv2d_nhwc_split) instead of the fp32-MFMA one."""
     lib = _lib.load()
     with torch.cuda.device(one_device(x, weight, scale, shift, residual, out, what="floodseg.conv2d_nhwc")):
         x = as_nhwc(x)
@@ -342,6 +343,12 @@ def conv2d_nhwc(x, weight, scale=None, shift=None, residual=None, stride=1, pad=
         if out is None:
             out = empty_nhwc(b, o, ho, wo, x.device)
         res = as_nhwc(residual) if residual is not None else None
-        check(lib.fs_conv2d_nhwc(ptr(x), cin, ptr(wp), ptr(scale), ptr(shift), ptr(res), o, ptr(out), o, b, h, w, cin, o, kh, kw,
-                                 stride, pad, dil, int(relu), tile, stream_ptr()))
+        if split:
+            planes = torch.empty(3 * wp.numel(), dtype=torch.bfloat16, device=x.device)
+            check(lib.fs_split_bf16x3(ptr(wp), wp.numel(), ptr(planes), stream_ptr()))
+            check(lib.fs_conv2d_nhwc_split(ptr(x), cin, ptr(planes), ptr(scale), ptr(shift), ptr(res), o, ptr(out), o, b, h, w, cin, o, kh, kw,
+                                           stride, pad, dil, int(relu), tile, stream_ptr()))
+        else:
+            check(lib.fs_conv2d_nhwc(ptr(x), cin, ptr(wp), ptr(scale), ptr(shift), ptr(res), o, ptr(out), o, b, h, w, cin, o, kh, kw,
+                                     stride, pad, dil, int(relu), tile, stream_ptr()))
     return out

@@ -61,8 +61,11 @@ enum {
     FS_OPT_NO_WINOGRAD = 1,   /* every 3x3 conv on the direct implicit-GEMM kernel                                      */
     FS_OPT_NO_FUSED_HEAD = 2, /* fs_segment_forward = fs_decoder_forward(fs_encoder_forward(x)) over the 4096-ch concat */
     FS_OPT_NO_FUSED_SHORTCUT = 4, /* projection blocks: downsample and conv3 as two launches instead of one concatenated-K GEMM */
-    FS_OPT_NO_FUSED_WINOGRAD = 8 /* the 3x3 convs with Cin <= 128 (deep stem, conv2 of layer1) on the direct kernel instead of the
+    FS_OPT_NO_FUSED_WINOGRAD = 8, /* the 3x3 convs with Cin <= 128 (deep stem, conv2 of layer1) on the direct kernel instead of the
                                     one-kernel Winograd F(4x4,3x3) (implied by FS_OPT_NO_WINOGRAD)                             */
+    FS_OPT_NO_SPLIT_BF16 = 16 /* implicit-GEMM launches (1x1 / 3x3 convs, Winograd GEMMs, nn.Linear) on the fp32 matrix-core kernel
+                                 (v_mfma_f32_32x32x2_f32) instead of the split-operand one: each fp32 operand as the exact sum of three
+                                 bf16 terms, six cross products on the bf16 matrix cores, fp32 accumulation (fs_conv2d_nhwc_split) */
 };
 
 int fs_version(void);
@@ -205,6 +208,15 @@ int fs_pack_conv_weight(const float* oihw, float* ohwi, int O, int I, int KH, in
 int fs_conv2d_nhwc(const float* in, int ld_in, const float* wgt_ohwi, const float* scale, const float* shift,
                    const float* res, int ld_res, float* out, int ld_out, int B, int H, int W, int Cin, int Cout, int KH,
                    int KW, int stride, int pad, int dil, int relu, int tile, fs_stream stream);
+/* The same convolution with SPLIT operands: every fp32 filter value and every fp32 pixel is written as the exact sum of three bf16
+ * terms (round-to-nearest residues) and the six cross products of order <= 2^-16 run on the bf16 matrix cores with fp32
+ * accumulation (the three dropped ones are <= 2^-23 of the product: below the rounding of one fp32 add).  fs_split_bf16x3 writes
+ * the three planes (3 * n bf16, n % 8 == 0) of a packed filter bank; fs_conv2d_nhwc_split takes them in place of wgt_ohwi
+ * (tiles 0..3). */
+int fs_split_bf16x3(const float* w, int64_t n, void* planes, fs_stream stream);
+int fs_conv2d_nhwc_split(const float* in, int ld_in, const void* wgt_planes, const float* scale, const float* shift,
+                         const float* res, int ld_res, float* out, int ld_out, int B, int H, int W, int Cin, int Cout, int KH,
+                         int KW, int stride, int pad, int dil, int relu, int tile, fs_stream stream);
 /* 3x3 stride-1 conv with padding == dilation as Winograd F(m x m,3x3) (transforms + (m+2)^2 grouped MFMA GEMMs); the network
  * uses it for every such conv with Cin >= 256.  tile_m: 4, 6, or 0 = whichever needs fewer GEMM rows for this map (a 90x90
  * map is exactly 15x15 tiles of 6x6).  workspace: fs_winograd_workspace_floats(..., same tile_m) floats of device memory. */

@@ -54,6 +54,50 @@ def test_conv_igemm(case, tile):
     assert rel(got, ref) < CONV_TOL
 
 
+@pytest.mark.parametrize("tile", [0, 1, 2, 3])
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_igemm_split_operands(case, tile):
+    """The split-operand kernel (round 3, the networks' default): every fp32 pixel / filter value as the exact sum of three bf16
+    terms, six of the nine cross products on the bf16 matrix cores, fp32 accumulation.  Same cases, same tolerance as the fp32-MFMA
+    kernel -- and measured against a float64 convolution of the same fp32 inputs its error is within 1.5x of that kernel's."""
+    b, h, w, cin, cout, k, stride, pad, dil, relu, res = case
+    g = torch.Generator().manual_seed(h * 1000 + cin + cout + k)
+    x = torch.randn(b, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, k, k, generator=g) * (2.0 / (cin * k * k)) ** 0.5
+    sc = torch.rand(cout, generator=g) + 0.5
+    sh = torch.randn(cout, generator=g) * 0.1
+    ref64 = F.conv2d(x.double(), wt.double(), None, stride, pad, dil) * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1)
+    r = torch.randn(ref64.shape, generator=g) if res else None
+    if res:
+        ref64 = ref64 + r.double()
+    if relu:
+        ref64 = ref64.relu()
+    args = (x.to(DEV), wt.to(DEV), sc.to(DEV), sh.to(DEV), r.to(DEV) if res else None, stride, pad, dil, relu, tile)
+    got = ops.conv2d_nhwc(*args, split=True)
+    f32 = ops.conv2d_nhwc(*args)
+    e_split, e_f32 = rel(got.double(), ref64), rel(f32.double(), ref64)
+    note(f"conv_split_vs_f64_tile{tile}_cin{cin}_k{k}", e_split)
+    note(f"conv_fp32mfma_vs_f64_tile{tile}_cin{cin}_k{k}", e_f32)
+    assert rel(got, ref64.float()) < CONV_TOL
+    assert e_split < 1.5 * e_f32 + 1e-7, (e_split, e_f32)
+
+
+def test_split_bf16x3_is_exact():
+    """fs_split_bf16x3: the three bf16 planes add up to the fp32 value bit for bit (any exponent, both signs, zeros)."""
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(3)
+    w = torch.randn(1 << 16, generator=g) * torch.exp2(torch.randint(-60, 60, (1 << 16,), generator=g).float())
+    w[:8] = torch.tensor([0.0, -0.0, 1.0, -1.0, 3.38e38, -3.38e38, 2.0 ** -100, -(2.0 ** -100) * 1.9999999])  # |x| <= bf16 max (3.389e38)
+    wd = w.to(DEV)
+    planes = torch.empty(3 * wd.numel(), dtype=torch.bfloat16, device=DEV)
+    check(lib.fs_split_bf16x3(ptr(wd), wd.numel(), ptr(planes), stream_ptr()))
+    p = planes.view(3, -1).double()
+    back = (p[0] + p[1] + p[2]).float().cpu()
+    bad = (back != w).nonzero().flatten()
+    assert bad.numel() == 0, (bad[:5], w[bad[:5]], back[bad[:5]])
+    assert lib.fs_split_bf16x3(ptr(wd), 12, ptr(planes), stream_ptr()) != 0  # n % 8 != 0 is refused
+
+
 def test_conv_and_winograd_on_seeded_random_shapes():
     """30 seeded random geometries (batch, ragged H x W, channel counts that leave partial n-tiles, kernel 1 / 3, stride, dilation,
     residual, activation) through fs_conv2d_nhwc with the cost model's tile, and -- where eligible -- through the Winograd route,
