@@ -61,6 +61,13 @@ NUM_CLIPS = 64                   # BASELINE configs[4]: 64 synthetic clips shard
 CLIP_FRAMES = 21                 # 4 key-frame windows of frame_delta 5 per clip (flow/dataset.py:64)
 KEYFRAME_GFLOP = 727.44          # PSPNet-R50 encoder+decoder at 713^2
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_BF16_MFMA_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense bf16 MFMA peak (v_mfma_f32_32x32x16_bf16), no sparsity
+SPLIT_TERMS = 6                  # bf16 MFMA FLOPs executed per fp32 FLOP of the split-operand kernel (6 of the 9 cross products)
+ARITHMETIC = ("fp32 tensors; in the implicit-GEMM kernels every fp32 operand is the exact sum of three bf16 terms (round-to-nearest residues) "
+              "and six of the nine cross products (all of order <= 2^-16) run on v_mfma_f32_32x32x16_bf16 with fp32 accumulation; the three "
+              "dropped ones are <= 2^-23 of a product.  Measured against float64 the kernel's error equals the fp32-MFMA kernel's "
+              "(tests/test_gpu_ops.py::test_conv_igemm_split_operands, profiles/r03_split_operands.txt); FS_OPT_NO_SPLIT_BF16 selects the "
+              "fp32-MFMA kernel (variants.fps_fp32_mfma_kernels_no_split)")
 
 
 class HP:
@@ -97,11 +104,11 @@ def newest_pmc_summary():
 
 
 def kernel_symbol(label):
-    """HIP-event label of the library's profile (igemm128x128, igemm128x64cat, ...) -> the kernel symbol rocprofv3 reports."""
-    m = re.match(r"igemm(\d+)x(\d+)(cat)?$", label)
-    bm, bn, cat = int(m.group(1)), int(m.group(2)), bool(m.group(3))
-    waves = "4, 2" if bm == 256 else "2, 2"
-    return f"conv_igemm_dma_f32<{bm}, {bn}, {waves}, {'true' if cat else 'false'}>"
+    """HIP-event label of the library's profile (split128x128, igemm128x64cat, ...) -> the kernel symbol rocprofv3 reports."""
+    m = re.match(r"(igemm|split)(\d+)x(\d+)(cat)?$", label)
+    split, bm, bn, cat = m.group(1) == "split", int(m.group(2)), int(m.group(3)), bool(m.group(4))
+    waves = "4, 2" if bm == 256 else "4, 1" if split and (bm, bn) == (128, 64) else "2, 2"
+    return f"conv_igemm_dma_f32<{bm}, {bn}, {waves}, {'true' if cat else 'false'}, {'true' if split else 'false'}>"
 
 
 def pmc_traffic(dom_kernel):
@@ -266,7 +273,7 @@ def main():
         "metric": "segmentation FPS @713x713 (PSPNet-ResNet50 keyframe + linear interp, frame_delta=5)",
         "value": round(fps, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed_max / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "vs_baseline": None, "dtype": "f32", "arithmetic": ARITHMETIC, "data": "synthetic",
         "config": {"workload": ("BASELINE configs[1]: PSPNet-ResNet50 keyframe + linear interp (no_warp=True, feature_based=False), "
                                 "frame_delta=5, 713x713, one window per step per GPU, both key frames segmented per window, "
                                 "argmax uint8 masks copied to host") if world == 1 else
@@ -314,21 +321,27 @@ def main():
             d["ms"] += ms
             d["flops"] += flops
             d["launches"] += 1
-        conv = {k: v for k, v in per.items() if k.startswith("igemm")}  # the implicit-GEMM launches (direct convs, Winograd position GEMMs, Linears)
+        conv = {k: v for k, v in per.items() if k.startswith(("igemm", "split"))}  # the implicit-GEMM launches (direct convs, Winograd position GEMMs, Linears)
         dom_name, dom = max(conv.items(), key=lambda kv: kv[1]["ms"])
-        ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
+        is_split = dom_name.startswith("split")
+        # split-operand kernel: the matrix cores execute 6 bf16 MFMA FLOPs per algorithmic (fp32) FLOP; the roofline is the bf16 pipe's
+        alg = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
+        ach = alg * (SPLIT_TERMS if is_split else 1)
+        peak = PEAK_BF16_MFMA_TFLOPS if is_split else PEAK_F32_MFMA_TFLOPS
         alg_bytes = sum(r[3] for r in rows if r[1] == dom_name) / max(1, dom["launches"])
         traffic, traffic_note = pmc_traffic(dom_name)
         all_ms = sum(v["ms"] for v in conv.values())
         all_fl = sum(v["flops"] for v in conv.values())
         result["roofline"] = {
             "bound": "mfma", "kernel": kernel_symbol(dom_name), "achieved": round(ach, 2),
-            "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
+            "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
+            "pipe": "bf16 MFMA (v_mfma_f32_32x32x16_bf16), 6 executed FLOPs per algorithmic fp32 FLOP" if is_split else "fp32 MFMA (v_mfma_f32_32x32x2_f32)",
+            "algorithmic_fp32_tflops": round(alg, 2),
             "traffic_unit": "B per launch", "traffic_source": traffic_note, "algorithmic_bytes_per_launch": round(alg_bytes),
             "avg_launch_ms": round(dom["ms"] / dom["launches"], 5), "launches_per_step": dom["launches"] // prof_steps,
             "gflop_per_launch": round(dom["flops"] / dom["launches"] / 1e9, 3),
             "pmc": pmc_traffic.extra,
-            "all_conv_kernels": {"achieved": round(all_fl / (all_ms * 1e-3) / 1e12, 2), "ms_per_step": round(all_ms / prof_steps, 4),
+            "all_conv_kernels": {"algorithmic_fp32_tflops": round(all_fl / (all_ms * 1e-3) / 1e12, 2), "ms_per_step": round(all_ms / prof_steps, 4),
                                  "gflop_per_step": round(all_fl / prof_steps / 1e9, 2)},
             "per_kernel_ms_per_step": {k: round(v["ms"] / prof_steps, 4) for k, v in sorted(per.items(), key=lambda kv: -kv[1]["ms"])},
         }
@@ -431,6 +444,20 @@ def variants(args, dev, rdev, net, state, fm, windows, dl, dr, host_masks, host_
         side.synchronize()
     run("fps_two_windows_in_flight_two_streams", step_two, max(1, steps // 2), 2 * N_DELTA)
     del net2, fm2
+
+    # (iv-b) the headline step with the implicit GEMMs on the fp32-MFMA kernel (FS_OPT_NO_SPLIT_BF16): the round-2 arithmetic
+    class HP32(HP):
+        hip_no_split_bf16 = True
+    net32 = FlowPSPNet(HP32()).eval()
+    net32.load_state_dict(state)
+    fm32 = FlowModel(net32, feature_based=False, no_warp=True).eval()
+
+    def step_f32(i):
+        prev, nxt = windows[i % 4]
+        host_masks.copy_(fm32.predict(prev, nxt, dl, dr, N_DELTA, None, with_mask=True)["mask"], non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+    run("fps_fp32_mfma_kernels_no_split", step_f32, steps, N_DELTA)
+    del net32, fm32
 
     # (v) BASELINE configs[0] on the GPU: single-frame PSPNet inference over a 4-frame clip, one frame per step
     frames4 = [windows[i][0] for i in range(4)]
