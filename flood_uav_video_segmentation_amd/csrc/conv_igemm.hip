@@ -1,6 +1,9 @@
-// fp32 implicit-GEMM convolution on the CDNA4 matrix cores.
+// fp32 implicit-GEMM convolution on the CDNA4 matrix cores, two arithmetic routes in one kernel template:
 //
-//   v_mfma_f32_32x32x2_f32: exact f32 fmaf-chain numerics at 64 FLOP/clk/SIMD (157 TFLOP/s chip peak).
+//   SPLIT = false  v_mfma_f32_32x32x2_f32: exact f32 fmaf-chain numerics at 64 FLOP/clk/SIMD (157 TFLOP/s chip peak).
+//   SPLIT = true   (round 3, the networks' default) every fp32 operand as the exact sum of three bf16 terms, six of the nine cross
+//                  products on v_mfma_f32_32x32x16_bf16 with fp32 accumulation: fp32 accuracy (the dropped terms are <= 2^-23 of a
+//                  product) at 2.67x the fp32 pipe's rate per clock.  See the comment at the split main loop, DESIGN.md 3.1b.
 //
 // Mapping (one 256-thread workgroup = 4 waves, one per SIMD, 2x2 over the block tile):
 //   GEMM M = B*Ho*Wo output pixels (A rows, gathered NHWC pixels: 32 channels = one 128-B line)
@@ -112,16 +115,6 @@ __device__ __forceinline__ void igemm_epilogue(const f32x16 (&acc)[TM][TN], cons
     }
 }
 #endif
-
-// (x0, x1) -> the packed bf16 pairs (h, m, l) with x = h + m + l exactly: v_cvt_pk_bf16_f32 rounds to nearest even, the residues
-// x - h and x - h - m are exact in fp32 (they fit in 16 / 8 significant bits).
-__device__ __forceinline__ void split3_pair(float x0, float x1, unsigned& hu, unsigned& mu, unsigned& lu) {
-    hu = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){x0, x1}, bf16x2));
-    const float r0 = x0 - __builtin_bit_cast(float, hu << 16), r1 = x1 - __builtin_bit_cast(float, hu & 0xffff0000u);
-    mu = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){r0, r1}, bf16x2));
-    const float q0 = r0 - __builtin_bit_cast(float, mu << 16), q1 = r1 - __builtin_bit_cast(float, mu & 0xffff0000u);
-    lu = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){q0, q1}, bf16x2));
-}
 
 #ifdef FS_TRACE
 // tools/probe_conv_trace.hip only (never in libfloodseg.so): per-workgroup timeline, 8 x u64 per workgroup:
@@ -421,8 +414,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_dma_f32(ConvParams 
     _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                                \
         _Pragma("unroll") for (int pl = 0; pl < 3; ++pl) AN_[i][pl] = __builtin_bit_cast(bf16x8, ah[i][pl]);
         FS_READ3(0, 0, araw, B3)
-        {
-            bf16x8 Z[TM][3];  // prologue: split step 0's pixels (no MFMA to hide under yet)
+        {   // prologue: split step 0's pixels (no MFMA to hide under yet)
 #pragma unroll
             for (int u = 0; u < NU; ++u) {
                 const int lvl = u / NP, pr = u % NP, pi = pr / 4, pe = pr % 4;
@@ -439,7 +431,6 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_dma_f32(ConvParams 
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int pl = 0; pl < 3; ++pl) A3[i][pl] = __builtin_bit_cast(bf16x8, ah[i][pl]);
-            (void)Z;
         }
         for (int kc = 0; kc < nchunks; ++kc) {
             FS_READ3(cur, 1, araw, B3n)
