@@ -268,15 +268,17 @@ def test_bench_quotes_pmc_traffic_only_for_the_running_build(tmp_path, monkeypat
     sys.path.insert(0, root)
     import bench
 
-    assert bench.kernel_symbol("igemm128x128") == "conv_igemm_dma_f32<128, 128, 2, 2, false>"
-    assert bench.kernel_symbol("igemm128x64cat") == "conv_igemm_dma_f32<128, 64, 2, 2, true>"
-    assert bench.kernel_symbol("igemm256x128") == "conv_igemm_dma_f32<256, 128, 4, 2, false>"
+    assert bench.kernel_symbol("igemm128x128") == "conv_igemm_dma_f32<128, 128, 2, 2, false, false>"
+    assert bench.kernel_symbol("igemm128x64cat") == "conv_igemm_dma_f32<128, 64, 2, 2, true, false>"
+    assert bench.kernel_symbol("igemm256x128") == "conv_igemm_dma_f32<256, 128, 4, 2, false, false>"
+    assert bench.kernel_symbol("split128x128") == "conv_igemm_dma_f32<128, 128, 2, 2, false, true>"      # the split-operand instantiations
+    assert bench.kernel_symbol("split128x64cat") == "conv_igemm_dma_f32<128, 64, 4, 1, true, true>"
     prof = tmp_path / "profiles"
     prof.mkdir()
     monkeypatch.setattr(bench, "ROOT", str(tmp_path))
     monkeypatch.setattr(bench, "build_id", lambda: "abc")
     assert bench.pmc_traffic("igemm128x128")[0] is None                      # nothing committed
-    key = "void fs::conv_igemm_dma_f32<128, 128, 2, 2, false>(fs::ConvParams, int, int)"
+    key = "void fs::conv_igemm_dma_f32<128, 128, 2, 2, false, false>(fs::ConvParams, int, int)"
     (prof / "r01_pmc_traffic.json").write_text(json.dumps({key: {"hbm_bytes_per_launch": 1.0}}))
     t, why = bench.pmc_traffic("igemm128x128")
     assert t is None and "stale" in why                                      # a file without build meta (round 1's format)
