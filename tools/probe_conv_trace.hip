@@ -2,7 +2,8 @@
 // Built with -DFS_TRACE (instrumentation that never ships in libfloodseg.so):
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 -DFS_TRACE -I flood_uav_video_segmentation_amd/csrc -I include \
 //         tools/probe_conv_trace.hip -o tools/bin/probe_conv_trace
-// usage: probe_conv_trace B H W Cin Cout K pad dil tile [dbg [groups [residual]]]  > trace.csv   (analysed by tools/analyze_conv_trace.py)
+// usage: probe_conv_trace B H W Cin Cout K pad dil tile [dbg [groups [residual [split]]]]  > trace.csv   (analysed by tools/analyze_conv_trace.py)
+//        split = 1: the split-operand instantiation (three bf16 planes of the filters, bf16 MFMA)
 //        groups > 1: grouped GEMM as the Winograd path launches it (use K = 1, W = 1, H = rows per group)
 #include "../flood_uav_video_segmentation_amd/csrc/conv_igemm.hip"
 
@@ -50,6 +51,12 @@ int main(int argc, char** argv) {
         if (hipMalloc(&res, n_out * 4) != hipSuccess || hipMemset(res, 0, n_out * 4) != hipSuccess) return 3;
         p.res = res;
         p.ld_res = Cout;
+    }
+    if (argc > 13 && atoi(argv[13])) {  // split-operand route
+        void* planes = nullptr;
+        if (hipMalloc(&planes, n_w * 6) != hipSuccess || fs::launch_split_bf16x3(wgt, (long long)n_w, planes, 0)) return 3;
+        p.wgt3 = planes;
+        p.plane_bytes = (unsigned)(n_w * 2);
     }
     if (groups > 1) {
         p.groups = groups;
