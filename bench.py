@@ -107,7 +107,7 @@ def kernel_symbol(label):
     """HIP-event label of the library's profile (split128x128, igemm128x64cat, ...) -> the kernel symbol rocprofv3 reports."""
     m = re.match(r"(igemm|split)(\d+)x(\d+)(cat)?$", label)
     split, bm, bn, cat = m.group(1) == "split", int(m.group(2)), int(m.group(3)), bool(m.group(4))
-    waves = "4, 2" if bm == 256 else "4, 1" if split and (bm, bn) == (128, 64) else "2, 2"
+    waves = "4, 2" if bm == 256 else "4, 1" if split and bm == 128 else "2, 2"
     return f"conv_igemm_dma_f32<{bm}, {bn}, {waves}, {'true' if cat else 'false'}, {'true' if split else 'false'}>"
 
 

@@ -619,7 +619,7 @@ int launch_conv_igemm(const ConvParams& p, hipStream_t s, int tile) {
     }
     if (p.in2 && p.wgt3) {
         if (tile == 2) hipLaunchKernelGGL((conv_igemm_dma_f32<128, 64, 4, 1, true, true>), grid, block, 0, s, p, tm, tn);
-        else if (tile == 1) hipLaunchKernelGGL((conv_igemm_dma_f32<128, 128, 2, 2, true, true>), grid, block, 0, s, p, tm, tn);
+        else if (tile == 1) hipLaunchKernelGGL((conv_igemm_dma_f32<128, 128, 4, 1, true, true>), grid, block, 0, s, p, tm, tn);
         else return fail("conv_igemm: concatenated-K launches use tile 1 or 2");
         FS_HIP(hipGetLastError());
         return 0;
@@ -633,7 +633,10 @@ int launch_conv_igemm(const ConvParams& p, hipStream_t s, int tile) {
     }
     if (p.wgt3) {  // split-operand route: same tiles, bf16 matrix pipe
         switch (tile) {
-            case 1: hipLaunchKernelGGL((conv_igemm_dma_f32<128, 128, 2, 2, false, true>), grid, block, 0, s, p, tm, tn); break;
+            // 4 x 1 waves (32 pixel rows x the whole tile width each): every pixel of the tile is split ONCE per workgroup (2 x 2 waves
+            // split it twice).  Under this kernel the chip is power-limited (1.25-1.8 GHz, box dependent), so VALU work saved comes
+            // back as clock: K = 2048 layers +6 %, the others +0..2 % (profiles/r03_split_operands.txt)
+            case 1: hipLaunchKernelGGL((conv_igemm_dma_f32<128, 128, 4, 1, false, true>), grid, block, 0, s, p, tm, tn); break;
             case 2: hipLaunchKernelGGL((conv_igemm_dma_f32<128, 64, 4, 1, false, true>), grid, block, 0, s, p, tm, tn); break;
             case 3: hipLaunchKernelGGL((conv_igemm_dma_f32<64, 64, 2, 2, false, true>), grid, block, 0, s, p, tm, tn); break;
             default: return fail("conv_igemm: the split-operand route has tiles 1, 2 and 3");

@@ -271,7 +271,7 @@ def test_bench_quotes_pmc_traffic_only_for_the_running_build(tmp_path, monkeypat
     assert bench.kernel_symbol("igemm128x128") == "conv_igemm_dma_f32<128, 128, 2, 2, false, false>"
     assert bench.kernel_symbol("igemm128x64cat") == "conv_igemm_dma_f32<128, 64, 2, 2, true, false>"
     assert bench.kernel_symbol("igemm256x128") == "conv_igemm_dma_f32<256, 128, 4, 2, false, false>"
-    assert bench.kernel_symbol("split128x128") == "conv_igemm_dma_f32<128, 128, 2, 2, false, true>"      # the split-operand instantiations
+    assert bench.kernel_symbol("split128x128") == "conv_igemm_dma_f32<128, 128, 4, 1, false, true>"      # the split-operand instantiations
     assert bench.kernel_symbol("split128x64cat") == "conv_igemm_dma_f32<128, 64, 4, 1, true, true>"
     prof = tmp_path / "profiles"
     prof.mkdir()
