@@ -222,6 +222,8 @@ def test_model_representation_wraps_a_hip_network(psp):
 # ------------------------------------------------------------------------------------------------ A/B options at full size
 @pytest.mark.parametrize("opts", [dict(hip_no_winograd=True), dict(hip_winograd_tile=4), dict(hip_winograd_tile=6),
                                   dict(hip_no_fused_head=True), dict(hip_no_fused_shortcut=True), dict(hip_no_fused_winograd=True),
+                                  dict(hip_no_split_bf16=True),  # the fp32-MFMA kernels (round 2's arithmetic)
+                                  dict(hip_no_split_bf16=True, hip_no_winograd=True),
                                   dict(hip_no_winograd=True, hip_no_fused_head=True, hip_no_fused_shortcut=True)])
 def test_every_shipped_option_matches_the_reference_golden_at_713(psp, opts):
     """Each arithmetic-changing route the library ships (direct conv instead of Winograd, F(4,3) / F(6,3) forced, head over

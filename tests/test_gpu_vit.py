@@ -56,6 +56,14 @@ def test_small_segmenters_against_oracle(cfg):
     ref = vit_oracle.forward(x, state, cfg["patch"], cfg["n_layers"], cfg["dec_layers"], cfg["image_size"], 5)["pred"]
     assert got.shape == ref.shape
     assert rel_err(got.cpu(), ref) < VIT_TOL
+    # the same network with its Linears on the fp32-MFMA kernel (FS_OPT_NO_SPLIT_BF16): same tolerance, and the two routes agree
+    # with each other to fp32 reassociation noise
+    net32 = VITSegmentModel(5, cfg["image_size"], patch_size=cfg["patch"], d_model=cfg["d_model"], n_layers=cfg["n_layers"],
+                            dec_layers=cfg["dec_layers"], hip_no_split_bf16=True).eval()
+    net32.load_state_dict(state)
+    got32 = net32(x.cuda())["pred"]
+    assert rel_err(got32.cpu(), ref) < VIT_TOL
+    assert rel_err(got.cpu(), got32.cpu()) < VIT_TOL
 
 
 def test_vit_feature_flow_extension_against_oracle_parity_unpinned():
