@@ -78,6 +78,8 @@ _SIGNATURES = {
     "fs_canvas_finish": (c_int, [c_void, c_void, c_int, c_int, c_i64, c_void, c_void]),
     "fs_pack_conv_weight": (c_int, [c_void, c_void, c_int, c_int, c_int, c_int, c_void]),
     "fs_conv2d_nhwc": (c_int, [c_void, c_int, c_void, c_void, c_void, c_void, c_int, c_void, c_int] + [c_int] * 12 + [c_void]),
+    "fs_attention_workspace_floats": (ctypes.c_size_t, [c_int] * 4),
+    "fs_attention": (c_int, [c_void, c_void, c_int, c_int, c_int, c_f32, c_int, c_void, c_void]),
     "fs_split_bf16x3": (c_int, [c_void, c_i64, c_void, c_void]),
     "fs_conv2d_nhwc_split": (c_int, [c_void, c_int, c_void, c_void, c_void, c_void, c_int, c_void, c_int] + [c_int] * 12 + [c_void]),
     "fs_winograd_workspace_floats": (ctypes.c_size_t, [c_int] * 7),

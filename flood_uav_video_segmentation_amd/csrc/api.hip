@@ -306,6 +306,19 @@ FS_API int fs_conv2d_nhwc_split(const float* in, int ld_in, const void* wgt_plan
     return conv2d_entry(in, ld_in, nullptr, wgt_planes, scale, shift, res, ld_res, out, ld_out, B, H, W, Cin, Cout, KH, KW, stride, pad, dil,
                         relu, tile, stream);
 }
+FS_API size_t fs_attention_workspace_floats(int B, int N, int heads, int split_operands) {
+    if (B < 1 || N < 1 || heads < 1) return 0;
+    return fs::attention_scratch_floats(B, N, heads) + (split_operands ? fs::attention_split_floats(B, N, heads) + 64 : 0) + 64;
+}
+FS_API int fs_attention(const float* qkv, float* out, int B, int N, int heads, float scale, int split_operands, float* workspace, fs_stream stream) {
+    if (!qkv || !out || !workspace || B < 1 || N < 1 || heads < 1) return fs::fail("fs_attention: bad arguments");
+    const size_t sc = fs::attention_scratch_floats(B, N, heads);
+    float* scratch = sc ? workspace : nullptr;
+    if (!split_operands) return fs::launch_attention_f32(qkv, out, B, N, heads, scale, scratch, S(stream));
+    float* planes = workspace + sc;
+    planes += (64 - ((uintptr_t)planes / 4) % 64) % 64;  // 256-B aligned
+    return fs::launch_attention_split(qkv, out, B, N, heads, scale, scratch, planes, S(stream));
+}
 FS_API size_t fs_winograd_workspace_floats(int B, int H, int W, int Cin, int Cout, int dil, int tile_m) {
     if (B < 1 || H < 1 || W < 1 || dil < 1 || !(tile_m == 0 || tile_m == 4 || tile_m == 6)) return 0;
     const int mt = tile_m ? tile_m : fs::winograd_pick_m(B, H, W, dil);

@@ -122,14 +122,15 @@ int run_norm(fs_net* h, const LNorm& n, const float* in, float* out, int rows, i
 }
 
 struct VitWs {
-    float *X, *Xn, *QKV, *A, *Hd, *patches, *emb, *att, *part;
+    float *X, *Xn, *QKV, *A, *Hd, *patches, *emb, *att, *part, *kv;  // kv: K / V^T planes of the split-operand attention
 };
 
 int vit_workspace(fs_net* h, int B, int tokens, VitWs* ws) {
     const size_t D = (size_t)h->cfg.d_model, T = (size_t)B * tokens;
     const size_t P2 = (size_t)3 * h->cfg.patch * h->cfg.patch;
     const size_t att = attention_scratch_floats(B, tokens, (int)(D / 64));
-    const size_t need = T * D * 3 + T * 3 * D + T * 4 * D + T * P2 + T * D + att + 4 * T * D + 64;  // + split-K partials (<= 4 slices)
+    const size_t kv = h->use_split ? attention_split_floats(B, tokens, (int)(D / 64)) : 0;
+    const size_t need = T * D * 3 + T * 3 * D + T * 4 * D + T * P2 + T * D + att + 4 * T * D + kv + 64;  // + split-K partials (<= 4 slices)
     FS_TRY(ws_grow(h, &h->vit_ws, &h->vit_ws_elems, need, false));
     float* p = h->vit_ws;
     ws->X = p; p += T * D;
@@ -142,6 +143,8 @@ int vit_workspace(fs_net* h, int B, int tokens, VitWs* ws) {
     ws->att = att ? p : nullptr;
     p += att;
     ws->part = p;
+    p += 4 * T * D;
+    ws->kv = kv ? p + ((64 - ((uintptr_t)p / 4) % 64) % 64) : nullptr;  // 256-B aligned inside the block (the + 64 of `need`)
     return 0;
 }
 
@@ -154,8 +157,9 @@ int run_block(fs_net* h, const VitBlock& blk, const VitWs& ws, int B, int tokens
     if (!n1_done) FS_TRY(run_norm(h, blk.n1, ws.X, ws.Xn, rows, tokens, 0, s));
     FS_TRY(run_linear(h, blk.qkv, ws.Xn, rows, ws.QKV, nullptr, 0, s));
     const double aflops = 4.0 * B * heads * (double)tokens * tokens * 64;
-    FS_TRY(prof_begin(h, blk.qkv.name + ".attention", "attention_f32", aflops, 4.0 * rows * 4.0 * D, s));
-    FS_TRY(launch_attention_f32(ws.QKV, ws.A, B, tokens, heads, 0.125f, ws.att, s));
+    FS_TRY(prof_begin(h, blk.qkv.name + ".attention", ws.kv ? "attention_split" : "attention_f32", aflops, 4.0 * rows * 4.0 * D, s));
+    if (ws.kv) FS_TRY(launch_attention_split(ws.QKV, ws.A, B, tokens, heads, 0.125f, ws.att, ws.kv, s));
+    else FS_TRY(launch_attention_f32(ws.QKV, ws.A, B, tokens, heads, 0.125f, ws.att, s));
     FS_TRY(prof_end(h, s));
     FS_TRY(run_linear(h, blk.proj, ws.A, rows, ws.X, ws.X, 0, s, ws.part, tokens));  // x = x + proj(attn)
     FS_TRY(run_norm(h, blk.n2, ws.X, ws.Xn, rows, tokens, 0, s));

@@ -486,6 +486,253 @@ __global__ __launch_bounds__(64 * ATT_NW, 3) void attention_dma_kernel(const flo
 #endif
 }
 
+// ------------------------------------------------------------------ attention on the bf16 matrix cores with SPLIT operands
+// (round 3, the default route; same idea as the split-operand conv kernel, conv_igemm.hip / DESIGN.md 3.1b): every fp32 value of
+// Q, K, V and of the probabilities P is the exact sum of three bf16 terms; the six cross products of order <= 2^-16 run on
+// v_mfma_f32_32x32x16_bf16 with fp32 accumulation, the three dropped ones are <= 2^-23 of a product.  Softmax stays in fp32.
+//   * a pre-pass (attention_split_kv_kernel) writes K as three planes [bh][key][64] and V TRANSPOSED as three planes
+//     [bh][64][key] (bf16; keys padded with zeros to a multiple of 32; inside every 16 keys the order is 0-3, 8-11, 4-7, 12-15,
+//     which is the order in which a lane of the S^T accumulator holds its eight keys of a 16-key step -- so P needs no shuffle);
+//   * a stage is 32 keys: 12 KB of K planes + 12 KB of V planes, DMA'd straight into LDS (two stage buffers, one barrier per
+//     stage, 3 workgroups per CU as before); K rows are 128 B (chunk ^ (row >> 1) & 7), V^T rows 64 B (piece ^ (row >> 2) & 3):
+//     both fragment reads are one conflict-free ds_read_b128 per plane;
+//   * S^T = K Q^T: 4 steps of 16 d x 6 terms; O^T += V^T P^T: 2 d-blocks x 2 steps of 16 keys x 6 terms: 48 MFMAs of 32 cycles per
+//     32 keys instead of 64 of 64 cycles; Q is split once per workgroup, P once per stage (72 VALU instructions).
+typedef __bf16 abf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 abf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned au32x4 __attribute__((ext_vector_type(4)));
+typedef float af32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void att_split_pair(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
+    h = __builtin_bit_cast(unsigned, __builtin_convertvector((af32x2){x0, x1}, abf16x2));
+    const float r0 = x0 - __builtin_bit_cast(float, h << 16), r1 = x1 - __builtin_bit_cast(float, h & 0xffff0000u);
+    m = __builtin_bit_cast(unsigned, __builtin_convertvector((af32x2){r0, r1}, abf16x2));
+    const float q0 = r0 - __builtin_bit_cast(float, m << 16), q1 = r1 - __builtin_bit_cast(float, m & 0xffff0000u);
+    l = __builtin_bit_cast(unsigned, __builtin_convertvector((af32x2){q0, q1}, abf16x2));
+}
+
+// thread = (bh, key, 8 consecutive d); Kp / Vtp: [3][BH][Npad][64] and [3][BH][64][Npad] bf16
+__global__ __launch_bounds__(256) void attention_split_kv_kernel(const float* __restrict__ qkv, unsigned short* __restrict__ Kp,
+                                                                 unsigned short* __restrict__ Vtp, int B, int N, int Npad, int heads) {
+    const int64_t total = (int64_t)B * heads * Npad * 8;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int dg = (int)(i & 7);
+    const int key = (int)((i >> 3) % Npad);
+    const int bh = (int)((i >> 3) / Npad);
+    const int b = bh / heads, head = bh - b * heads;
+    const int D = heads * ATT_DH;
+    const size_t plane = (size_t)B * heads * Npad * ATT_DH;
+    float k[8], v[8];
+    if (key < N) {
+        const float* src = qkv + ((size_t)b * N + key) * 3 * D + head * ATT_DH + 8 * dg;
+        const f32x4 k0 = *reinterpret_cast<const f32x4*>(src + D), k1 = *reinterpret_cast<const f32x4*>(src + D + 4);
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(src + 2 * D), v1 = *reinterpret_cast<const f32x4*>(src + 2 * D + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { k[e] = k0[e]; k[4 + e] = k1[e]; v[e] = v0[e]; v[4 + e] = v1[e]; }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) k[e] = v[e] = 0.f;
+    }
+    au32x4 kh, km, kl;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        unsigned h, m, l;
+        att_split_pair(k[2 * e], k[2 * e + 1], h, m, l);
+        kh[e] = h; km[e] = m; kl[e] = l;
+    }
+    const size_t ko = ((size_t)bh * Npad + key) * ATT_DH + 8 * dg;
+    *reinterpret_cast<au32x4*>(Kp + ko) = kh;
+    *reinterpret_cast<au32x4*>(Kp + plane + ko) = km;
+    *reinterpret_cast<au32x4*>(Kp + 2 * plane + ko) = kl;
+    // V transposed; position of key k inside its group of 16: (k & 3) + 4 (k >> 3) + 8 ((k >> 2) & 1)
+    const int kk = key & 15, pos = (key & ~15) + (kk & 3) + 4 * (kk >> 3) + 8 * ((kk >> 2) & 1);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float x = v[e];
+        const __bf16 hb = (__bf16)x;
+        const float r = x - (float)hb;
+        const __bf16 mb = (__bf16)r;
+        const __bf16 lb = (__bf16)(r - (float)mb);
+        const size_t vo = ((size_t)bh * ATT_DH + 8 * dg + e) * Npad + pos;
+        Vtp[vo] = __builtin_bit_cast(unsigned short, hb);
+        Vtp[plane + vo] = __builtin_bit_cast(unsigned short, mb);
+        Vtp[2 * plane + vo] = __builtin_bit_cast(unsigned short, lb);
+    }
+}
+
+template <bool SPLIT>
+__global__ __launch_bounds__(64 * ATT_NW, 3) void attention_bf16x3_kernel(const float* __restrict__ qkv, const unsigned short* __restrict__ Kp,
+                                                                        const unsigned short* __restrict__ Vtp, float* __restrict__ out,
+                                                                        float* __restrict__ part_o, float* __restrict__ part_ml, int N, int Npad,
+                                                                        int heads, float scale, int nsplit, unsigned plane_bytes) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int ST = 32;     // keys per stage
+    constexpr int PL = 1024;   // floats of LDS per plane and stage (4 KB: 32 keys x 128 B, or 64 d-rows x 64 B)
+    __shared__ __attribute__((aligned(1024))) float Ks[2][3 * PL];
+    __shared__ __attribute__((aligned(1024))) float Vs[2][3 * PL];
+    const int D = heads * ATT_DH, ld = 3 * D;
+    const int b = blockIdx.z, head = blockIdx.y, bh = b * heads + head;
+    const int t = threadIdx.x, lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int l31 = lane & 31, hh = lane >> 5;
+    const int qtiles = SPLIT ? gridDim.x / nsplit : gridDim.x;
+    const int qt = SPLIT ? blockIdx.x % qtiles : blockIdx.x, split = SPLIT ? blockIdx.x / qtiles : 0;
+    const int q = qt * (32 * ATT_NW) + wv * 32 + l31;
+    const int qc = min(q, N - 1);
+    const float scale2 = scale * 1.44269504088896340736f;
+    // Q of this lane's query: d = 16 ks + 8 hh .. + 7 for the four steps, scaled, split once
+    abf16x8 Qp[4][3];
+    {
+        const float* qp = qkv + ((size_t)b * N + qc) * ld + head * ATT_DH + 8 * hh;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(qp + 16 * ks), c = *reinterpret_cast<const f32x4*>(qp + 16 * ks + 4);
+            au32x4 h, m, l;
+            const float x[8] = {a[0], a[1], a[2], a[3], c[0], c[1], c[2], c[3]};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                unsigned hu, mu, lu;
+                att_split_pair(x[2 * e] * scale2, x[2 * e + 1] * scale2, hu, mu, lu);
+                h[e] = hu; m[e] = mu; l[e] = lu;
+            }
+            Qp[ks][0] = __builtin_bit_cast(abf16x8, h);
+            Qp[ks][1] = __builtin_bit_cast(abf16x8, m);
+            Qp[ks][2] = __builtin_bit_cast(abf16x8, l);
+        }
+    }
+    f32x16 acc_o[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc_o[i][e] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+
+    const int ntiles_all = (N + ATT_KT - 1) / ATT_KT;  // the same key ranges per split as the fp32 kernels
+    const int kt0 = SPLIT ? (ntiles_all * split) / nsplit : 0;
+    const int kt1 = SPLIT ? (ntiles_all * (split + 1)) / nsplit : ntiles_all;
+    const int s0 = 2 * kt0, s1 = min(2 * kt1, (N + ST - 1) / ST);
+
+    const __amdgpu_buffer_rsrc_t k_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)Kp, 0, 3u * plane_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t v_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)Vtp, 0, 3u * plane_bytes, 0x00020000);
+    // DMA pieces of this wave, per plane: K rows 8 wv + (lane >> 3), 16-B slot lane & 7; V^T rows 16 wv + (lane >> 2), slot lane & 3
+    const int krow = 8 * wv + (lane >> 3), vrow = 16 * wv + (lane >> 2);
+    const unsigned k_voff = (unsigned)((((size_t)bh * Npad + krow) * ATT_DH + 8 * ((lane & 7) ^ ((krow >> 1) & 7))) * 2);
+    const unsigned v_voff = (unsigned)((((size_t)bh * ATT_DH + vrow) * Npad + 8 * ((lane & 3) ^ ((vrow >> 2) & 3))) * 2);
+    auto issue = [&](int stage, int buf) {
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(k_rsrc, (__attribute__((address_space(3))) void*)(&Ks[buf][pl * PL + wv * 256]), 16, k_voff,
+                                                     (unsigned)pl * plane_bytes + (unsigned)(stage * ST * ATT_DH * 2), 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(v_rsrc, (__attribute__((address_space(3))) void*)(&Vs[buf][pl * PL + wv * 256]), 16, v_voff,
+                                                     (unsigned)pl * plane_bytes + (unsigned)(stage * ST * 2), 0, 0);
+        }
+    };
+    const int kx = (l31 >> 1) & 7, vx = (l31 >> 2) & 3;
+    constexpr int TA[6] = {0, 2, 1, 0, 1, 0}, TB[6] = {2, 0, 1, 1, 0, 0};  // (row-operand term, column-operand term): h l, l h, m m, h m, m h, h h
+
+    if (s0 < s1) issue(s0, 0);
+    for (int s = s0; s < s1; ++s) {
+        const int buf = (s - s0) & 1;
+        __builtin_amdgcn_s_waitcnt(0x0070);  // this wave's pieces of stage s have landed; the barrier: everybody's have, and nobody reads the other buffer any more
+        __syncthreads();
+        if (s + 1 < s1) issue(s + 1, buf ^ 1);
+        const int key0 = s * ST;
+        f32x16 sT;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) sT[e] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            abf16x8 kf[3];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+                kf[pl] = __builtin_bit_cast(abf16x8, *reinterpret_cast<const au32x4*>(&Ks[buf][pl * PL + l31 * 32 + 4 * ((2 * ks + hh) ^ kx)]));
+#pragma unroll
+            for (int tm = 0; tm < 6; ++tm) sT = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[TA[tm]], Qp[ks][TB[tm]], sT, 0, 0, 0);
+        }
+        if (key0 + 32 > N) {  // block-uniform: only the last stage has keys to mask
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (key0 + (r & 3) + 8 * (r >> 2) + 4 * hh >= N) sT[r] = -INFINITY;
+        }
+        float mloc = sT[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mloc = fmaxf(mloc, sT[r]);
+        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+        const float m_new = fmaxf(m_run, mloc);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        float lsum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            sT[r] = __builtin_amdgcn_exp2f(sT[r] - m_new);
+            lsum += sT[r];
+        }
+        l_run = l_run * alpha + lsum;
+        m_run = m_new;
+        if (__any(alpha != 1.f)) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc_o[i][e] *= alpha;
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            // this lane's eight keys of the step are accumulator registers 8 ks .. 8 ks + 7 (keys 16 ks + 4 hh + 0-3 and + 8-11)
+            au32x4 ph, pm, pl3;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                unsigned hu, mu, lu;
+                att_split_pair(sT[8 * ks + 2 * e], sT[8 * ks + 2 * e + 1], hu, mu, lu);
+                ph[e] = hu; pm[e] = mu; pl3[e] = lu;
+            }
+            const abf16x8 pp[3] = {__builtin_bit_cast(abf16x8, ph), __builtin_bit_cast(abf16x8, pm), __builtin_bit_cast(abf16x8, pl3)};
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                abf16x8 vf[3];
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+                    vf[pl] = __builtin_bit_cast(abf16x8, *reinterpret_cast<const au32x4*>(&Vs[buf][pl * PL + (i * 32 + l31) * 16 + 4 * ((2 * ks + hh) ^ vx)]));
+#pragma unroll
+                for (int tm = 0; tm < 6; ++tm) acc_o[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[TA[tm]], pp[TB[tm]], acc_o[i], 0, 0, 0);
+            }
+        }
+    }
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    if (SPLIT) {
+        if (q < N) {
+            const size_t row = ((size_t)(b * heads + head) * nsplit + split) * N + q;
+            float* op = part_o + row * ATT_DH;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = acc_o[i][4 * g + e];
+                    *reinterpret_cast<f32x4*>(op + i * 32 + 8 * g + 4 * hh) = v;
+                }
+            if (hh == 0) {
+                part_ml[2 * row] = m_run;
+                part_ml[2 * row + 1] = l_tot;
+            }
+        }
+        return;
+    }
+    const float inv = 1.f / l_tot;
+    if (q < N) {
+        float* op = out + ((size_t)b * N + q) * D + head * ATT_DH;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc_o[i][4 * g + e] * inv;
+                *reinterpret_cast<f32x4*>(op + i * 32 + 8 * g + 4 * hh) = v;
+            }
+    }
+#endif
+}
+
 // merge the key splits of one query: O = sum_s e^(m_s - M) O_s / sum_s e^(m_s - M) l_s ; thread = (query row, float4 of dh)
 __global__ __launch_bounds__(256) void attention_combine_kernel(const float* __restrict__ part_o, const float* __restrict__ part_ml,
                                                                 float* __restrict__ out, int B, int N, int heads, int nsplit) {
@@ -529,6 +776,41 @@ int attention_splits(int /*B*/, int N, int heads) {
 size_t attention_scratch_floats(int B, int N, int heads) {
     const int ns = attention_splits(B, N, heads);
     return ns > 1 ? (size_t)B * heads * ns * N * (ATT_DH + 2) : 0;
+}
+
+// floats of workspace the split-operand route needs for the K / V^T planes (two tensors x three bf16 planes, keys padded to 32)
+size_t attention_split_floats(int B, int N, int heads) { return (size_t)2 * 3 * B * heads * ((N + 31) / 32 * 32) * (ATT_DH / 2); }
+
+// softmax(Q K^T * scale) V with split operands (see attention_bf16x3_kernel).  planes: attention_split_floats(B, N, heads) floats;
+// scratch: as launch_attention_f32 (same key splits, same merge).
+int launch_attention_split(const float* qkv, float* out, int B, int N, int heads, float scale, float* scratch, float* planes, hipStream_t s) {
+    FS_REQUIRE(B >= 1 && N >= 1 && heads >= 1 && planes, "attention: bad shape");
+    const int Npad = (N + 31) / 32 * 32;
+    const size_t plane_elems = (size_t)B * heads * Npad * ATT_DH;
+    FS_REQUIRE(plane_elems * 2 * 3 < ((size_t)1 << 31) && ((uintptr_t)qkv & 15) == 0 && ((uintptr_t)planes & 15) == 0, "attention: K / V planes too large or unaligned");
+    unsigned short* Kp = reinterpret_cast<unsigned short*>(planes);
+    unsigned short* Vtp = Kp + 3 * plane_elems;
+    const int64_t total = (int64_t)B * heads * Npad * 8;
+    hipLaunchKernelGGL(attention_split_kv_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, s, qkv, Kp, Vtp, B, N, Npad, heads);
+    FS_HIP(hipGetLastError());
+    const int qtiles = cdiv(N, 32 * ATT_NW);
+    const int ns = scratch ? attention_splits(B, N, heads) : 1;
+    const unsigned plane_bytes = (unsigned)(plane_elems * 2);
+    if (ns == 1) {
+        hipLaunchKernelGGL(attention_bf16x3_kernel<false>, dim3(qtiles, heads, B), dim3(64 * ATT_NW), 0, s, qkv, Kp, Vtp, out, nullptr, nullptr, N, Npad,
+                           heads, scale, 1, plane_bytes);
+        FS_HIP(hipGetLastError());
+        return 0;
+    }
+    float* part_o = scratch;
+    float* part_ml = scratch + (size_t)B * heads * ns * N * ATT_DH;
+    hipLaunchKernelGGL(attention_bf16x3_kernel<true>, dim3(qtiles * ns, heads, B), dim3(64 * ATT_NW), 0, s, qkv, Kp, Vtp, out, part_o, part_ml, N, Npad,
+                       heads, scale, ns, plane_bytes);
+    FS_HIP(hipGetLastError());
+    const int64_t tot = (int64_t)B * heads * N * 16;
+    hipLaunchKernelGGL(attention_combine_kernel, dim3((unsigned)cdiv64(tot, 256)), dim3(256), 0, s, part_o, part_ml, out, B, N, heads, ns);
+    FS_HIP(hipGetLastError());
+    return 0;
 }
 
 int launch_attention_f32(const float* qkv, float* out, int B, int N, int heads, float scale, float* scratch, hipStream_t s) {

@@ -352,3 +352,18 @@ def conv2d_nhwc(x, weight, scale=None, shift=None, residual=None, stride=1, pad=
             check(lib.fs_conv2d_nhwc(ptr(x), cin, ptr(wp), ptr(scale), ptr(shift), ptr(res), o, ptr(out), o, b, h, w, cin, o, kh, kw,
                                      stride, pad, dil, int(relu), tile, stream_ptr()))
     return out
+
+
+def attention(qkv, heads, split_operands=True):
+    """softmax(q k^T / 8) v per head (segm/model/blocks.py:39-66) for qkv [B, N, 3 * heads * 64] -> [B, N, heads * 64].
+    split_operands: the bf16-matrix-core route with three bf16 terms per fp32 value (the networks' default) or the fp32-MFMA one."""
+    lib = _lib.load()
+    with torch.cuda.device(one_device(qkv, what="floodseg.attention")):
+        qkv = _f32c(qkv)
+        b, n, c = qkv.shape
+        if c != 3 * heads * 64:
+            raise ValueError(f"floodseg.attention: last dim {c} != 3 * {heads} * 64")
+        out = torch.empty((b, n, heads * 64), dtype=torch.float32, device=qkv.device)
+        ws = torch.empty(max(1, lib.fs_attention_workspace_floats(b, n, heads, int(split_operands))), dtype=torch.float32, device=qkv.device)
+        check(lib.fs_attention(ptr(qkv), ptr(out), b, n, heads, 0.125, int(split_operands), ptr(ws), stream_ptr()))
+    return out

@@ -213,6 +213,12 @@ int fs_conv2d_nhwc(const float* in, int ld_in, const float* wgt_ohwi, const floa
  * accumulation (the three dropped ones are <= 2^-23 of the product: below the rounding of one fp32 add).  fs_split_bf16x3 writes
  * the three planes (3 * n bf16, n % 8 == 0) of a packed filter bank; fs_conv2d_nhwc_split takes them in place of wgt_ohwi
  * (tiles 0..3). */
+/* Multi-head attention of the Segmenter (segm/model/blocks.py:39-66): out[b][n][h*64 + d] = softmax_keys(q k^T * scale) v for
+ * qkv = [B][N][3 * heads * 64] (q | k | v, head-major inside each third), head_dim 64.  split_operands = 0: fp32 matrix cores;
+ * 1: the split-operand route (three bf16 terms per fp32 value of q, k, v and of the probabilities, bf16 matrix cores, fp32
+ * accumulation and softmax).  workspace: fs_attention_workspace_floats(B, N, heads, split_operands) floats. */
+size_t fs_attention_workspace_floats(int B, int N, int heads, int split_operands);
+int fs_attention(const float* qkv, float* out, int B, int N, int heads, float scale, int split_operands, float* workspace, fs_stream stream);
 int fs_split_bf16x3(const float* w, int64_t n, void* planes, fs_stream stream);
 int fs_conv2d_nhwc_split(const float* in, int ld_in, const void* wgt_planes, const float* scale, const float* shift,
                          const float* res, int ld_res, float* out, int ld_out, int B, int H, int W, int Cin, int Cout, int KH,

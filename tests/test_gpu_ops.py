@@ -431,3 +431,21 @@ def test_conv_at_network_size_is_exact_and_repeatable(shape, tile):
     outs = [ops.conv2d_nhwc(x, wt, sc, sh, r, 1, pad, 1, True, tile) for _ in range(3)]
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2])
     assert ((outs[0].double() - ref).abs().max() / ref.abs().max()).item() < CONV_TOL
+
+
+@pytest.mark.parametrize("shape", [(2, 2026, 6), (1, 1937, 6), (3, 77, 2), (1, 1, 1), (2, 130, 12), (1, 530, 12), (1, 33, 3)])
+def test_attention_both_routes_against_float64(shape):
+    """fs_attention: softmax(q k^T / 8) v per head, head_dim 64, on the fp32 matrix cores and on the split-operand route (three bf16
+    terms per value of q, k, v and of the probabilities).  Token counts that are not multiples of 32 / 64 / 128 exercise the key
+    masking and the zero-padded K / V^T planes; 2026 and 1937 are the S/16 counts at 713 / 704 (key split + merge)."""
+    b, n, heads = shape
+    g = torch.Generator().manual_seed(n * 7 + heads)
+    qkv = torch.randn(b, n, 3 * heads * 64, generator=g) * 1.5
+    q, k, v = [t.view(b, n, heads, 64).permute(0, 2, 1, 3).double() for t in qkv.split(heads * 64, dim=2)]
+    ref = (torch.softmax(q @ k.transpose(-1, -2) * 0.125, dim=-1) @ v).permute(0, 2, 1, 3).reshape(b, n, heads * 64)
+    e = {}
+    for split in (False, True):
+        got = ops.attention(qkv.to(DEV), heads, split_operands=split)
+        e[split] = note(f"attention_{'split' if split else 'fp32'}_{b}x{n}x{heads}", rel(got.double(), ref))
+        assert e[split] < 2e-5, (split, e[split])
+    assert e[True] < 2.0 * e[False] + 2e-7, e  # the split route is as accurate as the fp32-MFMA one
