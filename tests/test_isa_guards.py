@@ -35,10 +35,11 @@ def test_conv_kernel_waits_for_its_lds_dma_before_every_barrier(tmp_path):
     checked = attention = 0
     for k in kernels:
         head = k.split("\n", 1)[0]
-        # round 3: the attention kernel stages K / V the same way (attention_dma_kernel) and is held to the same rule
-        if "conv_igemm_dma_f32" not in head and "attention_dma_kernel" not in head:
+        # round 3: the attention kernels stage K / V the same way (attention_dma_kernel; attention_bf16x3_kernel: the K / V^T planes of
+        # the split-operand route) and are held to the same rule, as are the split-operand conv instantiations
+        if "conv_igemm_dma_f32" not in head and "attention_dma_kernel" not in head and "attention_bf16x3_kernel" not in head:
             continue
-        attention += "attention_dma_kernel" in head
+        attention += "attention_dma_kernel" in head or "attention_bf16x3_kernel" in head
         lines = [l.split("\t", 1)[-1].strip() if "\t" in l else l.strip() for l in k.splitlines()[1:]]
         ops = [re.sub(r"\s*//.*", "", l) for l in lines if l]
         barriers = [i for i, o in enumerate(ops) if o.startswith("s_barrier")]
@@ -49,5 +50,5 @@ def test_conv_kernel_waits_for_its_lds_dma_before_every_barrier(tmp_path):
             assert any("lgkmcnt(0)" in o for o in window), f"{head}: s_barrier without a preceding s_waitcnt lgkmcnt(0): {ops[max(0, i - 4):i + 1]}"
         assert any("buffer_load_dwordx4" in o and "lds" in o for o in ops), f"{head}: the direct-to-LDS loads are gone"
         checked += 1
-    assert checked - attention >= 5, f"expected the five tile instantiations, found {checked - attention}"
-    assert attention == 2, f"expected both attention_dma_kernel instantiations (split / no split), found {attention}"
+    assert checked - attention >= 10, f"expected the fp32 and the split-operand tile instantiations, found {checked - attention}"
+    assert attention == 4, f"expected attention_dma_kernel and attention_bf16x3_kernel, key split / no split each, found {attention}"
