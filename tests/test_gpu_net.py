@@ -308,3 +308,25 @@ def test_first_forward_after_reserve_is_hip_graph_capturable():
     got_l, got_m = logits.clone(), mask.clone()
     ref_l, ref_m = window()
     assert torch.equal(got_l, ref_l) and torch.equal(got_m, ref_m)
+
+
+def test_split_operand_route_is_as_close_to_a_float64_network_as_the_fp32_mfma_route(psp):
+    """The default arithmetic route (fp32 operands as three exact bf16 terms on the bf16 matrix cores) against the
+    SAME network evaluated in float64 (the oracle's functions on double tensors): its error is that of the fp32-MFMA route
+    (hip_no_split_bf16) -- both are fp32 evaluations of the network, neither is a reduced-precision one."""
+    net, state = psp
+
+    class HP32(HP):
+        hip_no_split_bf16 = True
+    net32 = FlowPSPNet(HP32(50, 5)).eval()
+    net32.load_state_dict(state)
+    s64 = {k: (v.double() if v.is_floating_point() else v) for k, v in state.items()}
+    for size, seed in ((257, 71), (129, 72)):
+        x = synth.make_clip(2, size, seed=seed)
+        ref = pspnet_oracle.decoder(pspnet_oracle.encoder(x.double(), s64, 50), s64)
+        e_split = note(f"pspnet_{size}_split_route_vs_float64", rel_err(net.segment(x.cuda()).double().cpu(), ref))
+        e_f32 = note(f"pspnet_{size}_fp32_mfma_route_vs_float64", rel_err(net32.segment(x.cuda()).double().cpu(), ref))
+        e_cpu = note(f"pspnet_{size}_torch_cpu_fp32_vs_float64",
+                     rel_err(pspnet_oracle.decoder(pspnet_oracle.encoder(x, state, 50), state).double(), ref))
+        assert e_split < LOGIT_TOL and e_f32 < LOGIT_TOL
+        assert e_split < 2.0 * max(e_f32, e_cpu) + 2e-7, (e_split, e_f32, e_cpu)  # measured 0.86x / 1.49x (129 / 257)
