@@ -113,6 +113,17 @@ def reduce_run(hist, frames, seconds, device="cpu"):
     return hist.cpu(), int(cnt.item()), float(sec.item())
 
 
+def gather_floats(values, device="cpu"):
+    """Every rank's list of floats, as [rank][i] (one all_gather of len(values) float64 at the end of a run; a single process
+    gets [[...]]).  bench.py prints each rank's own ms per step with it, so that a straggler shows in the N > 1 line."""
+    mine = torch.tensor([float(v) for v in values], dtype=torch.float64, device=device)
+    if not (dist.is_available() and dist.is_initialized()):
+        return [mine.tolist()]
+    parts = [torch.empty_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(parts, mine)
+    return [p.tolist() for p in parts]
+
+
 def miou_from_hist(hist):
     """mIoU with the reference's epsilon (flow/base.py:332-336); hist = (intersection, |pred|, |target|)."""
     h = hist.double()

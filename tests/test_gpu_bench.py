@@ -23,9 +23,10 @@ def test_bench_json_line_has_the_contract_fields():
                        capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     j = _last_json(r.stdout)
-    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
-              "data", "config", "roofline", "distributed", "build_id", "parity"):
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "median_ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "distributed", "build_id", "parity"):
         assert k in j, k
+    assert 0.5 * j["ms_per_step"] < j["median_ms_per_step"] < 1.5 * j["ms_per_step"]  # median window latency
     assert j["n_gpus"] == 1 and j["steps"] == 3 and j["warmup"] == 1 and j["unit"] == "frames/s" and j["dtype"] == "f32"
     assert j["scaling"] == "weak" and j["higher_is_better"] is True and j["vs_baseline"] is None and j["data"] == "synthetic"
     assert "workload" in j["config"] and "model" not in j["config"]
@@ -38,7 +39,10 @@ def test_bench_json_line_has_the_contract_fields():
     assert ro["traffic"] is None or ro["traffic"] > 0
     if ro["traffic"] is None:
         assert "stale" in ro["traffic_source"] or "no " in ro["traffic_source"]  # never a silent number from another build
-    assert j["distributed"] == {"backend": "none", "rccl_world_size": 0, "world_size": 1, "collectives": j["distributed"]["collectives"]}
+    d = j["distributed"]
+    assert (d["backend"], d["rccl_world_size"], d["world_size"]) == ("none", 0, 1) and d["launch"]["by"] == "single process"
+    assert d["rank_ms_per_step"]["per_rank"] == [d["rank_ms_per_step"]["max"]] and abs(d["rank_ms_per_step"]["max"] - j["ms_per_step"]) < 0.05 * j["ms_per_step"]
+    assert "timing_source" in ro
     assert j["parity"]["mask_agreement_vs_reference"] > 0.9999 and j["parity"]["miou_delta_pp"] < 0.1
 
 
@@ -78,6 +82,24 @@ def test_bench_launched_directly_with_gpus_2_spawns_its_own_ranks():
     assert bad.returncode != 0 and "WORLD_SIZE=1 but --gpus 2" in bad.stderr
 
 
+def test_bench_five_ranks_spawned_by_the_launcher_on_one_gpu():
+    """The many-rank launch with real handles: `python bench.py --gpus 5 --rehearse-on-one-gpu` = five children, five library handles
+    (~1.2 GB each) on the one device, gloo reduction.  (The 8-rank launch itself is rehearsed on CPU, tests/test_shard_gloo.py:
+    a GPU box admits at most 6 processes on its card, this test runner included, so eight GPU ranks cannot be started here.)
+    64 clips over 5 ranks = 13 / 13 / 13 / 13 / 12 clips; every rank reports its own ms per step."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "5", "--steps", "4", "--warmup", "1", "--no-extras",
+                        "--no-cpu-baseline", "--rehearse-on-one-gpu"], capture_output=True, text=True, timeout=1500, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    j = _last_json(r.stdout)
+    assert j["n_gpus"] == 5 and j["distributed"]["world_size"] == 5 and j["config"]["windows_in_this_ranks_shard"] == 52
+    rk = j["distributed"]["rank_ms_per_step"]
+    assert len(rk["per_rank"]) == 5 and rk["min"] == min(rk["per_rank"]) and rk["max"] == max(rk["per_rank"])
+    assert abs(rk["max"] - j["ms_per_step"]) < 0.05 * j["ms_per_step"]  # the headline time IS the slowest rank's
+    assert j["distributed"]["launch"] == {"by": "bench.py spawn_ranks", "attempt": 0, "HSA_ENABLE_IPC_MODE_LEGACY": j["distributed"]["launch"]["HSA_ENABLE_IPC_MODE_LEGACY"]}
+    assert abs(j["value"] - 5 * 5 * 1000.0 / j["ms_per_step"]) < 1e-2 * j["value"]
+
+
 def test_rccl_code_path_with_a_world_of_one():
     """No second GPU on this box, so RCCL cannot be exercised across ranks here -- but the exact calls the N > 1 run makes
     (init_process_group("nccl"), barrier(device_ids=...), on-device all_reduce SUM / MAX, the boundary all_gather) do run
@@ -95,6 +117,7 @@ dev = torch.device("cuda", 0)
 shard.barrier(dev)
 hist, frames, sec = shard.reduce_run(torch.arange(15).view(3, 5), 20, 1.5, dev)
 assert hist.tolist() == torch.arange(15).view(3, 5).tolist() and frames == 20 and sec == 1.5
+assert shard.gather_floats([1.25, 2.5], dev) == [[1.25, 2.5]]
 nb = shard.exchange_boundary(torch.full((8, 8), 7, dtype=torch.uint8, device=dev), True, dev)
 assert nb is None
 shard.barrier(dev)

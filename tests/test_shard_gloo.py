@@ -105,39 +105,89 @@ def test_bench_schedule_covers_every_window_of_the_64_clips_once():
     assert shard.clip_window_schedule(1, 21, 5, 0, 1) == [(0, 0, 5), (0, 5, 10), (0, 10, 15), (0, 15, 20)]
 
 
-def test_bench_launches_its_own_ranks_without_touching_torch(monkeypatch):
-    """`python bench.py --gpus N` with no WORLD_SIZE (how the driver starts it): the parent only builds the
-    torch.distributed.run command for N fresh child ranks and returns their exit code -- it must not import torch (a process that
-    has initialised the GPU must never spawn-and-replace, and the launcher has no business paying the import)."""
-    import importlib
+_FAKE_POPEN = (
+    "import sys, subprocess, os\n"
+    "calls = []\n"
+    "class FakePopen:\n"
+    "    def __init__(self, cmd, **kw):\n"
+    "        calls.append((cmd, kw))\n"
+    "        rc, lines = SCRIPT[len(calls) - 1]\n"
+    "        self.rc, self.stdout = rc, iter(lines)\n"
+    "    def wait(self):\n"
+    "        return self.rc\n"
+    "subprocess.Popen = FakePopen\n"
+    "os.environ.pop('WORLD_SIZE', None)\n")
+
+
+def _run_launcher(script, argv, body, extra_env=None):
     import subprocess
     import sys
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    code = (
-        "import sys, subprocess\n"
-        "sys.argv = ['bench.py', '--gpus', '8', '--steps', '7', '--warmup', '2']\n"
-        "calls = []\n"
-        "class R: returncode = 5\n"
-        "subprocess.run = lambda cmd, **kw: (calls.append((cmd, kw)), R())[1]\n"
-        "import os; os.environ.pop('WORLD_SIZE', None)\n"
-        f"sys.path.insert(0, {root!r})\n"
-        "import bench\n"
-        "try:\n"
-        "    bench.main()\n"
-        "except SystemExit as e:\n"
-        "    rc = e.code\n"
+    code = (f"SCRIPT = {script!r}\n" + _FAKE_POPEN + f"sys.argv = {argv!r}\nsys.path.insert(0, {root!r})\nimport bench\n"
+            "try:\n    bench.main()\n    rc = 0\nexcept SystemExit as e:\n    rc = e.code\n" + body + "print('launcher-ok')\n")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "HSA_ENABLE_IPC_MODE_LEGACY")}
+    env.update(extra_env or {})
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120, env=env)
+    assert r.returncode == 0 and "launcher-ok" in r.stdout, (r.stdout, r.stderr[-2000:])
+    return r
+
+
+def test_bench_launches_its_own_ranks_without_touching_torch():
+    """`python bench.py --gpus N` with no WORLD_SIZE (how the driver starts it): the parent only builds the
+    torch.distributed.run command for N fresh child ranks, relays their stdout and returns their exit code -- it must not import
+    torch (a process that has initialised the GPU must never spawn-and-replace, and the launcher has no business paying the import)."""
+    body = (
         "cmd, kw = calls[0]\n"
-        "assert rc == 5, rc\n"
+        "assert rc == 0 and len(calls) == 1, (rc, len(calls))\n"
         "assert 'torch' not in sys.modules, 'the launcher imported torch'\n"
         "assert cmd[1:4] == ['-m', 'torch.distributed.run', '--nnodes=1'] and '--nproc-per-node=8' in cmd\n"
         "assert cmd[cmd.index('--master-addr') + 1] == '127.0.0.1' and int(cmd[cmd.index('--master-port') + 1]) > 0\n"
         "assert cmd[-6:] == ['--gpus', '8', '--steps', '7', '--warmup', '2'] and cmd[-7].endswith('bench.py')\n"
-        "assert kw['env']['HSA_ENABLE_IPC_MODE_LEGACY'] == '0'\n"
-        "print('launcher-ok')\n")
-    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
-    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120, env=env)
-    assert r.returncode == 0 and "launcher-ok" in r.stdout, (r.stdout, r.stderr[-2000:])
+        "assert kw['env']['HSA_ENABLE_IPC_MODE_LEGACY'] == '0' and kw['env']['FS_BENCH_LAUNCH_ATTEMPT'] == '0'\n")
+    r = _run_launcher([(0, ['{"value": 1}\n'])], ['bench.py', '--gpus', '8', '--steps', '7', '--warmup', '2'], body)
+    assert '{"value": 1}' in r.stdout  # rank 0's line is relayed
+    # the image exports the variable: the first attempt keeps what it finds
+    body1 = "assert calls[0][1]['env']['HSA_ENABLE_IPC_MODE_LEGACY'] == '1' and rc == 0\n"
+    _run_launcher([(0, ['{"value": 1}\n'])], ['bench.py', '--gpus', '8'], body1, {"HSA_ENABLE_IPC_MODE_LEGACY": "1"})
+
+
+def test_bench_launcher_retries_once_with_the_other_ipc_setting_only_when_no_result_line_came():
+    """The ranks died before rank 0 printed its line (e.g. RCCL could not exchange IPC handles): ONE more launch, fresh children,
+    HSA_ENABLE_IPC_MODE_LEGACY flipped.  A run that printed its line, or failed twice, is never repeated."""
+    body = (
+        "assert rc == 0 and len(calls) == 2, (rc, len(calls))\n"
+        "e0, e1 = calls[0][1]['env'], calls[1][1]['env']\n"
+        "assert (e0['HSA_ENABLE_IPC_MODE_LEGACY'], e1['HSA_ENABLE_IPC_MODE_LEGACY']) == ('0', '1')\n"
+        "assert (e0['FS_BENCH_LAUNCH_ATTEMPT'], e1['FS_BENCH_LAUNCH_ATTEMPT']) == ('0', '1')\n"
+        "p0, p1 = (c[0][c[0].index('--master-port') + 1] for c in calls)\n"
+        "assert calls[0][0][-2:] == calls[1][0][-2:] == ['--gpus', '8'] and 'torch' not in sys.modules\n")
+    r = _run_launcher([(1, ['some rank log\n']), (0, ['{"value": 2}\n'])], ['bench.py', '--gpus', '8'], body)
+    assert "starting them once more with HSA_ENABLE_IPC_MODE_LEGACY=1" in r.stderr and '{"value": 2}' in r.stdout
+    # a failure AFTER the result line: no second launch, the code is handed back
+    _run_launcher([(3, ['{"value": 1}\n'])], ['bench.py', '--gpus', '8'], "assert rc == 3 and len(calls) == 1, (rc, len(calls))\n")
+    # two failures: the second code is handed back, nothing is launched a third time
+    _run_launcher([(1, []), (7, [])], ['bench.py', '--gpus', '8'], "assert rc == 7 and len(calls) == 2, (rc, len(calls))\n")
+
+
+def test_bench_launch_check_with_eight_real_ranks_on_cpu():
+    """The 8-rank launch itself, for real: `python bench.py --gpus 8 --launch-check` spawns 8 torch.distributed.run children that
+    rendezvous on 127.0.0.1 over gloo, take their shard of the 64-clip schedule, and run the end-of-run collectives.  No GPU and
+    no measurement: the line carries no metric."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--launch-check"], capture_output=True, text=True,
+                       timeout=600, cwd=root, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert j["launch_check"] is True and j["n_gpus"] == 8 and "value" not in j and "metric" not in j
+    assert j["windows_per_rank"] == [32] * 8 and j["frames_of_all_shards"] == 64 * 4 * 5 and j["max_seconds"] == 8.0
+    assert j["distributed"] == {"backend": "gloo", "world_size": 8} and j["launch_attempt"] == 0
 
 
 def test_single_process_is_a_no_op():
