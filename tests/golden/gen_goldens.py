@@ -278,8 +278,56 @@ def gen_vit_s16():
     save("vit_s16.npz", **out)
 
 
+def gen_deeplab_backbone():
+    """A7, the part the reference's own code can pin: torchvision is absent (and the reference fetches deeplabv3_resnet101 over
+    torch.hub, model/deeplabv3.py:15), but the ENCODER of FlowDeepLabv3 is a torchvision-style ResNet-101 -- 7x7 stem, v1.5
+    bottlenecks (stride on the 3x3) -- and the reference ships exactly that network as its own code: model/resnet.py:99-165 with
+    deep_base=False, Bottleneck :60-96.  It is assembled here from those classes, avgpool / fc dropped (forward re-stated as the
+    module sequence of :147-156), with torchvision's replace_stride_with_dilation=[False, True, True] schedule applied to the
+    modules the same way model/pspnet.py:55-64 applies PSPNet's: layer3 block 0 keeps dilation 1 and loses its stride, the other
+    layer3 blocks dilate by 2; layer4 block 0 dilates by 2, the rest by 4.  The ASPP head stays unpinned."""
+    import model.resnet as ref_resnet  # reference
+
+    net = ref_resnet.ResNet(ref_resnet.Bottleneck, [3, 4, 23, 3], deep_base=False).eval()
+    for layer, first, rest in ((net.layer3, 1, 2), (net.layer4, 2, 4)):
+        for bi, blk in enumerate(layer):
+            d = first if bi == 0 else rest
+            blk.conv2.stride, blk.conv2.dilation, blk.conv2.padding = (1, 1), (d, d), (d, d)
+            if blk.downsample is not None:
+                blk.downsample[0].stride = (1, 1)
+    state = synth.make_deeplab_state(101, 5, 0)
+    res = net.load_state_dict({k[len("backbone."):]: v for k, v in state.items() if k.startswith("backbone.")}, strict=False)
+    assert not res.unexpected_keys, res.unexpected_keys
+    assert all(k.startswith("fc.") or k.endswith("num_batches_tracked") for k in res.missing_keys), res.missing_keys
+
+    def stages(x):
+        out = {}
+        y = net.maxpool(net.relu(net.bn1(net.conv1(x))))
+        out["stem"] = y
+        for i, layer in enumerate((net.layer1, net.layer2, net.layer3, net.layer4)):
+            y = layer(y)
+            out[f"layer{i + 1}"] = y
+        return out
+
+    arrays = {}
+    small = stages(synth.make_clip(2, 97, seed=150))
+    arrays["feat97_sub"] = small["layer4"][:, ::4]
+    full = stages(synth.make_clip(6, 713, seed=1000)[0:1])
+    f = full["layer4"]
+    assert f.shape == (1, 2048, 90, 90), f.shape
+    arrays["feat713_sub"] = f[:, ::32, ::3, ::3]
+    for k, v in full.items():
+        arrays["stat713_" + k] = np.array([v.double().mean().item(), v.double().abs().mean().item(), v.abs().max().item()])
+    for k, v in small.items():
+        arrays["stat97_" + k] = np.array([v.double().mean().item(), v.double().abs().mean().item(), v.abs().max().item()])
+    print("deeplab backbone 713: |feat| mean", f.double().abs().mean().item(), "max", f.abs().max().item())
+    save("deeplab_backbone.npz", **arrays)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["grid", "ops", "toy", "pspnet", "vit", "vit_s16", "pspnet_feature", "pspnet_deep"]
+    which = sys.argv[1:] or ["grid", "ops", "toy", "pspnet", "vit", "vit_s16", "pspnet_feature", "pspnet_deep", "deeplab_backbone"]
+    if "deeplab_backbone" in which:
+        gen_deeplab_backbone()
     if "pspnet_deep" in which:
         gen_pspnet_deep()
     if "vit_s16" in which:

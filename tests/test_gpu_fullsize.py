@@ -93,6 +93,27 @@ def test_config2_deeplabv3_r101_warp_713_against_oracle_parity_unpinned():
     assert note("cfg2_deeplab_r101_713_miou_delta_pp", (1 - miou) * 100) < 0.1  # north star: mIoU within 0.1 pp
 
 
+@pytest.mark.parametrize("size", [97, 713])
+def test_config2_deeplabv3_r101_encoder_against_the_references_own_resnet(size):
+    """A7, the part that IS pinned: FlowDeepLabv3(R101).encoder on the HIP path against the reference's own model/resnet.py
+    classes assembled as the torchvision backbone (7x7 stem, [3, 4, 23, 3] v1.5 bottlenecks, dilation schedule [False, True, True];
+    tests/golden/deeplab_backbone.npz, gen_goldens.py::gen_deeplab_backbone) -- about 70 % of configs[2]'s FLOPs.  The ASPP head
+    (torchvision DeepLabHead, model/deeplabv3.py:18) stays HIP <-> oracle only: parity unpinned for that part."""
+    z = load_golden("deeplab_backbone.npz")
+    net = FlowDeepLabv3(HP(101)).eval()
+    net.load_state_dict(synth.make_deeplab_state(101, 5, seed=0))
+    if size == 97:
+        f = net.encoder(synth.make_clip(2, 97, seed=150).cuda()).cpu()
+        assert f.shape == (2, 2048, 13, 13)
+        assert note("cfg2_deeplab_r101_encoder_97_vs_reference_resnet", rel_err(f[:, ::4], z["feat97_sub"])) < LOGIT_TOL
+    else:
+        f = net.encoder(synth.make_clip(6, 713, seed=1000)[0:1].cuda()).cpu()
+        assert f.shape == (1, 2048, 90, 90)
+        assert note("cfg2_deeplab_r101_encoder_713_vs_reference_resnet", rel_err(f[:, ::32, ::3, ::3], z["feat713_sub"])) < LOGIT_TOL
+    st = z[f"stat{size}_layer4"]
+    assert abs(f.double().abs().mean().item() - st[1]) < 1e-4 * st[1]
+
+
 # ------------------------------------------------------------------------------------------------ configs[3]
 S16 = dict(patch=16, d_model=384, n_layers=12, dec_layers=2, image_size=704)
 

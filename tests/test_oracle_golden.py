@@ -200,3 +200,26 @@ def test_pspnet_deep_oracle_matches_reference(layers, seed):
     x = synth.make_clip(1, 65, seed=8)
     out = pspnet_oracle.decoder(pspnet_oracle.encoder(x, s, layers), s)
     assert rel_err(out, load_golden("pspnet_deep_small.npz")[f"logits{layers}"]) < 1e-5
+
+
+@pytest.mark.parametrize("size", [97, 713])
+def test_deeplab_backbone_oracle_matches_the_references_own_resnet(size):
+    """A7, the pinned part: the ENCODER of FlowDeepLabv3 (model/deeplabv3.py:47-54: torchvision's ResNet-101 backbone, 7x7 stem,
+    stride on the 3x3, replace_stride_with_dilation=[False, True, True]) against the same network built from the reference's own
+    model/resnet.py:60-165 (ResNet(Bottleneck, [3, 4, 23, 3], deep_base=False) with that dilation schedule applied to its modules;
+    tests/golden/gen_goldens.py::gen_deeplab_backbone).  ~70 % of configs[2]'s FLOPs.  The ASPP head (torchvision DeepLabHead)
+    has no reference-held code and stays unpinned."""
+    from oracle import deeplab_oracle
+
+    z = load_golden("deeplab_backbone.npz")
+    state = synth.make_deeplab_state(101, 5, seed=0)
+    if size == 97:
+        f = deeplab_oracle.encoder(synth.make_clip(2, 97, seed=150), state, 101)
+        assert f.shape == (2, 2048, 13, 13)
+        assert rel_err(f[:, ::4], z["feat97_sub"]) < 1e-5
+    else:
+        f = deeplab_oracle.encoder(synth.make_clip(6, 713, seed=1000)[0:1], state, 101)
+        assert f.shape == (1, 2048, 90, 90)
+        assert rel_err(f[:, ::32, ::3, ::3], z["feat713_sub"]) < 1e-5
+    st = z[f"stat{size}_layer4"]
+    assert abs(f.double().abs().mean().item() - st[1]) < 1e-5 * st[1] and abs(f.abs().max().item() - st[2]) < 1e-5 * st[2]
