@@ -3,7 +3,7 @@ MLP+GELU, mask transformer) against the reference golden and the CPU oracle."""
 import pytest
 import torch
 
-from conftest import load_golden, rel_err
+from conftest import load_golden, note, rel_err
 from flood_uav_video_segmentation_amd import synth
 from flood_uav_video_segmentation_amd.flow.model import FlowModel
 from flood_uav_video_segmentation_amd.model.vit import VITSegmentModel
@@ -12,33 +12,39 @@ from oracle import flow_oracle, vit_oracle
 pytestmark = pytest.mark.gpu
 torch.set_grad_enabled(False)
 VIT_TOL = 1e-3   # 1e-3 x max|logit|.  The last op is a LayerNorm over K=5 cosine similarities, which
-                 # amplifies fp32 summation-order noise of the 14 blocks (measured 2.6e-4 on B/32, < 1e-4 on small nets)
+                 # amplifies fp32 summation-order noise of the 14 blocks (small nets: < 1e-4)
+B32_TOL = 5e-4   # ViT-B/32 as shipped vs the reference golden: the measured error of BOTH arithmetic routes is recorded by note()
+                 # (profiles/r04_parity_measured.txt) and this is kept at 3-5 x the larger of them
 TOKEN_TOL = 1e-4  # encoder tokens (before that amplification) against the oracle
 
 
-@pytest.fixture(scope="module")
-def vit_b32():
+@pytest.fixture(scope="module", params=["split_bf16x3", "fp32_mfma"])
+def vit_b32(request):
     state = synth.make_vit_state(5, 704, seed=0)
-    net = VITSegmentModel(5, 704).eval()
+    net = VITSegmentModel(5, 704, hip_no_split_bf16=request.param == "fp32_mfma").eval()
     net.load_state_dict({"model." + k: v for k, v in state.items()})  # the reference's key spelling
-    return net, state
+    return net, state, request.param
 
 
 def test_vit_b32_704_and_713_match_reference_golden(vit_b32):
-    net, _ = vit_b32
+    """The network as the reference ships it (model/vit.py:13-56: B/32, d_model 768) on both arithmetic routes; the goldens' masks
+    are mixed (no class above 70 % of a frame, tests/test_oracle_golden.py), so the mask comparison is not vacuous."""
+    net, state, route = vit_b32
     z = load_golden("vit_b32.npz")
     o704 = net(synth.make_clip(2, 704, seed=300).cuda())["pred"]
     assert o704.shape == (2, 5, 704, 704)
-    assert rel_err(o704[:, :, ::8, ::8].cpu(), z["pred704_sub"]) < VIT_TOL
-    assert (o704.max(1)[1].to(torch.uint8)[:, ::2, ::2].cpu().numpy() == z["mask704"]).mean() > 0.999
+    assert note(f"vit_b32_704_logits_vs_reference[{route}]", rel_err(o704[:, :, ::8, ::8].cpu(), z["pred704_sub"])) < B32_TOL
+    agree = (o704.max(1)[1].to(torch.uint8)[:, ::2, ::2].cpu().numpy() == z["mask704"]).mean()
+    assert note(f"vit_b32_704_mask_disagreement[{route}]", 1 - agree) < 1e-3
     x713 = synth.make_clip(1, 713, seed=301)
     tok = net.encoder(x713.cuda())  # [1, 768, 23, 23] view of the tokens
-    ref_tok = vit_oracle.encoder_tokens(torch.nn.functional.pad(x713, (0, 23, 0, 23)), vit_b32[1], 32, 12, 704)[:, 1:]
-    assert rel_err(tok.permute(0, 2, 3, 1).reshape(1, 529, 768).cpu(), ref_tok) < TOKEN_TOL
+    ref_tok = vit_oracle.encoder_tokens(torch.nn.functional.pad(x713, (0, 23, 0, 23)), state, 32, 12, 704)[:, 1:]
+    assert note(f"vit_b32_713_tokens_vs_oracle[{route}]", rel_err(tok.permute(0, 2, 3, 1).reshape(1, 529, 768).cpu(), ref_tok)) < TOKEN_TOL
     o713 = net(x713.cuda())["pred"]  # zero padding to 736 + pos-embed resize
     assert o713.shape == (1, 5, 713, 713)
-    assert rel_err(o713[:, :, ::8, ::8].cpu(), z["pred713_sub"]) < VIT_TOL
-    assert (o713.max(1)[1].to(torch.uint8)[:, ::2, ::2].cpu().numpy() == z["mask713"]).mean() > 0.999
+    assert note(f"vit_b32_713_logits_vs_reference[{route}]", rel_err(o713[:, :, ::8, ::8].cpu(), z["pred713_sub"])) < B32_TOL
+    agree = (o713.max(1)[1].to(torch.uint8)[:, ::2, ::2].cpu().numpy() == z["mask713"]).mean()
+    assert note(f"vit_b32_713_mask_disagreement[{route}]", 1 - agree) < 1e-3
 
 
 @pytest.mark.parametrize("cfg", [dict(patch=16, d_model=384, n_layers=3, dec_layers=2, image_size=96, size=96, b=2),

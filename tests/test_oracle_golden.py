@@ -223,3 +223,13 @@ def test_deeplab_backbone_oracle_matches_the_references_own_resnet(size):
         assert rel_err(f[:, ::32, ::3, ::3], z["feat713_sub"]) < 1e-5
     st = z[f"stat{size}_layer4"]
     assert abs(f.double().abs().mean().item() - st[1]) < 1e-5 * st[1] and abs(f.abs().max().item() - st[2]) < 1e-5 * st[2]
+
+
+def test_vit_mask_goldens_are_mixed():
+    """A mask comparison against a golden that is one class almost everywhere would pass for a constant output: every ViT mask
+    fixture shows all five classes and none covers more than 70 % of its frame (synth._VIT_LOGIT_CENTRES)."""
+    for name in ("vit_b32.npz", "vit_s16.npz"):
+        z = load_golden(name)
+        for k in ("mask704", "mask713"):
+            share = np.bincount(z[k].ravel(), minlength=5) / z[k].size
+            assert share.max() < 0.70 and share.min() > 0.005, (name, k, share)
