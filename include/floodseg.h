@@ -212,7 +212,15 @@ int fs_conv2d_nhwc(const float* in, int ld_in, const float* wgt_ohwi, const floa
  * terms (round-to-nearest residues) and the six cross products of order <= 2^-16 run on the bf16 matrix cores with fp32
  * accumulation (the three dropped ones are <= 2^-23 of the product: below the rounding of one fp32 add).  fs_split_bf16x3 writes
  * the three planes (3 * n bf16, n % 8 == 0) of a packed filter bank; fs_conv2d_nhwc_split takes them in place of wgt_ohwi
- * (tiles 0..3). */
+ * (tiles 0..3).
+ * Non-finite and out-of-range operands (tests/test_gpu_ops.py::test_conv_non_finite_operands): the split is exact for every
+ * finite fp32 value up to the largest bf16, |x| <= 3.3895e38 (and flushes nothing above 2^-110: the low-order term of a smaller
+ * value may be a bf16 denormal).  An operand that is +-inf, NaN, or finite with 3.3895e38 < |x| <= FLT_MAX makes EVERY output it
+ * contributes to NaN on this route (its leading bf16 term is infinite and the residue inf - inf); the fp32-MFMA route
+ * (fs_conv2d_nhwc, FS_OPT_NO_SPLIT_BF16) follows IEEE like the reference's convolution: +-inf where the sum diverges, NaN for
+ * NaN operands and inf - inf.  Outputs the operand does not contribute to are unaffected on both routes.  On BOTH routes the
+ * fused ReLU epilogue is max(v, 0) and maps a NaN to 0 (torch's F.relu keeps it): a caller that must detect corrupt frames
+ * checks its inputs -- an image normalised from 8-bit pixels and finite trained weights never reach any of these cases. */
 /* Multi-head attention of the Segmenter (segm/model/blocks.py:39-66): out[b][n][h*64 + d] = softmax_keys(q k^T * scale) v for
  * qkv = [B][N][3 * heads * 64] (q | k | v, head-major inside each third), head_dim 64.  split_operands = 0: fp32 matrix cores;
  * 1: the split-operand route (three bf16 terms per fp32 value of q, k, v and of the probabilities, bf16 matrix cores, fp32

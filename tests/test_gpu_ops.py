@@ -82,6 +82,46 @@ def test_conv_igemm_split_operands(case, tile):
     assert e_split < 1.5 * e_f32 + 1e-7, (e_split, e_f32)
 
 
+@pytest.mark.parametrize("relu", [False, True])
+def test_conv_non_finite_operands(relu):
+    """What include/floodseg.h promises about +-inf, NaN and finite values beyond the largest bf16 (3.3895e38) on both arithmetic
+    routes.  1x1 conv, so output pixel p depends on input pixel p only: five poisoned pixels, every other pixel must be BIT-equal to
+    the clean run.  fp32-MFMA route: IEEE, the torch-CPU convolution's NaN / inf pattern.  Split route: every output a poisoned
+    operand contributes to is NaN.  With the fused ReLU (max(v, 0)) a NaN becomes 0 on both routes -- documented, unlike F.relu."""
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(1, 64, 8, 8, generator=g)
+    wt = torch.randn(96, 64, 1, 1, generator=g) * 0.2
+    clean = {s: ops.conv2d_nhwc(x.to(DEV), wt.to(DEV), None, None, None, 1, 0, 1, relu, 0, split=s).cpu() for s in (False, True)}
+    xp = x.clone()
+    poison = {(0, 1): float("inf"), (2, 3): float("-inf"), (4, 4): float("nan"), (6, 0): 3.4e38, (7, 7): -3.4e38}
+    for (py, px), v in poison.items():
+        xp[0, 5, py, px] = v
+    xp[0, 9, 0, 1] = float("-inf")  # +inf and -inf meet in one dot product: NaN under IEEE as well
+    ref = F.conv2d(xp, wt)
+    if relu:
+        ref = ref.relu()
+    touched = torch.zeros(8, 8, dtype=torch.bool)
+    for (py, px) in poison:
+        touched[py, px] = True
+    for split in (False, True):
+        got = ops.conv2d_nhwc(xp.to(DEV), wt.to(DEV), None, None, None, 1, 0, 1, relu, 0, split=split).cpu()
+        assert torch.equal(got[0][:, ~touched], clean[split][0][:, ~touched])  # nothing leaks into the other pixels
+        bad = got[0][:, touched]
+        rbad = ref[0][:, touched]
+        if relu:
+            assert ((bad == 0) | ~torch.isfinite(bad) | torch.isfinite(rbad)).all()  # NaN -> 0 through max(v, 0); -inf -> 0; +inf stays
+            if not split:
+                keep = ~torch.isnan(rbad)
+                assert torch.equal(torch.isinf(bad[keep]), torch.isinf(rbad[keep]))
+        elif split:
+            assert torch.isnan(bad).all()
+        else:
+            assert torch.equal(torch.isnan(bad), torch.isnan(rbad)) and torch.equal(torch.isinf(bad), torch.isinf(rbad))
+            assert torch.equal(bad[torch.isinf(bad)], rbad[torch.isinf(rbad)])  # the same signs
+            fin = torch.isfinite(rbad)
+            assert ((bad[fin] - rbad[fin]).abs() <= 2e-5 * rbad[fin].abs().max()).all()  # 3.4e38 * w stays finite in fp32
+
+
 def test_split_bf16x3_is_exact():
     """fs_split_bf16x3: the three bf16 planes add up to the fp32 value bit for bit (any exponent, both signs, zeros)."""
     lib = _lib.load()
