@@ -360,6 +360,48 @@ FS_API int fs_conv3x3_winograd_nhwc(const float* in, int ld_in, const float* wgt
     if (int rc = fs::launch_conv_igemm(p, S(stream))) return rc;
     return fs::launch_winograd_output(Mb, scale, shift, out, ld_out, B, H, W, Cout, relu, dil, mt, S(stream));
 }
+FS_API int fs_gemm_bf16x3_planes(const void* a_planes, int64_t a_plane_elems, int ld_a, const void* b_planes, int64_t b_plane_elems, int ld_b,
+                                 const float* scale, const float* shift, float* out, int ld_out, int M, int N, int K, int relu, int groups,
+                                 int64_t g_a, int64_t g_b, int64_t g_out, int bn, fs_stream stream) {
+    if (!a_planes || !b_planes || !out || a_plane_elems < 1 || b_plane_elems < 1 || a_plane_elems * 2 >= ((int64_t)1 << 31) ||
+        b_plane_elems * 2 >= ((int64_t)1 << 31) || !(bn == 0 || bn == 64 || bn == 128) || relu < 0 || relu > 2)
+        return fs::fail("fs_gemm_bf16x3_planes: bad arguments (planes below 2 GiB, bn in {0, 64, 128}, relu in {0, 1, 2})");
+    fs::PlaneGemmParams p{};
+    p.a3 = a_planes; p.a_plane_bytes = (unsigned)(a_plane_elems * 2); p.ld_a = ld_a;
+    p.b3 = b_planes; p.b_plane_bytes = (unsigned)(b_plane_elems * 2); p.ld_b = ld_b;
+    p.scale = scale; p.shift = shift; p.out = out; p.ld_out = ld_out;
+    p.M = M; p.N = N; p.K = K; p.relu = relu;
+    p.groups = groups; p.g_a = g_a; p.g_b = g_b; p.g_out = g_out;
+    return fs::launch_gemm_planes(p, S(stream), bn);
+}
+FS_API size_t fs_winograd_planes_workspace_floats(int B, int H, int W, int Cin, int Cout, int dil, int tile_m) {
+    if (B < 1 || H < 1 || W < 1 || dil < 1 || Cin < 1 || Cout < 1 || !(tile_m == 0 || tile_m == 4 || tile_m == 6)) return 0;
+    const int mt = tile_m ? tile_m : fs::winograd_pick_m(B, H, W, dil);
+    const size_t G = (size_t)(mt + 2) * (mt + 2), T = (size_t)fs::winograd_tiles(B, H, W, dil, mt);
+    // U (fp32) + its planes + the planes of V + M (fp32); every block a multiple of 8 floats
+    return G * (size_t)Cout * Cin * 5 / 2 + G * T * (size_t)Cin * 3 / 2 + G * T * (size_t)Cout + 64;
+}
+FS_API int fs_conv3x3_winograd_planes_nhwc(const float* in, int ld_in, const float* wgt_oihw, const float* scale, const float* shift,
+                                           float* out, int ld_out, int B, int H, int W, int Cin, int Cout, int dil, int relu, int tile_m,
+                                           float* workspace, fs_stream stream) {
+    if (!in || !wgt_oihw || !out || !workspace || B < 1 || H < 1 || W < 1 || dil < 1 || Cin % 32 != 0 || Cout % 4 != 0 ||
+        !(tile_m == 0 || tile_m == 4 || tile_m == 6))
+        return fs::fail("fs_conv3x3_winograd_planes_nhwc: bad arguments (Cin %% 32, Cout %% 4, tile_m in {0, 4, 6} required)");
+    const int mt = tile_m ? tile_m : fs::winograd_pick_m(B, H, W, dil);
+    const size_t G = (size_t)(mt + 2) * (mt + 2), T = (size_t)fs::winograd_tiles(B, H, W, dil, mt);
+    const size_t u_elems = G * (size_t)Cout * Cin, v_elems = G * T * (size_t)Cin;
+    float* U = workspace;
+    float* U3 = U + u_elems;
+    float* V3 = U3 + (3 * u_elems + 1) / 2 + 8 - ((3 * u_elems + 1) / 2) % 8;
+    float* Mb = V3 + (3 * v_elems + 1) / 2 + 8 - ((3 * v_elems + 1) / 2) % 8;
+    if (int rc = fs::launch_winograd_filter(wgt_oihw, U, Cout, Cin, mt, S(stream))) return rc;
+    if (int rc = fs::launch_split_bf16x3(U, (long long)u_elems, U3, S(stream))) return rc;
+    if (int rc = fs::launch_winograd_input_planes(in, ld_in, V3, (long long)v_elems, B, H, W, Cin, dil, mt, S(stream))) return rc;
+    fs::PlaneGemmParams p{};
+    if (int rc = fs::winograd_plane_gemm_params(p, mt, (int)T, Cin, Cout, V3, U3, Mb)) return rc;
+    if (int rc = fs::launch_gemm_planes(p, S(stream))) return rc;
+    return fs::launch_winograd_output(Mb, scale, shift, out, ld_out, B, H, W, Cout, relu, dil, mt, S(stream));
+}
 FS_API size_t fs_winograd_fused_workspace_floats(int Cin, int Cout) { return fs::wino_fused_bank_floats(Cin, Cout); }
 FS_API int fs_conv3x3_winograd_fused_nhwc(const float* in, int ld_in, const float* wgt_oihw, const float* scale, const float* shift,
                                           float* out, int ld_out, int B, int H, int W, int Cin, int Cout, int relu, int variant,

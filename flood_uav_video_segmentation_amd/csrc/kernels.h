@@ -53,6 +53,24 @@ const char* conv_igemm_tile_name(const ConvParams& p, int tile = 0);
 int launch_split_bf16x3(const float* w, long long n, void* planes, hipStream_t s);
 
 // ---------------------------------------------------------------------------------
+// Split-operand GEMM with a PRE-SPLIT row operand (gemm_planes.hip): out[m][n] = act(scale[n] * sum_k A[m][k] * W[n][k] + shift[n]),
+// A and W both given as three bf16 planes whose sum is the fp32 operand exactly (launch_split_bf16x3 / a producer's epilogue).
+// Element (plane t, row r, column k) of an operand lives at base + t * plane_bytes + (r * ld + k) * 2; group g (Winograd: one GEMM
+// per transform position) adds g * g_a / g_b elements inside every plane and g * g_out floats to the output.
+// ---------------------------------------------------------------------------------
+struct PlaneGemmParams {
+    const void* a3; unsigned a_plane_bytes; int ld_a;   // row operand [M][K]
+    const void* b3; unsigned b_plane_bytes; int ld_b;   // filters [N][K]
+    const float* scale; const float* shift;             // [N] or nullptr
+    float* out; int ld_out;                             // fp32 [M][N]
+    int M, N, K;                                        // K % 32 == 0
+    int relu;                                           // 0 none, 1 ReLU, 2 GELU (erf)
+    int groups; long long g_a, g_b, g_out;
+};
+// bn: 128 or 64 output columns per workgroup (0 = by N); the row tile is 256
+int launch_gemm_planes(const PlaneGemmParams& p, hipStream_t s, int bn = 0);
+
+// ---------------------------------------------------------------------------------
 // Stem convolution with Cin = 3 read straight from the caller's NCHW frame
 // (model/resnet.py:110 3x3 s2 p1; torchvision ResNet 7x7 s2 p3), + BN + ReLU, NHWC out.
 // ---------------------------------------------------------------------------------
@@ -275,6 +293,10 @@ int launch_winograd_filter(const float* w, float* U /*[(m+2)^2][O][I]*/, int O, 
 // tiles are enumerated (b, py, px, ty, tx).
 int launch_winograd_input(const float* in, int ld_in, float* V /*[(m+2)^2][T][C]*/, int B, int H, int W, int C, int dil, int mt,
                           hipStream_t s);
+// the same transform written as the three bf16 planes of V (same element order inside every plane; plane t starts t * plane_elems
+// bf16 after V3): the row operand of launch_gemm_planes, split once here instead of once per 128 output channels in the GEMM
+int launch_winograd_input_planes(const float* in, int ld_in, void* V3, long long plane_elems, int B, int H, int W, int C, int dil, int mt,
+                                 hipStream_t s);
 int launch_winograd_output(const float* M /*[(m+2)^2][T][N]*/, const float* scale, const float* shift, float* out, int ld_out, int B,
                            int H, int W, int N, int relu, int dil, int mt, hipStream_t s);
 // element (position xi, tile t, channel c) of V (C = Cin) / M (C = Cout) lives at xi * s_pos + t * s_tile + c
@@ -287,6 +309,18 @@ static inline void winograd_gemm_params(ConvParams& p, int mt, int T, int Cin, i
     p.g_in = a.s_pos;
     p.ld_out = (int)o.s_tile;
     p.g_out = o.s_pos;
+}
+// the same grouped GEMM on gemm_planes.hip: V3 / U3 = the three bf16 planes of V (launch_winograd_input_planes) and of the filter
+// bank U[(m+2)^2][Cout][Cin] (launch_split_bf16x3), Mb = fp32 output in M's layout
+static inline int winograd_plane_gemm_params(PlaneGemmParams& p, int mt, int T, int Cin, int Cout, const void* V3, const void* U3, float* Mb) {
+    const long long G = (long long)(mt + 2) * (mt + 2);
+    const WinoLayout a = winograd_layout(mt, T, Cin), o = winograd_layout(mt, T, Cout);
+    if (G * T * Cin * 2 >= (1ll << 31) || G * Cout * Cin * 2 >= (1ll << 31)) return fail("winograd: operand planes beyond 2 GiB");
+    p.a3 = V3; p.a_plane_bytes = (unsigned)(G * T * Cin * 2); p.ld_a = (int)a.s_tile; p.g_a = a.s_pos;
+    p.b3 = U3; p.b_plane_bytes = (unsigned)(G * Cout * Cin * 2); p.ld_b = Cin; p.g_b = (long long)Cout * Cin;
+    p.out = Mb; p.ld_out = (int)o.s_tile; p.g_out = o.s_pos;
+    p.M = T; p.N = Cout; p.K = Cin; p.groups = (int)G;
+    return 0;
 }
 static inline int winograd_tiles(int B, int H, int W, int dil, int mt) {
     return B * dil * dil * ((cdiv(H, dil) + mt - 1) / mt) * ((cdiv(W, dil) + mt - 1) / mt);

@@ -202,6 +202,10 @@ int prof_end(fs_net* h, hipStream_t s) {
 
 namespace {
 
+// Winograd workspace: V (fp32, or -- the plane-operand route -- three bf16 planes = 1.5x the floats) followed by M (fp32)
+size_t wino_v_floats(size_t G, size_t T, int Cin) { return (G * T * Cin * 3 / 2 + 7) / 8 * 8; }
+size_t wino_ws_floats(size_t G, size_t T, int Cin, int Cout) { return wino_v_floats(G, T, Cin) + G * T * Cout; }
+
 // 3x3 s1 p1 conv as Winograd F(4x4,3x3): input transform -> 36 grouped GEMMs -> output transform (+BN, ReLU)
 int run_conv_winograd(fs_net* h, const ConvBN& c, const float* in, int ld_in, int B, int H, int W, float* out, int ld_out,
                       hipStream_t s) {
@@ -211,12 +215,9 @@ int run_conv_winograd(fs_net* h, const ConvBN& c, const float* in, int ld_in, in
     const float* U = nullptr;
     FS_TRY(wino_bank(h, c, mt, s, &U));
     const size_t v_elems = (size_t)G * T * c.Cin, m_elems = (size_t)G * T * c.Cout;
-    FS_TRY(ws_grow(h, &h->wino_ws, &h->wino_ws_elems, v_elems + m_elems, false));
+    FS_TRY(ws_grow(h, &h->wino_ws, &h->wino_ws_elems, wino_ws_floats(G, T, c.Cin, c.Cout), false));
     float* V = h->wino_ws;
-    float* Mb = h->wino_ws + v_elems;
-    FS_TRY(prof_begin(h, c.name + ".wino_in", "winograd_input", 0, 4.0 * ((double)B * H * W * c.Cin + (double)v_elems), s));
-    FS_TRY(launch_winograd_input(in, ld_in, V, B, H, W, c.Cin, c.dil, mt, s));
-    FS_TRY(prof_end(h, s));
+    float* Mb = h->wino_ws + wino_v_floats(G, T, c.Cin);
     ConvParams p{};
     p.in = V;
     p.ld_in = c.Cin;
@@ -238,9 +239,28 @@ int run_conv_winograd(fs_net* h, const ConvBN& c, const float* in, int ld_in, in
     winograd_gemm_params(p, mt, T, c.Cin, c.Cout);  // V / M are tile-major when that fits a buffer descriptor (winograd.hip)
     split_use(h, p);
     const double flops = 2.0 * G * (double)T * c.Cin * c.Cout;
-    FS_TRY(prof_begin(h, c.name + ".wino_gemm", conv_igemm_tile_name(p), flops, 4.0 * ((double)v_elems + (double)G * c.Cout * c.Cin + (double)m_elems), s));
-    FS_TRY(launch_conv_igemm(p, s));
-    FS_TRY(prof_end(h, s));
+    // Round 4: with the split route on, the input transform writes V as its three bf16 planes (each value split ONCE) and the
+    // position GEMMs run on gemm_planes_bf16x3, whose main loop is DMA + fragment reads + MFMAs only (gemm_planes.hip)
+    const bool planes = p.wgt3 && h->use_plane_operands && c.Cin % 32 == 0 && (long long)v_elems * 2 < (1ll << 31);
+    if (planes) {
+        FS_TRY(prof_begin(h, c.name + ".wino_in", "winograd_input_planes", 0, 4.0 * (double)B * H * W * c.Cin + 6.0 * (double)v_elems, s));
+        FS_TRY(launch_winograd_input_planes(in, ld_in, V, (long long)v_elems, B, H, W, c.Cin, c.dil, mt, s));
+        FS_TRY(prof_end(h, s));
+        PlaneGemmParams q{};
+        FS_TRY(winograd_plane_gemm_params(q, mt, T, c.Cin, c.Cout, V, p.wgt3, Mb));
+        q.b_plane_bytes = p.plane_bytes;  // the registered bank's plane size (the bank may hold more than this conv's U)
+        FS_TRY(prof_begin(h, c.name + ".wino_gemm", c.Cout <= 64 ? "planes256x64" : "planes256x128", flops,
+                          6.0 * ((double)v_elems + (double)G * c.Cout * c.Cin) + 4.0 * (double)m_elems, s));
+        FS_TRY(launch_gemm_planes(q, s));
+        FS_TRY(prof_end(h, s));
+    } else {
+        FS_TRY(prof_begin(h, c.name + ".wino_in", "winograd_input", 0, 4.0 * ((double)B * H * W * c.Cin + (double)v_elems), s));
+        FS_TRY(launch_winograd_input(in, ld_in, V, B, H, W, c.Cin, c.dil, mt, s));
+        FS_TRY(prof_end(h, s));
+        FS_TRY(prof_begin(h, c.name + ".wino_gemm", conv_igemm_tile_name(p), flops, 4.0 * ((double)v_elems + (double)G * c.Cout * c.Cin + (double)m_elems), s));
+        FS_TRY(launch_conv_igemm(p, s));
+        FS_TRY(prof_end(h, s));
+    }
     FS_TRY(prof_begin(h, c.name + ".wino_out", "winograd_output", 0, 4.0 * ((double)m_elems + (double)B * H * W * c.Cout), s));
     FS_TRY(launch_winograd_output(Mb, c.scale, c.shift, out, ld_out, B, H, W, c.Cout, c.relu, c.dil, mt, s));
     return prof_end(h, s);
@@ -263,7 +283,7 @@ int reserve_conv(fs_net* h, const ConvBN& c, int B, int H, int W, hipStream_t s,
     if (!takes_winograd(h, c, B, H, W, false)) return 0;
     const int mt = h->wino_force_m ? h->wino_force_m : winograd_pick_m(B, H, W, c.dil);
     const size_t G = (size_t)(mt + 2) * (mt + 2), T = (size_t)winograd_tiles(B, H, W, c.dil, mt);
-    *need = std::max(*need, G * T * ((size_t)c.Cin + (size_t)c.Cout));
+    *need = std::max(*need, wino_ws_floats(G, T, c.Cin, c.Cout));
     const float* U = nullptr;
     return wino_bank(h, c, mt, s, &U);
 }
@@ -370,7 +390,8 @@ int net_create(const fs_config* cfg, fs_handle* out) {
     FS_REQUIRE(cfg->arch == FS_ARCH_SEGMENTER || cfg->layers == 50 || cfg->layers == 101 || cfg->layers == 152,
                "fs_create: layers must be 50, 101 or 152");
     FS_REQUIRE(cfg->classes >= 1 && cfg->classes <= 255, "fs_create: classes out of range");
-    FS_REQUIRE((cfg->flags & ~(FS_OPT_NO_WINOGRAD | FS_OPT_NO_FUSED_HEAD | FS_OPT_NO_FUSED_SHORTCUT | FS_OPT_NO_FUSED_WINOGRAD | FS_OPT_NO_SPLIT_BF16)) == 0,
+    FS_REQUIRE((cfg->flags & ~(FS_OPT_NO_WINOGRAD | FS_OPT_NO_FUSED_HEAD | FS_OPT_NO_FUSED_SHORTCUT | FS_OPT_NO_FUSED_WINOGRAD | FS_OPT_NO_SPLIT_BF16 |
+                               FS_OPT_NO_PLANE_OPERANDS)) == 0,
                "fs_create: unknown option bits 0x%x", cfg->flags);
     FS_REQUIRE(cfg->winograd_tile == 0 || cfg->winograd_tile == 4 || cfg->winograd_tile == 6, "fs_create: winograd_tile must be 0, 4 or 6");
     fs_net* h = new fs_net();
@@ -381,6 +402,7 @@ int net_create(const fs_config* cfg, fs_handle* out) {
     h->use_fused_shortcut = !(cfg->flags & FS_OPT_NO_FUSED_SHORTCUT);
     h->use_fused_winograd = !(cfg->flags & (FS_OPT_NO_FUSED_WINOGRAD | FS_OPT_NO_WINOGRAD));
     h->use_split = !(cfg->flags & FS_OPT_NO_SPLIT_BF16);
+    h->use_plane_operands = h->use_split && !(cfg->flags & FS_OPT_NO_PLANE_OPERANDS);
     if (hipGetDevice(&h->device) != hipSuccess) {
         delete h;
         return fail("fs_create: no HIP device");

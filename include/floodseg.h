@@ -63,9 +63,12 @@ enum {
     FS_OPT_NO_FUSED_SHORTCUT = 4, /* projection blocks: downsample and conv3 as two launches instead of one concatenated-K GEMM */
     FS_OPT_NO_FUSED_WINOGRAD = 8, /* the 3x3 convs with Cin <= 128 (deep stem, conv2 of layer1) on the direct kernel instead of the
                                     one-kernel Winograd F(4x4,3x3) (implied by FS_OPT_NO_WINOGRAD)                             */
-    FS_OPT_NO_SPLIT_BF16 = 16 /* implicit-GEMM launches (1x1 / 3x3 convs, Winograd GEMMs, nn.Linear) on the fp32 matrix-core kernel
+    FS_OPT_NO_SPLIT_BF16 = 16, /* implicit-GEMM launches (1x1 / 3x3 convs, Winograd GEMMs, nn.Linear) on the fp32 matrix-core kernel
                                  (v_mfma_f32_32x32x2_f32) instead of the split-operand one: each fp32 operand as the exact sum of three
                                  bf16 terms, six cross products on the bf16 matrix cores, fp32 accumulation (fs_conv2d_nhwc_split) */
+    FS_OPT_NO_PLANE_OPERANDS = 32 /* round 4: split-operand GEMMs whose producer can write the row operand as three bf16 planes (the Winograd
+                                 input transform) take it as fp32 instead and split it in registers inside the GEMM, as in round 3
+                                 (fs_gemm_bf16x3_planes is the plane route's kernel; implied by FS_OPT_NO_SPLIT_BF16) */
 };
 
 int fs_version(void);
@@ -238,6 +241,21 @@ size_t fs_winograd_workspace_floats(int B, int H, int W, int Cin, int Cout, int 
 int fs_conv3x3_winograd_nhwc(const float* in, int ld_in, const float* wgt_oihw, const float* scale, const float* shift, float* out,
                              int ld_out, int B, int H, int W, int Cin, int Cout, int dil, int relu, int tile_m, float* workspace,
                              fs_stream stream);
+/* Round 4: the split-operand GEMM whose ROW operand is pre-split as well.  out[m][n] = act(scale[n] * sum_k A[m][k] W[n][k] + shift[n])
+ * with A [M][K] and W [N][K] each given as three bf16 planes (fs_split_bf16x3 layout: plane t starts t * plane_elems bf16 after the
+ * base; element (r, k) at (r * ld + k) inside a plane; K % 32 == 0, ld % 8 == 0); `groups` > 1: group g adds g * g_a / g_b elements
+ * inside every plane and g * g_out floats to out (the Winograd position GEMMs).  bn: 128 or 64 output columns per 256-row workgroup
+ * tile, 0 = by N.  Same six cross products in the same order as fs_conv2d_nhwc_split: bit-identical sums for the same operands.
+ * The networks use it for the Winograd GEMMs, whose input transform writes the planes (split once per value instead of once per
+ * 128 output channels inside the GEMM). */
+int fs_gemm_bf16x3_planes(const void* a_planes, int64_t a_plane_elems, int ld_a, const void* b_planes, int64_t b_plane_elems, int ld_b,
+                          const float* scale, const float* shift, float* out, int ld_out, int M, int N, int K, int relu, int groups,
+                          int64_t g_a, int64_t g_b, int64_t g_out, int bn, fs_stream stream);
+/* fs_conv3x3_winograd_nhwc on that route: filter bank split at call time, input transform writes the planes of V. */
+size_t fs_winograd_planes_workspace_floats(int B, int H, int W, int Cin, int Cout, int dil, int tile_m);
+int fs_conv3x3_winograd_planes_nhwc(const float* in, int ld_in, const float* wgt_oihw, const float* scale, const float* shift, float* out,
+                                    int ld_out, int B, int H, int W, int Cin, int Cout, int dil, int relu, int tile_m, float* workspace,
+                                    fs_stream stream);
 /* 3x3 stride-1 pad-1 conv with FEW input channels (32 <= Cin <= 256, Cin % 32 == 0, Cout % 64 == 0) as ONE fused Winograd
  * F(4x4,3x3) kernel: input transform, the 36 position GEMMs on the fp32 matrix cores and the output transform (+ scale/shift,
  * ReLU) without the Winograd-domain tensors ever reaching HBM.  The network uses it for the deep stem's 64-channel convs and

@@ -397,6 +397,94 @@ def test_winograd_conv3x3(case, tile_m):
     assert (out[..., :16] == -7.0).all() and (out[..., 16 + cout:] == -7.0).all()
 
 
+@pytest.mark.parametrize("case", [c for c in [
+    (1, 16, 16, 256, 64, 1, True), (2, 23, 29, 256, 96, 1, False), (1, 45, 45, 256, 128, 2, True), (1, 31, 27, 512, 64, 4, True),
+    (1, 3, 5, 256, 32, 4, False), (2, 30, 30, 256, 32, 24, False), (1, 90, 90, 2048, 256, 36, True), (2, 90, 90, 2048, 512, 1, True)]])
+@pytest.mark.parametrize("tile_m", [4, 6, 0])
+def test_winograd_conv3x3_planes_route(case, tile_m):
+    """Round 4, the networks' Winograd route: the input transform writes V as three bf16 planes and the position GEMMs run on
+    gemm_planes_bf16x3 (both operands pre-split, bf16 matrix cores).  Same cases and tolerances as the fp32 route above; the error is
+    noted next to it (the GEMM's own error is ~1e-6, the Winograd transforms' 1e-5 dominates both routes)."""
+    lib = _lib.load()
+    b, h, w, cin, cout, dil, relu = case
+    g = torch.Generator().manual_seed(h * 100 + cin + dil)
+    x = torch.randn(b, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (cin * 9)) ** 0.5
+    sc, sh = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.1
+    ref = F.conv2d(x, wt, None, 1, dil, dil) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)
+    if relu:
+        ref = ref.relu()
+    xd = ops.as_nhwc(x.to(DEV))
+    out = torch.full((b, h, w, cout + 32), -7.0, device=DEV)
+    ws = torch.empty(lib.fs_winograd_planes_workspace_floats(b, h, w, cin, cout, dil, tile_m), device=DEV)
+    wd, scd, shd = wt.to(DEV), sc.to(DEV), sh.to(DEV)
+    check(lib.fs_conv3x3_winograd_planes_nhwc(ptr(xd), cin, ptr(wd), ptr(scd), ptr(shd), ptr(out[..., 16:]), cout + 32, b, h, w, cin, cout, dil,
+                                              int(relu), tile_m, ptr(ws), stream_ptr()))
+    assert note(f"winograd_planes_op_{h}x{w}x{cin}_d{dil}_m{tile_m}", rel(out[..., 16:16 + cout].permute(0, 3, 1, 2), ref)) < (WINO_TOL if cin <= 1024 else WINO_TOL_2048)
+    assert (out[..., :16] == -7.0).all() and (out[..., 16 + cout:] == -7.0).all()
+
+
+def _planes(t):
+    lib = _lib.load()
+    t = t.contiguous()
+    out = torch.empty(3 * t.numel(), dtype=torch.bfloat16, device=t.device)
+    check(lib.fs_split_bf16x3(ptr(t), t.numel(), ptr(out), stream_ptr()))
+    return out
+
+
+@pytest.mark.parametrize("bn", [0, 64, 128])
+@pytest.mark.parametrize("shape", [
+    # M, N, K, groups, relu
+    (450, 512, 2048, 3, 0),     # rows of one Winograd position of the PSPNet head (B = 2: 450 tiles), 3 of its 64 groups
+    (225, 256, 256, 5, 1),      # layer3 conv2, B = 1: one ragged 256-row tile
+    (1000, 200, 96, 1, 2),      # ragged everything, GELU
+    (16200, 512, 512, 1, 1),    # a 1x1 conv of layer4 over the 2 x 90 x 90 map
+    (33, 40, 32, 2, 0),         # a single 32-deep chunk
+])
+def test_gemm_planes_against_float64_and_the_in_register_split(shape, bn):
+    """gemm_planes_bf16x3: out = act(scale * A W^T + shift) with BOTH operands given as three bf16 planes.  Against a float64 GEMM of
+    the same fp32 operands (error noted, same bound as the conv kernels), and bit for bit against fs_conv2d_nhwc_split (which
+    splits the rows in registers): the six products and their order are the same, only who performs the split differs."""
+    lib = _lib.load()
+    M, N, K, G, relu = shape
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randn(G, M, K, generator=g)
+    wt = torch.randn(G, N, K, generator=g) * (2.0 / K) ** 0.5
+    sc, sh = torch.rand(N, generator=g) + 0.5, torch.randn(N, generator=g) * 0.1
+    ref = torch.einsum("gmk,gnk->gmn", a.double(), wt.double()) * sc.double() + sh.double()
+    if relu == 1:
+        ref = ref.relu()
+    elif relu == 2:
+        ref = F.gelu(ref)
+    ad, wd, scd, shd = a.to(DEV), wt.to(DEV), sc.to(DEV), sh.to(DEV)
+    a3, w3 = _planes(ad), _planes(wd)
+    out = torch.full((G, M, N + 8), -3.0, device=DEV)
+    # planes of the whole [G][M][K] / [G][N][K] tensors: group g starts g * M * K / g * N * K elements into every plane
+    check(lib.fs_gemm_bf16x3_planes(ptr(a3), ad.numel(), K, ptr(w3), wd.numel(), K, ptr(scd), ptr(shd), ptr(out), N + 8, M, N, K, relu, G,
+                                    M * K, N * K, M * (N + 8), bn, stream_ptr()))
+    assert (out[..., N:] == -3.0).all()
+    err = rel(out[..., :N].double(), ref)
+    note(f"gemm_planes_vs_f64_M{M}_N{N}_K{K}_bn{bn}", err)
+    assert err < CONV_TOL
+    if relu != 2:
+        for gi in range(G):  # the in-register split kernel on the same operands, as a 1x1 conv over an M x 1 map
+            w3g = _planes(wd[gi])
+            o2 = torch.empty(M, N, device=DEV)
+            check(lib.fs_conv2d_nhwc_split(ptr(ad[gi]), K, ptr(w3g), ptr(scd), ptr(shd), None, 0, ptr(o2), N, 1, M, 1, K, N, 1, 1, 1, 0, 1, relu, 1,
+                                           stream_ptr()))
+            assert torch.equal(out[gi, :, :N], o2), (gi, (out[gi, :, :N] - o2).abs().max().item())
+
+
+def test_gemm_planes_refuses_what_it_cannot_address():
+    lib = _lib.load()
+    a3 = torch.zeros(3 * 64 * 64, dtype=torch.bfloat16, device=DEV)
+    out = torch.zeros(64, 64, device=DEV)
+    ok = lambda **kw: lib.fs_gemm_bf16x3_planes(ptr(a3), kw.get("pe", 64 * 64), kw.get("ld", 64), ptr(a3), 64 * 64, 64, None, None, ptr(out), 64,  # noqa: E731
+                                                kw.get("M", 64), 64, kw.get("K", 64), 0, kw.get("G", 1), kw.get("ga", 0), 0, 0, kw.get("bn", 0), stream_ptr())
+    assert ok() == 0
+    assert ok(K=48) != 0 and ok(ld=60) != 0 and ok(bn=32) != 0 and ok(M=65) != 0 and ok(G=2, ga=64) != 0  # K % 32, ld % 8, tile, rows / groups beyond the plane
+
+
 WINO_FUSED_TOL = 3e-5  # F(4x4,3x3) in fp32 at Cin <= 256: measured <= 1e-5 (gpurun_out/parity_measured.txt)
 
 

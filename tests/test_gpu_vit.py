@@ -13,8 +13,8 @@ pytestmark = pytest.mark.gpu
 torch.set_grad_enabled(False)
 VIT_TOL = 1e-3   # 1e-3 x max|logit|.  The last op is a LayerNorm over K=5 cosine similarities, which
                  # amplifies fp32 summation-order noise of the 14 blocks (small nets: < 1e-4)
-B32_TOL = 5e-4   # ViT-B/32 as shipped vs the reference golden: the measured error of BOTH arithmetic routes is recorded by note()
-                 # (profiles/r04_parity_measured.txt) and this is kept at 3-5 x the larger of them
+B32_TOL = 8e-4   # ViT-B/32 as shipped vs the reference golden: the measured error of BOTH arithmetic routes is recorded by note()
+                 # (profiles/r04_parity_measured.txt: 2.5e-4 split route, 2.1e-4 fp32-MFMA route) and this is ~3 x the larger of them
 TOKEN_TOL = 1e-4  # encoder tokens (before that amplification) against the oracle
 
 

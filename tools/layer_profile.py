@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-launch table (HIP events inside the library) of one key-frame batch at 713x713:
-    python tools/layer_profile.py [B=2] [pspnet50 | deeplab101]"""
+    python tools/layer_profile.py [B=2] [pspnet50 | deeplab101] [hip_no_plane_operands ...]   (further words: hparams options set True)"""
 import os
 import sys
 
@@ -14,6 +14,8 @@ from flood_uav_video_segmentation_amd.model.pspnet import FlowPSPNet  # noqa: E4
 class HP:
     def __init__(self, layers):
         self.layers, self.classes, self.pretrained = layers, 5, False
+        for opt in sys.argv[3:]:
+            setattr(self, opt, True)
 
 
 def main():
