@@ -32,7 +32,7 @@ OPT_NO_FUSED_HEAD = 2    # FS_OPT_NO_FUSED_HEAD
 OPT_NO_FUSED_SHORTCUT = 4  # FS_OPT_NO_FUSED_SHORTCUT
 OPT_NO_FUSED_WINOGRAD = 8  # FS_OPT_NO_FUSED_WINOGRAD
 OPT_NO_SPLIT_BF16 = 16  # FS_OPT_NO_SPLIT_BF16
-OPT_NO_PLANE_OPERANDS = 32  # FS_OPT_NO_PLANE_OPERANDS
+OPT_PLANE_OPERANDS = 32  # FS_OPT_PLANE_OPERANDS
 CONV_CHUNK_MAJOR = 0x400  # FS_CONV_CHUNK_MAJOR
 
 # name -> (restype, argtypes); must list every symbol of include/floodseg.h

@@ -364,7 +364,7 @@ FS_API int fs_gemm_bf16x3_planes(const void* a_planes, int64_t a_plane_elems, in
                                  const float* scale, const float* shift, float* out, int ld_out, int M, int N, int K, int relu, int groups,
                                  int64_t g_a, int64_t g_b, int64_t g_out, int bn, fs_stream stream) {
     if (!a_planes || !b_planes || !out || a_plane_elems < 1 || b_plane_elems < 1 || a_plane_elems * 2 >= ((int64_t)1 << 31) ||
-        b_plane_elems * 2 >= ((int64_t)1 << 31) || !(bn == 0 || bn == 64 || bn == 128) || relu < 0 || relu > 2)
+        b_plane_elems * 2 >= ((int64_t)1 << 31) || !((bn & 0xff) == 0 || (bn & 0xff) == 64 || (bn & 0xff) == 128) || bn < 0 || relu < 0 || relu > 2)
         return fs::fail("fs_gemm_bf16x3_planes: bad arguments (planes below 2 GiB, bn in {0, 64, 128}, relu in {0, 1, 2})");
     fs::PlaneGemmParams p{};
     p.a3 = a_planes; p.a_plane_bytes = (unsigned)(a_plane_elems * 2); p.ld_a = ld_a;

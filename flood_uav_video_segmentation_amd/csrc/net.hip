@@ -239,7 +239,7 @@ int run_conv_winograd(fs_net* h, const ConvBN& c, const float* in, int ld_in, in
     winograd_gemm_params(p, mt, T, c.Cin, c.Cout);  // V / M are tile-major when that fits a buffer descriptor (winograd.hip)
     split_use(h, p);
     const double flops = 2.0 * G * (double)T * c.Cin * c.Cout;
-    // Round 4: with the split route on, the input transform writes V as its three bf16 planes (each value split ONCE) and the
+    // Round 4, opt-in (FS_OPT_PLANE_OPERANDS): the input transform writes V as its three bf16 planes (each value split ONCE) and the
     // position GEMMs run on gemm_planes_bf16x3, whose main loop is DMA + fragment reads + MFMAs only (gemm_planes.hip)
     const bool planes = p.wgt3 && h->use_plane_operands && c.Cin % 32 == 0 && (long long)v_elems * 2 < (1ll << 31);
     if (planes) {
@@ -391,7 +391,7 @@ int net_create(const fs_config* cfg, fs_handle* out) {
                "fs_create: layers must be 50, 101 or 152");
     FS_REQUIRE(cfg->classes >= 1 && cfg->classes <= 255, "fs_create: classes out of range");
     FS_REQUIRE((cfg->flags & ~(FS_OPT_NO_WINOGRAD | FS_OPT_NO_FUSED_HEAD | FS_OPT_NO_FUSED_SHORTCUT | FS_OPT_NO_FUSED_WINOGRAD | FS_OPT_NO_SPLIT_BF16 |
-                               FS_OPT_NO_PLANE_OPERANDS)) == 0,
+                               FS_OPT_PLANE_OPERANDS)) == 0,
                "fs_create: unknown option bits 0x%x", cfg->flags);
     FS_REQUIRE(cfg->winograd_tile == 0 || cfg->winograd_tile == 4 || cfg->winograd_tile == 6, "fs_create: winograd_tile must be 0, 4 or 6");
     fs_net* h = new fs_net();
@@ -402,7 +402,7 @@ int net_create(const fs_config* cfg, fs_handle* out) {
     h->use_fused_shortcut = !(cfg->flags & FS_OPT_NO_FUSED_SHORTCUT);
     h->use_fused_winograd = !(cfg->flags & (FS_OPT_NO_FUSED_WINOGRAD | FS_OPT_NO_WINOGRAD));
     h->use_split = !(cfg->flags & FS_OPT_NO_SPLIT_BF16);
-    h->use_plane_operands = h->use_split && !(cfg->flags & FS_OPT_NO_PLANE_OPERANDS);
+    h->use_plane_operands = h->use_split && (cfg->flags & FS_OPT_PLANE_OPERANDS);
     if (hipGetDevice(&h->device) != hipSuccess) {
         delete h;
         return fail("fs_create: no HIP device");

@@ -66,9 +66,10 @@ enum {
     FS_OPT_NO_SPLIT_BF16 = 16, /* implicit-GEMM launches (1x1 / 3x3 convs, Winograd GEMMs, nn.Linear) on the fp32 matrix-core kernel
                                  (v_mfma_f32_32x32x2_f32) instead of the split-operand one: each fp32 operand as the exact sum of three
                                  bf16 terms, six cross products on the bf16 matrix cores, fp32 accumulation (fs_conv2d_nhwc_split) */
-    FS_OPT_NO_PLANE_OPERANDS = 32 /* round 4: split-operand GEMMs whose producer can write the row operand as three bf16 planes (the Winograd
-                                 input transform) take it as fp32 instead and split it in registers inside the GEMM, as in round 3
-                                 (fs_gemm_bf16x3_planes is the plane route's kernel; implied by FS_OPT_NO_SPLIT_BF16) */
+    FS_OPT_PLANE_OPERANDS = 32 /* round 4, opt-in A/B route: the Winograd input transform writes V as three bf16 planes (each value split
+                                 once) and the position GEMMs run on fs_gemm_bf16x3_planes instead of splitting fp32 rows in registers
+                                 inside the GEMM.  Measured slower end to end (1.5x the V bytes, profiles/r04_experiments.txt), so it
+                                 is not the default; ignored with FS_OPT_NO_SPLIT_BF16 */
 };
 
 int fs_version(void);
@@ -246,8 +247,8 @@ int fs_conv3x3_winograd_nhwc(const float* in, int ld_in, const float* wgt_oihw, 
  * base; element (r, k) at (r * ld + k) inside a plane; K % 32 == 0, ld % 8 == 0); `groups` > 1: group g adds g * g_a / g_b elements
  * inside every plane and g * g_out floats to out (the Winograd position GEMMs).  bn: 128 or 64 output columns per 256-row workgroup
  * tile, 0 = by N.  Same six cross products in the same order as fs_conv2d_nhwc_split: bit-identical sums for the same operands.
- * The networks use it for the Winograd GEMMs, whose input transform writes the planes (split once per value instead of once per
- * 128 output channels inside the GEMM). */
+ * With FS_OPT_PLANE_OPERANDS the networks use it for the Winograd GEMMs, whose input transform then writes the planes (split once per
+ * value instead of once per 128 output channels inside the GEMM). */
 int fs_gemm_bf16x3_planes(const void* a_planes, int64_t a_plane_elems, int ld_a, const void* b_planes, int64_t b_plane_elems, int ld_b,
                           const float* scale, const float* shift, float* out, int ld_out, int M, int N, int K, int relu, int groups,
                           int64_t g_a, int64_t g_b, int64_t g_out, int bn, fs_stream stream);

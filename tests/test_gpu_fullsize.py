@@ -244,7 +244,7 @@ def test_model_representation_wraps_a_hip_network(psp):
 @pytest.mark.parametrize("opts", [dict(hip_no_winograd=True), dict(hip_winograd_tile=4), dict(hip_winograd_tile=6),
                                   dict(hip_no_fused_head=True), dict(hip_no_fused_shortcut=True), dict(hip_no_fused_winograd=True),
                                   dict(hip_no_split_bf16=True),  # the fp32-MFMA kernels (round 2's arithmetic)
-                                  dict(hip_no_plane_operands=True),  # round 3's Winograd GEMMs: fp32 V, split in registers
+                                  dict(hip_plane_operands=True),  # round 4 A/B route: V as bf16 planes, position GEMMs on gemm_planes_bf16x3
                                   dict(hip_no_split_bf16=True, hip_no_winograd=True),
                                   dict(hip_no_winograd=True, hip_no_fused_head=True, hip_no_fused_shortcut=True)])
 def test_every_shipped_option_matches_the_reference_golden_at_713(psp, opts):
