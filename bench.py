@@ -271,6 +271,8 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary variants")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="multi-rank rehearsal on a 1-GPU box: every rank uses cuda:0 and the reduction runs over gloo")
+    ap.add_argument("--lib", default=None,
+                    help="development A/B only: load this build of the library instead of the in-tree libfloodseg.so (recorded in the JSON line)")
     ap.add_argument("--launch-check", action="store_true",
                     help="no GPU, no measurement: the N ranks rendezvous over gloo, build their shard of the configs[4] schedule, run the "
                          "end-of-run collectives and rank 0 prints a line WITHOUT a metric (rehearses the N-rank launch on CPU)")
@@ -281,6 +283,9 @@ def main():
         sys.exit(spawn_ranks(args.gpus))  # launcher only: no torch, no GPU in this process
     if args.launch_check:
         return launch_check(args)
+    if args.lib:
+        from flood_uav_video_segmentation_amd import _lib as _l
+        _l.LIB_PATH = os.path.abspath(args.lib)
     load_runtime()
 
     rank, local_rank, world = shard.init("gloo" if args.rehearse_on_one_gpu else None)
@@ -362,7 +367,7 @@ def main():
                                    "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")},
                         "collectives": "end-of-run all_reduce of int64 frame count + float64 seconds (and int64[3,K] histograms in tools/predict_video.py); "
                                        "none inside the timed loop"},
-        "build_id": build_id(),
+        "build_id": build_id() if not args.lib else f"--lib {os.path.basename(args.lib)} (not the in-tree build)",
         "reference_claim_fps_other_hw": 76.85,
     }
 

@@ -238,8 +238,12 @@ __global__ __launch_bounds__(256) void seg_fuse_kernel(SegTailParams p, float sy
     const int64_t HW = (int64_t)p.H * p.W;
     const int K = p.K, n = p.n;
     const size_t cHW = (size_t)p.cH * p.cW;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < HW; i += (int64_t)gridDim.x * 256) {
-        const int x = (int)(i % p.W), y = (int)(i / p.W);
+    // grid = (x blocks of 256 pixels, rows): no division per pixel (a flat 64-bit index cost ~200 instructions of i / W, i % W per
+    // thread -- as much as the 10 bilinear taps)
+    for (int y = blockIdx.y; y < p.H; y += gridDim.y) {
+        const int x = blockIdx.x * 256 + threadIdx.x;
+        if (x >= p.W) break;
+        const int64_t i = (int64_t)y * p.W + x;
         const size_t cpix = (size_t)(p.y0 + y) * p.cW + (p.x0 + x);
         float a[KMAX], b[KMAX], v[KMAX];
         // one output frame: logits v[0..K) of this pixel -> the requested outputs
@@ -347,8 +351,7 @@ int launch_seg_tail(const SegTailParams& p, hipStream_t s) {
                                p.H, p.W, p.Hg, p.Wg, j == 0 ? 1 : 0, sy_lo, sx_lo);
         }
     }
-    const int64_t HW = (int64_t)p.H * p.W;
-    const dim3 grid((unsigned)std::min<int64_t>(cdiv64(HW, 256), 16384)), block(256);
+    const dim3 grid((unsigned)cdiv(p.W, 256), (unsigned)std::min(p.H, 65535)), block(256);
     if (p.K <= 8)
         hipLaunchKernelGGL((seg_fuse_kernel<8>), grid, block, 0, s, p, sy_lo, sx_lo, sy_g, sx_g);
     else
@@ -406,8 +409,10 @@ __global__ __launch_bounds__(256) void crops_fuse_kernel(CropsFuseParams p) {
     const int64_t HW = (int64_t)p.H * p.W;
     const int K = p.K, n = p.n, G = p.Hg * p.Wg;
     const size_t lo_stride = (size_t)K * p.h * p.w, map = (size_t)K * G;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < HW; i += (int64_t)gridDim.x * 256) {
-        const int X = (int)(i % p.W), Y = (int)(i / p.W);
+    for (int Y = blockIdx.y; Y < p.H; Y += gridDim.y) {  // grid = (x blocks of 256 pixels, rows): no 64-bit division per pixel
+        const int X = blockIdx.x * 256 + threadIdx.x;
+        if (X >= p.W) break;
+        const int64_t i = (int64_t)Y * p.W + X;
         for (int f0 = 0; f0 < n; f0 += FN) {  // FN frames at a time: FN * K float64 sums per pixel stay in registers
             double acc[FN][KMAX];
 #pragma unroll
@@ -526,8 +531,7 @@ int launch_crops_fuse(CropsFuseParams p, const float* grids, float* scratch, hip
     } else {
         p.no_warp = 1;
     }
-    const int64_t HW = (int64_t)p.H * p.W;
-    hipLaunchKernelGGL((crops_fuse_kernel<8, 5>), dim3((unsigned)std::min<int64_t>(cdiv64(HW, 256), 16384)), dim3(256), 0, s, p);
+    hipLaunchKernelGGL((crops_fuse_kernel<8, 5>), dim3((unsigned)cdiv(p.W, 256), (unsigned)std::min(p.H, 65535)), dim3(256), 0, s, p);
     FS_HIP(hipGetLastError());
     return 0;
 }

@@ -142,11 +142,13 @@ int launch_pack_oihw_to_hwio(const float* w, float* out, int O, int I, int KH, i
 int launch_pack_oihw_chunk_major(const float* w, float* out, int O, int I, int KH, int KW, hipStream_t s);
 // out[(tap*O + o)*nc + c] = w[o][c0 + c][tap]: input-channel slice of an OIHW bank as a [taps*O][nc] 1x1 filter matrix
 int launch_pack_slice_tap_major(const float* w, float* out, int O, int I, int c0, int nc, int taps, hipStream_t s);
-// T = act(scale * (T + sum_b conv-of-upsampled-pyramid term from Z_b) + shift), see net_ops.hip (PSPNet head)
-// scratch: ppm_term_scratch_floats(B, H, C) floats (row-collapsed pyramid term)
+// PSPNet head finish (net_ops.hip): v = act(scale * (T + sum_b conv-of-upsampled-pyramid term from Z_b) + shift), then the classifier
+// 1x1 conv + bias (model/pspnet.py:75) on v while it is in registers: T (the raw backbone conv sums) is read once and never written
+// back, logits come out NCHW [B][K][H][W].  scratch: ppm_term_scratch_floats(B, H, C) floats (row-collapsed pyramid term)
 size_t ppm_term_scratch_floats(int B, int H, int C);
-int launch_ppm_term_finish(float* T, int ld, const float* const Z[4], const int bins[4], float* scratch, const float* scale,
-                           const float* shift, int B, int H, int W, int C, int relu, hipStream_t s);
+int launch_ppm_term_classify(const float* T, int ld, const float* const Z[4], const int bins[4], float* scratch, const float* scale,
+                             const float* shift, int B, int H, int W, int C, int relu, const float* cls_w /*[K][C]*/, const float* cls_b,
+                             float* logits_nchw, int K, hipStream_t s);
 // out[o][0..Ka) = sa[o] * wa[o][:], out[o][Ka..Ka+Kb) = sb[o] * wb[o][:]; shift_out[o] = ha[o] + hb[o]: the filter bank and bias of
 // BN_a(conv_a(x)) + BN_b(conv_b(y)) written as one GEMM over the concatenated K (both 1x1)
 int launch_concat_scaled_filters(const float* wa, const float* sa, const float* ha, int Ka, const float* wb, const float* sb, const float* hb,

@@ -914,11 +914,9 @@ int net_segment(fs_handle h, const FrameSrc& src, int B, int H, int W, float* ou
     raw.scale = raw.shift = nullptr;
     raw.relu = 0;
     FS_TRY(run_conv(h, raw, feat, 2048, B, fh, fw, T, O, nullptr, 0, s));
-    FS_TRY(prof_begin(h, "decoder.0.pyramid_term", "ppm_term_finish", 2.0 * px * O * 144.0, 4.0 * 2.0 * px * O, s));
-    FS_TRY(launch_ppm_term_finish(T, O, Z, h->bins, R, h->cls_main.scale, h->cls_main.shift, B, fh, fw, O, 1, s));
-    FS_TRY(prof_end(h, s));
-    FS_TRY(prof_begin(h, "decoder.4", "classifier_nchw", 2.0 * px * (double)O * K, 4.0 * px * O, s));
-    FS_TRY(launch_classifier_nchw(T, O, h->cls_w, h->cls_b, out_nchw, B, fh * fw, O, K, s));
+    // pyramid term + BatchNorm + ReLU + (Dropout2d: identity in eval) + the classifier 1x1 conv in one pass over the raw sums
+    FS_TRY(prof_begin(h, "decoder.0.pyramid_term+decoder.4", "ppm_term_classify", 2.0 * px * O * (24.0 + K), 4.0 * px * O, s));
+    FS_TRY(launch_ppm_term_classify(T, O, Z, h->bins, R, h->cls_main.scale, h->cls_main.shift, B, fh, fw, O, 1, h->cls_w, h->cls_b, out_nchw, K, s));
     return prof_end(h, s);
 }
 

@@ -3,6 +3,8 @@
 #include "interp.h"
 #include "kernels.h"
 
+#include <type_traits>
+
 namespace fs {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -211,39 +213,40 @@ int launch_stem_conv(const StemParams& p, hipStream_t s) {
 // -------------------------------------------------------------------------------------------
 // MaxPool 3x3 stride 2 pad 1 (padding never wins: -inf)
 // -------------------------------------------------------------------------------------------
+// grid = (blocks of 256 (pixel, channel quad) items of one output row, output rows, images): one 32-bit division per thread (the
+// flat 64-bit index this kernel started with cost four 64-bit divisions per thread, ~400 instructions for 9 loads and a store)
 __global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const float* __restrict__ in, int ld_in, float* __restrict__ out,
                                                            int ld_out, int B, int H, int W, int C4, int Ho, int Wo) {
-    const int64_t total = (int64_t)B * Ho * Wo * C4;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-        const int c4 = (int)(i % C4);
-        const int64_t m = i / C4;
-        const int ox = (int)(m % Wo);
-        const int oy = (int)((m / Wo) % Ho);
-        const int b = (int)(m / ((int64_t)Wo * Ho));
-        f32x4 best = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    const unsigned r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= (unsigned)(Wo * C4)) return;
+    const int ox = (int)(r / (unsigned)C4), c4 = (int)(r - (unsigned)ox * (unsigned)C4);
+    for (int b = blockIdx.z; b < B; b += gridDim.z) {
+        for (int oy = blockIdx.y; oy < Ho; oy += gridDim.y) {
+            f32x4 best = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky) {
-            const int iy = oy * 2 - 1 + ky;
-            if ((unsigned)iy >= (unsigned)H) continue;
+            for (int ky = 0; ky < 3; ++ky) {
+                const int iy = oy * 2 - 1 + ky;
+                if ((unsigned)iy >= (unsigned)H) continue;
 #pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-                const int ix = ox * 2 - 1 + kx;
-                if ((unsigned)ix >= (unsigned)W) continue;
-                const f32x4 v = *reinterpret_cast<const f32x4*>(in + ((size_t)(b * H + iy) * W + ix) * ld_in + c4 * 4);
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int ix = ox * 2 - 1 + kx;
+                    if ((unsigned)ix >= (unsigned)W) continue;
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(in + ((size_t)(b * H + iy) * W + ix) * ld_in + c4 * 4);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) best[e] = fmaxf(best[e], v[e]);
+                    for (int e = 0; e < 4; ++e) best[e] = fmaxf(best[e], v[e]);
+                }
             }
+            *reinterpret_cast<f32x4*>(out + ((size_t)(b * Ho + oy) * Wo + ox) * ld_out + c4 * 4) = best;
         }
-        *reinterpret_cast<f32x4*>(out + (size_t)m * ld_out + c4 * 4) = best;
     }
 }
 
 int launch_maxpool3x3s2(const float* in, int ld_in, float* out, int ld_out, int B, int H, int W, int C, int Ho, int Wo,
                         hipStream_t s) {
     FS_REQUIRE(C % 4 == 0 && ld_in % 4 == 0 && ld_out % 4 == 0, "maxpool: C/ld must be multiples of 4");
-    const int64_t total = (int64_t)B * Ho * Wo * (C / 4);
-    const int grid = (int)std::min<int64_t>(cdiv64(total, 256), 256 * 32);
-    hipLaunchKernelGGL(maxpool3x3s2_kernel, dim3(grid), dim3(256), 0, s, in, ld_in, out, ld_out, B, H, W, C / 4, Ho, Wo);
+    FS_REQUIRE((int64_t)Wo * (C / 4) < (int64_t)1 << 31, "maxpool: output row too large");
+    hipLaunchKernelGGL(maxpool3x3s2_kernel, dim3((unsigned)cdiv(Wo * (C / 4), 256), (unsigned)std::min(Ho, 65535), (unsigned)std::min(B, 65535)), dim3(256), 0, s,
+                       in, ld_in, out, ld_out, B, H, W, C / 4, Ho, Wo);
     FS_HIP(hipGetLastError());
     return 0;
 }
@@ -575,7 +578,7 @@ int launch_pack_slice_tap_major(const float* w, float* out, int O, int I, int c0
 // channel concat never exist: half of the head's GEMM and of its Winograd input transform disappear.
 // Two passes, using that the bilinear weights are separable:
 //   R_b[y][j][s][o] = sum_r [row y+r-1 inside] sum_i wy_b(y+r-1; i) Z_b[(i, j)][(r, s)][o]      ppm_rows_kernel (tiny)
-//   term[y][x][o]   = sum_b sum_s [column x+s-1 inside] sum_j wx_b(x+s-1; j) R_b[y][j][s][o]    ppm_term_finish_kernel
+//   term[y][x][o]   = sum_b sum_s [column x+s-1 inside] sum_j wx_b(x+s-1; j) R_b[y][j][s][o]    ppm_term_classify_kernel
 // i.e. 6 products per row entry and then <= 24 per output, instead of <= 144 per output in one pass (0.12 -> see profiles).
 // Finish pass: one block = PPM_P consecutive pixels of a row x all C channels (a float4 per thread).
 // -------------------------------------------------------------------------------------------
@@ -589,6 +592,9 @@ struct PpmTermParams {
     float sy[4], sx[4];      // resize_scale(bin, H, 1), resize_scale(bin, W, 1)
     const float* scale; const float* shift;
     int B, H, W, C, relu;
+    // the finished activations go straight into the classifier 1x1 conv + bias (model/pspnet.py:75; Dropout2d at :74 is the identity
+    // in eval) and never back to T: logits [B][K][H][W]
+    const float* cls_w; const float* cls_b; float* logits; int K;
 };
 
 __global__ __launch_bounds__(256) void ppm_rows_kernel(PpmTermParams p) {
@@ -613,65 +619,115 @@ __global__ __launch_bounds__(256) void ppm_rows_kernel(PpmTermParams p) {
     *reinterpret_cast<f32x4*>(p.R + (((size_t)(b * p.H + y) * PPM_J + slot) * 3 + s) * p.C + c) = acc;
 }
 
-__global__ __launch_bounds__(256) void ppm_term_finish_kernel(PpmTermParams p) {
+__global__ __launch_bounds__(256) void ppm_term_classify_kernel(PpmTermParams p) {
     const int xt = blockIdx.x, y = blockIdx.y, b = blockIdx.z;
     const int x0 = xt * PPM_P;
-    const int c = threadIdx.x * 4;
-    if (c >= p.C) return;
+    const bool dup = (int)threadIdx.x * 4 >= p.C;       // a block is whole waves: lanes beyond C stay alive for the barriers / shuffles,
+    const int c = dup ? p.C - 4 : (int)threadIdx.x * 4;  // recompute the last float4 and neither store nor contribute
+    // The interpolation weights depend on (level, tap column, pixel) only, not on the channel: the block works the 4 x 3 x 6 x 6 table
+    // wt[level][tap][jj][pixel] = weight of source column j0 + jj out once, in parallel (each of the block's 128+ channel threads
+    // used to redo all 72 coordinate computations: the pass was VALU-bound at 40 us for 66 MB), and every thread reads it back from
+    // LDS.  The source column grows with the pixel, so j0 / the column count of a (level, tap) come from its first / last valid pixel.
+    __shared__ int s_j0[4][3], s_nj[4][3];
+    __shared__ float wt[4][3][6][PPM_P + 2];
+    for (int e = threadIdx.x; e < 4 * 3 * 6 * PPM_P; e += blockDim.x) {
+        const int px = e % PPM_P, jj = (e / PPM_P) % 6, s = (e / (6 * PPM_P)) % 3, bi = e / (18 * PPM_P);
+        // valid pixels of this block for tap column s: 0 <= x0 + px + s - 1 < W and x0 + px < W
+        const int pf = max(0, 1 - s - x0), pl = min(PPM_P - 1, min(p.W - 1 - x0, p.W - x0 - s));
+        float w = 0.f;
+        int j0 = 0, nj = 0;
+        if (pf <= pl) {
+            const LinCoord cf = lin_coord(x0 + pf + s - 1, p.bin[bi], p.sx[bi], 1), cl = lin_coord(x0 + pl + s - 1, p.bin[bi], p.sx[bi], 1);
+            j0 = cf.i0;
+            nj = cl.i1 - cf.i0 + 1;  // <= bin <= 6
+            if (px >= pf && px <= pl) {
+                const LinCoord cx = lin_coord(x0 + px + s - 1, p.bin[bi], p.sx[bi], 1);
+                const int j = j0 + jj;
+                w = (j == cx.i0 ? cx.w0 : 0.f) + (j == cx.i1 ? cx.w1 : 0.f);
+            }
+        }
+        wt[bi][s][jj][px] = w;
+        if (px == 0 && jj == 0) {
+            s_j0[bi][s] = j0;
+            s_nj[bi][s] = nj;
+        }
+    }
+    __syncthreads();
     f32x4 acc[PPM_P];
 #pragma unroll
     for (int px = 0; px < PPM_P; ++px) acc[px] = f32x4{0.f, 0.f, 0.f, 0.f};
     const float* Rrow = p.R + (size_t)(b * p.H + y) * PPM_J * 3 * p.C + c;
-    for (int bi = 0; bi < 4; ++bi) {
-        const int bin = p.bin[bi];
-        for (int s = 0; s < 3; ++s) {
-            LinCoord cx[PPM_P];
-            bool ok[PPM_P];
-            int jmin = bin, jmax = -1;
+    for (int bs = 0; bs < 12; ++bs) {
+        const int bi = bs / 3, s = bs - bi * 3;
+        const int j0 = s_j0[bi][s], nj = s_nj[bi][s];
+        for (int jj = 0; jj < nj; ++jj) {
+            const f32x4 z = *reinterpret_cast<const f32x4*>(Rrow + ((size_t)(p.joff[bi] + j0 + jj) * 3 + s) * p.C);
 #pragma unroll
             for (int px = 0; px < PPM_P; ++px) {
-                const int X = x0 + px + s - 1;
-                ok[px] = X >= 0 && X < p.W && x0 + px < p.W;
-                cx[px] = lin_coord(ok[px] ? X : 0, bin, p.sx[bi], 1);
-                if (ok[px]) {
-                    jmin = min(jmin, cx[px].i0);
-                    jmax = max(jmax, cx[px].i1);
-                }
-            }
-            for (int j = jmin; j <= jmax; ++j) {
-                const f32x4 z = *reinterpret_cast<const f32x4*>(Rrow + ((size_t)(p.joff[bi] + j) * 3 + s) * p.C);
+                const float w = wt[bi][s][jj][px];
 #pragma unroll
-                for (int px = 0; px < PPM_P; ++px) {
-                    const float w = ok[px] ? (j == cx[px].i0 ? cx[px].w0 : 0.f) + (j == cx[px].i1 ? cx[px].w1 : 0.f) : 0.f;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) acc[px][e] = fmaf(w, z[e], acc[px][e]);
-                }
+                for (int e = 0; e < 4; ++e) acc[px][e] = fmaf(w, z[e], acc[px][e]);
             }
         }
     }
     const f32x4 sc = p.scale ? *reinterpret_cast<const f32x4*>(p.scale + c) : f32x4{1.f, 1.f, 1.f, 1.f};
     const f32x4 sh = p.shift ? *reinterpret_cast<const f32x4*>(p.shift + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+    // The finished values stay in registers and meet the classifier rows there (fixed summation order that depends on nothing but C:
+    // a frame's logits do not depend on its batch).  T is read once and never written back.
 #pragma unroll
     for (int px = 0; px < PPM_P; ++px) {
-        if (x0 + px >= p.W) break;
-        float* t = p.T + ((size_t)(b * p.H + y) * p.W + x0 + px) * p.ld + c;
-        f32x4 v = *reinterpret_cast<const f32x4*>(t);
+        const bool in = x0 + px < p.W && !dup;
+        const f32x4 v = in ? *reinterpret_cast<const f32x4*>(p.T + ((size_t)(b * p.H + y) * p.W + x0 + px) * p.ld + c) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            v[e] = (v[e] + acc[px][e]) * sc[e] + sh[e];
-            if (p.relu) v[e] = fmaxf(v[e], 0.f);
+            acc[px][e] = (v[e] + acc[px][e]) * sc[e] + sh[e];
+            if (p.relu) acc[px][e] = fmaxf(acc[px][e], 0.f);
+            if (dup) acc[px][e] = 0.f;
         }
-        *reinterpret_cast<f32x4*>(t) = v;
+    }
+    // Per class k and pixel a thread has the dot product of its 4 channels.  Sixteen lanes are added in registers (four DPP steps:
+    // quad swaps, then row shifts by 4 and 8 -- a shuffle tree through ds_bpermute cost three instructions per step and value), lane
+    // 15 of every row parks the row's sum in LDS and one thread per value adds the block's rows in order.
+    constexpr int KC = 8;  // classes per pass
+    __shared__ float part[PPM_P * KC][16];
+    const int nrows = blockDim.x >> 4;
+    auto dpp_add = [](float v, auto ctrl) {
+        return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), decltype(ctrl)::value, 0xf, 0xf, true));
+    };
+    for (int k0 = 0; k0 < p.K; k0 += KC) {
+        const int kc = min(KC, p.K - k0);
+        for (int k = 0; k < kc; ++k) {
+            const f32x4 w = *reinterpret_cast<const f32x4*>(p.cls_w + (size_t)(k0 + k) * p.C + c);
+#pragma unroll
+            for (int px = 0; px < PPM_P; ++px) {
+                float d = acc[px][0] * w[0] + acc[px][1] * w[1] + acc[px][2] * w[2] + acc[px][3] * w[3];
+                d = dpp_add(d, std::integral_constant<int, 0xB1>{});   // quad_perm [1,0,3,2]
+                d = dpp_add(d, std::integral_constant<int, 0x4E>{});   // quad_perm [2,3,0,1]: every lane of a quad has the quad's sum
+                d = dpp_add(d, std::integral_constant<int, 0x114>{});  // row_shr:4
+                d = dpp_add(d, std::integral_constant<int, 0x118>{});  // row_shr:8: lanes 12-15 of a row have the row's sum
+                if ((threadIdx.x & 15) == 15) part[px * KC + k][threadIdx.x >> 4] = d;
+            }
+        }
+        __syncthreads();
+        if ((int)threadIdx.x < PPM_P * kc) {
+            const int px = threadIdx.x / kc, k = threadIdx.x % kc;
+            float sum = part[px * KC + k][0];
+            for (int r = 1; r < nrows; ++r) sum += part[px * KC + k][r];
+            if (x0 + px < p.W) p.logits[(((size_t)b * p.K + k0 + k) * p.H + y) * p.W + x0 + px] = sum + (p.cls_b ? p.cls_b[k0 + k] : 0.f);
+        }
+        __syncthreads();
     }
 }
 
 size_t ppm_term_scratch_floats(int B, int H, int C) { return (size_t)B * H * PPM_J * 3 * C; }
 
-int launch_ppm_term_finish(float* T, int ld, const float* const Z[4], const int bins[4], float* scratch, const float* scale,
-                           const float* shift, int B, int H, int W, int C, int relu, hipStream_t s) {
-    FS_REQUIRE(C % 4 == 0 && C <= 1024 && ld % 4 == 0 && ((uintptr_t)T & 15) == 0, "ppm_term_finish: C must be a multiple of 4, <= 1024");
-    FS_REQUIRE(H <= 65535 && B <= 65535, "ppm_term_finish: map too large for the launch grid");
-    FS_REQUIRE(bins[0] + bins[1] + bins[2] + bins[3] == PPM_J && scratch, "ppm_term_finish: pyramid levels must add up to %d columns", PPM_J);
+namespace {
+int ppm_term_any(float* T, int ld, const float* const Z[4], const int bins[4], float* scratch, const float* scale, const float* shift, int B, int H,
+                 int W, int C, int relu, const float* cls_w, const float* cls_b, float* logits, int K, hipStream_t s) {
+    FS_REQUIRE(C % 4 == 0 && C <= 1024 && ld % 4 == 0 && ((uintptr_t)T & 15) == 0, "ppm_term_classify: C must be a multiple of 4, <= 1024");
+    FS_REQUIRE(logits && cls_w && K >= 1 && ((uintptr_t)cls_w & 15) == 0, "ppm_term_classify: bad classifier");
+    FS_REQUIRE(H <= 65535 && B <= 65535, "ppm_term_classify: map too large for the launch grid");
+    FS_REQUIRE(bins[0] + bins[1] + bins[2] + bins[3] == PPM_J && scratch, "ppm_term_classify: pyramid levels must add up to %d columns", PPM_J);
     PpmTermParams p{};
     p.T = T; p.ld = ld; p.R = scratch; p.scale = scale; p.shift = shift;
     p.B = B; p.H = H; p.W = W; p.C = C; p.relu = relu;
@@ -684,12 +740,21 @@ int launch_ppm_term_finish(float* T, int ld, const float* const Z[4], const int 
         p.sy[i] = resize_scale(bins[i], H, 1);
         p.sx[i] = resize_scale(bins[i], W, 1);
     }
+    p.cls_w = cls_w; p.cls_b = cls_b; p.logits = logits; p.K = K;
     const dim3 block(((C / 4 + 63) / 64) * 64);
     hipLaunchKernelGGL(ppm_rows_kernel, dim3(PPM_J * 3, H, B), block, 0, s, p);
     FS_HIP(hipGetLastError());
-    hipLaunchKernelGGL(ppm_term_finish_kernel, dim3(cdiv(W, PPM_P), H, B), block, 0, s, p);
+    hipLaunchKernelGGL(ppm_term_classify_kernel, dim3(cdiv(W, PPM_P), H, B), block, 0, s, p);
     FS_HIP(hipGetLastError());
     return 0;
+}
+}  // namespace
+
+int launch_ppm_term_classify(const float* T, int ld, const float* const Z[4], const int bins[4], float* scratch, const float* scale,
+                             const float* shift, int B, int H, int W, int C, int relu, const float* cls_w, const float* cls_b, float* logits_nchw,
+                             int K, hipStream_t s) {
+    FS_REQUIRE(logits_nchw, "ppm_term_classify: no output");
+    return ppm_term_any(const_cast<float*>(T), ld, Z, bins, scratch, scale, shift, B, H, W, C, relu, cls_w, cls_b, logits_nchw, K, s);
 }
 
 // 32x32 LDS-tiled transposes between [B][C][HW] and [B][HW][ld]

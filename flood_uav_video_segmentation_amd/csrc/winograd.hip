@@ -69,16 +69,16 @@ __global__ __launch_bounds__((MT + 2) * 32) void winograd_input_kernel(const flo
     __shared__ f32x4 tmp[A][A][32];  // [r][x][channel quad]
     // dilation d: the conv splits into d*d independent undilated convs on the pixel lattices (py + d*i, px + d*j);
     // tile t = (b, py, px, ty, tx) covers lattice rows m*ty-1 .. m*ty+m of phase (py, px)
-    const int64_t T = (int64_t)B * dil * dil * th * tw;
-    const int cblocks = (C4 + 31) / 32;
+    const unsigned T = (unsigned)(B * dil * dil * th * tw);  // < 2^31 (launcher)
     const int cq = threadIdx.x & 31, lane_x = threadIdx.x >> 5;  // lane_x: column in pass 1, row in pass 2
-    for (int64_t blk = blockIdx.x; blk < T * cblocks; blk += gridDim.x) {
-        const int cb = (int)(blk % cblocks);
-        const int64_t t = blk / cblocks;
-        const int c4 = cb * 32 + cq;
-        const bool cok = c4 < C4;
-        const int tx = (int)(t % tw), ty = (int)((t / tw) % th);
-        const int ph = (int)((t / ((int64_t)tw * th)) % (dil * dil)), b = (int)(t / ((int64_t)tw * th * dil * dil));
+    // grid = (channel blocks, tiles): the tile index is decomposed with 32-bit divisions (a flat 64-bit block index cost six 64-bit
+    // divisions per tile in every thread -- several times the transform's own arithmetic)
+    const int c4 = blockIdx.x * 32 + cq;
+    const bool cok = c4 < C4;
+    for (unsigned t = blockIdx.y; t < T; t += gridDim.y) {
+        const unsigned tw_u = (unsigned)tw, th_u = (unsigned)th, dd = (unsigned)(dil * dil);
+        const unsigned q1 = t / tw_u, q2 = q1 / th_u, q3 = q2 / dd;
+        const int tx = (int)(t - q1 * tw_u), ty = (int)(q1 - q2 * th_u), ph = (int)(q2 - q3 * dd), b = (int)q3;
         const int py = ph / dil, px = ph - py * dil;
         const int y0 = py + dil * (ty * MT - 1), x0 = px + dil * (tx * MT - 1);  // pad = dil <=> lattice pad 1
         {
@@ -153,8 +153,8 @@ int winograd_input_any(const float* in, int ld_in, void* V, long long plane_elem
     const int th = (cdiv(H, dil) + mt - 1) / mt, tw = (cdiv(W, dil) + mt - 1) / mt;
     const long long T = (long long)B * dil * dil * th * tw;
     FS_REQUIRE(plane_elems == 0 || plane_elems >= T * (mt + 2) * (mt + 2) * C, "winograd_input: a plane of %lld elements does not hold V", plane_elems);
-    const int64_t blocks = (int64_t)T * cdiv(C / 4, 32);
-    const dim3 grid((unsigned)std::min<int64_t>(blocks, 1 << 20));
+    FS_REQUIRE(T < (1ll << 31), "winograd_input: too many tiles");
+    const dim3 grid((unsigned)cdiv(C / 4, 32), (unsigned)std::min<long long>(T, 65535));
     const WinoLayout lay = winograd_layout(mt, T, C);
     float* Vf = reinterpret_cast<float*>(V);
     if (plane_elems) {
@@ -187,16 +187,14 @@ __global__ __launch_bounds__((MT + 2) * 32) void winograd_output_kernel(const fl
                                                                         long long s_tile) {
     constexpr int A = Wino<MT>::A;
     __shared__ f32x4 tmp[MT][A][32];  // [a][q][channel quad]
-    const int64_t T = (int64_t)B * dil * dil * th * tw;
-    const int nblocks = (N4 + 31) / 32;
+    const unsigned T = (unsigned)(B * dil * dil * th * tw);
     const int oq = threadIdx.x & 31, lane_q = threadIdx.x >> 5;
-    for (int64_t blk = blockIdx.x; blk < T * nblocks; blk += gridDim.x) {
-        const int nb = (int)(blk % nblocks);
-        const int64_t t = blk / nblocks;
-        const int n4 = nb * 32 + oq;
-        const bool nok = n4 < N4;
-        const int tx = (int)(t % tw), ty = (int)((t / tw) % th);
-        const int ph = (int)((t / ((int64_t)tw * th)) % (dil * dil)), b = (int)(t / ((int64_t)tw * th * dil * dil));
+    const int n4 = blockIdx.x * 32 + oq;  // grid = (channel blocks, tiles), as in the input transform
+    const bool nok = n4 < N4;
+    for (unsigned t = blockIdx.y; t < T; t += gridDim.y) {
+        const unsigned tw_u = (unsigned)tw, th_u = (unsigned)th, dd = (unsigned)(dil * dil);
+        const unsigned q1 = t / tw_u, q2 = q1 / th_u, q3 = q2 / dd;
+        const int tx = (int)(t - q1 * tw_u), ty = (int)(q1 - q2 * th_u), ph = (int)(q2 - q3 * dd), b = (int)q3;
         const int py = ph / dil, px = ph - py * dil;
         {
             f32x4 col[A], y[MT];
@@ -239,9 +237,10 @@ int launch_winograd_output(const float* M, const float* scale, const float* shif
     FS_REQUIRE(((uintptr_t)M & 15) == 0 && ((uintptr_t)out & 15) == 0 && ((uintptr_t)scale & 15) == 0 && ((uintptr_t)shift & 15) == 0,
                "winograd_output: unaligned operand");
     const int th = (cdiv(H, dil) + mt - 1) / mt, tw = (cdiv(W, dil) + mt - 1) / mt;
-    const int64_t blocks = (int64_t)B * dil * dil * th * tw * cdiv(N / 4, 32);
-    const dim3 grid((unsigned)std::min<int64_t>(blocks, 1 << 20));
-    const WinoLayout lay = winograd_layout(mt, (long long)B * dil * dil * th * tw, N);
+    const long long T = (long long)B * dil * dil * th * tw;
+    FS_REQUIRE(T < (1ll << 31), "winograd_output: too many tiles");
+    const dim3 grid((unsigned)cdiv(N / 4, 32), (unsigned)std::min<long long>(T, 65535));
+    const WinoLayout lay = winograd_layout(mt, T, N);
     if (mt == 4)
         hipLaunchKernelGGL(winograd_output_kernel<4>, grid, dim3(6 * 32), 0, s, M, scale, shift, out, ld_out, B, H, W, N / 4, th, tw, relu, dil,
                            lay.s_pos, lay.s_tile);
