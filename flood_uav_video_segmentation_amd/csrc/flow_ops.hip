@@ -233,7 +233,10 @@ __global__ __launch_bounds__(256) void seg_warp_step_kernel(const float* __restr
 // (flow/base.py:204-205, 226-234) without the [n,K,h,w] logits ever reaching HBM: softmax over K in fp32 exactly as
 // softmax_accumulate_kernel does it on materialised logits (max, exp(x - max), sum, divide), added to the float64 canvas at
 // the crop's offset; successive crops are successive launches on one stream, so overlapping pixels never race.
-template <int KMAX>
+// WARP / CANVAS are compile-time: the headline route (linear interpolation, logits + masks) carries neither the warp path's eight
+// gathers per class and frame nor the softmax / float64 canvas code (one run-time kernel for all modes needed 167 registers: three
+// waves per SIMD for a pass that only waits for its stores).  Same operations in the same order in every instantiation.
+template <int KMAX, bool WARP, bool CANVAS>
 __global__ __launch_bounds__(256) void seg_fuse_kernel(SegTailParams p, float sy_lo, float sx_lo, float sy_g, float sx_g) {
     const int64_t HW = (int64_t)p.H * p.W;
     const int K = p.K, n = p.n;
@@ -244,6 +247,8 @@ __global__ __launch_bounds__(256) void seg_fuse_kernel(SegTailParams p, float sy
         const int x = blockIdx.x * 256 + threadIdx.x;
         if (x >= p.W) break;
         const int64_t i = (int64_t)y * p.W + x;
+        const unsigned off4 = (unsigned)i * 4u;  // byte offset inside one H x W plane (H * W < 2^30, launcher): with a uniform plane base
+                                                 // the stores take the scalar-base + 32-bit-offset form, no 64-bit address per plane
         const size_t cpix = (size_t)(p.y0 + y) * p.cW + (p.x0 + x);
         float a[KMAX], b[KMAX], v[KMAX];
         // one output frame: logits v[0..K) of this pixel -> the requested outputs
@@ -251,7 +256,7 @@ __global__ __launch_bounds__(256) void seg_fuse_kernel(SegTailParams p, float sy
             if (p.out_logits)
 #pragma unroll
                 for (int k = 0; k < KMAX; ++k)
-                    if (k < K) p.out_logits[((size_t)f * K + k) * HW + i] = v[k];
+                    if (k < K) *reinterpret_cast<float*>(reinterpret_cast<char*>(p.out_logits + ((size_t)f * K + k) * HW) + off4) = v[k];
             if (p.out_mask) {
                 float best = -INFINITY;
                 int arg = 0;
@@ -260,7 +265,7 @@ __global__ __launch_bounds__(256) void seg_fuse_kernel(SegTailParams p, float sy
                     if (k < K && v[k] > best) { best = v[k]; arg = k; }
                 p.out_mask[(size_t)f * HW + i] = (uint8_t)arg;
             }
-            if (p.canvas) {
+            if (CANVAS) {
                 float mx = v[0];
 #pragma unroll
                 for (int k = 1; k < KMAX; ++k)
@@ -284,7 +289,7 @@ __global__ __launch_bounds__(256) void seg_fuse_kernel(SegTailParams p, float sy
                     const float* pl = p.lo_prev + (size_t)k * p.h * p.w;
                     a[k] = bilerp(pl[cy.i0 * p.w + cx.i0], pl[cy.i0 * p.w + cx.i1], pl[cy.i1 * p.w + cx.i0],
                                   pl[cy.i1 * p.w + cx.i1], cy, cx);
-                    if (p.lo_next && p.no_warp) {
+                    if (p.lo_next && !WARP) {
                         const float* pn = p.lo_next + (size_t)k * p.h * p.w;
                         b[k] = bilerp(pn[cy.i0 * p.w + cx.i0], pn[cy.i0 * p.w + cx.i1], pn[cy.i1 * p.w + cx.i0],
                                       pn[cy.i1 * p.w + cx.i1], cy, cx);
@@ -296,7 +301,7 @@ __global__ __launch_bounds__(256) void seg_fuse_kernel(SegTailParams p, float sy
         }
         if (!p.lo_next) continue;
         LinCoord gy_c, gx_c;
-        if (!p.no_warp) {
+        if (WARP) {
             gy_c = lin_coord(y, p.Hg, sy_g, 1);
             gx_c = lin_coord(x, p.Wg, sx_g, 1);
         }
@@ -308,7 +313,7 @@ __global__ __launch_bounds__(256) void seg_fuse_kernel(SegTailParams p, float sy
             for (int k = 0; k < KMAX; ++k) {
                 if (k < K) {
                     float va, vb;
-                    if (p.no_warp) {
+                    if (!WARP) {
                         va = a[k];
                         vb = b[k];
                     } else {
@@ -332,6 +337,7 @@ int launch_seg_tail(const SegTailParams& p, hipStream_t s) {
     FS_REQUIRE(p.K >= 1 && p.K <= 32, "seg_tail: K=%d out of range (1..32)", p.K);
     FS_REQUIRE(p.n >= 1, "seg_tail: n must be >= 1");
     FS_REQUIRE(p.out_logits || p.out_mask || p.canvas, "seg_tail: no output requested");
+    FS_REQUIRE((int64_t)p.H * p.W < ((int64_t)1 << 30), "seg_tail: frames of at most 2^30 pixels");
     FS_REQUIRE(!p.canvas || (p.count && p.y0 >= 0 && p.x0 >= 0 && p.y0 + p.H <= p.cH && p.x0 + p.W <= p.cW), "seg_tail: crop outside the canvas");
     const float sy_lo = resize_scale(p.h, p.H, 1), sx_lo = resize_scale(p.w, p.W, 1);
     float sy_g = 0.f, sx_g = 0.f;
@@ -352,10 +358,16 @@ int launch_seg_tail(const SegTailParams& p, hipStream_t s) {
         }
     }
     const dim3 grid((unsigned)cdiv(p.W, 256), (unsigned)std::min(p.H, 65535)), block(256);
-    if (p.K <= 8)
-        hipLaunchKernelGGL((seg_fuse_kernel<8>), grid, block, 0, s, p, sy_lo, sx_lo, sy_g, sx_g);
-    else
-        hipLaunchKernelGGL((seg_fuse_kernel<32>), grid, block, 0, s, p, sy_lo, sx_lo, sy_g, sx_g);
+    const bool canvas = p.canvas != nullptr;
+#define FS_SEG_FUSE(KM_, W_, C_) hipLaunchKernelGGL((seg_fuse_kernel<KM_, W_, C_>), grid, block, 0, s, p, sy_lo, sx_lo, sy_g, sx_g)
+    if (p.K <= 8) {
+        if (warp) { if (canvas) FS_SEG_FUSE(8, true, true); else FS_SEG_FUSE(8, true, false); }
+        else { if (canvas) FS_SEG_FUSE(8, false, true); else FS_SEG_FUSE(8, false, false); }
+    } else {
+        if (warp) { if (canvas) FS_SEG_FUSE(32, true, true); else FS_SEG_FUSE(32, true, false); }
+        else { if (canvas) FS_SEG_FUSE(32, false, true); else FS_SEG_FUSE(32, false, false); }
+    }
+#undef FS_SEG_FUSE
     FS_HIP(hipGetLastError());
     return 0;
 }
