@@ -9,7 +9,7 @@ O=$R/gpurun_out/pmcb
 rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 SQSET="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE"
-for C in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum" "$SQSET"; do
+for C in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum" "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum" "$SQSET"; do
   d=$O/$(echo $C | tr ' ' '_' | cut -c1-40)
   timeout -k 10 400 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $d -- python3 $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-extras > $d.log 2>&1; echo "pass $C exit=$?"
 done
@@ -28,6 +28,10 @@ for k, cs in agg.items():
     e = {c: {"launches": len(v), "mean": sum(v) / len(v), "sum": sum(v)} for c, v in cs.items()}
     if "TCC_HIT_sum" in e and e["TCC_HIT_sum"]["sum"] + e.get("TCC_MISS_sum", {"sum": 0})["sum"] > 0:
         e["l2_hit_rate"] = e["TCC_HIT_sum"]["sum"] / (e["TCC_HIT_sum"]["sum"] + e["TCC_MISS_sum"]["sum"])
+    if "TCP_TCC_READ_REQ_sum" in e and e.get("GRBM_GUI_ACTIVE", {}).get("mean", 0) > 0:
+        # read requests the CUs' L1s send to the XCD L2s (64 B each): the L2 -> CU stream, per shader clock and CU
+        e["l2_read_bytes_per_launch"] = e["TCP_TCC_READ_REQ_sum"]["mean"] * 64.0
+        e["l2_read_bytes_per_clk_per_cu"] = e["l2_read_bytes_per_launch"] / (e["GRBM_GUI_ACTIVE"]["mean"] / 8.0) / 256.0
     if "FETCH_SIZE" in e and "WRITE_SIZE" in e:
         # rocprofv3 reports KiB; on gfx950 FETCH_SIZE counts 128-B requests as 64 B -> x2 (MI355X_MICROARCH.md, HBM)
         e["hbm_bytes_per_launch"] = (2.0 * e["FETCH_SIZE"]["mean"] + e["WRITE_SIZE"]["mean"]) * 1024.0
@@ -52,6 +56,6 @@ meta = {"build_id": bench.build_id(), "git_head": os.environ.get("GIT_HEAD", "un
                    "SQ_ACTIVE_INST_ANY over SQ_WAVE_CYCLES"}
 json.dump({"meta": meta, "kernels": out}, open("$R/gpurun_out/pmc_bench_summary.json", "w"), indent=1)
 for k, e in out.items():
-    print(k[:60], {c: (round(v["mean"], 1) if isinstance(v, dict) and "mean" in v else v) for c, v in e.items() if c in ("hbm_bytes_per_launch", "wave_time_shares", "lds_bank_conflict_share_of_lds_cycles", "mfma_busy_cycles_per_launch", "mfma_utilisation", "l2_hit_rate")})
+    print(k[:60], {c: (round(v["mean"], 1) if isinstance(v, dict) and "mean" in v else v) for c, v in e.items() if c in ("hbm_bytes_per_launch", "wave_time_shares", "lds_bank_conflict_share_of_lds_cycles", "mfma_busy_cycles_per_launch", "mfma_utilisation", "l2_hit_rate", "l2_read_bytes_per_clk_per_cu")})
 PY
 find $O -name "*kernel_trace.csv" -delete
