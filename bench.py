@@ -286,6 +286,7 @@ def main():
     if args.lib:
         from flood_uav_video_segmentation_amd import _lib as _l
         _l.LIB_PATH = os.path.abspath(args.lib)
+        _l.ALLOW_MISSING = True  # an older build may lack the newest entry points; the headline step does not use them
     load_runtime()
 
     rank, local_rank, world = shard.init("gloo" if args.rehearse_on_one_gpu else None)

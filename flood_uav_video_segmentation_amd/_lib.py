@@ -99,6 +99,7 @@ _SIGNATURES = {
 }
 
 _lib = None
+ALLOW_MISSING = False  # development A/B against an OLDER build only (bench.py --lib): symbols it lacks are skipped, not an error
 
 
 def load():
@@ -112,6 +113,8 @@ def load():
             "(hipcc --offload-arch=gfx950); there is no CPU fallback for this path")
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in _SIGNATURES.items():
+        if ALLOW_MISSING and not hasattr(lib, name):
+            continue
         fn = getattr(lib, name)  # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
