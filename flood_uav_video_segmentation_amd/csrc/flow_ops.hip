@@ -11,14 +11,18 @@ namespace fs {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// The flat element index of these kernels is decomposed with divisions by run-time sizes: as a 64-bit value that is ~100 instructions
+// per division, several times the interpolation itself.  Every kernel is a template on the index type and runs on unsigned 32-bit
+// indices whenever the element count fits (always, for the frame sizes of this path); int64_t remains for anything larger.
 // ------------------------------------------------------------------ grid_sample, NCHW
+template <typename I>
 __global__ __launch_bounds__(256) void grid_sample_nchw_kernel(const float* __restrict__ in, int B, int C, int Hi, int Wi,
                                                                const float* __restrict__ grid, int Hg, int Wg,
                                                                float* __restrict__ out, int ac) {
-    const int64_t total = (int64_t)B * Hg * Wg;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-        const int b = (int)(i / ((int64_t)Hg * Wg));
-        const int64_t g = i - (int64_t)b * Hg * Wg;
+    const I total = (I)B * Hg * Wg;
+    for (I i = (I)blockIdx.x * 256 + threadIdx.x; i < total; i += (I)gridDim.x * 256) {
+        const int b = (int)(i / ((I)Hg * Wg));
+        const I g = i - (I)b * Hg * Wg;
         const float gx = grid[i * 2 + 0], gy = grid[i * 2 + 1];
         const GsTaps t = gs_taps(gx, gy, Wi, Hi, ac);
         const int x1 = t.x1ok ? t.x0 + 1 : t.x0, y1 = t.y1ok ? t.y0 + 1 : t.y0;
@@ -36,7 +40,9 @@ __global__ __launch_bounds__(256) void grid_sample_nchw_kernel(const float* __re
 int launch_grid_sample_nchw(const float* in, int B, int C, int Hi, int Wi, const float* grid, int Hg, int Wg, float* out,
                             int align_corners, hipStream_t s) {
     const int64_t total = (int64_t)B * Hg * Wg;
-    hipLaunchKernelGGL(grid_sample_nchw_kernel, dim3((unsigned)std::min<int64_t>(cdiv64(total, 256), 8192)), dim3(256), 0, s, in,
+    if (total < ((int64_t)1 << 31)) hipLaunchKernelGGL((grid_sample_nchw_kernel<unsigned>), dim3((unsigned)std::min<int64_t>(cdiv64(total, 256), 8192)), dim3(256), 0, s, in,
+                       B, C, Hi, Wi, grid, Hg, Wg, out, align_corners);
+    else hipLaunchKernelGGL((grid_sample_nchw_kernel<int64_t>), dim3((unsigned)std::min<int64_t>(cdiv64(total, 256), 8192)), dim3(256), 0, s, in,
                        B, C, Hi, Wi, grid, Hg, Wg, out, align_corners);
     FS_HIP(hipGetLastError());
     return 0;
@@ -45,14 +51,15 @@ int launch_grid_sample_nchw(const float* in, int B, int C, int Hi, int Wi, const
 // ------------------------------------------------------------------ grid_sample, NHWC (C % 4 == 0)
 // One wave-sized group of float4 lanes sweeps the channels of one output pixel: every tap is a
 // contiguous C*4-byte run, so the gather is fully coalesced.
+template <typename I>
 __global__ __launch_bounds__(256) void grid_sample_nhwc_kernel(const float* __restrict__ in, int ld_in, int B, int C4, int Hi,
                                                                int Wi, const float* __restrict__ grid, int Hg, int Wg,
                                                                float* __restrict__ out, int ld_out, int ac) {
-    const int64_t total = (int64_t)B * Hg * Wg * C4;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const I total = (I)B * Hg * Wg * C4;
+    for (I i = (I)blockIdx.x * 256 + threadIdx.x; i < total; i += (I)gridDim.x * 256) {
         const int c4 = (int)(i % C4);
-        const int64_t m = i / C4;
-        const int b = (int)(m / ((int64_t)Hg * Wg));
+        const I m = i / C4;
+        const int b = (int)(m / ((I)Hg * Wg));
         const float gx = grid[m * 2 + 0], gy = grid[m * 2 + 1];
         const GsTaps t = gs_taps(gx, gy, Wi, Hi, ac);
         const int x1 = t.x1ok ? t.x0 + 1 : t.x0, y1 = t.y1ok ? t.y0 + 1 : t.y0;
@@ -73,21 +80,24 @@ int launch_grid_sample_nhwc(const float* in, int ld_in, int B, int C, int Hi, in
                             float* out, int ld_out, int align_corners, hipStream_t s) {
     FS_REQUIRE(C % 4 == 0 && ld_in % 4 == 0 && ld_out % 4 == 0, "grid_sample_nhwc: C/ld must be multiples of 4");
     const int64_t total = (int64_t)B * Hg * Wg * (C / 4);
-    hipLaunchKernelGGL(grid_sample_nhwc_kernel, dim3((unsigned)std::min<int64_t>(cdiv64(total, 256), 8192)), dim3(256), 0, s, in,
+    if (total < ((int64_t)1 << 31)) hipLaunchKernelGGL((grid_sample_nhwc_kernel<unsigned>), dim3((unsigned)std::min<int64_t>(cdiv64(total, 256), 8192)), dim3(256), 0, s, in,
+                       ld_in, B, C / 4, Hi, Wi, grid, Hg, Wg, out, ld_out, align_corners);
+    else hipLaunchKernelGGL((grid_sample_nhwc_kernel<int64_t>), dim3((unsigned)std::min<int64_t>(cdiv64(total, 256), 8192)), dim3(256), 0, s, in,
                        ld_in, B, C / 4, Hi, Wi, grid, Hg, Wg, out, ld_out, align_corners);
     FS_HIP(hipGetLastError());
     return 0;
 }
 
 // ------------------------------------------------------------------ bilinear resize
+template <typename I>
 __global__ __launch_bounds__(256) void resize_bilinear_nchw_kernel(const float* __restrict__ in, int BC, int Hi, int Wi,
                                                                    float* __restrict__ out, int Ho, int Wo, int ac, float sy,
                                                                    float sx) {
-    const int64_t total = (int64_t)BC * Ho * Wo;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const I total = (I)BC * Ho * Wo;
+    for (I i = (I)blockIdx.x * 256 + threadIdx.x; i < total; i += (I)gridDim.x * 256) {
         const int ox = (int)(i % Wo);
         const int oy = (int)((i / Wo) % Ho);
-        const int64_t pc = i / ((int64_t)Wo * Ho);
+        const I pc = i / ((I)Wo * Ho);
         const LinCoord cy = lin_coord(oy, Hi, sy, ac), cx = lin_coord(ox, Wi, sx, ac);
         const float* pl = in + (size_t)pc * Hi * Wi;
         out[i] = bilerp(pl[cy.i0 * Wi + cx.i0], pl[cy.i0 * Wi + cx.i1], pl[cy.i1 * Wi + cx.i0], pl[cy.i1 * Wi + cx.i1], cy, cx);
@@ -97,23 +107,27 @@ __global__ __launch_bounds__(256) void resize_bilinear_nchw_kernel(const float* 
 int launch_resize_bilinear_nchw(const float* in, int BC, int Hi, int Wi, float* out, int Ho, int Wo, int align_corners,
                                 hipStream_t s) {
     const int64_t total = (int64_t)BC * Ho * Wo;
-    hipLaunchKernelGGL(resize_bilinear_nchw_kernel, dim3((unsigned)std::min<int64_t>(cdiv64(total, 256), 16384)), dim3(256), 0, s,
+    if (total < ((int64_t)1 << 31)) hipLaunchKernelGGL((resize_bilinear_nchw_kernel<unsigned>), dim3((unsigned)std::min<int64_t>(cdiv64(total, 256), 16384)), dim3(256), 0, s,
+                       in, BC, Hi, Wi, out, Ho, Wo, align_corners, resize_scale(Hi, Ho, align_corners),
+                       resize_scale(Wi, Wo, align_corners));
+    else hipLaunchKernelGGL((resize_bilinear_nchw_kernel<int64_t>), dim3((unsigned)std::min<int64_t>(cdiv64(total, 256), 16384)), dim3(256), 0, s,
                        in, BC, Hi, Wi, out, Ho, Wo, align_corners, resize_scale(Hi, Ho, align_corners),
                        resize_scale(Wi, Wo, align_corners));
     FS_HIP(hipGetLastError());
     return 0;
 }
 
+template <typename I>
 __global__ __launch_bounds__(256) void resize_bilinear_nhwc_kernel(const float* __restrict__ in, int ld_in, int B, int C4, int Hi,
                                                                    int Wi, float* __restrict__ out, int ld_out, int Ho, int Wo,
                                                                    int ac, float sy, float sx) {
-    const int64_t total = (int64_t)B * Ho * Wo * C4;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const I total = (I)B * Ho * Wo * C4;
+    for (I i = (I)blockIdx.x * 256 + threadIdx.x; i < total; i += (I)gridDim.x * 256) {
         const int c4 = (int)(i % C4);
-        const int64_t m = i / C4;
+        const I m = i / C4;
         const int ox = (int)(m % Wo);
         const int oy = (int)((m / Wo) % Ho);
-        const int b = (int)(m / ((int64_t)Wo * Ho));
+        const int b = (int)(m / ((I)Wo * Ho));
         const LinCoord cy = lin_coord(oy, Hi, sy, ac), cx = lin_coord(ox, Wi, sx, ac);
         const float* base = in + (size_t)b * Hi * Wi * ld_in + c4 * 4;
         const f32x4 v00 = *reinterpret_cast<const f32x4*>(base + ((size_t)cy.i0 * Wi + cx.i0) * ld_in);
@@ -131,7 +145,10 @@ int launch_resize_bilinear_nhwc(const float* in, int ld_in, int B, int C, int Hi
                                 int align_corners, hipStream_t s) {
     FS_REQUIRE(C % 4 == 0 && ld_in % 4 == 0 && ld_out % 4 == 0, "resize_nhwc: C/ld must be multiples of 4");
     const int64_t total = (int64_t)B * Ho * Wo * (C / 4);
-    hipLaunchKernelGGL(resize_bilinear_nhwc_kernel, dim3((unsigned)std::min<int64_t>(cdiv64(total, 256), 16384)), dim3(256), 0, s,
+    if (total < ((int64_t)1 << 31)) hipLaunchKernelGGL((resize_bilinear_nhwc_kernel<unsigned>), dim3((unsigned)std::min<int64_t>(cdiv64(total, 256), 16384)), dim3(256), 0, s,
+                       in, ld_in, B, C / 4, Hi, Wi, out, ld_out, Ho, Wo, align_corners, resize_scale(Hi, Ho, align_corners),
+                       resize_scale(Wi, Wo, align_corners));
+    else hipLaunchKernelGGL((resize_bilinear_nhwc_kernel<int64_t>), dim3((unsigned)std::min<int64_t>(cdiv64(total, 256), 16384)), dim3(256), 0, s,
                        in, ld_in, B, C / 4, Hi, Wi, out, ld_out, Ho, Wo, align_corners, resize_scale(Hi, Ho, align_corners),
                        resize_scale(Wi, Wo, align_corners));
     FS_HIP(hipGetLastError());
@@ -574,13 +591,14 @@ int launch_argmax_u8(const float* in, int B, int K, int64_t HW, uint8_t* out, hi
     return 0;
 }
 
+template <typename I>
 __global__ __launch_bounds__(256) void resize_argmax_u8_kernel(const float* __restrict__ in, int B, int K, int Hi, int Wi,
                                                                uint8_t* __restrict__ out, int Ho, int Wo, float sy, float sx) {
-    const int64_t total = (int64_t)B * Ho * Wo;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const I total = (I)B * Ho * Wo;
+    for (I i = (I)blockIdx.x * 256 + threadIdx.x; i < total; i += (I)gridDim.x * 256) {
         const int ox = (int)(i % Wo);
         const int oy = (int)((i / Wo) % Ho);
-        const int64_t b = i / ((int64_t)Wo * Ho);
+        const I b = i / ((I)Wo * Ho);
         const LinCoord cy = lin_coord(oy, Hi, sy, 1), cx = lin_coord(ox, Wi, sx, 1);
         float best = -INFINITY;
         int arg = 0;
@@ -597,7 +615,9 @@ __global__ __launch_bounds__(256) void resize_argmax_u8_kernel(const float* __re
 int launch_resize_argmax_u8(const float* in, int B, int K, int Hi, int Wi, uint8_t* out, int Ho, int Wo, hipStream_t s) {
     FS_REQUIRE(K >= 1 && K <= 255, "resize_argmax_u8: K out of range");
     const int64_t total = (int64_t)B * Ho * Wo;
-    hipLaunchKernelGGL(resize_argmax_u8_kernel, dim3((unsigned)std::min<int64_t>(cdiv64(total, 256), 16384)), dim3(256), 0, s, in, B,
+    if (total < ((int64_t)1 << 31)) hipLaunchKernelGGL((resize_argmax_u8_kernel<unsigned>), dim3((unsigned)std::min<int64_t>(cdiv64(total, 256), 16384)), dim3(256), 0, s, in, B,
+                       K, Hi, Wi, out, Ho, Wo, resize_scale(Hi, Ho, 1), resize_scale(Wi, Wo, 1));
+    else hipLaunchKernelGGL((resize_argmax_u8_kernel<int64_t>), dim3((unsigned)std::min<int64_t>(cdiv64(total, 256), 16384)), dim3(256), 0, s, in, B,
                        K, Hi, Wi, out, Ho, Wo, resize_scale(Hi, Ho, 1), resize_scale(Wi, Wo, 1));
     FS_HIP(hipGetLastError());
     return 0;
