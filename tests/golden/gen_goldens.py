@@ -248,6 +248,18 @@ def gen_pspnet_deep():
     save("pspnet_deep_small.npz", **out)
 
 
+def gen_pspnet_deep_713():
+    """FlowPSPNet on ResNet-101 at the BASELINE frame size (713x713, one frame): the deeper plan at the geometry the configs use
+    (23 layer3 blocks on the 90x90 map: every Winograd / fused-head route of the R50 network, more often)."""
+    state = synth.make_pspnet_state(101, 5, seed=1)
+    net = build_ref_pspnet(state, 101)
+    x = synth.make_clip(6, 713, seed=1000)[0:1]
+    feat = net.encoder(x)
+    lo = net.decoder(feat)
+    print("pspnet101 713: logits range", lo.min().item(), lo.max().item(), "|feat| mean", feat.double().abs().mean().item())
+    save("pspnet101_713.npz", logits_lo=lo, feat_absmean=feat.double().abs().mean().item(), feat_slice=feat[:, ::256, ::6, ::6])
+
+
 def gen_vit_s16():
     """BASELINE configs[3] names a ViT-S/16; model/vit.py hard-codes B/32 (patch 32, d_model 768), so the S/16 network is
     assembled from THE REFERENCE'S OWN CLASSES exactly as model/vit.py:24-52 assembles them, with S/16 numbers (patch 16,
@@ -325,9 +337,11 @@ def gen_deeplab_backbone():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["grid", "ops", "toy", "pspnet", "vit", "vit_s16", "pspnet_feature", "pspnet_deep", "deeplab_backbone"]
+    which = sys.argv[1:] or ["grid", "ops", "toy", "pspnet", "vit", "vit_s16", "pspnet_feature", "pspnet_deep", "deeplab_backbone", "pspnet_deep_713"]
     if "deeplab_backbone" in which:
         gen_deeplab_backbone()
+    if "pspnet_deep_713" in which:
+        gen_pspnet_deep_713()
     if "pspnet_deep" in which:
         gen_pspnet_deep()
     if "vit_s16" in which:

@@ -240,6 +240,21 @@ def test_model_representation_wraps_a_hip_network(psp):
         wrapped.train()(x)
 
 
+def test_pspnet_r101_713_against_the_reference():
+    """A6 on the deeper backbone at the BASELINE frame size: FlowPSPNet(layers=101) -- 23 layer3 blocks on the 90x90 map -- against
+    the reference's own output on one 713x713 frame (tests/golden/pspnet101_713.npz): the fused segment route and the
+    encoder -> decoder route."""
+    state = synth.make_pspnet_state(101, 5, seed=1)
+    net = FlowPSPNet(HP(101)).eval()
+    net.load_state_dict(state)
+    z = load_golden("pspnet101_713.npz")
+    x = synth.make_clip(6, 713, seed=1000)[0:1].cuda()
+    assert note("pspnet101_713_segment_logits_vs_reference", rel_err(net.segment(x).cpu(), z["logits_lo"])) < LOGIT_TOL
+    feat = net.encoder(x)
+    assert note("pspnet101_713_encoder_vs_reference", rel_err(feat[:, ::256, ::6, ::6].cpu(), z["feat_slice"])) < LOGIT_TOL
+    assert note("pspnet101_713_decoder_logits_vs_reference", rel_err(net.decoder(feat).cpu(), z["logits_lo"])) < LOGIT_TOL
+
+
 # ------------------------------------------------------------------------------------------------ A/B options at full size
 @pytest.mark.parametrize("opts", [dict(hip_no_winograd=True), dict(hip_winograd_tile=4), dict(hip_winograd_tile=6),
                                   dict(hip_no_fused_head=True), dict(hip_no_fused_shortcut=True), dict(hip_no_fused_winograd=True),

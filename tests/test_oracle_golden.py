@@ -233,3 +233,14 @@ def test_vit_mask_goldens_are_mixed():
         for k in ("mask704", "mask713"):
             share = np.bincount(z[k].ravel(), minlength=5) / z[k].size
             assert share.max() < 0.70 and share.min() > 0.005, (name, k, share)
+
+
+def test_pspnet101_713_oracle_matches_reference():
+    """The ResNet-101 plan at the BASELINE frame size (tests/golden/pspnet101_713.npz: FlowPSPNet(layers=101) of the reference on one
+    713x713 frame).  ~25 s of CPU."""
+    s = synth.make_pspnet_state(101, 5, seed=1)
+    z = load_golden("pspnet101_713.npz")
+    x = synth.make_clip(6, 713, seed=1000)[0:1]
+    feat = pspnet_oracle.encoder(x, s, 101)
+    assert rel_err(feat[:, ::256, ::6, ::6], z["feat_slice"]) < 1e-5
+    assert rel_err(pspnet_oracle.decoder(feat, s), z["logits_lo"]) < 1e-5
