@@ -330,3 +330,32 @@ def test_split_operand_route_is_as_close_to_a_float64_network_as_the_fp32_mfma_r
                      rel_err(pspnet_oracle.decoder(pspnet_oracle.encoder(x, state, 50), state).double(), ref))
         assert e_split < LOGIT_TOL and e_f32 < LOGIT_TOL
         assert e_split < 2.0 * max(e_f32, e_cpu) + 2e-7, (e_split, e_f32, e_cpu)  # measured 0.86x / 1.49x (129 / 257)
+
+
+@pytest.mark.parametrize("classes", [19, 3, 9])
+def test_other_class_counts_through_the_fused_head_and_the_tail(classes):
+    """Every test above uses the dataset's K = 5.  The head finish applies the classifier in passes of 8 classes (19 = 8 + 8 + 3,
+    9 = 8 + 1) and the fused tail has an instantiation for K > 8: a PSPNet with K classes at 97x97 against the oracle -- the fused
+    segment route, the decoder(encoder) route, and a whole logit-warp window (logits and masks)."""
+    from flood_uav_video_segmentation_amd.flow.model import FlowModel
+    from oracle import flow_oracle
+
+    state = synth.make_pspnet_state(50, classes, seed=5)
+    net = FlowPSPNet(HP(50, classes)).eval()
+    net.load_state_dict(state)
+    clip = synth.make_clip(2, 97, seed=41)
+    ref_lo = pspnet_oracle.decoder(pspnet_oracle.encoder(clip, state, 50), state)
+    assert ref_lo.shape[1] == classes
+    assert note(f"pspnet50_K{classes}_97_segment_vs_oracle", rel_err(net.segment(clip.cuda()).cpu(), ref_lo)) < LOGIT_TOL
+    assert rel_err(net.decoder(net.encoder(clip.cuda())).cpu(), ref_lo) < LOGIT_TOL
+    n = 4
+    mvl, mvr = synth.make_grids(n, 6, 6, seed=42, frame=(97, 97), jitter=0.05)
+    fm = FlowModel(net, feature_based=False, no_warp=False).eval()
+    got = fm.predict(clip[0:1].cuda(), clip[1:2].cuda(), [m.cuda() for m in mvl], [m.cuda() for m in mvr], n, None, with_mask=True)
+    enc = lambda x: pspnet_oracle.encoder(x, state, 50)  # noqa: E731
+    dec = lambda f: pspnet_oracle.decoder(f, state)  # noqa: E731
+    ref = flow_oracle.predict_segmentation(enc, dec, clip[0:1], clip[1:2], mvl, mvr, n, False)["pred"]
+    assert got["pred"].shape == (n, classes, 97, 97)
+    assert note(f"pspnet50_K{classes}_97_window_logits_vs_oracle", rel_err(got["pred"].cpu(), ref)) < LOGIT_TOL
+    assert (got["mask"].cpu() == ref.max(1)[1].to(torch.uint8)).float().mean().item() > 0.999
+    assert torch.equal(got["mask"], got["pred"].max(1)[1].to(torch.uint8))
