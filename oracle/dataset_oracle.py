@@ -1,10 +1,13 @@
 """Oracle for the index arithmetic of FlowData (flow/dataset.py:16-43 `make_dataset`, :80-181 `__getitem__`) and the
 label side of the test transforms (flow/transform.py:91-106 Resize -> INTER_NEAREST, :361-371 IgnoreClasses).
 
-PARITY UNPINNED: flow/dataset.py imports skimage and flow/transform.py imports cv2 -- both absent offline, so the
-module cannot be imported to generate vectors, and the reference holds no fixtures for it.  The restatement follows
-the source line by line (the `exists` predicate is passed in, so it runs on an in-memory file set).  cv2's
-INTER_NEAREST is restated from its documented rule: src = min(floor(dst * src_size / dst_size), src_size - 1).
+PINNED (round 4) for the index arithmetic: tests/golden/dataset_index.npz holds what the reference's OWN FlowData class returns
+on a synthetic file set with missing images / grids (predict, val and test splits, frame_delta 5 / 8 / 25); the generator
+registers a stand-in for skimage.io.imread -- the only skimage call of flow/dataset.py -- that returns the number in the file name,
+and runs with transform=None so flow/transform.py (cv2) is never touched (tests/test_oracle_golden.py::
+test_window_indexing_matches_the_references_flowdata).  The restatement follows the source line by line (the `exists` predicate is
+passed in, so it runs on an in-memory file set).  PARITY UNPINNED for the label transforms: flow/transform.py imports cv2, absent
+offline; cv2's INTER_NEAREST is restated from its documented rule: src = min(floor(dst * src_size / dst_size), src_size - 1).
 TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).
 """
 import random

@@ -260,6 +260,95 @@ def gen_pspnet_deep_713():
     save("pspnet101_713.npz", logits_lo=lo, feat_absmean=feat.double().abs().mean().item(), feat_slice=feat[:, ::256, ::6, ::6])
 
 
+# The synthetic "dataset" the FlowData index fixtures are generated on; tests/test_oracle_golden.py rebuilds the same file set.
+DATASET_FRAMES = 47                           # frames 0..46 of video "vid"
+DATASET_MISSING_IMAGES = (10, 20, 21, 35)     # no <id>.jpg
+DATASET_MISSING_GRIDS = (5, 30)               # no grids/<id>.npy
+DATASET_MISSING_INV = (15, 16)                # no inv_grids/<id>.npy
+DATASET_LABELLED = (1, 2, 4, 7, 11, 12, 19, 22, 23, 26, 31, 33, 36, 40, 44)  # labelled frame ids, in list order
+
+
+def make_index_dataset(root):
+    """Empty image files + tiny grid files whose VALUES are their frame ids, label PNG stand-ins, a 4-field list file."""
+    for sub in ("images", "grids", "inv_grids"):
+        os.makedirs(os.path.join(root, "frames", "vid", sub), exist_ok=True)
+    os.makedirs(os.path.join(root, "labels"), exist_ok=True)
+    for i in range(DATASET_FRAMES):
+        if i not in DATASET_MISSING_IMAGES:
+            open(os.path.join(root, "frames", "vid", "images", f"{i}.jpg"), "wb").close()
+        if i not in DATASET_MISSING_GRIDS:
+            np.save(os.path.join(root, "frames", "vid", "grids", f"{i}.npy"), np.full((2, 2, 2), i + 0.25))
+        if i not in DATASET_MISSING_INV:
+            np.save(os.path.join(root, "frames", "vid", "inv_grids", f"{i}.npy"), np.full((2, 2, 2), i + 0.5))
+    with open(os.path.join(root, "list.txt"), "w") as fh:
+        for f in DATASET_LABELLED:
+            open(os.path.join(root, "labels", f"{f}.png"), "wb").close()
+            fh.write(f"labels/{f}.png vid {f} x\n")   # four fields: make_dataset's check (flow/dataset.py:28)
+
+
+def gen_dataset_index():
+    """Index arithmetic of the reference's FlowData (flow/dataset.py:45-216) -- which key frames and grids make up item i of the
+    predict / val / test splits, the forward / backward search for a complete key frame, the default-grid padding, make_dataset's
+    filter -- run in THE REFERENCE'S OWN CLASS.  flow/dataset.py imports skimage.io for one call, io.imread (:217-218, :174);
+    skimage is absent offline, so a stand-in module is registered whose imread returns an array filled with the NUMBER IN THE FILE
+    NAME (the recipe of the timm stand-ins above: the stand-in decodes nothing and takes no part in the arithmetic under test; the
+    frames' content is irrelevant to which frames are chosen).  transform=None, so flow/transform.py (cv2) is never touched."""
+    import tempfile
+    import types
+
+    if "skimage" not in sys.modules:
+        sk, sk_io = types.ModuleType("skimage"), types.ModuleType("skimage.io")
+        sk_io.imread = lambda path: np.full((2, 2, 3), int(os.path.splitext(os.path.basename(path))[0]), dtype=np.int64)
+        sk.io = sk_io
+        sys.modules["skimage"], sys.modules["skimage.io"] = sk, sk_io
+    import flow.dataset as ref_ds  # reference
+
+    default = ref_flow.get_default_grid()
+    out = {}
+    with tempfile.TemporaryDirectory() as root, contextlib.redirect_stdout(open(os.devnull, "w")):
+        make_index_dataset(root)
+
+        def gid(g):  # grid array -> frame id, -1 = the identity default grid
+            return -1 if g.shape == default.shape and np.array_equal(g, default) else int(g.flat[0])
+
+        for delta in (5, 8, 25):
+            ds = ref_ds.FlowData(split="predict", data_root=root, transform=None, frame_delta=delta, no_warp=False, predict_v_id="vid")
+            rows = []
+            for i in range(len(ds)):
+                try:
+                    it = ds[i]
+                except FileNotFoundError:  # the window's grids are missing: np.load raises (the reference has no fallback in predict)
+                    rows.append([i, -9, -9, -9] + [-9] * (2 * (delta - 1)))
+                    continue
+                rows.append([i, int(it["frame_prev"].flat[0]), int(it["frame_next"].flat[0]), it["frame_id"]] +
+                            [gid(g) for g in it["mvs_left"]] + [gid(g) for g in it["mvs_right"]])
+            out[f"predict_d{delta}"] = np.array(rows, dtype=np.int64)
+            out[f"predict_len_d{delta}"] = np.array(len(ds))
+            for split in ("val", "test"):
+                ds = ref_ds.FlowData(split=split, type="l", data_root=root, data_list=os.path.join(root, "list.txt"), transform=None,
+                                     frame_delta=delta, no_warp=False)
+                rows = []
+                for i in range(len(ds)):
+                    try:
+                        it = ds[i]
+                    except FileNotFoundError:  # a grid BETWEEN the key frames is missing: only the key frames are searched for
+                        rows.append([i, -9, -9, -9, -9, -9] + [-9] * (2 * (delta - 1)))
+                        continue
+                    rows.append([i, int(it["label"].flat[0]), int(it["frame_prev"].flat[0]), int(it["frame_next"].flat[0]),
+                                 it["left_index"], it["right_index"]] + [gid(g) for g in it["mvs_left"]] + [gid(g) for g in it["mvs_right"]])
+                out[f"{split}_d{delta}"] = np.array(rows, dtype=np.int64)
+        # no_warp: placeholders whose COUNT encodes n (flow/dataset.py:198-205)
+        ds = ref_ds.FlowData(split="predict", data_root=root, transform=None, frame_delta=5, no_warp=True, predict_v_id="vid")
+        it = ds[1]
+        out["nowarp_counts"] = np.array([len(it["mvs_left"]), len(it["mvs_right"]), int(it["mvs_left"][0].numel())])
+    # the file set itself, so that a test can rebuild it without this module
+    out.update(frames=np.array(DATASET_FRAMES), missing_images=np.array(DATASET_MISSING_IMAGES), missing_grids=np.array(DATASET_MISSING_GRIDS),
+               missing_inv=np.array(DATASET_MISSING_INV), labelled=np.array(DATASET_LABELLED))
+    for k, v in out.items():
+        print(k, v.shape)
+    save("dataset_index.npz", **out)
+
+
 def gen_vit_s16():
     """BASELINE configs[3] names a ViT-S/16; model/vit.py hard-codes B/32 (patch 32, d_model 768), so the S/16 network is
     assembled from THE REFERENCE'S OWN CLASSES exactly as model/vit.py:24-52 assembles them, with S/16 numbers (patch 16,
@@ -337,11 +426,13 @@ def gen_deeplab_backbone():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["grid", "ops", "toy", "pspnet", "vit", "vit_s16", "pspnet_feature", "pspnet_deep", "deeplab_backbone", "pspnet_deep_713"]
+    which = sys.argv[1:] or ["grid", "ops", "toy", "pspnet", "vit", "vit_s16", "pspnet_feature", "pspnet_deep", "deeplab_backbone", "pspnet_deep_713", "dataset_index"]
     if "deeplab_backbone" in which:
         gen_deeplab_backbone()
     if "pspnet_deep_713" in which:
         gen_pspnet_deep_713()
+    if "dataset_index" in which:
+        gen_dataset_index()
     if "pspnet_deep" in which:
         gen_pspnet_deep()
     if "vit_s16" in which:

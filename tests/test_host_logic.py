@@ -208,7 +208,8 @@ def _fake_labelled_video(root, n_frames, labelled, missing=()):
 def test_eval_window_plan_matches_the_restated_flowdata_indexing(tmp_path):
     """flow/dataset.py:16-43, 89-92, 115-171 (val / test split): seeded l/r split, missing key frames slide inward,
     grids at or before the real previous key / after the real next key become the identity grid, inverse grids reversed,
-    both lists padded to frame_delta - 1.  PARITY UNPINNED (skimage / cv2 absent): checked against oracle/dataset_oracle."""
+    both lists padded to frame_delta - 1.  Checked against oracle/dataset_oracle, which tests/test_oracle_golden.py pins to the
+    reference's own FlowData (dataset_index.npz, round 4)."""
     import os
 
     from flood_uav_video_segmentation_amd.flow.dataset import EvalWindows, read_label_list
