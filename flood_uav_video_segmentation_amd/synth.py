@@ -216,3 +216,27 @@ def make_grids(n, hg, wg, seed, shift=(2, 1), frame=(713, 713), jitter=0.02):
 def dummy_grids(n):
     """no_warp placeholders: n-1 zeros(1) tensors whose count encodes n (flow/dataset.py:198-205)."""
     return [torch.zeros(1, 1) for _ in range(n - 1)], [torch.zeros(1, 1) for _ in range(n - 1)]
+
+
+def motion_vectors(h, w, n, seed):
+    """Seeded H.264 block motion vectors of one h x w frame in mvextractor's row layout (source, w, h, src_x, src_y, dst_x, dst_y,
+    motion_x, motion_y, motion_scale; dataset/flow/extract_motion_vectors.py:25-28): sources and destinations reach past every
+    frame edge (negative and too large), and with more vectors than blocks many blocks are hit several times."""
+    rng = np.random.default_rng(seed)
+    src = np.stack([rng.integers(-40, w + 40, n), rng.integers(-40, h + 40, n)], 1)
+    dst = src + rng.integers(-48, 49, (n, 2))
+    return np.concatenate([np.full((n, 1), -1), np.full((n, 2), 16), src, dst, dst - src, np.full((n, 1), 4)], 1).astype(np.int64)
+
+
+def transform_frames(h, w, gh, gw, ids, ignore, seed):
+    """Raw files of a tiny labelled video as FlowData reads them (flow/dataset.py:172-187): per frame id a uint8 image [h,w,3], a
+    forward and an inverse float64 grid [gh,gw,2], and a uint8 label [h,w] holding every class, the ignored ones and 255."""
+    out = {}
+    ident = identity_grid(gh, gw)
+    for f in ids:
+        rng = _rng(seed * 1000 + f)
+        label = rng.integers(0, max(ignore) + 1, (h, w)).astype(np.uint8)
+        label[rng.random((h, w)) < 0.05] = 255
+        out[f] = dict(image=rng.integers(0, 256, (h, w, 3)).astype(np.uint8), label=label,
+                      grid=ident + rng.uniform(-0.03, 0.03, ident.shape), inv_grid=ident + rng.uniform(-0.03, 0.03, ident.shape))
+    return out

@@ -1,10 +1,13 @@
 """Oracle for the sliding-crop route: flow/transform.py:215-261 (`crop_motion_vector`) and
 flow/base.py:182-234 (`compute_output` + `compute_predict_crop`).
 
-PARITY UNPINNED for the grid resize: the reference calls cv2.resize(INTER_LINEAR) and cv2 is absent offline
-(flow/transform.py cannot even be imported: cv2, skimage and `collections.Iterable`); the restatement uses
-F.interpolate(bilinear, align_corners=False), the same half-pixel-centre formula cv2 documents for float data.
-Everything else (block rounding with Python's banker's round, renormalisation, float64 accumulation, crop
+PINNED (round 4) wherever cv2 does not interpolate: tests/golden/transforms.npz holds what the reference's OWN
+crop_motion_vector returns for every 704-crop window of a 1072x1920 frame, offsets off the block edges and two
+round-half-to-even block ranges (the generator's cv2 stand-in knows only the same-size case of cv2.resize, a copy), and
+tests/golden/mv_grids.npz what its own extract_motion_vectors.py writes on a synthetic frame source: both bit-exact here
+(tests/test_oracle_golden.py).  PARITY UNPINNED for the interpolating grid resize (713 crops: 45 -> 44 blocks): cv2 is
+absent offline; the restatement uses F.interpolate(bilinear, align_corners=False), the same half-pixel-centre formula cv2
+documents for float data.  Everything else (block rounding with Python's banker's round, renormalisation, float64 accumulation, crop
 order) is restated literally.  TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).
 """
 import numpy as np

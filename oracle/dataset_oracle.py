@@ -6,8 +6,10 @@ on a synthetic file set with missing images / grids (predict, val and test split
 registers a stand-in for skimage.io.imread -- the only skimage call of flow/dataset.py -- that returns the number in the file name,
 and runs with transform=None so flow/transform.py (cv2) is never touched (tests/test_oracle_golden.py::
 test_window_indexing_matches_the_references_flowdata).  The restatement follows the source line by line (the `exists` predicate is
-passed in, so it runs on an in-memory file set).  PARITY UNPINNED for the label transforms: flow/transform.py imports cv2, absent
-offline; cv2's INTER_NEAREST is restated from its documented rule: src = min(floor(dst * src_size / dst_size), src_size - 1).
+passed in, so it runs on an in-memory file set).  IgnoreClasses, Crop('center'), ToTensor and Normalize are pinned to the reference's own
+transform_val / transform_test chains at the native size (tests/golden/transforms.npz).  PARITY UNPINNED for an interpolating
+Resize: flow/transform.py calls cv2, absent offline; cv2's INTER_NEAREST is restated from its documented rule:
+src = min(floor(dst * src_size / dst_size), src_size - 1).
 TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).
 """
 import random

@@ -26,6 +26,7 @@ import util.util as ref_util  # reference
 from flood_uav_video_segmentation_amd import synth
 
 OUT = os.path.dirname(os.path.abspath(__file__))
+REFERENCE = os.path.dirname(os.path.dirname(os.path.abspath(ref_flow.__file__)))
 torch.manual_seed(0)
 torch.set_grad_enabled(False)
 
@@ -349,6 +350,158 @@ def gen_dataset_index():
     save("dataset_index.npz", **out)
 
 
+MV_FRAMES = ((1080, 1920, 9000, 11), (1072, 1920, 4000, 12), (720, 1280, 6000, 13), (1080, 1920, 0, 14))  # (H, W, vectors, seed)
+
+
+def gen_mv_grids():
+    """The grid producer (dataset/flow/extract_motion_vectors.py) run AS THE REFERENCE'S OWN SCRIPT, top to bottom: it is a script,
+    so importing it opens the videos and writes frames/<video>/{grids,inv_grids}/<i>.npy.  Its two absent imports are the H.264
+    decoder (mvextractor.videocap.VideoCap) and cv2 (one call, cv2.imwrite of the decoded frame); decoding is out of this
+    repository's scope, so the stand-ins are a frame SOURCE -- VideoCap.read() hands out the seeded motion-vector rows of
+    synth.motion_vectors with an empty frame of the stated size, then ret=False -- and an imwrite that writes nothing.  Neither takes
+    part in the arithmetic under test (lines 21-43 and the np.save at :101-104), which the script performs itself."""
+    import runpy
+    import tempfile
+    import types
+
+    class SyntheticCap:
+        def open(self, name):
+            self.i = 0
+            return True
+
+        def read(self):
+            if self.i >= len(MV_FRAMES):
+                return False, None, None, None, None
+            h, w, n, seed = MV_FRAMES[self.i]
+            self.i += 1
+            return True, np.zeros((h, w, 3), np.uint8), synth.motion_vectors(h, w, n, seed), "P", float(self.i)
+
+        def release(self):
+            pass
+
+    cv2 = types.ModuleType("cv2")
+    cv2.imwrite = lambda path, frame: open(path, "wb").close()   # the script re-extracts a frame whose .jpg is missing
+    mvx, mvx_cap = types.ModuleType("mvextractor"), types.ModuleType("mvextractor.videocap")
+    mvx_cap.VideoCap = SyntheticCap
+    mvx.videocap = mvx_cap
+    saved = {k: sys.modules.get(k) for k in ("cv2", "mvextractor", "mvextractor.videocap")}
+    sys.modules.update({"cv2": cv2, "mvextractor": mvx, "mvextractor.videocap": mvx_cap})
+    out = {}
+    cwd, argv = os.getcwd(), sys.argv
+    try:
+        with tempfile.TemporaryDirectory() as root, contextlib.redirect_stdout(open(os.devnull, "w")):
+            os.chdir(root)
+            sys.argv = ["extract_motion_vectors.py", "synthetic.mp4"]
+            runpy.run_path(os.path.join(REFERENCE, "dataset", "flow", "extract_motion_vectors.py"), run_name="__main__")
+            for i in range(len(MV_FRAMES)):
+                for kind in ("grids", "inv_grids"):
+                    a = np.load(os.path.join(root, "frames", "synthetic", kind, f"{i}.npy"), allow_pickle=False)
+                    assert a.dtype == np.float64 and a.shape == (67, 120, 2)
+                    out[f"{kind}_{i}"] = a
+            assert not os.path.exists(os.path.join(root, "frames", "synthetic", "grids", f"{len(MV_FRAMES)}.npy"))
+    finally:
+        os.chdir(cwd)
+        sys.argv = argv
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+    out["frames"] = np.array(MV_FRAMES, dtype=np.int64)
+    save("mv_grids.npz", **out)
+
+
+# (height, width, grid_h, grid_w, crop_h, crop_w, h_off, w_off): every window the ViT sliding-crop route cuts out of a 1072 x 1920
+# frame (crop 704, stride ceil(704 * 2/3): flow/base.py:183-203), then offsets off the block edges, then two whose block
+# quotients end in .5 (Python's round-half-to-even decides the range), then the small centre crop of transform_val below.
+CROP_GEOMETRIES = [(1072, 1920, 67, 120, 704, 704, ho, wo) for ho in (0, 368) for wo in (0, 470, 940, 1216)] + [
+    (1072, 1920, 67, 120, 704, 704, 100, 333), (1072, 1920, 67, 120, 704, 704, 8, 24), (1072, 1920, 67, 120, 704, 704, 24, 8),
+    (160, 256, 10, 16, 96, 128, 32, 64)]
+# the default route's 713 crops cut 45 blocks and resize them to 44: cv2 interpolates, the stand-in refuses -> NOT covered
+CROP_GEOMETRIES_INTERPOLATED = [(1072, 1920, 67, 120, 713, 713, 0, 0), (1072, 1920, 67, 120, 713, 713, 359, 476)]
+TRANSFORM_ITEM = dict(h=160, w=256, gh=10, gw=16, crop=(96, 128), delta=5, ignore=(5,), seed=77, frames=24, items=((10, 4), (20, 2)))
+
+
+def _cv2_same_size_stand_in():
+    """flow/transform.py imports cv2 (absent offline).  The stand-in knows ONE case of cv2.resize: the requested size is the
+    size the array already has, for which cv2::resize copies its source (its early-out for dsize == ssize) -- so the stand-in
+    returns src.copy() and takes no part in the arithmetic; any other call raises, and the generator records that geometry as
+    not covered.  `collections.Iterable` (removed in Python 3.10, used by the reference's Resize / Crop constructors) is aliased to
+    collections.abc.Iterable, which is what it was."""
+    import collections
+    import collections.abc
+    import types
+
+    class Interpolating(Exception):
+        pass
+
+    def resize(src, dsize, fx=None, fy=None, interpolation=None):
+        if dsize is None or (dsize[1], dsize[0]) != tuple(src.shape[:2]):
+            raise Interpolating(f"{src.shape[:2]} -> {dsize}")
+        return src.copy()
+
+    cv2 = types.ModuleType("cv2")
+    cv2.INTER_LINEAR, cv2.INTER_NEAREST, cv2.resize, cv2.Interpolating = 1, 0, resize, Interpolating
+    if not hasattr(collections, "Iterable"):
+        collections.Iterable = collections.abc.Iterable
+    return cv2
+
+
+def gen_transforms():
+    """The reference's OWN flow/transform.py on the cases where its cv2.resize calls are same-size copies (see
+    _cv2_same_size_stand_in): (a) crop_motion_vector (:215-261) -- block range by round(), renormalisation to the crop -- for every
+    704-crop window of a 1072 x 1920 frame and offsets off the block edges, on float32 CPU tensors [1,67,120,2] (the branch
+    compute_output feeds, flow/base.py:208); (b) transform_val = Resize, IgnoreClasses, Crop('center'), ToTensor, Normalize
+    (flow/base.py:396-406) on one seeded item whose frames already have the Resize size."""
+    saved = sys.modules.get("cv2")
+    sys.modules["cv2"] = cv2 = _cv2_same_size_stand_in()
+    try:
+        import flow.transform as ref_t  # reference
+    finally:
+        if saved is None:
+            sys.modules.pop("cv2", None)
+        else:
+            sys.modules["cv2"] = saved
+    out = {"geometries": np.array(CROP_GEOMETRIES, dtype=np.int64), "interpolated": np.array(CROP_GEOMETRIES_INTERPOLATED, dtype=np.int64)}
+    for k, (h, w, gh, gw, ch, cw, ho, wo) in enumerate(CROP_GEOMETRIES):
+        ml, mr = synth.make_grids(3, gh, gw, seed=300 + k, frame=(h, w), jitter=0.03)
+        cl, cr = ref_t.crop_motion_vector([m.clone() for m in ml], [m.clone() for m in mr], h, w, ch, cw, ho, wo)
+        assert all(tuple(m.shape) == (1, ch // 16, cw // 16, 2) and m.dtype == torch.float32 for m in cl + cr)
+        out[f"crop_left_{k}"] = torch.cat(cl).numpy()
+        out[f"crop_right_{k}"] = torch.cat(cr).numpy()
+    for h, w, gh, gw, ch, cw, ho, wo in CROP_GEOMETRIES_INTERPOLATED:
+        ml, mr = synth.make_grids(2, gh, gw, seed=1, frame=(h, w))
+        try:
+            ref_t.crop_motion_vector(ml, mr, h, w, ch, cw, ho, wo)
+            raise SystemExit("expected an interpolating resize")
+        except cv2.Interpolating:
+            pass
+    # (b) the validation / test transform chains on the two items of a tiny labelled video
+    t = TRANSFORM_ITEM
+    files = synth.transform_frames(t["h"], t["w"], t["gh"], t["gw"], range(t["frames"]), t["ignore"], t["seed"])
+    ident = synth.identity_grid(t["gh"], t["gw"])                                                    # stands where FlowData pads (:147-171)
+    mean, std = [0.485 * 255, 0.456 * 255, 0.406 * 255], [0.229 * 255, 0.224 * 255, 0.225 * 255]   # base/foundation.py:27-31 in [0, 255]
+    val = ref_t.Compose([ref_t.Resize((t["h"], t["w"])), ref_t.IgnoreClasses(list(t["ignore"])),
+                         ref_t.Crop(list(t["crop"]), crop_type="center", ignore_label=255), ref_t.ToTensor(), ref_t.Normalize(mean=mean, std=std)])
+    test = ref_t.Compose([ref_t.Resize((t["h"], t["w"])), ref_t.IgnoreClasses(list(t["ignore"])), ref_t.ToTensor(),
+                          ref_t.Normalize(mean=mean, std=std)])                                      # flow/base.py:410-431: no Crop
+    n1 = t["delta"] - 1
+    for k, (f, l) in enumerate(t["items"]):   # l = Random(index).randrange(1, delta), pinned by dataset_index.npz
+        r = t["delta"] - l
+        left = [files[g]["grid"] for g in range(f - l + 1, f + 1)]
+        right = [files[g]["inv_grid"] for g in range(f + 1, f + r + 1)][::-1]
+        left, right = left + [ident] * (n1 - len(left)), right + [ident] * (n1 - len(right))
+        for name, chain in (("val", val), ("test", test)):
+            _, fp, fn, mvl, mvr, lab = chain(None, files[f - l]["image"].copy(), files[f + r]["image"].copy(), [g.copy() for g in left],
+                                             [g.copy() for g in right], files[f]["label"].copy())
+            assert fp.dtype == torch.float32 and lab.dtype == torch.int64 and mvl[0].dtype == torch.float32
+            out.update({f"{name}{k}_frame_prev": fp.numpy(), f"{name}{k}_frame_next": fn.numpy(), f"{name}{k}_label": lab.numpy(),
+                        f"{name}{k}_mvs_left": torch.stack(mvl).numpy(), f"{name}{k}_mvs_right": torch.stack(mvr).numpy()})
+    out.update(item_shape=np.array([t["h"], t["w"], t["gh"], t["gw"], t["crop"][0], t["crop"][1], t["delta"], t["seed"], t["frames"]]),
+               item_ignore=np.array(t["ignore"]), items=np.array(t["items"]))
+    save("transforms.npz", **out)
+
+
 def gen_vit_s16():
     """BASELINE configs[3] names a ViT-S/16; model/vit.py hard-codes B/32 (patch 32, d_model 768), so the S/16 network is
     assembled from THE REFERENCE'S OWN CLASSES exactly as model/vit.py:24-52 assembles them, with S/16 numbers (patch 16,
@@ -426,13 +579,17 @@ def gen_deeplab_backbone():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["grid", "ops", "toy", "pspnet", "vit", "vit_s16", "pspnet_feature", "pspnet_deep", "deeplab_backbone", "pspnet_deep_713", "dataset_index"]
+    which = sys.argv[1:] or ["grid", "ops", "toy", "pspnet", "vit", "vit_s16", "pspnet_feature", "pspnet_deep", "deeplab_backbone", "pspnet_deep_713", "dataset_index", "mv_grids", "transforms"]
     if "deeplab_backbone" in which:
         gen_deeplab_backbone()
     if "pspnet_deep_713" in which:
         gen_pspnet_deep_713()
     if "dataset_index" in which:
         gen_dataset_index()
+    if "mv_grids" in which:
+        gen_mv_grids()
+    if "transforms" in which:
+        gen_transforms()
     if "pspnet_deep" in which:
         gen_pspnet_deep()
     if "vit_s16" in which:

@@ -187,7 +187,7 @@ def test_sliding_crop_inference_with_the_reference_default_frame_delta_25():
 
 
 def test_motion_vectors_to_grids_last_writer_wins_and_npy_round_trip(tmp_path):
-    """the grid producer (the reference script needs cv2 + mvextractor at import: restated, unpinned)."""
+    """the grid producer against the oracle restatement (pinned to the reference's script by the next test)."""
     from flood_uav_video_segmentation_amd.flow import grids
     from oracle import crops_oracle
 
@@ -209,6 +209,89 @@ def test_motion_vectors_to_grids_last_writer_wins_and_npy_round_trip(tmp_path):
         bad = mv.copy()
         bad[3, 0] = 1
         grids.motion_vectors_to_grids(bad, 1080, 1920)
+
+
+def test_motion_vectors_to_grids_matches_the_references_script():
+    """fs_mv_to_grids against the reference's own script run top to bottom (tests/golden/mv_grids.npz, see
+    test_oracle_golden.py::test_grid_producer_oracle_matches_the_references_script): float64, bit-exact, four frames."""
+    from flood_uav_video_segmentation_amd.flow import grids
+
+    z = load_golden("mv_grids.npz")
+    for i, (h, w, n, seed) in enumerate(z["frames"]):
+        grid, inv = grids.motion_vectors_to_grids(synth.motion_vectors(int(h), int(w), int(n), int(seed)), int(h), int(w))
+        assert np.array_equal(grid.cpu().numpy(), z[f"grids_{i}"]) and np.array_equal(inv.cpu().numpy(), z[f"inv_grids_{i}"]), i
+
+
+def test_crop_motion_vector_matches_the_references_function():
+    """fs_crop_grids (flow/crops.py::crop_motion_vector) against the reference's own flow/transform.py:215-261 on the windows
+    whose block range already has the final size (tests/golden/transforms.npz; see test_oracle_golden.py::
+    test_crop_motion_vector_oracle_matches_the_references_function for what is and is not covered): all eight 704-crop windows
+    of a 1072 x 1920 frame, offsets off the block edges, two round-half-to-even cases, a small centre crop."""
+    from flood_uav_video_segmentation_amd.flow import crops
+
+    z = load_golden("transforms.npz")
+    worst = 0.0
+    for k, (h, w, gh, gw, ch, cw, ho, wo) in enumerate(z["geometries"].tolist()):
+        ml, mr = synth.make_grids(3, gh, gw, seed=300 + k, frame=(h, w), jitter=0.03)
+        cl, cr = crops.crop_motion_vector(cu(ml), cu(mr), h, w, ch, cw, ho, wo)
+        assert cl[0].shape == (1, ch // 16, cw // 16, 2)
+        worst = max(worst, (torch.cat(cl).cpu() - torch.from_numpy(z[f"crop_left_{k}"])).abs().max().item(),
+                    (torch.cat(cr).cpu() - torch.from_numpy(z[f"crop_right_{k}"])).abs().max().item())
+    note("crop_motion_vector_vs_reference_same_size_abs", worst)
+    assert worst < 1e-6   # coordinates in [-1.1, 1.1], fp32 chain of 6 operations (the compiler may contract mul + add)
+
+
+@pytest.mark.parametrize("split", ["val", "test"])
+def test_eval_windows_match_the_references_transform_chain(tmp_path, split):
+    """EvalWindows.__getitem__ (decode, Resize at the native size, IgnoreClasses, Crop('center') incl. the grids, ToTensor,
+    Normalize on the GPU) against the reference's own transform_val / transform_test chains (flow/base.py:396-431,
+    flow/transform.py) on the two items of a tiny labelled video -- tests/golden/transforms.npz.  Frames are stored as PNG
+    (lossless: the decoded bytes are the seeded ones), so the .jpg suffix of frame_path is overridden; the 10 x 16 raster's
+    identity grid stands in for get_default_grid() where FlowData pads, as it does in the generator."""
+    import os
+
+    from PIL import Image
+
+    from flood_uav_video_segmentation_amd.flow.dataset import EvalWindows
+
+    class PngWindows(EvalWindows):
+        def frame_path(self, f_id):
+            return os.path.join(self.data_root, "frames", self.video_id, "images", f"{f_id}.png")
+
+    z = load_golden("transforms.npz")
+    h, w, gh, gw, ch, cw, delta, seed, frames = z["item_shape"].tolist()
+    ignore = tuple(z["item_ignore"].tolist())
+    files = synth.transform_frames(h, w, gh, gw, range(frames), ignore, seed)
+    base = os.path.join(tmp_path, "frames", "vid")
+    for d in ("images", "grids", "inv_grids"):
+        os.makedirs(os.path.join(base, d))
+    os.makedirs(os.path.join(tmp_path, "masks"))
+    for f, rec in files.items():
+        Image.fromarray(rec["image"]).save(os.path.join(base, "images", f"{f}.png"))
+        np.save(os.path.join(base, "grids", f"{f}.npy"), rec["grid"])
+        np.save(os.path.join(base, "inv_grids", f"{f}.npy"), rec["inv_grid"])
+    with open(os.path.join(tmp_path, "list.txt"), "w") as fh:
+        for f, _ in z["items"].tolist():
+            Image.fromarray(files[f]["label"]).save(os.path.join(tmp_path, "masks", f"{f}.png"))
+            fh.write(f"masks/{f}.png vid {f}\n")
+    ds = PngWindows(str(tmp_path), os.path.join(tmp_path, "list.txt"), split=split, frame_delta=delta, size=(h, w),
+                    center_crop=(ch, cw) if split == "val" else None, classes_ignore=ignore)
+    ds.default_grid = torch.from_numpy(synth.identity_grid(gh, gw)).float()
+    assert len(ds) == 2
+    for k, (f, l) in enumerate(z["items"].tolist()):
+        item = ds[k]
+        assert int(item["left_index"][0]) == l and int(item["right_index"][0]) == delta - l
+        assert torch.equal(item["label"][0].cpu(), torch.from_numpy(z[f"{split}{k}_label"]))                    # int64, bit-exact
+        for name in ("frame_prev", "frame_next"):
+            ref = torch.from_numpy(z[f"{split}{k}_{name}"])
+            assert item[name].shape[1:] == ref.shape
+            assert (item[name][0].cpu() - ref).abs().max().item() < 1e-6                                         # (x - mean) / std, |x| < 2.7
+        for name in ("mvs_left", "mvs_right"):
+            ref = torch.from_numpy(z[f"{split}{k}_{name}"])
+            got = torch.cat(item[name]).cpu()
+            assert got.shape == ref.shape
+            # test: float64 -> float32 only (bit-exact).  val: the reference crops in float64 and then rounds, the HIP path rounds first
+            assert torch.equal(got, ref) if split == "test" else (got - ref).abs().max().item() < 1e-6
 
 
 def test_predict_step_mirror_masks_metric_and_palette(psp_flow):

@@ -320,3 +320,78 @@ def test_window_indexing_matches_the_references_flowdata(delta, tmp_path):
     if delta == 5:  # no_warp placeholders: delta - 1 tensors of one element each (flow/dataset.py:198-205)
         nw = PredictWindows(str(tmp_path), "vid", frame_delta=5, no_warp=True, device="cpu")
         assert z["nowarp_counts"].tolist() == [4, 4, 1] and nw.frame_delta - 1 == 4
+
+
+def test_grid_producer_oracle_matches_the_references_script():
+    """oracle/crops_oracle.motion_vectors_to_grids against the reference's OWN script run top to bottom
+    (dataset/flow/extract_motion_vectors.py; tests/golden/mv_grids.npz -- the generator replaces the H.264 decoder with a synthetic
+    frame source and cv2.imwrite with a no-op, the script does lines 21-43 and the np.save itself).  float64, bit-exact: frames of
+    1080, 1072 and 720 rows (H and W of the FRAME normalise, the 67 x 120 block raster is fixed), vectors that leave the raster on
+    every side, blocks hit several times (the last row wins), and a frame with no vectors (both grids = the default grid)."""
+    from flood_uav_video_segmentation_amd import synth
+    from oracle import crops_oracle, flow_oracle
+
+    z = load_golden("mv_grids.npz")
+    default = flow_oracle.get_default_grid()
+    for i, (h, w, n, seed) in enumerate(z["frames"]):
+        mv = synth.motion_vectors(int(h), int(w), int(n), int(seed))
+        grid, inv = crops_oracle.motion_vectors_to_grids(mv, int(h), int(w), default)
+        assert grid.dtype == np.float64 and np.array_equal(grid, z[f"grids_{i}"]) and np.array_equal(inv, z[f"inv_grids_{i}"]), i
+        if n == 0:
+            assert np.array_equal(grid, default) and np.array_equal(inv, default)
+        else:
+            assert not np.array_equal(grid, inv)
+
+
+def test_crop_motion_vector_oracle_matches_the_references_function():
+    """oracle/crops_oracle.crop_motion_vector against the reference's OWN flow/transform.py:215-261 (tests/golden/transforms.npz):
+    every 704-crop window of a 1072 x 1920 frame (the ViT sliding-crop route), offsets off the block edges, two whose block
+    quotients end in .5 (round-half-to-even decides the block range) and a small centre crop.  In all of them the cropped block
+    range already has the final size, for which cv2.resize copies -- the generator's cv2 stand-in knows only that case.  The 713
+    crops of the default route cut 45 blocks and interpolate to 44: listed in `interpolated`, NOT covered (cv2 absent).  Bit-exact:
+    float32, same operation order."""
+    from flood_uav_video_segmentation_amd import synth
+    from oracle import crops_oracle
+
+    z = load_golden("transforms.npz")
+    assert len(z["geometries"]) == 12 and len(z["interpolated"]) == 2
+    for k, (h, w, gh, gw, ch, cw, ho, wo) in enumerate(z["geometries"].tolist()):
+        ml, mr = synth.make_grids(3, gh, gw, seed=300 + k, frame=(h, w), jitter=0.03)
+        cl, cr = crops_oracle.crop_motion_vector(ml, mr, h, w, ch, cw, ho, wo)
+        assert np.array_equal(torch.cat(cl).numpy(), z[f"crop_left_{k}"]) and np.array_equal(torch.cat(cr).numpy(), z[f"crop_right_{k}"]), k
+        assert torch.equal(ml[0], synth.make_grids(3, gh, gw, seed=300 + k, frame=(h, w), jitter=0.03)[0][0])   # inputs untouched
+    for h, w, gh, gw, ch, cw, ho, wo in z["interpolated"].tolist():   # what the fixture does NOT cover: the block range is resized
+        ppb = h / gh
+        assert round((ho + ch) / ppb) - round(ho / ppb) != ch // 16
+
+
+def test_label_transforms_oracle_matches_the_references_chain():
+    """dataset_oracle.resize_label_nearest / ignore_classes + the centre-crop offsets against the reference's own transform_val and
+    transform_test chains (flow/base.py:396-431 -> flow/transform.py Resize, IgnoreClasses, Crop, ToTensor, Normalize) run on a
+    seeded item whose frames already have the Resize size (tests/golden/transforms.npz).  Labels bit-exact; frames (x - mean) / std
+    in float32, bit-exact on the CPU."""
+    from flood_uav_video_segmentation_amd import synth
+    from flood_uav_video_segmentation_amd.flow.dataset import MEAN, STD
+    from oracle import crops_oracle, dataset_oracle
+
+    z = load_golden("transforms.npz")
+    h, w, gh, gw, ch, cw, delta, seed, frames = z["item_shape"].tolist()
+    ignore = tuple(z["item_ignore"].tolist())
+    files = synth.transform_frames(h, w, gh, gw, range(frames), ignore, seed)
+    ho, wo = int((h - ch) / 2), int((w - cw) / 2)
+    ident = synth.identity_grid(gh, gw)
+    for k, (f, l) in enumerate(z["items"].tolist()):
+        r = delta - l
+        lab = dataset_oracle.ignore_classes(dataset_oracle.resize_label_nearest(files[f]["label"], (h, w)), ignore).astype(np.int64)
+        assert np.array_equal(lab, z[f"test{k}_label"]) and np.array_equal(lab[ho:ho + ch, wo:wo + cw], z[f"val{k}_label"])
+        assert (lab == ignore[0]).sum() == 0 and (lab == 255).sum() > 0
+        x = torch.from_numpy(files[f - l]["image"]).permute(2, 0, 1).float()
+        x = (x - torch.tensor(MEAN).view(3, 1, 1)) / torch.tensor(STD).view(3, 1, 1)
+        assert np.array_equal(x.numpy(), z[f"test{k}_frame_prev"]) and np.array_equal(x[:, ho:ho + ch, wo:wo + cw].numpy(), z[f"val{k}_frame_prev"])
+        left = [files[g]["grid"] for g in range(f - l + 1, f + 1)]
+        left += [ident] * (delta - 1 - len(left))
+        assert np.array_equal(np.stack(left).astype(np.float32), z[f"test{k}_mvs_left"])                       # ToTensor: float64 -> float32
+        # Crop on the float64 grids, then float32 (the reference's order); the oracle crops float32 tensors: 1 ulp apart at most
+        cl, _ = crops_oracle.crop_motion_vector([torch.from_numpy(g).float()[None] for g in left], [torch.from_numpy(g).float()[None] for g in left],
+                                                h, w, ch, cw, ho, wo)
+        assert np.abs(torch.cat(cl).numpy() - z[f"val{k}_mvs_left"]).max() < 5e-7
