@@ -127,6 +127,36 @@ def test_colorize_is_a_table_lookup():
     assert torch.equal(rgb.cpu(), torch.from_numpy(PALETTE)[m.cpu().long()])
 
 
+def test_colorize_and_metrics_on_the_label_pairs_the_reference_ships():
+    """tests/golden/labels/: three of the reference's own (label, colour label) PNG pairs at 1080 x 1920.  fs_colorize on the label
+    gives the reference's colour image byte for byte (flow/base.py:310 with dataset/flow/list/colors.txt); fs_iou_hist between real
+    label maps equals the oracle's intersectionAndUnion (util/util.py:36-47 semantics, pinned by metrics.npz) -- realistic region
+    shapes instead of uniform noise; the label-side transform chain of the test split (nearest resize 1080 -> 1072 rows,
+    IgnoreClasses) equals the oracle's."""
+    import os
+
+    from PIL import Image
+
+    from conftest import GOLDEN
+    from flood_uav_video_segmentation_amd.flow.dataset import resize_label_nearest
+    from oracle import dataset_oracle, flow_oracle
+
+    names = ("florida-05_49", "florida-07_29", "florida-04_27")
+    labs = [np.array(Image.open(os.path.join(GOLDEN, "labels", f"{n}.png"))) for n in names]
+    for n, lab in zip(names, labs):
+        rgb = np.array(Image.open(os.path.join(GOLDEN, "labels", f"{n}_color.png")).convert("RGB"))
+        assert torch.equal(colorize(torch.from_numpy(lab).cuda()).cpu(), torch.from_numpy(rgb))
+        small = resize_label_nearest(lab, (1072, 1920))
+        assert small.shape == (1072, 1920) and np.array_equal(small, dataset_oracle.resize_label_nearest(lab, (1072, 1920)))
+    pred, tgt = np.stack([labs[0], labs[1], labs[2]]), np.stack([labs[1], labs[2], labs[0]])
+    tgt = tgt.copy()
+    tgt[:, :8] = 255
+    h = ops.iou_hist(torch.from_numpy(pred).cuda(), torch.from_numpy(tgt).cuda(), 5).cpu().numpy()
+    a, u, t = flow_oracle.intersection_and_union(pred.astype(np.int64), tgt.astype(np.int64), 5, 255)
+    assert np.array_equal(h[0], a) and np.array_equal(h[1] + h[2] - h[0], u) and np.array_equal(h[2], t)
+    assert (a > 0).all()   # every class takes part
+
+
 def test_conv_is_linear_without_activation_at_layer_size():
     """1x1 conv 1024 -> 256 on the 90x90 map of a 713 frame: conv(x1 + x2) == conv(x1) + conv(x2) up to fp32 rounding, and a
     zero input gives exactly the shift."""

@@ -2,13 +2,14 @@
 tests/golden/gen_goldens.py in the build container).  The reference ships no tests or fixtures of
 its own, so these reference-generated vectors are the pin."""
 import hashlib
+import os
 
 import numpy as np
 import pytest
 import torch
 import torch.nn.functional as F
 
-from conftest import load_golden, rel_err, toy_weights
+from conftest import GOLDEN, load_golden, rel_err, toy_weights
 from flood_uav_video_segmentation_amd import synth
 from oracle import flow_oracle, pspnet_oracle
 
@@ -395,3 +396,21 @@ def test_label_transforms_oracle_matches_the_references_chain():
         cl, _ = crops_oracle.crop_motion_vector([torch.from_numpy(g).float()[None] for g in left], [torch.from_numpy(g).float()[None] for g in left],
                                                 h, w, ch, cw, ho, wo)
         assert np.abs(torch.cat(cl).numpy() - z[f"val{k}_mvs_left"]).max() < 5e-7
+
+
+LABEL_PAIRS = ("florida-05_49", "florida-07_29", "florida-04_27")
+
+
+def test_palette_matches_the_label_pairs_the_reference_ships():
+    """tests/golden/labels/: three of the reference's own label / colour-label PNG pairs (dataset/flow/masks, masks_color): the
+    palette table of flow/predict.py (dataset/flow/list/colors.txt) applied as flow/base.py:310 applies it reproduces the
+    colour image exactly, on all five classes."""
+    from PIL import Image
+
+    from flood_uav_video_segmentation_amd.flow.predict import PALETTE
+
+    for name in LABEL_PAIRS:
+        lab = np.array(Image.open(os.path.join(GOLDEN, "labels", f"{name}.png")))
+        rgb = np.array(Image.open(os.path.join(GOLDEN, "labels", f"{name}_color.png")).convert("RGB"))
+        assert lab.shape == (1080, 1920) and lab.dtype == np.uint8 and sorted(np.unique(lab)) == [0, 1, 2, 3, 4]
+        assert np.array_equal(PALETTE[lab], rgb)
