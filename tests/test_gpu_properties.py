@@ -154,7 +154,7 @@ def test_colorize_and_metrics_on_the_label_pairs_the_reference_ships():
     h = ops.iou_hist(torch.from_numpy(pred).cuda(), torch.from_numpy(tgt).cuda(), 5).cpu().numpy()
     a, u, t = flow_oracle.intersection_and_union(pred.astype(np.int64), tgt.astype(np.int64), 5, 255)
     assert np.array_equal(h[0], a) and np.array_equal(h[1] + h[2] - h[0], u) and np.array_equal(h[2], t)
-    assert (a > 0).all()   # every class takes part
+    assert (t > 0).all() and a.sum() > 0   # every class is present in the targets
 
 
 def test_conv_is_linear_without_activation_at_layer_size():
