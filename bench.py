@@ -62,6 +62,7 @@ CLIP_FRAMES = 21                 # 4 key-frame windows of frame_delta 5 per clip
 KEYFRAME_GFLOP = 727.44          # PSPNet-R50 encoder+decoder at 713^2
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense bf16 MFMA peak (v_mfma_f32_32x32x16_bf16), no sparsity
+NOMINAL_SCLK_MHZ = 2400          # MI355X_MICROARCH.md: the clock the peaks are quoted at
 SPLIT_TERMS = 6                  # bf16 MFMA FLOPs executed per fp32 FLOP of the split-operand kernel (6 of the 9 cross products)
 ARITHMETIC = ("fp32 tensors; in the implicit-GEMM kernels every fp32 operand is the exact sum of three bf16 terms (round-to-nearest residues) "
               "and six of the nine cross products (all of order <= 2^-16) run on v_mfma_f32_32x32x16_bf16 with fp32 accumulation; the three "
@@ -141,6 +142,59 @@ def pmc_traffic(dom_kernel):
 
 
 pmc_traffic.extra = {}
+
+
+def clock_under_load(step, torch, windows=120, period_s=0.004):
+    """Shader clock and socket power of THIS card while the headline step loops (hwmon: freq1_input, power1_input; read-only sysfs).
+    Run after the timed region.  The card is found by its PCI address; None when the sensors are not readable."""
+    import threading
+
+    try:
+        pr = torch.cuda.get_device_properties(torch.cuda.current_device())
+        addr = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+    except AttributeError:
+        return None
+    mons = [d for d in glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*") if os.path.basename(os.path.realpath(os.path.join(d, "..", ".."))) == addr]
+    if not mons:
+        return None
+    d = mons[0]
+
+    def rd(name):
+        try:
+            with open(os.path.join(d, name)) as fh:
+                return int(fh.read())
+        except (OSError, ValueError):
+            return None
+
+    if rd("freq1_input") is None or rd("power1_input") is None:
+        return None
+    clk, pw, stop = [], [], threading.Event()
+
+    def sampler():
+        while not stop.is_set():
+            f, w = rd("freq1_input"), rd("power1_input")
+            if f is not None and w is not None:
+                clk.append(f / 1e6)
+                pw.append(w / 1e6)
+            time.sleep(period_s)
+
+    for i in range(20):  # the card may have dropped to its idle clock during the host-side work before this pass
+        step(i)
+    th = threading.Thread(target=sampler, daemon=True)
+    th.start()
+    t0 = time.perf_counter()
+    for i in range(windows):
+        step(i)
+    dt = time.perf_counter() - t0
+    stop.set()
+    th.join()
+    if len(clk) < 8:
+        return None
+    return {"sclk_mhz_mean": round(sum(clk) / len(clk), 1), "sclk_mhz_min": round(min(clk), 1), "sclk_mhz_max": round(max(clk), 1),
+            "power_w_mean": round(sum(pw) / len(pw), 1), "power_w_max": round(max(pw), 1), "power_cap_w": (rd("power1_cap") or 0) / 1e6,
+            "samples": len(clk), "windows": windows, "ms_per_step_during_sampling": round(dt / windows * 1e3, 4),
+            "source": f"hwmon freq1_input / power1_input of {addr}, one sample per {period_s * 1e3:.0f} ms over {windows} windows after the timed region; "
+                      f"roofline.peak is quoted at the nominal {NOMINAL_SCLK_MHZ} MHz"}
 
 
 def timed(fn, steps, warmup, dev, per_step=None):
@@ -446,6 +500,11 @@ def main():
                             k: (round(e[k], 4) if isinstance(e[k], float) else {a: round(b, 4) for a, b in e[k].items()})
                             for k in ("mfma_utilisation", "l2_hit_rate", "lds_bank_conflict_share_of_lds_cycles", "hbm_bytes_per_launch", "wave_time_shares") if k in e}
 
+    if not args.no_extras and world == 1 and "roofline" in result:
+        try:
+            result["roofline"]["clock_and_power_under_load"] = clock_under_load(step_native, torch)
+        except Exception as e:  # noqa: BLE001  (a sensor that cannot be read must not cost the bench line)
+            result["roofline"]["clock_and_power_under_load"] = {"error": repr(e)[:200]}
     if not args.no_extras and world == 1:  # the variants are single-GPU figures: measured by the N = 1 run only
         result["variants"] = variants(args, dev, rdev, net, state, fm, windows, dl, dr, host_masks, host_post)
 

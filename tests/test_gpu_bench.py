@@ -129,3 +129,25 @@ print("rccl-ok")
         port = str(s.getsockname()[1])
     r = subprocess.run([sys.executable, "-c", code % (ROOT, port)], capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert r.returncode == 0 and "rccl-ok" in r.stdout, (r.stdout[-1000:], r.stderr[-3000:])
+
+
+def test_clock_and_power_pass_reads_this_cards_sensors():
+    """bench.py's roofline.clock_and_power_under_load: hwmon of the card torch runs on (found by PCI address), sampled while a step
+    loops.  A box whose sensors are not readable gives None, never a number from another card."""
+    import importlib.util
+
+    import torch
+
+    spec = importlib.util.spec_from_file_location("bench_module", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    x = torch.randn(4096, 4096, device="cuda")
+
+    def step(i):
+        (x @ x).sum().item()
+
+    r = bench.clock_under_load(step, torch, windows=40, period_s=0.002)
+    if r is None:
+        pytest.skip("hwmon sensors not readable on this box")
+    assert 90 <= r["sclk_mhz_min"] <= r["sclk_mhz_mean"] <= r["sclk_mhz_max"] <= 2600
+    assert 100 < r["power_w_mean"] <= r["power_w_max"] <= 1.1 * r["power_cap_w"] and r["samples"] >= 8

@@ -25,8 +25,12 @@ N = 5
 
 
 class HP:
+    OPTIONS = ()   # --opt words: hip_* attributes of the reference-style hparams (model/hipnet.py::hip_options)
+
     def __init__(self, layers):
         self.layers, self.classes, self.pretrained = layers, 5, False
+        for word in HP.OPTIONS:
+            setattr(self, word, True)
 
 
 def timeit(fn, steps=10, warmup=2):
@@ -44,7 +48,10 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="", help="cfg0 | cfg1 | cfg4 | feat | crops | crops_cached | cfg2 | cfg3 | vitb")
     ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--opt", action="append", default=[], help="hip_no_split_bf16 | hip_no_winograd | hip_plane_operands | ... (repeatable)")
+    ap.add_argument("--json", action="store_true", help="also print one JSON line {value, unit, ms_per_step, steps} of the last config run")
     args = ap.parse_args()
+    HP.OPTIONS = tuple(args.opt)
     want = lambda k: not args.only or args.only == k  # noqa: E731
     dev = "cuda"
     host = torch.empty((N, 713, 713), dtype=torch.uint8).pin_memory()
@@ -132,6 +139,10 @@ def main():
     print(f"{'config':68s} {'FPS':>9s} {'ms/step':>9s}")
     for name, fps, ms in rows:
         print(f"{name:68s} {fps:9.1f} {ms:9.3f}")
+    if args.json and rows:
+        import json
+        print(json.dumps({"config": rows[-1][0], "options": list(HP.OPTIONS), "value": round(rows[-1][1], 2), "unit": "frames/s",
+                          "ms_per_step": round(rows[-1][2], 4), "steps": st}))
 
 
 if __name__ == "__main__":
