@@ -5,7 +5,8 @@ PINNED (round 4) wherever cv2 does not interpolate: tests/golden/transforms.npz 
 crop_motion_vector returns for every 704-crop window of a 1072x1920 frame, offsets off the block edges and two
 round-half-to-even block ranges (the generator's cv2 stand-in knows only the same-size case of cv2.resize, a copy), and
 tests/golden/mv_grids.npz what its own extract_motion_vectors.py writes on a synthetic frame source: both bit-exact here
-(tests/test_oracle_golden.py).  PARITY UNPINNED for the interpolating grid resize (713 crops: 45 -> 44 blocks): cv2 is
+(tests/test_oracle_golden.py); compute_output inside the reference's own predict_step / test_step on 704 crops likewise
+(tests/golden/lightning_steps.npz).  PARITY UNPINNED for the interpolating grid resize (713 crops: 45 -> 44 blocks): cv2 is
 absent offline; the restatement uses F.interpolate(bilinear, align_corners=False), the same half-pixel-centre formula cv2
 documents for float data.  Everything else (block rounding with Python's banker's round, renormalisation, float64 accumulation, crop
 order) is restated literally.  TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).

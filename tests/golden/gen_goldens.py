@@ -502,6 +502,161 @@ def gen_transforms():
     save("transforms.npz", **out)
 
 
+STEP_FRAME = (1072, 1920)          # the frame geometry predict_step hard-codes for its output (flow/base.py:275)
+STEP_CROP = (704, 704)             # test_h / test_w of the sliding-crop runs: every window's cv2.resize is a same-size copy
+STEP_KEYS = (0, 5, 10, 15)         # three consecutive predict windows of one clip (seed 1300)
+STEP_LABELS = ("florida-05_49", "florida-07_29", "florida-04_27")   # tests/golden/labels: the reference's own label maps, rows [:1072]
+STEP_INDEX = ((2, 3), (1, 4), (4, 1))  # (left_index, right_index) of the three test items
+
+
+def gen_lightning_steps():
+    """predict_step / on_predict_end and test_step / test_epoch_end run in THE REFERENCE'S OWN FlowBaseModel (flow/base.py:143-343,
+    base/foundation.py:224-262, 333-344): compute_output's crop order, softmax, float64 canvas and count normalisation,
+    crop_motion_vector per window, the hard-coded 1072 x 1920 upsample + argmax, the temporal-consistency meters across windows
+    (last_output), the palette frames handed to the video writer, the Florida / Texas meter split and the epoch summaries.
+    flow/base.py imports the training stack (pytorch_lightning, wandb, imageio, dataclasses_json, torchvision, skimage, cv2), all
+    absent offline and none of them part of this arithmetic: import-only stand-ins are registered (LightningModule = an empty
+    class, so the object is made with object.__new__ and given the attributes the methods read: hparams, model_G, trainer.profiler,
+    logger; wandb.summary = a dict the reference writes its results into; imageio.get_writer = a collector of the frames the
+    reference appends; cv2.resize = the same-size copy of _cv2_same_size_stand_in).  The network is the toy encoder / decoder of
+    toy_predict.npz inside the reference's own FlowModel (logit warp), frames are 1072 x 1920 with 67 x 120 grids."""
+    import tempfile
+    import time
+    import types
+
+    def mod(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+
+    class Collector:
+        def __init__(self):
+            self.frames = []
+
+        def append_data(self, frame):
+            self.frames.append(np.array(frame))
+
+        def close(self):
+            pass
+
+    class LightningModule:   # what FlowBaseModel's methods call on their base class
+        def log(self, name, value, **kw):
+            self.logged[name] = float(value)
+
+        def test_epoch_end(self, outputs):
+            return None
+
+    class StepProfiler:      # trainer.profiler: context manager + recorded_durations (flow/base.py:321-323)
+        def __init__(self):
+            self.recorded_durations = {}
+
+        @contextlib.contextmanager
+        def profile(self, name):
+            t0 = time.perf_counter()
+            yield
+            self.recorded_durations.setdefault(name, []).append(time.perf_counter() - t0)
+
+    class OnDevice(torch.Tensor):
+        """crop_motion_vector takes `m.cpu().numpy()[0]` and writes into it (flow/transform.py:245-248): for a CUDA tensor -- the
+        reference's real runs -- .cpu() is a copy and the caller's grid is untouched, for a CPU tensor it is the tensor itself and
+        every crop window would see the previous windows' renormalisation (SURVEY 8c quirk v).  The grids are handed over as this
+        subclass, whose .cpu() returns a copy like a device tensor's: no arithmetic, the GPU semantics on a CPU-only machine."""
+
+        def cpu(self, *a, **k):
+            return torch.Tensor.cpu(self, *a, **k).clone().as_subclass(torch.Tensor)
+
+    def on_device(grids):
+        return [g.as_subclass(OnDevice) for g in grids]
+
+    collector = Collector()
+    saved = {k: sys.modules.get(k) for k in ("cv2", "wandb", "imageio", "pytorch_lightning", "pytorch_lightning.profilers", "dataclasses_json",
+                                             "torchvision", "skimage", "skimage.io")}
+    sys.modules["cv2"] = _cv2_same_size_stand_in()
+    wandb = mod("wandb", run=object(), summary={})
+    mod("imageio", get_writer=lambda *a, **k: collector)
+    prof_mod = mod("pytorch_lightning.profilers", PyTorchProfiler=type("PyTorchProfiler", (), {}))
+    mod("pytorch_lightning", LightningModule=LightningModule, LightningDataModule=type("LightningDataModule", (), {}), profilers=prof_mod)
+    mod("dataclasses_json", dataclass_json=lambda cls: cls)
+    mod("torchvision")
+    if "skimage" not in sys.modules or not hasattr(sys.modules["skimage"], "io"):
+        mod("skimage", io=mod("skimage.io", imread=None))
+    try:
+        import flow.base as ref_base  # reference
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+    from PIL import Image
+
+    toy, _ = toy_model()
+    H, W = STEP_FRAME
+    clip = synth.make_clip(16, (H, W), seed=1300, only=list(STEP_KEYS))
+    colors = np.loadtxt(os.path.join(REFERENCE, "dataset", "flow", "list", "colors.txt")).astype(np.uint8)
+    out = {"keys": np.array(STEP_KEYS), "crop": np.array(STEP_CROP), "index": np.array(STEP_INDEX)}
+
+    def make(no_cropping, log_dir):
+        obj = object.__new__(ref_base.FlowBaseModel)
+        obj.hparams = types.SimpleNamespace(no_cropping=no_cropping, test_h=STEP_CROP[0], test_w=STEP_CROP[1], classes=5, ignore_index=255,
+                                            compute_metrics=True, save_images=False, save_video=True, predict_v_id="vid",
+                                            data_root=os.path.join(REFERENCE, "dataset", "flow"))
+        obj.logger = types.SimpleNamespace(log_dir=log_dir)
+        obj.trainer = types.SimpleNamespace(profiler=StepProfiler())
+        obj.model_G = ref_flow.FlowModel(toy, feature_based=False, no_warp=False).eval()
+        obj.logged = {}
+        return obj
+
+    with tempfile.TemporaryDirectory() as tmp:
+        for route, no_cropping in (("whole", True), ("crops", False)):
+            # ---- predict_step over three consecutive windows
+            obj = make(no_cropping, tmp)
+            collector.frames.clear()
+            wandb.summary.clear()
+            obj.on_predict_start()
+            assert obj.video_writer is collector
+            for k in range(3):
+                mvl, mvr = synth.make_grids(5, 67, 120, seed=1310 + k, frame=(H, W), jitter=0.01)
+                obj.predict_step({"frame_prev": clip[k:k + 1], "frame_next": clip[k + 1:k + 2], "mvs_left": on_device(mvl), "mvs_right": on_device(mvr),
+                                  "frame_id": torch.tensor([5 * k])}, k)
+            obj.on_predict_end()
+            frames = np.stack(collector.frames)                                   # [15,1072,1920,3] palette frames
+            assert frames.shape == (15, H, W, 3)
+            ids = np.zeros(frames.shape[:3], np.uint8)
+            for c in range(5):
+                ids[(frames == colors[c]).all(-1)] = c
+            assert np.array_equal(colors[ids], frames)
+            out[f"predict_{route}_masks_sub"] = ids[:, ::8, ::8].copy()
+            out[f"predict_{route}_class_pixels"] = np.stack([np.bincount(m.ravel(), minlength=5) for m in ids]).astype(np.int64)
+            out[f"predict_{route}_meters"] = np.stack([obj.intersection_meter_predict.sum, obj.union_meter_predict.sum, obj.target_meter_predict.sum]).astype(np.int64)
+            out[f"predict_{route}_summary"] = np.array([wandb.summary["predict_miou1_epoch"], wandb.summary["predict_macc1_epoch"],
+                                                        wandb.summary["predict_accuracy1_epoch"]], dtype=np.float64)
+            out[f"predict_{route}_iou_classes"] = np.asarray(wandb.summary["predict_miou1_epoch_classes"], dtype=np.float64)
+            assert len(obj.trainer.profiler.recorded_durations["predict_interference"]) == 3
+            # ---- test_step on three labelled items (two in the Florida meters, one in the Texas meters) + test_epoch_end
+            obj = make(no_cropping, tmp)
+            obj.init_metrics_test()
+            wandb.summary.clear()
+            for k in range(3):
+                lab = np.array(Image.open(os.path.join(OUT, "labels", STEP_LABELS[k] + ".png")))[:H].astype(np.int64)
+                lab[:4] = 255
+                mvl, mvr = synth.make_grids(5, 67, 120, seed=1320 + k, frame=(H, W), jitter=0.01)
+                l, r = STEP_INDEX[k]
+                batch = {"frame_prev": clip[k:k + 1], "frame_next": clip[k + 1:k + 2], "mvs_left": on_device(mvl), "mvs_right": on_device(mvr),
+                         "left_index": torch.tensor([l]), "right_index": torch.tensor([r]), "label": torch.from_numpy(lab)[None]}
+                obj.test_step((batch, 1 if k == 2 else 0), k)
+            out[f"test_{route}_meters1"] = np.stack([obj.intersection_meter_test1.sum, obj.union_meter_test1.sum, obj.target_meter_test1.sum]).astype(np.int64)
+            out[f"test_{route}_meters2"] = np.stack([obj.intersection_meter_test2.sum, obj.union_meter_test2.sum, obj.target_meter_test2.sum]).astype(np.int64)
+            obj.test_epoch_end([])
+            out[f"test_{route}_logged"] = np.array([obj.logged[k] for k in ("test_miou1_epoch", "test_macc1_epoch", "test_accuracy1_epoch",
+                                                                             "test_miou2_epoch", "test_macc2_epoch", "test_accuracy2_epoch",
+                                                                             "test_miou_epoch")], dtype=np.float64)
+            out[f"test_{route}_iou_classes1"] = np.asarray(wandb.summary["test_miou1_epoch_classes"], dtype=np.float64)
+            print(route, out[f"predict_{route}_summary"], out[f"test_{route}_logged"])
+    save("lightning_steps.npz", **out)
+
+
 def gen_vit_s16():
     """BASELINE configs[3] names a ViT-S/16; model/vit.py hard-codes B/32 (patch 32, d_model 768), so the S/16 network is
     assembled from THE REFERENCE'S OWN CLASSES exactly as model/vit.py:24-52 assembles them, with S/16 numbers (patch 16,
@@ -579,7 +734,7 @@ def gen_deeplab_backbone():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["grid", "ops", "toy", "pspnet", "vit", "vit_s16", "pspnet_feature", "pspnet_deep", "deeplab_backbone", "pspnet_deep_713", "dataset_index", "mv_grids", "transforms"]
+    which = sys.argv[1:] or ["grid", "ops", "toy", "pspnet", "vit", "vit_s16", "pspnet_feature", "pspnet_deep", "deeplab_backbone", "pspnet_deep_713", "dataset_index", "mv_grids", "transforms", "lightning_steps"]
     if "deeplab_backbone" in which:
         gen_deeplab_backbone()
     if "pspnet_deep_713" in which:
@@ -590,6 +745,8 @@ if __name__ == "__main__":
         gen_mv_grids()
     if "transforms" in which:
         gen_transforms()
+    if "lightning_steps" in which:
+        gen_lightning_steps()
     if "pspnet_deep" in which:
         gen_pspnet_deep()
     if "vit_s16" in which:

@@ -294,6 +294,68 @@ def test_eval_windows_match_the_references_transform_chain(tmp_path, split):
             assert torch.equal(got, ref) if split == "test" else (got - ref).abs().max().item() < 1e-6
 
 
+@pytest.mark.parametrize("route", ["whole", "crops"])
+def test_predictor_and_evaluator_match_the_references_lightning_steps(route):
+    """FlowPredictor.predict_window / temporal_consistency and FlowEvaluator.test_step / summary on the HIP path against THE
+    REFERENCE'S OWN predict_step / on_predict_end and test_step / test_epoch_end (tests/golden/lightning_steps.npz; how the
+    reference's FlowBaseModel is run without its training stack is described in the generator and in
+    test_oracle_golden.py::test_oracle_chain_matches_the_references_predict_step_and_test_step).  Three consecutive windows of a
+    1072 x 1920 clip, whole frame and 704 x 704 sliding crops; the toy encoder / decoder are torch convs on the GPU, everything
+    around them (crop grids, warp chain, softmax canvas, resize + argmax, histograms, palette) is the HIP path."""
+    import os
+
+    from PIL import Image
+
+    from conftest import GOLDEN
+    from flood_uav_video_segmentation_amd.flow.predict import PALETTE, FlowEvaluator, FlowPredictor, colorize
+
+    z = load_golden("lightning_steps.npz")
+    H, W = 1072, 1920
+    crop = None if route == "whole" else tuple(z["crop"].tolist())
+    clip = synth.make_clip(16, (H, W), seed=1300, only=z["keys"].tolist()).cuda()
+    fm = FlowModel(toy_model(), feature_based=False, no_warp=False).eval()
+    pred = FlowPredictor(fm, classes=5, out_size=(H, W), crop=crop, compute_metrics=True)
+    masks = []
+    for k in range(3):
+        mvl, mvr = synth.make_grids(5, 67, 120, seed=1310 + k, frame=(H, W), jitter=0.01)
+        masks.append(pred.predict_window(clip[k:k + 1], clip[k + 1:k + 2], cu(mvl), cu(mvr)))
+    masks = np.concatenate(masks)
+    assert masks.shape == (15, H, W) and masks.dtype == np.uint8
+    agree = (masks[:, ::8, ::8] == z[f"predict_{route}_masks_sub"]).mean()
+    note(f"lightning_predict_{route}_mask_disagreement", 1 - agree)
+    assert agree > 0.9999                                                          # measured: identical on the sub-grid
+    counts = np.stack([np.bincount(m.ravel(), minlength=5) for m in masks])
+    assert np.abs(counts - z[f"predict_{route}_class_pixels"]).max() <= 400        # of 2.06 M pixels per frame
+    h = pred.hist.cpu().numpy()
+    meters = np.stack([h[0], h[1] + h[2] - h[0], h[2]])
+    ref = z[f"predict_{route}_meters"]
+    assert np.abs(meters - ref).max() <= 1e-3 * ref.max()
+    got = np.array(pred.temporal_consistency())
+    note(f"lightning_predict_{route}_miou_delta", float(np.abs(got - z[f"predict_{route}_summary"]).max()))
+    assert np.abs(got - z[f"predict_{route}_summary"]).max() < 1e-4               # mIoU, mAcc, accuracy as wandb.summary holds them (measured 1.4e-7)
+    rgb = colorize(torch.from_numpy(masks[7]).cuda()).cpu().numpy()               # the frame the reference hands to its video writer
+    assert np.array_equal(rgb[::8, ::8], PALETTE[masks[7][::8, ::8]])
+    # ---- test_step on three labelled items (real label maps), Florida / Texas meters, test_epoch_end's logs
+    ev = FlowEvaluator(fm, classes=5, crop=crop)
+    for k in range(3):
+        lab = np.array(Image.open(os.path.join(GOLDEN, "labels", ("florida-05_49", "florida-07_29", "florida-04_27")[k] + ".png")))[:H].astype(np.int64)
+        lab[:4] = 255
+        mvl, mvr = synth.make_grids(5, 67, 120, seed=1320 + k, frame=(H, W), jitter=0.01)
+        l, r = z["index"][k].tolist()
+        ev.test_step({"frame_prev": clip[k:k + 1], "frame_next": clip[k + 1:k + 2], "mvs_left": cu(mvl), "mvs_right": cu(mvr),
+                      "left_index": torch.tensor([l]), "right_index": torch.tensor([r]), "label": torch.from_numpy(lab)[None].cuda()},
+                     test_idx=1 if k == 2 else 0)
+    logged = []
+    for meter, name in ((0, "meters1"), (1, "meters2")):
+        h = ev.hist[meter].cpu().numpy()
+        got_m, ref = np.stack([h[0], h[1] + h[2] - h[0], h[2]]), z[f"test_{route}_{name}"]
+        assert np.array_equal(got_m[2], ref[2]) and np.abs(got_m - ref).max() <= 1e-3 * ref.max()
+        logged += list(ev.summary(meter)[:3])
+    logged.append((logged[0] + logged[3]) / 2)                                     # test_miou_epoch (base/foundation.py:254)
+    assert np.abs(np.array(logged) - z[f"test_{route}_logged"]).max() < 1e-3
+    assert np.abs(ev.summary(0)[3] - z[f"test_{route}_iou_classes1"]).max() < 2e-3
+
+
 def test_predict_step_mirror_masks_metric_and_palette(psp_flow):
     """flow/base.py:259-343 on the HIP path: 1072x1920 masks, temporal-consistency mIoU over two windows, palette."""
     from flood_uav_video_segmentation_amd.flow.predict import PALETTE, FlowPredictor, colorize

@@ -414,3 +414,81 @@ def test_palette_matches_the_label_pairs_the_reference_ships():
         rgb = np.array(Image.open(os.path.join(GOLDEN, "labels", f"{name}_color.png")).convert("RGB"))
         assert lab.shape == (1080, 1920) and lab.dtype == np.uint8 and sorted(np.unique(lab)) == [0, 1, 2, 3, 4]
         assert np.array_equal(PALETTE[lab], rgb)
+
+
+STEP_LABELS = ("florida-05_49", "florida-07_29", "florida-04_27")
+
+
+def _toy_enc_dec():
+    w = toy_weights()
+    enc = lambda x: torch.relu(F.conv2d(x, w["enc_w"], w["enc_b"], 4, 1))  # noqa: E731
+    dec = lambda f: F.conv2d(f, w["dec_w"], w["dec_b"])  # noqa: E731
+    return enc, dec
+
+
+@pytest.mark.parametrize("route", ["whole", "crops"])
+def test_oracle_chain_matches_the_references_predict_step_and_test_step(route):
+    """oracle/ (crops_oracle.compute_output, flow_oracle.predict_segmentation / forward / postprocess / intersection_and_union)
+    chained the way flow/base.py:143-343 chains them, against THE REFERENCE'S OWN predict_step / on_predict_end and test_step /
+    test_epoch_end (tests/golden/lightning_steps.npz: FlowBaseModel made with import-only stand-ins for the absent training stack,
+    see the generator): three consecutive windows of a 1072 x 1920 clip, whole-frame and 704-crop routes -- masks on an 8 x 8
+    sub-grid and per-class pixel counts of every frame, the temporal-consistency meters across windows, the summaries the
+    reference writes to wandb.summary; three labelled items split over the Florida / Texas meters and test_epoch_end's logs."""
+    from PIL import Image
+
+    from oracle import crops_oracle
+
+    z = load_golden("lightning_steps.npz")
+    H, W = 1072, 1920
+    ch, cw = z["crop"].tolist()
+    enc, dec = _toy_enc_dec()
+    clip = synth.make_clip(16, (H, W), seed=1300, only=z["keys"].tolist())
+    seg = lambda p, q, a, b: flow_oracle.predict_segmentation(enc, dec, p, q, a, b, 5, False)["pred"]  # noqa: E731
+    meters, last, masks = np.zeros((3, 5), np.int64), None, []
+    for k in range(3):
+        mvl, mvr = synth.make_grids(5, 67, 120, seed=1310 + k, frame=(H, W), jitter=0.01)
+        if route == "whole":
+            out = seg(clip[k:k + 1], clip[k + 1:k + 2], mvl, mvr)
+        else:
+            out = crops_oracle.compute_output(seg, 5, clip[k:k + 1], clip[k + 1:k + 2], mvl, mvr, ch, cw, 5)
+        m = flow_oracle.postprocess(out)
+        for p_ in range(5):
+            prev = m[p_ - 1] if p_ > 0 else last
+            if prev is not None:
+                meters += np.stack(flow_oracle.intersection_and_union(m[p_][None], prev[None], 5, 255)).astype(np.int64)
+        last = m[4]
+        masks.append(m)
+    masks = np.concatenate(masks)
+    assert masks.shape == (15, H, W) and (masks[:, ::8, ::8] == z[f"predict_{route}_masks_sub"]).mean() > 0.9999
+    counts = np.stack([np.bincount(x.ravel(), minlength=5) for x in masks])
+    assert np.abs(counts - z[f"predict_{route}_class_pixels"]).max() <= 40          # of 2.06 M pixels per frame: near-tie flips only
+    ref = z[f"predict_{route}_meters"]
+    assert np.abs(meters - ref).max() <= 1e-4 * ref.max()
+    iou = meters[0] / (meters[1] + 1e-10)
+    assert np.abs(iou - z[f"predict_{route}_iou_classes"]).max() < 1e-4
+    got = np.array([iou.mean(), (meters[0] / (meters[2] + 1e-10)).mean(), meters[0].sum() / (meters[2].sum() + 1e-10)])
+    assert np.abs(got - z[f"predict_{route}_summary"]).max() < 1e-4
+    # ---- test_step: one interpolated frame per item against a real label map, Florida (0) / Texas (1) meters
+    m1, m2 = np.zeros((3, 5), np.int64), np.zeros((3, 5), np.int64)
+    for k in range(3):
+        lab = np.array(Image.open(os.path.join(GOLDEN, "labels", STEP_LABELS[k] + ".png")))[:H].astype(np.int64)
+        lab[:4] = 255
+        mvl, mvr = synth.make_grids(5, 67, 120, seed=1320 + k, frame=(H, W), jitter=0.01)
+        l, r = z["index"][k].tolist()
+        fwd = lambda p, q, a, b: flow_oracle.forward(enc, dec, p, q, a, b, [l], [r], False, False)["pred"]  # noqa: E731
+        if route == "whole":
+            out = fwd(clip[k:k + 1], clip[k + 1:k + 2], mvl, mvr)
+        else:
+            out = crops_oracle.compute_output(fwd, 1, clip[k:k + 1], clip[k + 1:k + 2], mvl, mvr, ch, cw, 5)
+        pred = out.max(1)[1].numpy()
+        upd = np.stack(flow_oracle.intersection_and_union(pred, lab[None], 5, 255)).astype(np.int64)
+        if k == 2:
+            m2 += upd
+        else:
+            m1 += upd
+    for got_m, name in ((m1, "meters1"), (m2, "meters2")):
+        ref = z[f"test_{route}_{name}"]
+        assert np.array_equal(got_m[2], ref[2]) and np.abs(got_m - ref).max() <= 1e-4 * ref.max()     # target areas exact (labels only)
+    s1 = [np.mean(m1[0] / (m1[1] + 1e-10)), np.mean(m1[0] / (m1[2] + 1e-10)), m1[0].sum() / (m1[2].sum() + 1e-10)]
+    s2 = [np.mean(m2[0] / (m2[1] + 1e-10)), np.mean(m2[0] / (m2[2] + 1e-10)), m2[0].sum() / (m2[2].sum() + 1e-10)]
+    assert np.abs(np.array(s1 + s2 + [(s1[0] + s2[0]) / 2]) - z[f"test_{route}_logged"]).max() < 1e-4
