@@ -657,6 +657,56 @@ def gen_lightning_steps():
     save("lightning_steps.npz", **out)
 
 
+def gen_checkpoint_keys():
+    """Names and shapes of a Lightning checkpoint's state_dict as the reference's own modules produce them: FlowBaseModel.
+    get_new_model_arch_G (flow/base.py:87-108) for arch = pspnet (layers 50), i.e. FlowModel(FlowPSPNet) under the attribute
+    model_G, and VITSegmentModel (model/vit.py) under `model` -- every alias the modules register (layer0..4, layers.*, encoder.*,
+    ppm, decoder, aux heads, num_batches_tracked).  A JSON of names -> shapes: the drop-in loaders are tested against it."""
+    import json
+    import types
+
+    def mod(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+
+    names = ("cv2", "wandb", "imageio", "pytorch_lightning", "pytorch_lightning.profilers", "dataclasses_json", "torchvision", "skimage", "skimage.io")
+    saved = {k: sys.modules.get(k) for k in names}
+    sys.modules["cv2"] = _cv2_same_size_stand_in()
+    mod("wandb", run=None, summary={})
+    mod("imageio")
+    prof_mod = mod("pytorch_lightning.profilers", PyTorchProfiler=type("PyTorchProfiler", (), {}))
+    mod("pytorch_lightning", LightningModule=type("LightningModule", (), {}), LightningDataModule=type("LightningDataModule", (), {}), profilers=prof_mod)
+    mod("dataclasses_json", dataclass_json=lambda cls: cls)
+    mod("torchvision")
+    if "skimage" not in sys.modules or not hasattr(sys.modules["skimage"], "io"):
+        mod("skimage", io=mod("skimage.io", imread=None))
+    try:
+        import flow.base as ref_base  # reference
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+    obj = object.__new__(ref_base.FlowBaseModel)
+    obj.hparams = types.SimpleNamespace(arch="pspnet", layers=50, classes=5, pretrained=False, test_h=713, test_w=713, feature_based=False,
+                                        no_warp=True, no_interpolation_percentage=0.0)
+    model_G, heads, backs = obj.get_new_model_arch_G()
+    out = {"pspnet50": {"model_G." + k: list(v.shape) for k, v in model_G.state_dict().items()},
+           "pspnet50_optimizer_groups": {"head_modules": len(heads), "backbone_modules": len(backs)}}
+    _timm_stand_ins()
+    import model.vit as ref_vit  # reference
+
+    vit = ref_vit.VITSegmentModel(5, 704)
+    out["vit_b32"] = {"model." + k: list(v.shape) for k, v in vit.state_dict().items()}
+    path = os.path.join(OUT, "checkpoint_keys.json")
+    with open(path, "w") as fh:
+        json.dump(out, fh, indent=0, sort_keys=True)
+    print("checkpoint_keys.json", {k: len(v) for k, v in out.items()}, f"{os.path.getsize(path) / 1024:.1f} KiB")
+
+
 def gen_vit_s16():
     """BASELINE configs[3] names a ViT-S/16; model/vit.py hard-codes B/32 (patch 32, d_model 768), so the S/16 network is
     assembled from THE REFERENCE'S OWN CLASSES exactly as model/vit.py:24-52 assembles them, with S/16 numbers (patch 16,
@@ -734,7 +784,7 @@ def gen_deeplab_backbone():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["grid", "ops", "toy", "pspnet", "vit", "vit_s16", "pspnet_feature", "pspnet_deep", "deeplab_backbone", "pspnet_deep_713", "dataset_index", "mv_grids", "transforms", "lightning_steps"]
+    which = sys.argv[1:] or ["grid", "ops", "toy", "pspnet", "vit", "vit_s16", "pspnet_feature", "pspnet_deep", "deeplab_backbone", "pspnet_deep_713", "dataset_index", "mv_grids", "transforms", "lightning_steps", "checkpoint_keys"]
     if "deeplab_backbone" in which:
         gen_deeplab_backbone()
     if "pspnet_deep_713" in which:
@@ -747,6 +797,8 @@ if __name__ == "__main__":
         gen_transforms()
     if "lightning_steps" in which:
         gen_lightning_steps()
+    if "checkpoint_keys" in which:
+        gen_checkpoint_keys()
     if "pspnet_deep" in which:
         gen_pspnet_deep()
     if "vit_s16" in which:

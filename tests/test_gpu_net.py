@@ -39,24 +39,35 @@ def test_weights_required_before_forward():
 
 
 def test_state_dict_aliases_are_accepted(psp):
-    _, state = psp
-    aliased = {}
-    for k, v in state.items():
-        if k.startswith("layer"):
-            aliased["model_G.model.encoder.0." + k[5] + k[6:]] = v     # encoder.0.<N>.*
-            aliased["model_G.model.layers." + k[5] + k[6:]] = v        # layers.<N>.*
-        elif k.startswith("ppm."):
-            aliased["model_G.model.encoder.1." + k[4:]] = v
-        else:
-            aliased["model_G.model." + k] = v
-    aliased["model_G.model.layer0.1.num_batches_tracked"] = torch.tensor(0)
+    """A Lightning checkpoint as the reference's own modules name it (tests/golden/checkpoint_keys.json: FlowBaseModel.model_G =
+    FlowModel(FlowPSPNet), 1046 keys with every alias and the num_batches_tracked counters) loads strictly into
+    FlowModel(FlowPSPNet) on the HIP path and gives the same logits as the canonical names."""
+    import json
+    import os
+
+    from conftest import GOLDEN
+    from flood_uav_video_segmentation_amd.flow.model import FlowModel
+
+    ref, state = psp
+    with open(os.path.join(GOLDEN, "checkpoint_keys.json")) as fh:
+        keys = json.load(fh)["pspnet50"]
+    ckpt = {}
+    for k, shape in keys.items():
+        c = FlowPSPNet.canonical_name(k[len("model_G.model."):])
+        ckpt[k[len("model_G."):]] = torch.zeros(shape, dtype=torch.int64) if c is None else state[c]
+        assert c is None or list(state[c].shape) == shape
     net = FlowPSPNet(HP()).eval()
-    missing, unexpected, errors = [], [], []
-    net._load_from_state_dict(aliased, "model_G.model.", {}, True, missing, unexpected, errors)
-    assert not missing and not unexpected and not errors
+    fm = FlowModel(net, feature_based=False, no_warp=True)
+    res = fm.load_state_dict(ckpt, strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
     x = synth.make_clip(1, 65, seed=100).cuda()
-    ref, _ = psp
     assert torch.equal(net.decoder(net.encoder(x)), ref.decoder(ref.encoder(x)))
+    # the sub-module form used by the round-1 test: prefix handed to _load_from_state_dict
+    net2 = FlowPSPNet(HP()).eval()
+    missing, unexpected, errors = [], [], []
+    net2._load_from_state_dict({"model_G." + k: v for k, v in ckpt.items()}, "model_G.model.", {}, True, missing, unexpected, errors)
+    assert not missing and not unexpected and not errors
+    assert torch.equal(net2.decoder(net2.encoder(x)), ref.decoder(ref.encoder(x)))
 
 
 def test_pspnet_small_against_oracle_and_reference_golden(psp):
