@@ -502,7 +502,9 @@ def main():
 
     if not args.no_extras and world == 1 and "roofline" in result:
         try:
-            result["roofline"]["clock_and_power_under_load"] = clock_under_load(step_native, torch)
+            cp = result["roofline"]["clock_and_power_under_load"] = clock_under_load(step_native, torch)
+            if cp:  # the same achieved rate against the peak at the clock the card holds over the window (frac stays at the nominal clock)
+                result["roofline"]["frac_of_peak_at_held_clock"] = round(result["roofline"]["frac"] * NOMINAL_SCLK_MHZ / cp["sclk_mhz_mean"], 4)
         except Exception as e:  # noqa: BLE001  (a sensor that cannot be read must not cost the bench line)
             result["roofline"]["clock_and_power_under_load"] = {"error": repr(e)[:200]}
     if not args.no_extras and world == 1:  # the variants are single-GPU figures: measured by the N = 1 run only
