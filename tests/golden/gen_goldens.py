@@ -547,6 +547,9 @@ def gen_lightning_steps():
         def test_epoch_end(self, outputs):
             return None
 
+        def validation_epoch_end(self, outputs):
+            return None
+
     class StepProfiler:      # trainer.profiler: context manager + recorded_durations (flow/base.py:321-323)
         def __init__(self):
             self.recorded_durations = {}
@@ -654,6 +657,24 @@ def gen_lightning_steps():
                                                                              "test_miou_epoch")], dtype=np.float64)
             out[f"test_{route}_iou_classes1"] = np.asarray(wandb.summary["test_miou1_epoch_classes"], dtype=np.float64)
             print(route, out[f"predict_{route}_summary"], out[f"test_{route}_logged"])
+        # ---- validation_step with a BATCH of three items (per-sample warp counts, flow/model.py:92-106) + validation_epoch_end
+        hv, wv = 160, 272
+        obj = make(True, tmp)
+        obj.init_metrics_val()
+        vclip = synth.make_clip(6, (hv, wv), seed=1340)
+        per = [synth.make_grids(5, hv // 16, wv // 16, seed=1341 + b, frame=(hv, wv), jitter=0.02) for b in range(3)]
+        mvl = [torch.cat([per[b][0][j] for b in range(3)], 0) for j in range(4)]
+        mvr = [torch.cat([per[b][1][j] for b in range(3)], 0) for j in range(4)]
+        lab = torch.from_numpy(np.random.default_rng(1345).integers(0, 5, (3, hv, wv))).long()
+        lab[:, :3] = 255
+        for rep in range(2):   # two batches: the meters accumulate over the epoch
+            li, ri = (torch.tensor([1, 2, 4]), torch.tensor([4, 3, 1])) if rep == 0 else (torch.tensor([3, 3, 2]), torch.tensor([2, 2, 3]))
+            obj.validation_step({"frame_prev": vclip[0:3], "frame_next": vclip[3:6], "mvs_left": mvl, "mvs_right": mvr, "left_index": li,
+                                 "right_index": ri, "label": lab}, rep)
+        out["val_meters"] = np.stack([obj.intersection_meter_val.sum, obj.union_meter_val.sum, obj.target_meter_val.sum]).astype(np.int64)
+        obj.validation_epoch_end([])
+        out["val_logged"] = np.array([obj.logged[k] for k in ("val_miou_epoch", "val_macc_epoch", "val_accuracy_epoch")], dtype=np.float64)
+        print("val", out["val_logged"])
     save("lightning_steps.npz", **out)
 
 

@@ -356,6 +356,29 @@ def test_predictor_and_evaluator_match_the_references_lightning_steps(route):
     assert np.abs(ev.summary(0)[3] - z[f"test_{route}_iou_classes1"]).max() < 2e-3
 
 
+def test_evaluator_validation_step_matches_the_references_with_a_batch_of_three():
+    """FlowEvaluator.validation_step (FlowModel.forward at B = 3 with per-sample warp counts, fs_argmax_u8, fs_iou_hist) against the
+    reference's own validation_step / validation_epoch_end over two batches (tests/golden/lightning_steps.npz)."""
+    from flood_uav_video_segmentation_amd.flow.predict import FlowEvaluator
+
+    z = load_golden("lightning_steps.npz")
+    hv, wv = 160, 272
+    vclip = synth.make_clip(6, (hv, wv), seed=1340).cuda()
+    per = [synth.make_grids(5, hv // 16, wv // 16, seed=1341 + b, frame=(hv, wv), jitter=0.02) for b in range(3)]
+    mvl = [torch.cat([per[b][0][j] for b in range(3)], 0).cuda() for j in range(4)]
+    mvr = [torch.cat([per[b][1][j] for b in range(3)], 0).cuda() for j in range(4)]
+    lab = np.random.default_rng(1345).integers(0, 5, (3, hv, wv)).astype(np.int64)
+    lab[:, :3] = 255
+    ev = FlowEvaluator(FlowModel(toy_model(), feature_based=False, no_warp=False).eval(), classes=5)
+    for li, ri in (([1, 2, 4], [4, 3, 1]), ([3, 3, 2], [2, 2, 3])):
+        ev.validation_step({"frame_prev": vclip[0:3], "frame_next": vclip[3:6], "mvs_left": mvl, "mvs_right": mvr,
+                            "left_index": torch.tensor(li), "right_index": torch.tensor(ri), "label": torch.from_numpy(lab).cuda()})
+    h = ev.hist["val"].cpu().numpy()
+    meters, ref = np.stack([h[0], h[1] + h[2] - h[0], h[2]]), z["val_meters"]
+    assert np.array_equal(meters[2], ref[2]) and np.abs(meters - ref).max() <= 1e-3 * ref.max()
+    assert np.abs(np.array(ev.summary("val")[:3]) - z["val_logged"]).max() < 1e-3
+
+
 def test_predict_step_mirror_masks_metric_and_palette(psp_flow):
     """flow/base.py:259-343 on the HIP path: 1072x1920 masks, temporal-consistency mIoU over two windows, palette."""
     from flood_uav_video_segmentation_amd.flow.predict import PALETTE, FlowPredictor, colorize

@@ -492,3 +492,26 @@ def test_oracle_chain_matches_the_references_predict_step_and_test_step(route):
     s1 = [np.mean(m1[0] / (m1[1] + 1e-10)), np.mean(m1[0] / (m1[2] + 1e-10)), m1[0].sum() / (m1[2].sum() + 1e-10)]
     s2 = [np.mean(m2[0] / (m2[1] + 1e-10)), np.mean(m2[0] / (m2[2] + 1e-10)), m2[0].sum() / (m2[2].sum() + 1e-10)]
     assert np.abs(np.array(s1 + s2 + [(s1[0] + s2[0]) / 2]) - z[f"test_{route}_logged"]).max() < 1e-4
+
+
+def test_oracle_forward_matches_the_references_validation_step_with_a_batch_of_three():
+    """flow_oracle.forward (warp_batch with per-sample warp counts) + argmax + intersection_and_union against the reference's own
+    validation_step / validation_epoch_end (flow/base.py:143-154, base/foundation.py:160-172) on two batches of three items with
+    mixed (left_index, right_index): the meters accumulated over the epoch and the logged mIoU / mAcc / accuracy."""
+    z = load_golden("lightning_steps.npz")
+    enc, dec = _toy_enc_dec()
+    hv, wv = 160, 272
+    vclip = synth.make_clip(6, (hv, wv), seed=1340)
+    per = [synth.make_grids(5, hv // 16, wv // 16, seed=1341 + b, frame=(hv, wv), jitter=0.02) for b in range(3)]
+    mvl = [torch.cat([per[b][0][j] for b in range(3)], 0) for j in range(4)]
+    mvr = [torch.cat([per[b][1][j] for b in range(3)], 0) for j in range(4)]
+    lab = np.random.default_rng(1345).integers(0, 5, (3, hv, wv)).astype(np.int64)
+    lab[:, :3] = 255
+    meters = np.zeros((3, 5), np.int64)
+    for li, ri in (([1, 2, 4], [4, 3, 1]), ([3, 3, 2], [2, 2, 3])):
+        out = flow_oracle.forward(enc, dec, vclip[0:3], vclip[3:6], mvl, mvr, li, ri, False, False)["pred"]
+        meters += np.stack(flow_oracle.intersection_and_union(out.max(1)[1].numpy(), lab, 5, 255)).astype(np.int64)
+    ref = z["val_meters"]
+    assert np.array_equal(meters[2], ref[2]) and np.abs(meters - ref).max() <= 1e-4 * ref.max()
+    got = [np.mean(meters[0] / (meters[1] + 1e-10)), np.mean(meters[0] / (meters[2] + 1e-10)), meters[0].sum() / (meters[2].sum() + 1e-10)]
+    assert np.abs(np.array(got) - z["val_logged"]).max() < 1e-4
