@@ -254,7 +254,13 @@ def cpu_baseline(state, windows_cpu):
             out.max(1)[1].to(torch.uint8)
             done += 1
         dt = time.perf_counter() - t0
-    return {"value": round(done * N_DELTA / dt, 4), "unit": "frames/s", "cores": threads, "kind": "port",
+    model = None
+    try:  # core count AND CPU model beside the baseline
+        with open("/proc/cpuinfo") as fh:
+            model = next((ln.split(":", 1)[1].strip() for ln in fh if ln.startswith("model name")), None)
+    except OSError:
+        pass
+    return {"value": round(done * N_DELTA / dt, 4), "unit": "frames/s", "cores": threads, "cpu_model": model, "kind": "port",
             "sample": f"{done} windows ({dt:.1f} s) of the same config (PSPNet-R50, no_warp, n=5, 713x713, both key frames segmented per window) "
                       "through oracle/ on torch-CPU fp32"}
 
