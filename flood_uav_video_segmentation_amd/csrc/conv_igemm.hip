@@ -582,6 +582,12 @@ int launch_conv_igemm(const ConvParams& p, hipStream_t s, int tile) {
             case 1: hipLaunchKernelGGL((conv_igemm_dma_f32<128, 128, 4, 1, false, true>), grid, block, 0, s, p, tm, tn); break;
             case 2: hipLaunchKernelGGL((conv_igemm_dma_f32<128, 64, 4, 1, false, true>), grid, block, 0, s, p, tm, tn); break;
             case 3: hipLaunchKernelGGL((conv_igemm_dma_f32<64, 64, 2, 2, false, true>), grid, block, 0, s, p, tm, tn); break;
+#ifdef FS_DEV
+            // experiment (tools/tile256_bench.py, profiles/r04_experiments.txt section 9): a 256 x 128 tile, 4 x 1 waves of 64 x 128, one
+            // workgroup per CU with the accumulators in AGPRs -- 41 % fewer LDS read bytes per MFMA at the same VALU count per MFMA (every
+            // filter fragment feeds two row blocks).  Bit-identical; EQUAL to two 128 x 128 workgroups per CU at K = 2048, slower below.
+            case 5: hipLaunchKernelGGL((conv_igemm_dma_f32<256, 128, 4, 1, false, true>), grid, block, 0, s, p, tm, tn); break;
+#endif
             default: return fail("conv_igemm: the split-operand route has tiles 1, 2 and 3");
         }
         FS_HIP(hipGetLastError());
