@@ -505,7 +505,7 @@ def gen_transforms():
 STEP_FRAME = (1072, 1920)          # the frame geometry predict_step hard-codes for its output (flow/base.py:275)
 STEP_CROP = (704, 704)             # test_h / test_w of the sliding-crop runs: every window's cv2.resize is a same-size copy
 STEP_KEYS = (0, 5, 10, 15)         # three consecutive predict windows of one clip (seed 1300)
-STEP_LABELS = ("florida-05_49", "florida-07_29", "florida-04_27")   # tests/golden/labels: the reference's own label maps, rows [:1072]
+STEP_LABELS = ("florida-05_49", "florida-07_29", "florida-04_27")   # tests/golden/label_pairs.npz: the reference's own label maps, rows [:1072]
 STEP_INDEX = ((2, 3), (1, 4), (4, 1))  # (left_index, right_index) of the three test items
 
 
@@ -642,7 +642,8 @@ def gen_lightning_steps():
             obj.init_metrics_test()
             wandb.summary.clear()
             for k in range(3):
-                lab = np.array(Image.open(os.path.join(OUT, "labels", STEP_LABELS[k] + ".png")))[:H].astype(np.int64)
+                with np.load(os.path.join(OUT, "label_pairs.npz")) as lz:
+                    lab = lz[STEP_LABELS[k]][:H].astype(np.int64)
                 lab[:4] = 255
                 mvl, mvr = synth.make_grids(5, 67, 120, seed=1320 + k, frame=(H, W), jitter=0.01)
                 l, r = STEP_INDEX[k]
@@ -728,6 +729,37 @@ def gen_checkpoint_keys():
     print("checkpoint_keys.json", {k: len(v) for k, v in out.items()}, f"{os.path.getsize(path) / 1024:.1f} KiB")
 
 
+LABEL_PAIRS = ("florida-05/49", "florida-07/29", "florida-04/27")   # the three smallest pairs that hold every class
+
+
+def gen_label_pairs():
+    """Known-answer vectors the reference ships as DATA: dataset/flow/masks/<video>/<i>.png (uint8 classes 0..4 at 1080 x 1920) and
+    dataset/flow/masks_color/<video>/<i>.png, the same frame through the palette dataset/flow/list/colors.txt -- input and expected
+    output of the palette lookup at flow/base.py:308-312 (`colors[output]`), and realistic label maps for the metric / label-transform
+    tests.  All 314 pairs of the reference satisfy colors[mask] == masks_color exactly (checked here); three are decoded and stored
+    as arrays (label_pairs.npz): labels as uint8 [1080,1920], colour images as uint8 [1080,1920,3]."""
+    import glob
+
+    from PIL import Image
+
+    root = os.path.join(REFERENCE, "dataset", "flow")
+    colors = np.loadtxt(os.path.join(root, "list", "colors.txt")).astype(np.uint8)
+    n = 0
+    for m in sorted(glob.glob(os.path.join(root, "masks", "*", "*.png"))):
+        lab = np.array(Image.open(m))
+        rgb = np.array(Image.open(m.replace(os.sep + "masks" + os.sep, os.sep + "masks_color" + os.sep)).convert("RGB"))
+        assert np.array_equal(colors[lab], rgb), m
+        n += 1
+    out = {"pairs_checked": np.array(n), "colors": colors}
+    for pair in LABEL_PAIRS:
+        name = pair.replace("/", "_")
+        out[name] = np.array(Image.open(os.path.join(root, "masks", pair + ".png")))
+        out[name + "_color"] = np.array(Image.open(os.path.join(root, "masks_color", pair + ".png")).convert("RGB"))
+        assert out[name].shape == (1080, 1920) and out[name].dtype == np.uint8 and sorted(np.unique(out[name])) == [0, 1, 2, 3, 4]
+    print("label pairs checked:", n)
+    save("label_pairs.npz", **out)
+
+
 def gen_vit_s16():
     """BASELINE configs[3] names a ViT-S/16; model/vit.py hard-codes B/32 (patch 32, d_model 768), so the S/16 network is
     assembled from THE REFERENCE'S OWN CLASSES exactly as model/vit.py:24-52 assembles them, with S/16 numbers (patch 16,
@@ -805,7 +837,7 @@ def gen_deeplab_backbone():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["grid", "ops", "toy", "pspnet", "vit", "vit_s16", "pspnet_feature", "pspnet_deep", "deeplab_backbone", "pspnet_deep_713", "dataset_index", "mv_grids", "transforms", "lightning_steps", "checkpoint_keys"]
+    which = sys.argv[1:] or ["grid", "ops", "toy", "pspnet", "vit", "vit_s16", "pspnet_feature", "pspnet_deep", "deeplab_backbone", "pspnet_deep_713", "dataset_index", "mv_grids", "transforms", "lightning_steps", "checkpoint_keys", "label_pairs"]
     if "deeplab_backbone" in which:
         gen_deeplab_backbone()
     if "pspnet_deep_713" in which:
@@ -816,6 +848,8 @@ if __name__ == "__main__":
         gen_mv_grids()
     if "transforms" in which:
         gen_transforms()
+    if "label_pairs" in which:
+        gen_label_pairs()
     if "lightning_steps" in which:
         gen_lightning_steps()
     if "checkpoint_keys" in which:

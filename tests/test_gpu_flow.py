@@ -302,11 +302,6 @@ def test_predictor_and_evaluator_match_the_references_lightning_steps(route):
     test_oracle_golden.py::test_oracle_chain_matches_the_references_predict_step_and_test_step).  Three consecutive windows of a
     1072 x 1920 clip, whole frame and 704 x 704 sliding crops; the toy encoder / decoder are torch convs on the GPU, everything
     around them (crop grids, warp chain, softmax canvas, resize + argmax, histograms, palette) is the HIP path."""
-    import os
-
-    from PIL import Image
-
-    from conftest import GOLDEN
     from flood_uav_video_segmentation_amd.flow.predict import PALETTE, FlowEvaluator, FlowPredictor, colorize
 
     z = load_golden("lightning_steps.npz")
@@ -338,7 +333,7 @@ def test_predictor_and_evaluator_match_the_references_lightning_steps(route):
     # ---- test_step on three labelled items (real label maps), Florida / Texas meters, test_epoch_end's logs
     ev = FlowEvaluator(fm, classes=5, crop=crop)
     for k in range(3):
-        lab = np.array(Image.open(os.path.join(GOLDEN, "labels", ("florida-05_49", "florida-07_29", "florida-04_27")[k] + ".png")))[:H].astype(np.int64)
+        lab = load_golden("label_pairs.npz")[("florida-05_49", "florida-07_29", "florida-04_27")[k]][:H].astype(np.int64)
         lab[:4] = 255
         mvl, mvr = synth.make_grids(5, 67, 120, seed=1320 + k, frame=(H, W), jitter=0.01)
         l, r = z["index"][k].tolist()

@@ -128,23 +128,20 @@ def test_colorize_is_a_table_lookup():
 
 
 def test_colorize_and_metrics_on_the_label_pairs_the_reference_ships():
-    """tests/golden/labels/: three of the reference's own (label, colour label) PNG pairs at 1080 x 1920.  fs_colorize on the label
+    """tests/golden/label_pairs.npz: three of the reference's own (label, colour label) pairs at 1080 x 1920.  fs_colorize on the label
     gives the reference's colour image byte for byte (flow/base.py:310 with dataset/flow/list/colors.txt); fs_iou_hist between real
     label maps equals the oracle's intersectionAndUnion (util/util.py:36-47 semantics, pinned by metrics.npz) -- realistic region
     shapes instead of uniform noise; the label-side transform chain of the test split (nearest resize 1080 -> 1072 rows,
     IgnoreClasses) equals the oracle's."""
-    import os
-
-    from PIL import Image
-
-    from conftest import GOLDEN
+    from conftest import load_golden
     from flood_uav_video_segmentation_amd.flow.dataset import resize_label_nearest
     from oracle import dataset_oracle, flow_oracle
 
     names = ("florida-05_49", "florida-07_29", "florida-04_27")
-    labs = [np.array(Image.open(os.path.join(GOLDEN, "labels", f"{n}.png"))) for n in names]
+    z = load_golden("label_pairs.npz")
+    labs = [z[n] for n in names]
     for n, lab in zip(names, labs):
-        rgb = np.array(Image.open(os.path.join(GOLDEN, "labels", f"{n}_color.png")).convert("RGB"))
+        rgb = z[n + "_color"]
         assert torch.equal(colorize(torch.from_numpy(lab).cuda()).cpu(), torch.from_numpy(rgb))
         small = resize_label_nearest(lab, (1072, 1920))
         assert small.shape == (1072, 1920) and np.array_equal(small, dataset_oracle.resize_label_nearest(lab, (1072, 1920)))

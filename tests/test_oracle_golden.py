@@ -402,16 +402,15 @@ LABEL_PAIRS = ("florida-05_49", "florida-07_29", "florida-04_27")
 
 
 def test_palette_matches_the_label_pairs_the_reference_ships():
-    """tests/golden/labels/: three of the reference's own label / colour-label PNG pairs (dataset/flow/masks, masks_color): the
-    palette table of flow/predict.py (dataset/flow/list/colors.txt) applied as flow/base.py:310 applies it reproduces the
-    colour image exactly, on all five classes."""
-    from PIL import Image
-
+    """tests/golden/label_pairs.npz: three of the reference's own label / colour-label pairs (dataset/flow/masks, masks_color; all
+    314 pairs were checked by the generator): the palette table of flow/predict.py (dataset/flow/list/colors.txt) applied as
+    flow/base.py:310 applies it reproduces the colour image exactly, on all five classes."""
     from flood_uav_video_segmentation_amd.flow.predict import PALETTE
 
+    z = load_golden("label_pairs.npz")
+    assert int(z["pairs_checked"]) == 314 and np.array_equal(z["colors"], PALETTE)
     for name in LABEL_PAIRS:
-        lab = np.array(Image.open(os.path.join(GOLDEN, "labels", f"{name}.png")))
-        rgb = np.array(Image.open(os.path.join(GOLDEN, "labels", f"{name}_color.png")).convert("RGB"))
+        lab, rgb = z[name], z[name + "_color"]
         assert lab.shape == (1080, 1920) and lab.dtype == np.uint8 and sorted(np.unique(lab)) == [0, 1, 2, 3, 4]
         assert np.array_equal(PALETTE[lab], rgb)
 
@@ -434,8 +433,6 @@ def test_oracle_chain_matches_the_references_predict_step_and_test_step(route):
     see the generator): three consecutive windows of a 1072 x 1920 clip, whole-frame and 704-crop routes -- masks on an 8 x 8
     sub-grid and per-class pixel counts of every frame, the temporal-consistency meters across windows, the summaries the
     reference writes to wandb.summary; three labelled items split over the Florida / Texas meters and test_epoch_end's logs."""
-    from PIL import Image
-
     from oracle import crops_oracle
 
     z = load_golden("lightning_steps.npz")
@@ -471,7 +468,7 @@ def test_oracle_chain_matches_the_references_predict_step_and_test_step(route):
     # ---- test_step: one interpolated frame per item against a real label map, Florida (0) / Texas (1) meters
     m1, m2 = np.zeros((3, 5), np.int64), np.zeros((3, 5), np.int64)
     for k in range(3):
-        lab = np.array(Image.open(os.path.join(GOLDEN, "labels", STEP_LABELS[k] + ".png")))[:H].astype(np.int64)
+        lab = load_golden("label_pairs.npz")[STEP_LABELS[k]][:H].astype(np.int64)
         lab[:4] = 255
         mvl, mvr = synth.make_grids(5, 67, 120, seed=1320 + k, frame=(H, W), jitter=0.01)
         l, r = z["index"][k].tolist()
