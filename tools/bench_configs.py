@@ -49,9 +49,13 @@ def main():
     ap.add_argument("--only", default="", help="cfg0 | cfg1 | cfg4 | feat | crops | crops_cached | cfg2 | cfg3 | vitb")
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--opt", action="append", default=[], help="hip_no_split_bf16 | hip_no_winograd | hip_plane_operands | ... (repeatable)")
+    ap.add_argument("--lib", default=None, help="development A/B: load this build of the library instead of the in-tree one")
     ap.add_argument("--json", action="store_true", help="also print one JSON line {value, unit, ms_per_step, steps} of the last config run")
     args = ap.parse_args()
     HP.OPTIONS = tuple(args.opt)
+    if args.lib:
+        from flood_uav_video_segmentation_amd import _lib
+        _lib.LIB_PATH, _lib.ALLOW_MISSING = os.path.abspath(args.lib), True
     want = lambda k: not args.only or args.only == k  # noqa: E731
     dev = "cuda"
     host = torch.empty((N, 713, 713), dtype=torch.uint8).pin_memory()
