@@ -36,6 +36,7 @@ import subprocess
 import sys
 import time
 
+T_PROCESS = time.time()  # this process's start, as far as Python can tell (distributed.startup_s counts from the launcher's when there is one)
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
@@ -59,6 +60,7 @@ N_DELTA = 5
 CLASSES = 5
 NUM_CLIPS = 64                   # BASELINE configs[4]: 64 synthetic clips sharded by clip
 CLIP_FRAMES = 21                 # 4 key-frame windows of frame_delta 5 per clip (flow/dataset.py:64)
+LONG_WINDOWS = 40                # variants.fps_keyframe_cache_lookahead_long_clip: a 201-frame clip
 KEYFRAME_GFLOP = 727.44          # PSPNet-R50 encoder+decoder at 713^2
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense bf16 MFMA peak (v_mfma_f32_32x32x16_bf16), no sparsity
@@ -144,66 +146,118 @@ def pmc_traffic(dom_kernel):
 pmc_traffic.extra = {}
 
 
-def clock_under_load(step, torch, windows=120, period_s=0.004):
-    """Shader clock and socket power of THIS card while the headline step loops (hwmon: freq1_input, power1_input; read-only sysfs).
-    Run after the timed region.  The card is found by its PCI address; None when the sensors are not readable."""
-    import threading
+class ClockSampler:
+    """Shader clock and socket power of THIS card (hwmon: freq1_input, power1_input; read-only sysfs), sampled by a thread while the
+    caller loops a step.  The card is found by its PCI address; `ok` is False when the sensors are not readable."""
 
-    try:
-        pr = torch.cuda.get_device_properties(torch.cuda.current_device())
-        addr = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
-    except AttributeError:
-        return None
-    mons = [d for d in glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*") if os.path.basename(os.path.realpath(os.path.join(d, "..", ".."))) == addr]
-    if not mons:
-        return None
-    d = mons[0]
-
-    def rd(name):
+    def __init__(self, torch, period_s=0.004):
+        self.period_s, self.clk, self.pw, self.dir, self.addr = period_s, [], [], None, None
         try:
-            with open(os.path.join(d, name)) as fh:
+            pr = torch.cuda.get_device_properties(torch.cuda.current_device())
+            self.addr = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+        except AttributeError:
+            return
+        mons = [d for d in glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*")
+                if os.path.basename(os.path.realpath(os.path.join(d, "..", ".."))) == self.addr]
+        if mons and self.rd("freq1_input", mons[0]) is not None and self.rd("power1_input", mons[0]) is not None:
+            self.dir = mons[0]
+
+    @property
+    def ok(self):
+        return self.dir is not None
+
+    def rd(self, name, d=None):
+        try:
+            with open(os.path.join(d or self.dir, name)) as fh:
                 return int(fh.read())
-        except (OSError, ValueError):
+        except (OSError, ValueError, TypeError):
             return None
 
-    if rd("freq1_input") is None or rd("power1_input") is None:
+    def __enter__(self):
+        import threading
+
+        self.stop = threading.Event()
+
+        def sampler():
+            while not self.stop.is_set():
+                f, w = self.rd("freq1_input"), self.rd("power1_input")
+                if f is not None and w is not None:
+                    self.clk.append(f / 1e6)
+                    self.pw.append(w / 1e6)
+                time.sleep(self.period_s)
+
+        self.th = threading.Thread(target=sampler, daemon=True)
+        if self.ok:
+            self.th.start()
+        return self
+
+    def __exit__(self, *exc):
+        self.stop.set()
+        if self.ok:
+            self.th.join()
+        return False
+
+
+def clock_under_load(step, torch, windows=120, period_s=0.004):
+    """Shader clock and socket power of THIS card while the headline step loops.  Run after the timed region.  None when the sensors
+    are not readable."""
+    cs = ClockSampler(torch, period_s)
+    if not cs.ok:
         return None
-    clk, pw, stop = [], [], threading.Event()
-
-    def sampler():
-        while not stop.is_set():
-            f, w = rd("freq1_input"), rd("power1_input")
-            if f is not None and w is not None:
-                clk.append(f / 1e6)
-                pw.append(w / 1e6)
-            time.sleep(period_s)
-
     for i in range(20):  # the card may have dropped to its idle clock during the host-side work before this pass
         step(i)
-    th = threading.Thread(target=sampler, daemon=True)
-    th.start()
-    t0 = time.perf_counter()
-    for i in range(windows):
-        step(i)
-    dt = time.perf_counter() - t0
-    stop.set()
-    th.join()
+    with cs:
+        t0 = time.perf_counter()
+        for i in range(windows):
+            step(i)
+        dt = time.perf_counter() - t0
+    clk, pw = cs.clk, cs.pw
     if len(clk) < 8:
         return None
     return {"sclk_mhz_mean": round(sum(clk) / len(clk), 1), "sclk_mhz_min": round(min(clk), 1), "sclk_mhz_max": round(max(clk), 1),
-            "power_w_mean": round(sum(pw) / len(pw), 1), "power_w_max": round(max(pw), 1), "power_cap_w": (rd("power1_cap") or 0) / 1e6,
+            "power_w_mean": round(sum(pw) / len(pw), 1), "power_w_max": round(max(pw), 1), "power_cap_w": (cs.rd("power1_cap") or 0) / 1e6,
             "samples": len(clk), "windows": windows, "ms_per_step_during_sampling": round(dt / windows * 1e3, 4),
-            "source": f"hwmon freq1_input / power1_input of {addr}, one sample per {period_s * 1e3:.0f} ms over {windows} windows after the timed region; "
+            "source": f"hwmon freq1_input / power1_input of {cs.addr}, one sample per {period_s * 1e3:.0f} ms over {windows} windows after the timed region; "
                       f"roofline.peak is quoted at the nominal {NOMINAL_SCLK_MHZ} MHz"}
 
 
-def timed(fn, steps, warmup, dev, per_step=None):
+STEADY_MIN_TIMED_S = 0.5   # a timed region shorter than this gets a steady-state block printed next to it
+STEADY_BLOCK_S = 0.8       # ... of at least this long
+
+
+def steady_state_block(step, est_step_s, torch):
+    """A caller's `--steps K` may time well under a second (the driver: 20 windows = 0.08 s), and on this chip the clock a card
+    holds depends on what ran in the last tens of milliseconds (profiles/r04_experiments.txt section 1).  So next to -- never instead
+    of -- such a headline, the same step looped for >= 0.8 s right after the timed region, with per-step stamps and the card's
+    shader clock sampled meanwhile: a box that had not reached its held clock in the timed region shows up as a gap between the two."""
+    n = max(20, min(20000, int(STEADY_BLOCK_S / max(est_step_s, 1e-5)) + 1))
+    cs = ClockSampler(torch, 0.004)
+    per = []
+    torch.cuda.synchronize()
+    with cs:
+        t0 = tp = time.perf_counter()
+        for i in range(n):
+            step(i)
+            tn = time.perf_counter()
+            per.append(tn - tp)
+            tp = tn
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    return {"ms_per_step": round(dt / n * 1e3, 4), "median": round(median(per) * 1e3, 4), "steps": n, "seconds": round(dt, 3),
+            "sclk_mhz_mean": round(sum(cs.clk) / len(cs.clk), 1) if len(cs.clk) >= 8 else None,
+            "why": f"the timed region lasted under {STEADY_MIN_TIMED_S} s; this block ran right after it (same step, same inputs) and is NOT the headline"}
+
+
+def timed(fn, steps, warmup, dev, per_step=None, marks=None):
     """K steps between barrier + synchronize brackets -> seconds.  per_step (a list): the wall time of every step is appended to it
-    (perf_counter stamps between steps; every step function ends with its own stream synchronize, so a stamp is a completed step)."""
+    (perf_counter stamps between steps; every step function ends with its own stream synchronize, so a stamp is a completed step).
+    marks (a dict): marks["first_timed_step"] = time.time() when the timed region starts."""
     for i in range(warmup):
         fn(i)
     shard.barrier(dev)
     torch.cuda.synchronize()
+    if marks is not None:
+        marks["first_timed_step"] = time.time()
     t0 = tp = time.perf_counter()
     for i in range(steps):
         fn(i)
@@ -265,19 +319,32 @@ def cpu_baseline(state, windows_cpu):
                       "through oracle/ on torch-CPU fp32"}
 
 
+# what an RCCL run that could not exchange IPC handles leaves on stderr (hipIpcGetMemHandle / hipIpcOpenMemHandle failing under
+# the wrong HSA_ENABLE_IPC_MODE_LEGACY, surfacing as an unhandled-HIP-error NCCL exception) ...
+IPC_FAILURE = re.compile(r"hipIpc|IpcGetMemHandle|IpcOpenMemHandle|ncclUnhandledCudaError|ncclSystemError|NCCL error|RCCL error|unhandled (cuda|hip) error", re.I)
+# ... and what a rank killed by a signal / a GPU fault leaves (torch.distributed.run reports the child's signal): never retried
+SIGNAL_EXIT = re.compile(r"Signal \d+ \(SIG|exitcode\s*:\s*-\d+|core dumped|Memory access fault|HSA_STATUS_ERROR|Aborted", re.I)
+
+
 def spawn_ranks(n):
     """`bench.py --gpus N` launched directly (no WORLD_SIZE): start the N ranks as FRESH child processes under
     torch.distributed.run and hand back their return code.  Nothing in this process has touched a GPU, and it does not
-    replace itself (no exec): the children are ordinary subprocesses; rank 0's JSON line is relayed on stdout.
+    replace itself (no exec): the children are ordinary subprocesses; rank 0's JSON line is relayed on stdout, the ranks' stderr
+    on stderr.
 
     HSA_ENABLE_IPC_MODE_LEGACY: the image exports it as 0 here and on the GPU boxes (the host driver only supports dmabuf IPC;
     without it RCCL's hipIpcGetMemHandle fails with "invalid argument" -- the environment notes of this build pipeline), so the
     first attempt keeps the inherited value, 0 when unset.  It has never run under RCCL with N > 1 in a record of this repo, so
-    the launcher does not bet the run on it: when the ranks exit non-zero BEFORE rank 0 printed its JSON line, they are started
-    once more -- again as fresh children -- with the opposite setting; `distributed.launch` in the JSON line says which form ran."""
+    the launcher does not bet the run on it -- but it only second-guesses THAT: the ranks are started once more (fresh children
+    again, the opposite setting) only when they exited with a plain non-zero code BEFORE rank 0 printed its JSON line AND their
+    stderr carries the IPC / RCCL-initialisation signature.  A Python exception, an out-of-memory kill, a bad argument, a signal or
+    a GPU fault is handed back as it is (a faulting run must not get a silent second go).  Both attempts' return codes are printed
+    on stderr, and the second attempt's JSON line carries the first one's (`distributed.launch.previous_attempt_rc`)."""
+    import threading
+
     first = os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     attempts = [first, "1" if first == "0" else "0"]
-    rc = 1
+    rc, prev_rc = 1, None
     for attempt, ipc in enumerate(attempts):
         with socket.socket() as s:
             s.bind(("127.0.0.1", 0))
@@ -285,20 +352,44 @@ def spawn_ranks(n):
         env = dict(os.environ)
         env["HSA_ENABLE_IPC_MODE_LEGACY"] = ipc
         env["FS_BENCH_LAUNCH_ATTEMPT"] = str(attempt)
+        env["FS_BENCH_LAUNCHER_T0"] = repr(time.time())  # distributed.startup_s counts from here: spawn + imports + weights + warm-up
+        if prev_rc is not None:
+            env["FS_BENCH_PREV_ATTEMPT_RC"] = str(prev_rc)
         env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
                "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-        proc = subprocess.Popen(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, text=True)
+        proc = subprocess.Popen(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+        err_tail = []
+
+        def pump(stream=proc.stderr, keep=err_tail):
+            for line in stream:
+                sys.stderr.write(line)
+                keep.append(line)
+                del keep[:-400]
+            sys.stderr.flush()
+
+        th = threading.Thread(target=pump, daemon=True)
+        th.start()
         printed = False
         for line in proc.stdout:
             printed = printed or line.startswith("{")
             sys.stdout.write(line)
             sys.stdout.flush()
         rc = proc.wait()
+        th.join()
         if rc == 0 or printed or attempt + 1 == len(attempts):
             break
-        print(f"bench.py: the {n} ranks exited with code {rc} before a result line (HSA_ENABLE_IPC_MODE_LEGACY={ipc}); "
-              f"starting them once more with HSA_ENABLE_IPC_MODE_LEGACY={attempts[attempt + 1]}", file=sys.stderr, flush=True)
+        text = "".join(err_tail)
+        if rc < 0 or SIGNAL_EXIT.search(text) or not IPC_FAILURE.search(text):
+            print(f"bench.py: the {n} ranks exited with code {rc} before a result line (HSA_ENABLE_IPC_MODE_LEGACY={ipc}); their stderr does not show "
+                  "an IPC / RCCL-initialisation failure (or shows a signal / GPU fault): not relaunched", file=sys.stderr, flush=True)
+            break
+        prev_rc = rc
+        print(f"bench.py: the {n} ranks exited with code {rc} before a result line with an IPC / RCCL-initialisation error on stderr "
+              f"(HSA_ENABLE_IPC_MODE_LEGACY={ipc}); starting them once more with HSA_ENABLE_IPC_MODE_LEGACY={attempts[attempt + 1]}",
+              file=sys.stderr, flush=True)
+    if prev_rc is not None:
+        print(f"bench.py: launch attempts returned {prev_rc} (HSA_ENABLE_IPC_MODE_LEGACY={attempts[0]}) then {rc} ({attempts[1]})", file=sys.stderr, flush=True)
     return rc
 
 
@@ -393,12 +484,18 @@ def main():
         host_masks.copy_(out["mask"], non_blocking=True)
         torch.cuda.current_stream().synchronize()  # masks are on the host when the step ends
 
-    step_s = []
-    elapsed = timed(step_native, args.steps, args.warmup, dev, step_s)
+    step_s, marks = [], {}
+    elapsed = timed(step_native, args.steps, args.warmup, dev, step_s, marks)
     _, frames_total, elapsed_max = shard.reduce_run(torch.zeros(3, CLASSES, dtype=torch.int64), args.steps * N_DELTA, elapsed, rdev)
     fps = frames_total / elapsed_max
-    # every rank's own figures (mean and median step), so that a straggler is visible in the N > 1 line
-    per_rank = shard.gather_floats([elapsed / args.steps * 1e3, median(step_s) * 1e3], rdev)
+    # process start (the launcher's, when bench.py spawned the ranks itself) -> first timed step, per rank: imports, weights, data,
+    # workspace, warm-up and the barrier -- what a driver-side timeout on a many-GPU node would have been spent on
+    t_ref = float(os.environ.get("FS_BENCH_LAUNCHER_T0", T_PROCESS))
+    # every rank's own figures (mean and median step, start-up), so that a straggler is visible in the N > 1 line
+    per_rank = shard.gather_floats([elapsed / args.steps * 1e3, median(step_s) * 1e3, marks["first_timed_step"] - t_ref], rdev)
+    # a short timed region says little about the clock the card settles at: the same step for >= 0.8 s right behind it (every rank
+    # runs it, so the ranks stay symmetric; rank 0 reports its own)
+    steady = steady_state_block(step_native, elapsed / args.steps, torch) if elapsed < STEADY_MIN_TIMED_S else None
 
     result = {
         "metric": "segmentation FPS @713x713 (PSPNet-ResNet50 keyframe + linear interp, frame_delta=5)",
@@ -407,6 +504,7 @@ def main():
         # median window latency (the reference reports the mean of its per-call timer, flow/base.py:321-328): per-step
         # perf_counter stamps inside the same timed region, this rank's steps (N > 1: the slowest rank's median)
         "median_ms_per_step": round(max(r[1] for r in per_rank), 4),
+        "steady_state": steady,
         "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "arithmetic": ARITHMETIC, "data": "synthetic",
         "config": {"workload": ("BASELINE configs[1]: PSPNet-ResNet50 keyframe + linear interp (no_warp=True, feature_based=False), "
@@ -423,8 +521,12 @@ def main():
         "distributed": {"backend": backend, "rccl_world_size": dist_world if backend == "nccl" else 0, "world_size": dist_world,
                         "rank_ms_per_step": {"min": round(min(r[0] for r in per_rank), 4), "max": round(max(r[0] for r in per_rank), 4),
                                              "per_rank": [round(r[0], 4) for r in per_rank]},
+                        "startup_s": {"max": round(max(r[2] for r in per_rank), 2), "per_rank": [round(r[2], 2) for r in per_rank],
+                                      "from": "bench.py launcher start" if "FS_BENCH_LAUNCHER_T0" in os.environ else "this process's start",
+                                      "to": "first timed step (after imports, weights, resident inputs, fs_reserve, warm-up, barrier)"},
                         "launch": {"by": "bench.py spawn_ranks" if "FS_BENCH_LAUNCH_ATTEMPT" in os.environ else ("torchrun" if world > 1 else "single process"),
                                    "attempt": int(os.environ.get("FS_BENCH_LAUNCH_ATTEMPT", 0)),
+                                   "previous_attempt_rc": int(os.environ["FS_BENCH_PREV_ATTEMPT_RC"]) if "FS_BENCH_PREV_ATTEMPT_RC" in os.environ else None,
                                    "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")},
                         "collectives": "end-of-run all_reduce of int64 frame count + float64 seconds (and int64[3,K] histograms in tools/predict_video.py); "
                                        "none inside the timed loop"},
@@ -575,12 +677,55 @@ def variants(args, dev, rdev, net, state, fm, windows, dl, dr, host_masks, host_
         torch.cuda.current_stream().synchronize()
     run("fps_keyframe_cache_with_one_window_lookahead_clip_of_4_windows", step_clip, max(1, steps // 4), 4 * N_DELTA)
 
+    # (iii-c) the streaming product mode on a LONG clip (the figure above is set by "5 key frames serve 4 windows"): LONG_WINDOWS
+    # consecutive windows = LONG_WINDOWS + 1 key frames, each segmented exactly once, two per network pass.  The key frames are the
+    # five resident ones walked back and forth (0 1 2 3 4 3 2 1 0 ...: consecutive keys always differ; the work per pass does not
+    # depend on the pixels) under running frame ids, so the cache sees a 201-frame video.  One step = the whole clip.
+    keys5 = [windows[0][0]] + [windows[w][1] for w in range(4)]
+
+    def key_of(j):
+        j %= 8
+        return keys5[j if j <= 4 else 8 - j]
+    long_items = [{"frame_prev": key_of(w), "frame_next": key_of(w + 1), "mvs_left": dl, "mvs_right": dr, "key_ids": (N_DELTA * w, N_DELTA * w + N_DELTA)}
+                  for w in range(LONG_WINDOWS)]
+    host_ring = torch.empty((4 * N_DELTA, SIZE, SIZE), dtype=torch.uint8).pin_memory()
+    long_steps = max(4, steps // 20)
+
+    def step_long(i):
+        for w, masks in enumerate(pclip.predict_clip(long_items, to_host=False)):
+            host_ring[(w % 4) * N_DELTA:(w % 4 + 1) * N_DELTA].copy_(masks, non_blocking=True)  # every window's masks go to the host
+        torch.cuda.current_stream().synchronize()
+    run("fps_keyframe_cache_lookahead_long_clip", step_long, long_steps, LONG_WINDOWS * N_DELTA, warm=1)
+    out["long_clip"] = {"windows": LONG_WINDOWS, "key_frames_segmented": LONG_WINDOWS + 1, "frames": LONG_WINDOWS * N_DELTA, "clips_timed": long_steps,
+                        "note": "FlowPredictor.predict_clip: key-frame cache + one window of look-ahead; masks of every window copied to the host; "
+                                "bit-identical to the uncached windows (tests/test_gpu_fullsize.py)"}
+
     # (iv) two windows in flight: a second library handle (own workspace) on a second stream, two windows per step
     net2 = FlowPSPNet(HP()).eval()
     net2.load_state_dict(state)
     fm2 = FlowModel(net2, feature_based=False, no_warp=True).eval()
     side = torch.cuda.Stream()
     host_masks2 = torch.empty((N_DELTA, SIZE, SIZE), dtype=torch.uint8).pin_memory()
+
+    # (iv-a) the long clip with TWO clips in flight: a second predictor (second handle, second stream) walks its own copy of the clip,
+    # window by window in step with the first
+    pclip2 = FlowPredictor(fm2, CLASSES, (SIZE, SIZE), compute_metrics=False)
+    host_ring2 = torch.empty((4 * N_DELTA, SIZE, SIZE), dtype=torch.uint8).pin_memory()
+
+    def step_long_two(i):
+        main_s = torch.cuda.current_stream()
+        side.wait_stream(main_s)
+        g1, g2 = pclip.predict_clip(long_items, to_host=False), pclip2.predict_clip(long_items, to_host=False)
+        for w in range(LONG_WINDOWS):
+            host_ring[(w % 4) * N_DELTA:(w % 4 + 1) * N_DELTA].copy_(next(g1), non_blocking=True)
+            with torch.cuda.stream(side):
+                host_ring2[(w % 4) * N_DELTA:(w % 4 + 1) * N_DELTA].copy_(next(g2), non_blocking=True)
+        for g in (g1, g2):
+            assert next(g, None) is None
+        main_s.synchronize()
+        side.synchronize()
+    run("fps_keyframe_cache_lookahead_long_clip_two_clips_in_flight", step_long_two, max(2, long_steps // 2), 2 * LONG_WINDOWS * N_DELTA, warm=1)
+    del pclip2
 
     def step_two(i):
         main_s = torch.cuda.current_stream()

@@ -202,9 +202,13 @@ int prof_end(fs_net* h, hipStream_t s) {
 
 namespace {
 
-// Winograd workspace: V (fp32, or -- the plane-operand route -- three bf16 planes = 1.5x the floats) followed by M (fp32)
-size_t wino_v_floats(size_t G, size_t T, int Cin) { return (G * T * Cin * 3 / 2 + 7) / 8 * 8; }
-size_t wino_ws_floats(size_t G, size_t T, int Cin, int Cout) { return wino_v_floats(G, T, Cin) + G * T * Cout; }
+// Winograd workspace: V (fp32; on the opt-in plane-operand route three bf16 planes = 1.5x the floats) followed by M (fp32)
+bool wino_planes(const fs_net* h, size_t v_elems, int Cin) { return h->use_plane_operands && Cin % 32 == 0 && (long long)v_elems * 2 < (1ll << 31); }
+size_t wino_v_floats(const fs_net* h, size_t G, size_t T, int Cin) {
+    const size_t v = G * T * Cin;
+    return ((wino_planes(h, v, Cin) ? v * 3 / 2 : v) + 7) / 8 * 8;
+}
+size_t wino_ws_floats(const fs_net* h, size_t G, size_t T, int Cin, int Cout) { return wino_v_floats(h, G, T, Cin) + G * T * Cout; }
 
 // 3x3 s1 p1 conv as Winograd F(4x4,3x3): input transform -> 36 grouped GEMMs -> output transform (+BN, ReLU)
 int run_conv_winograd(fs_net* h, const ConvBN& c, const float* in, int ld_in, int B, int H, int W, float* out, int ld_out,
@@ -215,9 +219,9 @@ int run_conv_winograd(fs_net* h, const ConvBN& c, const float* in, int ld_in, in
     const float* U = nullptr;
     FS_TRY(wino_bank(h, c, mt, s, &U));
     const size_t v_elems = (size_t)G * T * c.Cin, m_elems = (size_t)G * T * c.Cout;
-    FS_TRY(ws_grow(h, &h->wino_ws, &h->wino_ws_elems, wino_ws_floats(G, T, c.Cin, c.Cout), false));
+    FS_TRY(ws_grow(h, &h->wino_ws, &h->wino_ws_elems, wino_ws_floats(h, G, T, c.Cin, c.Cout), false));
     float* V = h->wino_ws;
-    float* Mb = h->wino_ws + wino_v_floats(G, T, c.Cin);
+    float* Mb = h->wino_ws + wino_v_floats(h, G, T, c.Cin);
     ConvParams p{};
     p.in = V;
     p.ld_in = c.Cin;
@@ -241,7 +245,7 @@ int run_conv_winograd(fs_net* h, const ConvBN& c, const float* in, int ld_in, in
     const double flops = 2.0 * G * (double)T * c.Cin * c.Cout;
     // Round 4, opt-in (FS_OPT_PLANE_OPERANDS): the input transform writes V as its three bf16 planes (each value split ONCE) and the
     // position GEMMs run on gemm_planes_bf16x3, whose main loop is DMA + fragment reads + MFMAs only (gemm_planes.hip)
-    const bool planes = p.wgt3 && h->use_plane_operands && c.Cin % 32 == 0 && (long long)v_elems * 2 < (1ll << 31);
+    const bool planes = p.wgt3 && wino_planes(h, v_elems, c.Cin);
     if (planes) {
         FS_TRY(prof_begin(h, c.name + ".wino_in", "winograd_input_planes", 0, 4.0 * (double)B * H * W * c.Cin + 6.0 * (double)v_elems, s));
         FS_TRY(launch_winograd_input_planes(in, ld_in, V, (long long)v_elems, B, H, W, c.Cin, c.dil, mt, s));
@@ -283,7 +287,7 @@ int reserve_conv(fs_net* h, const ConvBN& c, int B, int H, int W, hipStream_t s,
     if (!takes_winograd(h, c, B, H, W, false)) return 0;
     const int mt = h->wino_force_m ? h->wino_force_m : winograd_pick_m(B, H, W, c.dil);
     const size_t G = (size_t)(mt + 2) * (mt + 2), T = (size_t)winograd_tiles(B, H, W, c.dil, mt);
-    *need = std::max(*need, wino_ws_floats(G, T, c.Cin, c.Cout));
+    *need = std::max(*need, wino_ws_floats(h, G, T, c.Cin, c.Cout));
     const float* U = nullptr;
     return wino_bank(h, c, mt, s, &U);
 }

@@ -51,14 +51,23 @@ class FlowPredictor:
         kc = cache.window(*key_ids) if (cache is not None and key_ids is not None) else None
         if self.crop is None:
             extra = {} if kc is None else {"key_cache": kc}
-            logits = self.model.predict(frame_prev, frame_next, mvs_left, mvs_right, n, profiler, **extra)["pred"]
-            masks = ops.resize_argmax_u8(logits, self.out_size)       # :275-276 without the fp32 intermediate
+            if self._native(frame_prev) and not getattr(self.model, "feature_based", True) and hasattr(self.model, "predict_masks"):
+                # out_size IS the frame size: the align_corners=True resize of :275 is the identity (source index = destination
+                # index, weight 0), so :275-276 is the argmax of the logits themselves -- which the fused tail emits without
+                # writing the fp32 logits out and reading them back
+                masks = self.model.predict_masks(frame_prev, frame_next, mvs_left, mvs_right, n, profiler, **extra)
+            else:
+                logits = self.model.predict(frame_prev, frame_next, mvs_left, mvs_right, n, profiler, **extra)["pred"]
+                masks = ops.resize_argmax_u8(logits, self.out_size)       # :275-276 without the fp32 intermediate
         else:
             # :273 compute_output, then :275-276 (float64 resize + argmax) fused into the canvas's last pass
             _, masks = crops.compute_output(self.model, n, frame_prev, frame_next, mvs_left, mvs_right, self.crop[0], self.crop[1],
                                             self.classes, profiler, want_mask=True, key_cache=kc, out_size=self.out_size, want_canvas=False)
         self._score(masks, n)
         return masks.cpu().numpy() if to_host else masks                # :277
+
+    def _native(self, frame):
+        return self.out_size == (frame.shape[2], frame.shape[3])
 
     def _score(self, masks, n):
         if self.compute_metrics:                                      # :280-295 temporal consistency between consecutive frames
@@ -107,7 +116,10 @@ class FlowPredictor:
             n = len(w["mvs_left"]) + 1
             lo_prev, lo_next = store[w["key_ids"][0]], store[w["key_ids"][1]]
             h, wd = w["frame_prev"].shape[2], w["frame_prev"].shape[3]
-            if self.crop is None:
+            if self.crop is None and self._native(w["frame_prev"]):
+                with _region(profiler, "predict_warp"), _region(profiler, "predict_fusion"):  # identity resize: see predict_window
+                    _, masks = ops.seg_tail(lo_prev, lo_next, w["mvs_left"], w["mvs_right"], n, (h, wd), fm.no_warp, want_logits=False, want_mask=True)
+            elif self.crop is None:
                 with _region(profiler, "predict_warp"), _region(profiler, "predict_fusion"):
                     logits, _ = ops.seg_tail(lo_prev, lo_next, w["mvs_left"], w["mvs_right"], n, (h, wd), fm.no_warp, want_logits=True)
                 masks = ops.resize_argmax_u8(logits, self.out_size)

@@ -63,20 +63,38 @@ def toy_weights():
     return {k: torch.from_numpy(z[k]) for k in ("enc_w", "enc_b", "dec_w", "dec_b")}
 
 
-def rel_err(got, ref):
+class Err(float):
+    """A max-relative error that also carries the RMS-relative error of the same comparison (note() records both)."""
+    rms = None
+
+
+def rms_rel_err(got, ref):
+    """sqrt(mean((got - ref)^2) / mean(ref^2)): the error relative to the tensor's typical magnitude, not to its one largest
+    element (with synthetic weights the deep networks' logits reach +-1e3..1e4, VERDICT r4 weak #3)."""
     got = torch.as_tensor(got).double()
     ref = torch.as_tensor(ref).double()
-    return ((got - ref).abs().max() / ref.abs().max().clamp_min(1e-12)).item()
+    return ((got - ref).pow(2).mean() / ref.pow(2).mean().clamp_min(1e-300)).sqrt().item()
+
+
+def rel_err(got, ref):
+    """max |got - ref| / max |ref|  (the figure every tolerance in tests/ is stated in); `.rms` = rms_rel_err of the same pair."""
+    got = torch.as_tensor(got).double()
+    ref = torch.as_tensor(ref).double()
+    e = Err(((got - ref).abs().max() / ref.abs().max().clamp_min(1e-12)).item())
+    e.rms = rms_rel_err(got, ref)
+    return e
 
 
 def note(name, value):
     """Record a measured parity error (GPU runs): appended to gpurun_out/parity_measured.txt so that the asserted tolerances can
-    be kept at a small multiple of what is actually measured (DESIGN.md section 5 quotes this file)."""
+    be kept at a small multiple of what is actually measured (DESIGN.md section 5 quotes this file).  A value that came from
+    rel_err() is written with its RMS-relative companion: `name max_rel rms_rel=...`."""
     d = os.path.join(ROOT, "gpurun_out")
     try:
         os.makedirs(d, exist_ok=True)
+        rms = getattr(value, "rms", None)
         with open(os.path.join(d, "parity_measured.txt"), "a") as f:
-            f.write(f"{name} {value:.3e}\n")
+            f.write(f"{name} {value:.3e}" + (f" rms_rel={rms:.3e}" if rms is not None else "") + "\n")
     except OSError:
         pass
     return value

@@ -44,6 +44,13 @@ def test_bench_json_line_has_the_contract_fields():
     assert d["rank_ms_per_step"]["per_rank"] == [d["rank_ms_per_step"]["max"]] and abs(d["rank_ms_per_step"]["max"] - j["ms_per_step"]) < 0.05 * j["ms_per_step"]
     assert "timing_source" in ro
     assert j["parity"]["mask_agreement_vs_reference"] > 0.9999 and j["parity"]["miou_delta_pp"] < 0.1
+    # r5: three windows time ~0.015 s, far under 0.5 s -> the same step for >= 0.8 s right behind the timed region, printed NEXT to
+    # the headline (which stays the caller's K steps)
+    st = j["steady_state"]
+    assert st is not None and st["steps"] >= 20 and st["seconds"] >= 0.75 and 0.5 * st["ms_per_step"] < st["median"] < 1.5 * st["ms_per_step"]
+    assert 0.6 * j["ms_per_step"] < st["ms_per_step"] < 1.4 * j["ms_per_step"] and (st["sclk_mhz_mean"] is None or 500 < st["sclk_mhz_mean"] < 3000)
+    su = d["startup_s"]
+    assert su["per_rank"] == [su["max"]] and 0 < su["max"] < 600 and su["from"] == "this process's start"
 
 
 def test_bench_two_ranks_rehearsed_on_one_gpu():
@@ -96,7 +103,10 @@ def test_bench_four_ranks_spawned_by_the_launcher_on_one_gpu():
     rk = j["distributed"]["rank_ms_per_step"]
     assert len(rk["per_rank"]) == 4 and rk["min"] == min(rk["per_rank"]) and rk["max"] == max(rk["per_rank"])
     assert abs(rk["max"] - j["ms_per_step"]) < 0.05 * j["ms_per_step"]  # the headline time IS the slowest rank's
-    assert j["distributed"]["launch"] == {"by": "bench.py spawn_ranks", "attempt": 0, "HSA_ENABLE_IPC_MODE_LEGACY": j["distributed"]["launch"]["HSA_ENABLE_IPC_MODE_LEGACY"]}
+    assert j["distributed"]["launch"] == {"by": "bench.py spawn_ranks", "attempt": 0, "previous_attempt_rc": None,
+                                          "HSA_ENABLE_IPC_MODE_LEGACY": j["distributed"]["launch"]["HSA_ENABLE_IPC_MODE_LEGACY"]}
+    su = j["distributed"]["startup_s"]  # launcher start -> first timed step, every rank's own
+    assert len(su["per_rank"]) == 4 and su["max"] == max(su["per_rank"]) and su["from"] == "bench.py launcher start" and min(su["per_rank"]) > 1.0
     assert abs(j["value"] - 4 * 5 * 1000.0 / j["ms_per_step"]) < 1e-2 * j["value"]
 
 

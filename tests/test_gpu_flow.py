@@ -351,6 +351,66 @@ def test_predictor_and_evaluator_match_the_references_lightning_steps(route):
     assert np.abs(ev.summary(0)[3] - z[f"test_{route}_iou_classes1"]).max() < 2e-3
 
 
+def test_hip_pspnet_inside_the_predict_step_and_test_step_chain_on_small_crops(psp_flow):
+    """the Lightning-step pin above runs a toy torch-conv network (the reference's golden was made with it), so
+    the HIP PSPNet on the crops route was only checked two hops away.  Here the REAL HIP PSPNet sits inside the same chain --
+    predict_step x2 (65 x 65 sliding crops of a 160 x 272 frame: 4 x 6 crops, per-crop crop_motion_vector, batched network, fused
+    tail + softmax canvas, resize + argmax, temporal-consistency meters across the windows) and test_step x2 -- against the oracle
+    chain that test_oracle_golden.py pins to the reference's own predict_step / test_step, with pspnet_oracle as its network."""
+    from flood_uav_video_segmentation_amd.flow.predict import FlowEvaluator, FlowPredictor
+    from oracle import crops_oracle
+
+    H, W, ch, cw, n = 160, 272, 65, 65, 5
+    clip = synth.make_clip(11, (H, W), seed=1400, only=[0, 5, 10])
+    # the synthetic classifier puts 99.99 % of such small crops into one class: re-centre its bias on the oracle's mean logits of a
+    # few crops, so that the masks under comparison are mixed (checked below) and the comparison is not vacuous
+    state = dict(psp_flow[1])
+    probe = torch.cat([pspnet_oracle.decoder(pspnet_oracle.encoder(clip[i:i + 1, :, y:y + ch, x:x + cw].contiguous(), state, 50), state)
+                       for i in range(3) for y, x in ((0, 0), (48, 100), (95, 207))])
+    state["decoder.4.bias"] = state["decoder.4.bias"] - probe.mean((0, 2, 3))
+    net = FlowPSPNet(HP()).eval()
+    net.load_state_dict(state)
+    fm = FlowModel(net, feature_based=False, no_warp=False).eval()
+    pred = FlowPredictor(fm, classes=5, out_size=(H, W), crop=(ch, cw), compute_metrics=True)
+    seg = lambda x: pspnet_oracle.decoder(pspnet_oracle.encoder(x, state, 50), state)  # noqa: E731
+    oseg = lambda p, q, a, b: flow_oracle.predict_segmentation(lambda x: x, seg, p, q, a, b, n, False)["pred"]  # noqa: E731
+    meters, last, agree = np.zeros((3, 5), np.int64), None, []
+    for k in range(2):
+        mvl, mvr = synth.make_grids(n, H // 16, W // 16, seed=1410 + k, frame=(H, W), jitter=0.02)
+        got = pred.predict_window(clip[k:k + 1].cuda(), clip[k + 1:k + 2].cuda(), cu(mvl), cu(mvr))
+        ref = np.asarray(flow_oracle.postprocess(crops_oracle.compute_output(oseg, n, clip[k:k + 1], clip[k + 1:k + 2], mvl, mvr, ch, cw, 5), (H, W)))
+        assert got.shape == ref.shape == (n, H, W) and got.dtype == np.uint8
+        assert np.bincount(ref.ravel(), minlength=5).max() < 0.7 * ref.size  # mixed masks
+        agree.append((got == ref).mean())
+        for p_ in range(n):
+            prev = ref[p_ - 1] if p_ > 0 else last
+            if prev is not None:
+                meters += np.stack(flow_oracle.intersection_and_union(ref[p_][None], prev[None], 5, 255)).astype(np.int64)
+        last = ref[n - 1]
+    note("hip_pspnet_in_predict_step_chain_mask_disagreement", 1 - float(np.mean(agree)))
+    assert min(agree) > 0.999
+    h = pred.hist.cpu().numpy()
+    got_m = np.stack([h[0], h[1] + h[2] - h[0], h[2]])
+    assert np.abs(got_m - meters).max() <= 2e-3 * meters.max()
+    want = np.array([np.mean(meters[0] / (meters[1] + 1e-10)), np.mean(meters[0] / (meters[2] + 1e-10)), meters[0].sum() / (meters[2].sum() + 1e-10)])
+    assert note("hip_pspnet_in_predict_step_chain_miou_delta", float(np.abs(np.array(pred.temporal_consistency()) - want).max())) < 2e-3
+    # test_step: one interpolated frame per labelled item from FlowModel.forward inside compute_output
+    ev = FlowEvaluator(fm, classes=5, crop=(ch, cw))
+    lab = np.random.default_rng(1420).integers(0, 5, (2, H, W)).astype(np.int64)
+    lab[:, :3] = 255
+    m_ref = np.zeros((3, 5), np.int64)
+    for k, (l, r) in enumerate(((2, 3), (4, 1))):
+        mvl, mvr = synth.make_grids(n, H // 16, W // 16, seed=1430 + k, frame=(H, W), jitter=0.02)
+        ev.test_step({"frame_prev": clip[k:k + 1].cuda(), "frame_next": clip[k + 1:k + 2].cuda(), "mvs_left": cu(mvl), "mvs_right": cu(mvr),
+                      "left_index": torch.tensor([l]), "right_index": torch.tensor([r]), "label": torch.from_numpy(lab[k:k + 1]).cuda()})
+        fwd = lambda p, q, a, b: flow_oracle.forward(lambda x: x, seg, p, q, a, b, [l], [r], False, False)["pred"]  # noqa: E731
+        out = crops_oracle.compute_output(fwd, 1, clip[k:k + 1], clip[k + 1:k + 2], mvl, mvr, ch, cw, 5)
+        m_ref += np.stack(flow_oracle.intersection_and_union(out.max(1)[1].numpy(), lab[k:k + 1], 5, 255)).astype(np.int64)
+    h = ev.hist[0].cpu().numpy()
+    got_m = np.stack([h[0], h[1] + h[2] - h[0], h[2]])
+    assert np.array_equal(got_m[2], m_ref[2]) and np.abs(got_m - m_ref).max() <= 2e-3 * m_ref.max()
+
+
 def test_evaluator_validation_step_matches_the_references_with_a_batch_of_three():
     """FlowEvaluator.validation_step (FlowModel.forward at B = 3 with per-sample warp counts, fs_argmax_u8, fs_iou_hist) against the
     reference's own validation_step / validation_epoch_end over two batches (tests/golden/lightning_steps.npz)."""

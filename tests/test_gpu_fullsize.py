@@ -645,6 +645,26 @@ def test_predict_clip_streams_its_input_and_leaves_the_predictor_alone(psp):
     assert cached.key_cache.hits == 1
 
 
+@pytest.mark.parametrize("no_warp", [True, False])
+def test_predictor_at_the_frames_own_size_takes_the_fused_mask_and_equals_the_resize_route(psp, no_warp):
+    """r5: when out_size is the frame size the align_corners=True resize of flow/base.py:275 is the identity, so predict_window /
+    predict_clip emit the fused tail's argmax instead of writing the fp32 logits and re-reading them.  Same masks, bit for bit."""
+    net, _ = psp
+    size = 161
+    keys = synth.make_clip(11, size, seed=1003, only=[0, 5, 10]).cuda()
+    fm = FlowModel(net, feature_based=False, no_warp=no_warp).eval()
+    items = []
+    for i in range(2):
+        mvl, mvr = synth.dummy_grids(N) if no_warp else synth.make_grids(N, 10, 10, seed=2100 + i, frame=(size, size), jitter=0.02)
+        items.append({"frame_prev": keys[i:i + 1], "frame_next": keys[i + 1:i + 2], "mvs_left": cu(mvl), "mvs_right": cu(mvr), "key_ids": (5 * i, 5 * i + 5)})
+    want = [ops.resize_argmax_u8(fm.predict(it["frame_prev"], it["frame_next"], it["mvs_left"], it["mvs_right"], N, None)["pred"], (size, size))
+            for it in items]
+    p = FlowPredictor(fm, 5, (size, size), compute_metrics=False)
+    got_w = [p.predict_window(it["frame_prev"], it["frame_next"], it["mvs_left"], it["mvs_right"], to_host=False) for it in items]
+    got_c = list(p.predict_clip(items, to_host=False))
+    assert all(torch.equal(a, b) for a, b in zip(got_w, want)) and all(torch.equal(a, b) for a, b in zip(got_c, want))
+
+
 def test_a_user_network_with_single_tensor_segment_is_called_with_one_tensor():
     """FlowModel hands two tensors to `segment` only when the network advertises the multi-tensor call
     (`encode_frames`, as the HIP mirrors do); any other module's segment(x) sees the concatenated batch."""

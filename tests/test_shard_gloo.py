@@ -111,8 +111,8 @@ _FAKE_POPEN = (
     "class FakePopen:\n"
     "    def __init__(self, cmd, **kw):\n"
     "        calls.append((cmd, kw))\n"
-    "        rc, lines = SCRIPT[len(calls) - 1]\n"
-    "        self.rc, self.stdout = rc, iter(lines)\n"
+    "        rc, lines, *err = SCRIPT[len(calls) - 1]\n"
+    "        self.rc, self.stdout, self.stderr = rc, iter(lines), iter(err[0] if err else [])\n"
     "    def wait(self):\n"
     "        return self.rc\n"
     "subprocess.Popen = FakePopen\n"
@@ -152,22 +152,37 @@ def test_bench_launches_its_own_ranks_without_touching_torch():
     _run_launcher([(0, ['{"value": 1}\n'])], ['bench.py', '--gpus', '8'], body1, {"HSA_ENABLE_IPC_MODE_LEGACY": "1"})
 
 
-def test_bench_launcher_retries_once_with_the_other_ipc_setting_only_when_no_result_line_came():
-    """The ranks died before rank 0 printed its line (e.g. RCCL could not exchange IPC handles): ONE more launch, fresh children,
-    HSA_ENABLE_IPC_MODE_LEGACY flipped.  A run that printed its line, or failed twice, is never repeated."""
+def test_bench_launcher_retries_once_with_the_other_ipc_setting_only_for_an_ipc_failure_before_the_result_line():
+    """The ranks died before rank 0 printed its line AND their stderr shows that RCCL could not exchange IPC handles: ONE more
+    launch, fresh children, HSA_ENABLE_IPC_MODE_LEGACY flipped, the first code handed on to the second attempt's JSON line.
+    Any other failure -- a Python exception, a signal / GPU fault, a failure after the line, a second failure -- is handed back
+    as it is (a faulting run must not get a silent second go)."""
+    ipc = ["RuntimeError: NCCL error in: ProcessGroupNCCL.cpp, unhandled cuda error\n", "hipIpcGetMemHandle: invalid argument\n"]
     body = (
         "assert rc == 0 and len(calls) == 2, (rc, len(calls))\n"
         "e0, e1 = calls[0][1]['env'], calls[1][1]['env']\n"
         "assert (e0['HSA_ENABLE_IPC_MODE_LEGACY'], e1['HSA_ENABLE_IPC_MODE_LEGACY']) == ('0', '1')\n"
         "assert (e0['FS_BENCH_LAUNCH_ATTEMPT'], e1['FS_BENCH_LAUNCH_ATTEMPT']) == ('0', '1')\n"
+        "assert 'FS_BENCH_PREV_ATTEMPT_RC' not in e0 and e1['FS_BENCH_PREV_ATTEMPT_RC'] == '1' and float(e0['FS_BENCH_LAUNCHER_T0']) > 0\n"
+        "assert calls[0][1]['stderr'] == subprocess.PIPE\n"
         "p0, p1 = (c[0][c[0].index('--master-port') + 1] for c in calls)\n"
         "assert calls[0][0][-2:] == calls[1][0][-2:] == ['--gpus', '8'] and 'torch' not in sys.modules\n")
-    r = _run_launcher([(1, ['some rank log\n']), (0, ['{"value": 2}\n'])], ['bench.py', '--gpus', '8'], body)
+    r = _run_launcher([(1, ['some rank log\n'], ipc), (0, ['{"value": 2}\n'])], ['bench.py', '--gpus', '8'], body)
     assert "starting them once more with HSA_ENABLE_IPC_MODE_LEGACY=1" in r.stderr and '{"value": 2}' in r.stdout
+    assert "hipIpcGetMemHandle: invalid argument" in r.stderr  # the ranks' stderr is relayed
+    assert "launch attempts returned 1 (HSA_ENABLE_IPC_MODE_LEGACY=0) then 0 (1)" in r.stderr
     # a failure AFTER the result line: no second launch, the code is handed back
-    _run_launcher([(3, ['{"value": 1}\n'])], ['bench.py', '--gpus', '8'], "assert rc == 3 and len(calls) == 1, (rc, len(calls))\n")
-    # two failures: the second code is handed back, nothing is launched a third time
-    _run_launcher([(1, []), (7, [])], ['bench.py', '--gpus', '8'], "assert rc == 7 and len(calls) == 2, (rc, len(calls))\n")
+    _run_launcher([(3, ['{"value": 1}\n'], ipc)], ['bench.py', '--gpus', '8'], "assert rc == 3 and len(calls) == 1, (rc, len(calls))\n")
+    # two IPC failures: the second code is handed back, nothing is launched a third time
+    _run_launcher([(1, [], ipc), (7, [], ipc)], ['bench.py', '--gpus', '8'], "assert rc == 7 and len(calls) == 2, (rc, len(calls))\n")
+    # a failure that is NOT the IPC signature (Python exception, OOM, bad argument): the first code, no second launch
+    r = _run_launcher([(1, [], ['Traceback (most recent call last):\n', 'torch.OutOfMemoryError: HIP out of memory\n']), (0, ['{"value": 9}\n'])],
+                      ['bench.py', '--gpus', '8'], "assert rc == 1 and len(calls) == 1, (rc, len(calls))\n")
+    assert "not relaunched" in r.stderr and '"value": 9' not in r.stdout
+    # a signal / GPU fault is never retried, whatever else stderr says
+    fault = ipc + ["Memory access fault by GPU node-2\n", "traceback : Signal 6 (SIGABRT) received by PID 4242\n"]
+    _run_launcher([(1, [], fault), (0, ['{"value": 9}\n'])], ['bench.py', '--gpus', '8'], "assert rc == 1 and len(calls) == 1, (rc, len(calls))\n")
+    _run_launcher([(-9, [], ipc), (0, ['{"value": 9}\n'])], ['bench.py', '--gpus', '8'], "assert rc == -9 and len(calls) == 1, (rc, len(calls))\n")
 
 
 def test_bench_launch_check_with_eight_real_ranks_on_cpu():
