@@ -111,6 +111,9 @@ def kernel_symbol(label):
     m = re.match(r"planes256x(\d+)$", label)
     if m:
         return f"gemm_planes_bf16x3<{m.group(1)}>"
+    m = re.match(r"chain(\d+)x(\d+)$", label)
+    if m:  # round 5: conv3 + next conv1 in one launch (both the residual and the concatenated-K form carry this label)
+        return f"conv_chain_dma_f32<{m.group(1)}, {m.group(2)}, {'4, 1' if m.group(1) == '128' else '2, 2'}, "
     m = re.match(r"(igemm|split)(\d+)x(\d+)(cat)?$", label)
     split, bm, bn, cat = m.group(1) == "split", int(m.group(2)), int(m.group(3)), bool(m.group(4))
     waves = "4, 2" if bm == 256 else "4, 1" if split and bm == 128 else "2, 2"
@@ -563,9 +566,9 @@ def main():
             d["ms"] += ms
             d["flops"] += flops
             d["launches"] += 1
-        conv = {k: v for k, v in per.items() if k.startswith(("igemm", "split", "planes"))}  # the implicit-GEMM launches (direct convs, Winograd position GEMMs, Linears)
+        conv = {k: v for k, v in per.items() if k.startswith(("igemm", "split", "planes", "chain"))}  # the implicit-GEMM launches (direct convs, Winograd position GEMMs, Linears)
         dom_name, dom = max(conv.items(), key=lambda kv: kv[1]["ms"])
-        is_split = dom_name.startswith(("split", "planes"))
+        is_split = dom_name.startswith(("split", "planes", "chain"))
         # split-operand kernel: the matrix cores execute 6 bf16 MFMA FLOPs per algorithmic (fp32) FLOP; the roofline is the bf16 pipe's
         alg = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
         ach = alg * (SPLIT_TERMS if is_split else 1)

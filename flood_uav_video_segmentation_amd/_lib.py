@@ -33,6 +33,7 @@ OPT_NO_FUSED_SHORTCUT = 4  # FS_OPT_NO_FUSED_SHORTCUT
 OPT_NO_FUSED_WINOGRAD = 8  # FS_OPT_NO_FUSED_WINOGRAD
 OPT_NO_SPLIT_BF16 = 16  # FS_OPT_NO_SPLIT_BF16
 OPT_PLANE_OPERANDS = 32  # FS_OPT_PLANE_OPERANDS
+OPT_CHAIN = 64  # FS_OPT_CHAIN
 CONV_CHUNK_MAJOR = 0x400  # FS_CONV_CHUNK_MAJOR
 
 # name -> (restype, argtypes); must list every symbol of include/floodseg.h
@@ -83,6 +84,8 @@ _SIGNATURES = {
     "fs_attention": (c_int, [c_void, c_void, c_int, c_int, c_int, c_f32, c_int, c_void, c_void]),
     "fs_split_bf16x3": (c_int, [c_void, c_i64, c_void, c_void]),
     "fs_conv2d_nhwc_split": (c_int, [c_void, c_int, c_void, c_void, c_void, c_void, c_int, c_void, c_int] + [c_int] * 12 + [c_void]),
+    "fs_conv_chain_nhwc": (c_int, [c_void, c_int, c_void, c_int, c_void, c_void, c_void, c_void, c_void, c_int, c_int, c_void, c_void, c_void, c_void,
+                                   c_int, c_int, c_int, c_int, c_void]),
     "fs_gemm_bf16x3_planes": (c_int, [c_void, c_i64, c_int, c_void, c_i64, c_int, c_void, c_void, c_void, c_int, c_int, c_int, c_int, c_int, c_int,
                                       c_i64, c_i64, c_i64, c_int, c_void]),
     "fs_winograd_planes_workspace_floats": (ctypes.c_size_t, [c_int] * 7),

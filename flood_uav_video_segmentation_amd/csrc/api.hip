@@ -306,6 +306,22 @@ FS_API int fs_conv2d_nhwc_split(const float* in, int ld_in, const void* wgt_plan
     return conv2d_entry(in, ld_in, nullptr, wgt_planes, scale, shift, res, ld_res, out, ld_out, B, H, W, Cin, Cout, KH, KW, stride, pad, dil,
                         relu, tile, stream);
 }
+FS_API int fs_conv_chain_nhwc(const float* in, int K1, const float* in2, int K1b, const void* w1_planes, const float* scale1, const float* shift1,
+                              const float* res, float* mid, int C1, int relu1, const void* w2_planes, const float* scale2, const float* shift2,
+                              float* out, int C2, int relu2, int M, int tile, fs_stream stream) {
+    if (!in || !w1_planes || !mid || !w2_planes || !out || M < 1 || K1 < 32 || C1 < 1 || C2 < 1 || (in2 != nullptr) != (K1b > 0) || (in2 && res))
+        return fs::fail("fs_conv_chain_nhwc: bad arguments");
+    if (!(tile == 0 || tile == 1 || tile == 2 || tile == 3 || tile == 6)) return fs::fail("fs_conv_chain_nhwc: tile must be 0, 1, 2, 3 or 6 (got %d)", tile);
+    fs::ConvParams a{}, b{};
+    a.in = in; a.ld_in = K1; a.wgt = (const float*)w1_planes; a.wgt3 = w1_planes; a.plane_bytes = (unsigned)((size_t)C1 * (K1 + K1b) * 2);
+    a.scale = scale1; a.shift = shift1; a.res = res; a.ld_res = C1; a.out = mid; a.ld_out = C1;
+    a.B = 1; a.H = M; a.W = 1; a.Cin = K1; a.Ho = M; a.Wo = 1; a.Cout = C1; a.KH = a.KW = 1; a.stride = 1; a.dil = 1; a.relu = relu1;
+    if (in2) { a.in2 = in2; a.ld_in2 = K1b; a.Cin2 = K1b; a.stride2 = 1; a.H2 = M; a.W2 = 1; }
+    b.in = mid; b.ld_in = C1; b.wgt = (const float*)w2_planes; b.wgt3 = w2_planes; b.plane_bytes = (unsigned)((size_t)C2 * C1 * 2);
+    b.scale = scale2; b.shift = shift2; b.out = out; b.ld_out = C2;
+    b.B = 1; b.H = M; b.W = 1; b.Cin = C1; b.Ho = M; b.Wo = 1; b.Cout = C2; b.KH = b.KW = 1; b.stride = 1; b.dil = 1; b.relu = relu2;
+    return fs::launch_conv_chain(a, b, S(stream), tile);
+}
 FS_API size_t fs_attention_workspace_floats(int B, int N, int heads, int split_operands) {
     if (B < 1 || N < 1 || heads < 1) return 0;
     return fs::attention_scratch_floats(B, N, heads) + (split_operands ? fs::attention_split_floats(B, N, heads) + 64 : 0) + 64;

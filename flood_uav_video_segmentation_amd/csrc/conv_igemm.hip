@@ -81,8 +81,15 @@ __device__ unsigned long long fs_trace_buf[8 * 65536];
 // DUAL = true: concatenated-K GEMM of two 1x1 convs (ConvParams::in2): the K chunks beyond the first conv's come from a second
 // map with its own pixel stride / conv stride.  A separate instantiation (no residual input: the shortcut IS the second
 // operand), so the plain kernel's register budget -- 252 of the 256 VGPRs that let two workgroups share a CU -- is untouched.
-template <int BM, int BN, int WGM = 2, int WGN = 2, bool DUAL = false, bool SPLIT = false>
-__global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_dma_f32(ConvParams p, int tiles_m, int tiles_n) {
+// LDS floats of one workgroup: two stages of (pixel tile + filter tile)
+template <int BM, int BN, bool SPLIT>
+constexpr int conv_tile_lds_floats() { return 2 * (BM * 32 + (SPLIT ? 3 * BN * 16 : BN * 32)); }
+
+// One BM x BN output tile at (m0, n0): prologue, main loop, epilogue.  `lds` = conv_tile_lds_floats() floats, 1 KiB aligned; every
+// wave of the workgroup calls it with the same arguments.  A_AUX: cache-policy bits of the PIXEL operand's DMA loads (16 = sc1,
+// served by L2 past this CU's L1: conv_chain_dma_f32 below reads rows the same workgroup stored a moment ago).
+template <int BM, int BN, int WGM, int WGN, bool DUAL, bool SPLIT, int A_AUX = 0>
+__device__ __forceinline__ void conv_tile(ConvParams p, const int m0, const int n0, float* __restrict__ lds, const int bid) {
 #if defined(__HIP_DEVICE_COMPILE__)  // the buffer-resource builtins do not exist in the host pass, which only needs the launch stub
     constexpr int BK = 32;
     constexpr int NT = 64 * WGM * WGN;   // threads
@@ -94,30 +101,8 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_dma_f32(ConvParams 
     constexpr int RA = BM / RSTEP, RB = SPLIT ? 3 * (BN / 16) / (NT / 64) : BN / RSTEP;
     constexpr int RB1 = SPLIT ? (BN / 16) / (NT / 64) : RB;  // of them per plane
     static_assert(!SPLIT || (BN / 16) % (NT / 64) == 0, "split filters: every wave stages whole 16-row groups");
-    constexpr int PM = 8;  // m-tiles per raster panel (panels sized to the ~64 tiles co-resident on an XCD: same time, +3 % L2 misses)
     constexpr int STAGE = BM * BK + (SPLIT ? 3 * BPL : BN * BK);
-    __shared__ __attribute__((aligned(1024))) float lds[2 * STAGE];
     FS_TRACE_DECL
-
-    const int nblk = gridDim.x, bid = blockIdx.x;
-#ifdef FS_TRACE
-    // experiment: de-phase the workgroups that share a CU (dispatch order puts bid and bid + 256 on the same CU)
-    if ((p.dbg & 32) && ((bid >> 8) & 1))
-        for (int i = 0; i < (p.dbg >> 8); ++i) __builtin_amdgcn_s_sleep(16);  // 1024 cycles each
-#endif
-    const int q = nblk >> 3, rr = nblk & 7, xcd = bid & 7;
-    const int lid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (bid >> 3);
-    const int per_group = tiles_m * tiles_n;
-    const int grp = lid / per_group;           // grouped GEMM: consecutive logical ids walk one group's tiles
-    const int lig = lid - grp * per_group;
-    const int panel = lig / (PM * tiles_n);
-    const int within = lig - panel * (PM * tiles_n);
-    const int prow = min(PM, tiles_m - panel * PM);
-    const int m0 = (panel * PM + within % prow) * BM, n0 = (within / prow) * BN;
-    p.in += (long long)grp * p.g_in;
-    p.wgt += (long long)grp * p.g_wgt;
-    if (SPLIT) p.wgt3 = (const char*)p.wgt3 + (long long)grp * p.g_wgt * 2;  // the group's rows inside every plane
-    p.out += (long long)grp * p.g_out;
 
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     const int wm = wv / WGN, wn = wv % WGN, l31 = lane & 31, hh = lane >> 5;
@@ -225,11 +210,11 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_dma_f32(ConvParams 
         if (DUAL && second) {                                                                                     \
             const unsigned vo = (a_mask[j] & 1u) ? a2_voff[DUAL ? j : 0] : SENT;                                  \
             __builtin_amdgcn_raw_ptr_buffer_load_lds(a2_rsrc, (__attribute__((address_space(3))) void*)(lds + (STG) * STAGE + (8 * wv_u + RSTEP * j) * BK), \
-                                                     16, vo, a_soff, 0, 0);                                       \
+                                                     16, vo, a_soff, 0, A_AUX);                                   \
         } else {                                                                                                  \
             const unsigned vo = ((a_mask[j] >> tap_bit) & 1u) ? a_voff[j] : SENT;                                 \
             __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (__attribute__((address_space(3))) void*)(lds + (STG) * STAGE + (8 * wv_u + RSTEP * j) * BK), \
-                                                     16, vo, a_soff, 0, 0);                                       \
+                                                     16, vo, a_soff, 0, A_AUX);                                   \
         }                                                                                                         \
     } else if (SPLIT) {                                                                                           \
         const int jj = (ROW_) >= RA ? (ROW_) - RA : 0;                                                            \
@@ -461,6 +446,74 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_dma_f32(ConvParams 
 #endif
 }
 
+template <int BM, int BN, int WGM = 2, int WGN = 2, bool DUAL = false, bool SPLIT = false>
+__global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_dma_f32(ConvParams p, int tiles_m, int tiles_n) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int PM = 8;  // m-tiles per raster panel (panels sized to the ~64 tiles co-resident on an XCD: same time, +3 % L2 misses)
+    __shared__ __attribute__((aligned(1024))) float lds[conv_tile_lds_floats<BM, BN, SPLIT>()];
+    const int nblk = gridDim.x, bid = blockIdx.x;
+#ifdef FS_TRACE
+    // experiment: de-phase the workgroups that share a CU (dispatch order puts bid and bid + 256 on the same CU)
+    if ((p.dbg & 32) && ((bid >> 8) & 1))
+        for (int i = 0; i < (p.dbg >> 8); ++i) __builtin_amdgcn_s_sleep(16);  // 1024 cycles each
+#endif
+    const int q = nblk >> 3, rr = nblk & 7, xcd = bid & 7;
+    const int lid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (bid >> 3);
+    const int per_group = tiles_m * tiles_n;
+    const int grp = lid / per_group;           // grouped GEMM: consecutive logical ids walk one group's tiles
+    const int lig = lid - grp * per_group;
+    const int panel = lig / (PM * tiles_n);
+    const int within = lig - panel * (PM * tiles_n);
+    const int prow = min(PM, tiles_m - panel * PM);
+    const int m0 = (panel * PM + within % prow) * BM, n0 = (within / prow) * BN;
+    p.in += (long long)grp * p.g_in;
+    p.wgt += (long long)grp * p.g_wgt;
+    if (SPLIT) p.wgt3 = (const char*)p.wgt3 + (long long)grp * p.g_wgt * 2;  // the group's rows inside every plane
+    p.out += (long long)grp * p.g_out;
+    conv_tile<BM, BN, WGM, WGN, DUAL, SPLIT>(p, m0, n0, lds, bid);
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// conv_chain_dma_f32 (round 5): TWO dependent 1x1 convolutions of a bottleneck boundary in one launch --
+//   phase 1  X' = relu(bn3(conv3(f)) + x)           (or, DUAL: relu(bn3(conv3(f)) + bn_ds(downsample(x))), concatenated K)
+//   phase 2  g  = relu(bn1'(conv1'(X')))             the NEXT block's conv1 (model/resnet.py:76-96, two consecutive Bottlenecks)
+// A workgroup owns BM pixel rows: it computes ALL Cout1 / BN column tiles of phase 1 for them (the pixel operand is re-staged per
+// tile: L2 hits), stores X' (the next block's shortcut needs it in memory anyway), and then multiplies those same BM rows of X'
+// by the next conv1's filters.  The rows it reads in phase 2 are rows IT wrote: no other workgroup's data is involved, so the
+// only ordering needed is inside the workgroup -- every wave's stores complete (s_waitcnt vmcnt(0)) before the barrier that ends
+// a tile -- plus phase-2 pixel loads that do not trust this CU's L1 (sc1: conv3 may run in place over the shortcut, whose lines
+// the L1 may hold from the residual read).  What it saves against two launches: one launch ramp and tail per boundary, and the
+// 2 x M x Cout1 x 4 B re-read of X' from memory (it is read back from L2 microseconds after it was written).
+// ---------------------------------------------------------------------------------------------------------
+template <int BM, int BN, int WGM, int WGN, bool DUAL>
+__global__ __launch_bounds__(64 * WGM * WGN) void conv_chain_dma_f32(ConvParams pa, ConvParams pb, int tiles_m) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __shared__ __attribute__((aligned(1024))) float lds[conv_tile_lds_floats<BM, BN, true>()];
+    // blocks b, b + 8, ... share an XCD (L2): give every XCD a contiguous run of m-tiles
+    const int nblk = gridDim.x, bid = blockIdx.x;
+    const int q = nblk >> 3, rr = nblk & 7, xcd = bid & 7;
+    const int lid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (bid >> 3);
+    if (lid >= tiles_m) return;
+    const int m0 = lid * BM;
+    const int tn_a = (pa.Cout + BN - 1) / BN, tn_b = (pb.Cout + BN - 1) / BN;
+    // (m0 is laundered through an empty asm per tile: otherwise the per-lane row offsets, invariant across the column tiles, are
+    //  hoisted out of the loops and kept in ~50 VGPRs, which costs the 128 x 128 form its second workgroup per CU)
+    for (int j = 0; j < tn_a; ++j) {
+        int m0j = m0;
+        asm volatile("" : "+s"(m0j));
+        conv_tile<BM, BN, WGM, WGN, DUAL, true>(pa, m0j, j * BN, lds, bid);
+        FS_DMA_PUBLISH()  // this tile's stores have completed, every wave is done with the LDS stages
+    }
+    for (int j = 0; j < tn_b; ++j) {
+        int m0j = m0;
+        asm volatile("" : "+s"(m0j));
+        conv_tile<BM, BN, WGM, WGN, false, true, 16>(pb, m0j, j * BN, lds, bid);
+        if (j + 1 < tn_b) FS_DMA_PUBLISH()
+    }
+#endif
+}
+
 namespace {
 struct TileCfg { int bm, bn; const char* name; };
 const TileCfg kTiles[6] = {{0, 0, "auto"}, {128, 128, "igemm128x128"}, {128, 64, "igemm128x64"},
@@ -519,7 +572,9 @@ int launch_split_bf16x3(const float* w, long long n, void* planes, hipStream_t s
     return 0;
 }
 
-int launch_conv_igemm(const ConvParams& p, hipStream_t s, int tile) {
+namespace {
+// argument checks shared by launch_conv_igemm and launch_conv_chain
+int check_conv_params(const ConvParams& p) {
     FS_REQUIRE(p.Cin % 32 == 0, "conv_igemm: Cin=%d must be a multiple of 32", p.Cin);
     if (p.in2) {
         FS_REQUIRE(p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0 && p.res == nullptr && p.groups <= 1,
@@ -547,6 +602,12 @@ int launch_conv_igemm(const ConvParams& p, hipStream_t s, int tile) {
                "conv_igemm: output tensor must be smaller than 2 GiB");
     FS_REQUIRE(p.res == nullptr || (int64_t)p.B * p.Ho * p.Wo * p.ld_res * 4 < (int64_t)1 << 31, "conv_igemm: residual tensor must be smaller than 2 GiB");
     if (!(p.res == nullptr || p.ld_res >= p.Cout)) return fail("conv_igemm: bad ld_res");
+    return 0;
+}
+}  // namespace
+
+int launch_conv_igemm(const ConvParams& p, hipStream_t s, int tile) {
+    FS_TRY(check_conv_params(p));
     tile &= 0xff;
     if (tile <= 0 || tile > 5) tile = pick_tile(p);
     const int M = p.B * p.Ho * p.Wo;
@@ -611,6 +672,63 @@ int launch_conv_igemm(const ConvParams& p, hipStream_t s, int tile) {
         default: FS_CONV_LAUNCH(64, 128) break;
     }
 #undef FS_CONV_LAUNCH
+    FS_HIP(hipGetLastError());
+    return 0;
+}
+
+
+namespace {
+int check_split_bank(const ConvParams& p) {
+    FS_REQUIRE(p.wgt3 && ((uintptr_t)p.wgt3 & 15) == 0 && p.plane_bytes % 16 == 0 && (int64_t)3 * p.plane_bytes < (int64_t)1 << 31 && ldw_ok(p),
+               "conv_igemm: bad split filter bank (plane_bytes=%u)", p.plane_bytes);
+    return 0;
+}
+const TileCfg kChainTiles[7] = {{0, 0, "auto"}, {128, 128, "chain128x128"}, {128, 64, "chain128x64"}, {64, 64, "chain64x64"}, {0, 0, ""}, {0, 0, ""},
+                                {64, 128, "chain64x128"}};
+// Row tile by the number of workgroups it leaves (one per row tile): 128 rows while that still gives every CU about two
+// workgroups; column tile 64 only when neither conv has more than 64 output channels to fill a wider one.
+int pick_chain_tile(const ConvParams& pa, const ConvParams& pb) {
+    const int M = pa.B * pa.Ho * pa.Wo;
+    const bool wide = pb.Cout > 64;
+    if (cdiv(M, 128) >= 384) return wide ? 1 : 2;
+    return wide ? 6 : 3;
+}
+}  // namespace
+
+const char* conv_chain_tile_name(const ConvParams& pa, const ConvParams& pb, int tile) {
+    if (!(tile == 1 || tile == 2 || tile == 3 || tile == 6)) tile = pick_chain_tile(pa, pb);
+    return kChainTiles[tile].name;
+}
+
+// Two dependent 1x1 convolutions over the same pixel rows in one launch (conv_chain_dma_f32): pa = block i's conv3 with its
+// shortcut (residual input, or the concatenated-K projection form), pb = block i + 1's conv1 reading pa's output in place.
+int launch_conv_chain(const ConvParams& pa, const ConvParams& pb, hipStream_t s, int tile) {
+    FS_TRY(check_conv_params(pa));
+    FS_TRY(check_conv_params(pb));
+    FS_TRY(check_split_bank(pa));
+    FS_TRY(check_split_bank(pb));
+    for (const ConvParams* p : {&pa, &pb})
+        FS_REQUIRE(p->KH == 1 && p->KW == 1 && p->stride == 1 && p->pad == 0 && p->groups <= 1 && p->korder == 0 && p->ld_wgt == 0,
+                   "conv_chain: both convolutions must be plain 1x1 stride-1 convs");
+    FS_REQUIRE(pb.in == pa.out && pb.ld_in == pa.ld_out && pb.Cin == pa.Cout && pb.B * pb.Ho * pb.Wo == pa.B * pa.Ho * pa.Wo,
+               "conv_chain: the second conv must read the first one's output in place (Cin %d vs Cout %d)", pb.Cin, pa.Cout);
+    FS_REQUIRE(pb.res == nullptr && pb.in2 == nullptr && pb.out != pa.out && pb.out != pa.in, "conv_chain: the second conv takes no shortcut and writes its own buffer");
+    if (!(tile == 1 || tile == 2 || tile == 3 || tile == 6)) tile = pick_chain_tile(pa, pb);
+    const int M = pa.B * pa.Ho * pa.Wo;
+    const int bm = kChainTiles[tile].bm;
+    const int tm = cdiv(M, bm);
+    const dim3 grid(tm), block(256);
+    const bool dual = pa.in2 != nullptr;
+#define FS_CHAIN_LAUNCH(BM_, BN_, WGM_, WGN_)                                                                                  \
+    if (dual) hipLaunchKernelGGL((conv_chain_dma_f32<BM_, BN_, WGM_, WGN_, true>), grid, block, 0, s, pa, pb, tm);             \
+    else hipLaunchKernelGGL((conv_chain_dma_f32<BM_, BN_, WGM_, WGN_, false>), grid, block, 0, s, pa, pb, tm);
+    switch (tile) {
+        case 1: FS_CHAIN_LAUNCH(128, 128, 4, 1) break;
+        case 2: FS_CHAIN_LAUNCH(128, 64, 4, 1) break;
+        case 3: FS_CHAIN_LAUNCH(64, 64, 2, 2) break;
+        default: FS_CHAIN_LAUNCH(64, 128, 2, 2) break;
+    }
+#undef FS_CHAIN_LAUNCH
     FS_HIP(hipGetLastError());
     return 0;
 }

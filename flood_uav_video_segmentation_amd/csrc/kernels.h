@@ -49,6 +49,12 @@ struct ConvParams {
 // tile: 0 = heuristic, 1 = 128x128, 2 = 128x64, 3 = 64x64, 4 = 64x128
 int launch_conv_igemm(const ConvParams& p, hipStream_t s, int tile = 0);
 const char* conv_igemm_tile_name(const ConvParams& p, int tile = 0);
+// Round 5: two dependent 1x1 convolutions of a bottleneck boundary in ONE launch (conv_chain_dma_f32): pa = block i's conv3 with
+// its shortcut (residual, or the concatenated-K projection form), pb = block i + 1's conv1 with pb.in == pa.out.  Split-operand
+// route only (both need wgt3).  tile: 0 = by row count, 1 = 128x128, 2 = 128x64, 3 = 64x64, 6 = 64x128.  Results are bit-identical
+// to the two launches (same tile arithmetic per output: a tile's k order does not depend on its shape).
+int launch_conv_chain(const ConvParams& pa, const ConvParams& pb, hipStream_t s, int tile = 0);
+const char* conv_chain_tile_name(const ConvParams& pa, const ConvParams& pb, int tile = 0);
 // planes[t][i] (t = 0, 1, 2; bf16) with w[i] == planes[0][i] + planes[1][i] + planes[2][i] exactly (ConvParams::wgt3)
 int launch_split_bf16x3(const float* w, long long n, void* planes, hipStream_t s);
 

@@ -302,16 +302,9 @@ bool takes_fused_winograd(const fs_net* h, const ConvBN& c, int B, int H, int W,
     return c.wf && h->use_fused_winograd && !has_res && fits && (long)cdiv(H, 4) * cdiv(W, 4) >= 500;
 }
 
-int run_conv(fs_net* h, const ConvBN& c, const float* in, int ld_in, int B, int H, int W, float* out, int ld_out,
-             const float* res, int ld_res, hipStream_t s) {
-    if (takes_winograd(h, c, B, H, W, res != nullptr)) return run_conv_winograd(h, c, in, ld_in, B, H, W, out, ld_out, s);
-    if (takes_fused_winograd(h, c, B, H, W, ld_in, ld_out, res != nullptr)) {
-        const double tiles = (double)B * cdiv(H, 4) * cdiv(W, 4);
-        FS_TRY(prof_begin(h, c.name, "wino_fused", 2.0 * 36.0 * tiles * c.Cin * c.Cout,
-                          4.0 * ((double)B * H * W * (c.Cin + c.Cout) + 36.0 * c.Cin * c.Cout), s));
-        FS_TRY(launch_wino4_fused(in, ld_in, c.wf, c.scale, c.shift, out, ld_out, B, H, W, c.Cin, c.Cout, c.relu, s));
-        return prof_end(h, s);
-    }
+// launch parameters of one conv + (BatchNorm | bias) + activation (+ residual) on the implicit-GEMM kernel
+ConvParams conv_params(const fs_net* h, const ConvBN& c, const float* in, int ld_in, int B, int H, int W, float* out, int ld_out, const float* res,
+                       int ld_res) {
     ConvParams p{};
     p.in = in;
     p.ld_in = ld_in;
@@ -337,6 +330,20 @@ int run_conv(fs_net* h, const ConvBN& c, const float* in, int ld_in, int B, int 
     p.relu = c.relu;
     p.korder = c.korder;
     split_use(h, p);
+    return p;
+}
+
+int run_conv(fs_net* h, const ConvBN& c, const float* in, int ld_in, int B, int H, int W, float* out, int ld_out,
+             const float* res, int ld_res, hipStream_t s) {
+    if (takes_winograd(h, c, B, H, W, res != nullptr)) return run_conv_winograd(h, c, in, ld_in, B, H, W, out, ld_out, s);
+    if (takes_fused_winograd(h, c, B, H, W, ld_in, ld_out, res != nullptr)) {
+        const double tiles = (double)B * cdiv(H, 4) * cdiv(W, 4);
+        FS_TRY(prof_begin(h, c.name, "wino_fused", 2.0 * 36.0 * tiles * c.Cin * c.Cout,
+                          4.0 * ((double)B * H * W * (c.Cin + c.Cout) + 36.0 * c.Cin * c.Cout), s));
+        FS_TRY(launch_wino4_fused(in, ld_in, c.wf, c.scale, c.shift, out, ld_out, B, H, W, c.Cin, c.Cout, c.relu, s));
+        return prof_end(h, s);
+    }
+    ConvParams p = conv_params(h, c, in, ld_in, B, H, W, out, ld_out, res, ld_res);
     const double M = (double)B * p.Ho * p.Wo;
     const double flops = 2.0 * M * c.Cout * c.KH * c.KW * c.Cin;
     const double bytes = 4.0 * ((double)B * H * W * c.Cin + (double)c.Cout * c.KH * c.KW * c.Cin + M * c.Cout * (res ? 2 : 1));
@@ -395,7 +402,7 @@ int net_create(const fs_config* cfg, fs_handle* out) {
                "fs_create: layers must be 50, 101 or 152");
     FS_REQUIRE(cfg->classes >= 1 && cfg->classes <= 255, "fs_create: classes out of range");
     FS_REQUIRE((cfg->flags & ~(FS_OPT_NO_WINOGRAD | FS_OPT_NO_FUSED_HEAD | FS_OPT_NO_FUSED_SHORTCUT | FS_OPT_NO_FUSED_WINOGRAD | FS_OPT_NO_SPLIT_BF16 |
-                               FS_OPT_PLANE_OPERANDS)) == 0,
+                               FS_OPT_PLANE_OPERANDS | FS_OPT_CHAIN)) == 0,
                "fs_create: unknown option bits 0x%x", cfg->flags);
     FS_REQUIRE(cfg->winograd_tile == 0 || cfg->winograd_tile == 4 || cfg->winograd_tile == 6, "fs_create: winograd_tile must be 0, 4 or 6");
     fs_net* h = new fs_net();
@@ -407,6 +414,7 @@ int net_create(const fs_config* cfg, fs_handle* out) {
     h->use_fused_winograd = !(cfg->flags & (FS_OPT_NO_FUSED_WINOGRAD | FS_OPT_NO_WINOGRAD));
     h->use_split = !(cfg->flags & FS_OPT_NO_SPLIT_BF16);
     h->use_plane_operands = h->use_split && (cfg->flags & FS_OPT_PLANE_OPERANDS);
+    h->use_chain = h->use_split && (cfg->flags & FS_OPT_CHAIN);
     if (hipGetDevice(&h->device) != hipSuccess) {
         delete h;
         return fail("fs_create: no HIP device");
@@ -779,17 +787,23 @@ int encoder_core(fs_handle h, const FrameSrc& src, int B, int H, int W, float* o
     // ---- residual stages.  X holds the block input; F1..F3 are free.
     int curH = g.H2, curW = g.W2;
     const int nblocks = (int)h->blocks.size();
+    bool c1_done = false;  // this block's conv1 output is already in F1: the previous block's chained launch wrote it
     for (int bi = 0; bi < nblocks; ++bi) {
         const Bottleneck& blk = h->blocks[bi];
         const bool last = bi == nblocks - 1;
         const int oH = blk.c2.out_size(curH), oW = blk.c2.out_size(curW);
-        FS_TRY(run_conv(h, blk.c1, X, C, B, curH, curW, F1, blk.c1.Cout, nullptr, 0, s));
+        if (!c1_done) FS_TRY(run_conv(h, blk.c1, X, C, B, curH, curW, F1, blk.c1.Cout, nullptr, 0, s));
+        c1_done = false;
         FS_TRY(run_conv(h, blk.c2, F1, blk.c1.Cout, B, curH, curW, F2, blk.c2.Cout, nullptr, 0, s));
         const int Cn = blk.c3.Cout;
         float* dst = last ? (fused ? F1 : out) : nullptr;  // F1 (conv1's output) is free again once conv2 has run
         const int ld_dst = last && !fused ? h->feat_channels() : Cn;
         ConvBN c3 = blk.c3;
         c3.relu = 1;  // ReLU after the residual add (model/resnet.py:93-94)
+        // Round 5, opt-in (FS_OPT_CHAIN): in layer1 / layer2 (bottleneck width <= 128: short-K, bandwidth- and ramp-bound launches) conv3 +
+        // shortcut of this block and conv1 of the NEXT block run as ONE launch (conv_chain_dma_f32).  Decided on the layer shapes alone.
+        const ConvBN* nc1 = (!last && h->use_chain && blk.c3.Cin <= 128 && blk.c3.KH == 1) ? &h->blocks[bi + 1].c1 : nullptr;
+        if (nc1 && !(nc1->KH == 1 && nc1->KW == 1 && nc1->stride == 1 && nc1->pad == 0 && nc1->Cin == Cn && nc1->Cin % 32 == 0)) nc1 = nullptr;
         if (blk.has_ds && blk.c3ds.w && h->use_fused_shortcut) {
             // conv3 and the projection shortcut as one launch over the concatenated K: the shortcut map is never written
             if (!dst) dst = F3;
@@ -800,9 +814,17 @@ int encoder_core(fs_handle h, const FrameSrc& src, int B, int H, int W, float* o
             p.in2 = X; p.ld_in2 = C; p.Cin2 = blk.ds_cin; p.stride2 = blk.ds_stride; p.H2 = curH; p.W2 = curW;
             split_use(h, p);
             const double M = (double)B * oH * oW;
-            FS_TRY(prof_begin(h, blk.c3ds.name, conv_igemm_tile_name(p), 2.0 * M * Cn * (p.Cin + p.Cin2),
-                              4.0 * (M * p.Cin + (double)B * curH * curW * p.Cin2 + (double)Cn * (p.Cin + p.Cin2) + M * Cn), s));
-            FS_TRY(launch_conv_igemm(p, s));
+            const double fl = 2.0 * M * Cn * (p.Cin + p.Cin2), by = 4.0 * (M * p.Cin + (double)B * curH * curW * p.Cin2 + (double)Cn * (p.Cin + p.Cin2) + M * Cn);
+            ConvParams pb = nc1 ? conv_params(h, *nc1, dst, ld_dst, B, oH, oW, F1, nc1->Cout, nullptr, 0) : ConvParams{};
+            if (nc1 && p.wgt3 && pb.wgt3) {
+                FS_TRY(prof_begin(h, blk.c3ds.name + " -> " + nc1->name, conv_chain_tile_name(p, pb), fl + 2.0 * M * Cn * nc1->Cout,
+                                  by + 4.0 * ((double)Cn * nc1->Cout + M * nc1->Cout), s));
+                FS_TRY(launch_conv_chain(p, pb, s));
+                c1_done = true;
+            } else {
+                FS_TRY(prof_begin(h, blk.c3ds.name, conv_igemm_tile_name(p), fl, by, s));
+                FS_TRY(launch_conv_igemm(p, s));
+            }
             FS_TRY(prof_end(h, s));
             if (!last) std::swap(X, F3);
         } else if (blk.has_ds) {
@@ -812,7 +834,18 @@ int encoder_core(fs_handle h, const FrameSrc& src, int B, int H, int W, float* o
             if (!last) std::swap(X, F3);
         } else {
             if (!dst) dst = X;  // in place over the identity shortcut
-            FS_TRY(run_conv(h, c3, F2, blk.c2.Cout, B, oH, oW, dst, ld_dst, X, C, s));
+            ConvParams pa = conv_params(h, c3, F2, blk.c2.Cout, B, oH, oW, dst, ld_dst, X, C);
+            ConvParams pb = nc1 ? conv_params(h, *nc1, dst, ld_dst, B, oH, oW, F1, nc1->Cout, nullptr, 0) : ConvParams{};
+            if (nc1 && pa.wgt3 && pb.wgt3) {
+                const double M = (double)B * oH * oW;
+                FS_TRY(prof_begin(h, c3.name + " -> " + nc1->name, conv_chain_tile_name(pa, pb), 2.0 * M * Cn * (c3.Cin + nc1->Cout),
+                                  4.0 * (M * c3.Cin + 2.0 * M * Cn + M * nc1->Cout + (double)Cn * (c3.Cin + nc1->Cout)), s));
+                FS_TRY(launch_conv_chain(pa, pb, s));
+                FS_TRY(prof_end(h, s));
+                c1_done = true;
+            } else {
+                FS_TRY(run_conv(h, c3, F2, blk.c2.Cout, B, oH, oW, dst, ld_dst, X, C, s));
+            }
         }
         C = Cn;
         curH = oH;

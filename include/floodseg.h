@@ -66,10 +66,15 @@ enum {
     FS_OPT_NO_SPLIT_BF16 = 16, /* implicit-GEMM launches (1x1 / 3x3 convs, Winograd GEMMs, nn.Linear) on the fp32 matrix-core kernel
                                  (v_mfma_f32_32x32x2_f32) instead of the split-operand one: each fp32 operand as the exact sum of three
                                  bf16 terms, six cross products on the bf16 matrix cores, fp32 accumulation (fs_conv2d_nhwc_split) */
-    FS_OPT_PLANE_OPERANDS = 32 /* round 4, opt-in A/B route: the Winograd input transform writes V as three bf16 planes (each value split
+    FS_OPT_PLANE_OPERANDS = 32, /* round 4, opt-in A/B route: the Winograd input transform writes V as three bf16 planes (each value split
                                  once) and the position GEMMs run on fs_gemm_bf16x3_planes instead of splitting fp32 rows in registers
                                  inside the GEMM.  Measured slower end to end (1.5x the V bytes, profiles/r04_experiments.txt), so it
                                  is not the default; ignored with FS_OPT_NO_SPLIT_BF16 */
+    FS_OPT_CHAIN = 64          /* round 5, opt-in A/B route: conv3 (+ shortcut) of a layer1 / layer2 bottleneck and conv1 of the NEXT block as
+                                 ONE chained launch (conv_chain_dma_f32: a workgroup multiplies the pixel rows it has just stored by the
+                                 next filters) instead of two.  Bit-identical results either way.  Measured equal in layer1 and slower
+                                 in layer2 (profiles/r05_experiments.txt), so it is not the default; needs the split-operand route
+                                 (ignored with FS_OPT_NO_SPLIT_BF16) */
 };
 
 int fs_version(void);
@@ -235,6 +240,16 @@ int fs_split_bf16x3(const float* w, int64_t n, void* planes, fs_stream stream);
 int fs_conv2d_nhwc_split(const float* in, int ld_in, const void* wgt_planes, const float* scale, const float* shift,
                          const float* res, int ld_res, float* out, int ld_out, int B, int H, int W, int Cin, int Cout, int KH,
                          int KW, int stride, int pad, int dil, int relu, int tile, fs_stream stream);
+/* Round 5: two dependent 1x1 convolutions over the same M pixel rows in ONE launch (conv_chain_dma_f32; the networks use it at the
+ * layer1 / layer2 bottleneck boundaries of model/resnet.py:76-96: conv3 + shortcut of block i, then conv1 of block i + 1):
+ *   mid[M][C1] = act1(scale1 * (in @ W1a^T + in2 @ W1b^T) + shift1 + res)        in [M][K1]; in2 [M][K1b] optional (then no res);
+ *   out[M][C2] = act2(scale2 * (mid @ W2^T) + shift2)                            res [M][C1] optional, may BE mid (in place)
+ * All tensors dense (pixel stride = channel count).  w1_planes: fs_split_bf16x3 of the [C1][K1 + K1b] filter rows, w2_planes of
+ * [C2][C1]; scale* / shift* may be NULL.  tile: 0 = by M, 1 = 128x128, 2 = 128x64, 3 = 64x64, 6 = 64x128 (rows x columns per
+ * workgroup).  Every output is bit-identical to the two fs_conv2d_nhwc_split calls it replaces. */
+int fs_conv_chain_nhwc(const float* in, int K1, const float* in2, int K1b, const void* w1_planes, const float* scale1, const float* shift1,
+                       const float* res, float* mid, int C1, int relu1, const void* w2_planes, const float* scale2, const float* shift2,
+                       float* out, int C2, int relu2, int M, int tile, fs_stream stream);
 /* 3x3 stride-1 conv with padding == dilation as Winograd F(m x m,3x3) (transforms + (m+2)^2 grouped MFMA GEMMs); the network
  * uses it for every such conv with Cin >= 256.  tile_m: 4, 6, or 0 = whichever needs fewer GEMM rows for this map (a 90x90
  * map is exactly 15x15 tiles of 6x6).  workspace: fs_winograd_workspace_floats(..., same tile_m) floats of device memory. */

@@ -54,7 +54,7 @@ def test_unknown_option_bits_and_tile_sizes_are_rejected():
     """The A/B routes are explicit fs_config options (nothing is read from the environment); anything undefined is refused."""
     lib = _lib.load()
     h = ctypes.c_void_p()
-    cfg = _lib.FsConfig(_lib.ARCH_PSPNET, 50, 5, 0, 0, 0, 0, 0, 64, 0)   # flags = 64: not an FS_OPT_* bit
+    cfg = _lib.FsConfig(_lib.ARCH_PSPNET, 50, 5, 0, 0, 0, 0, 0, 1 << 20, 0)   # flags = 2^20: not an FS_OPT_* bit
     assert lib.fs_create(ctypes.byref(cfg), ctypes.byref(h)) != 0 and b"option" in lib.fs_last_error()
     cfg = _lib.FsConfig(_lib.ARCH_PSPNET, 50, 5, 0, 0, 0, 0, 0, 0, 5)   # winograd_tile = 5
     assert lib.fs_create(ctypes.byref(cfg), ctypes.byref(h)) != 0 and b"winograd_tile" in lib.fs_last_error()

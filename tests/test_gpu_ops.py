@@ -82,6 +82,52 @@ def test_conv_igemm_split_operands(case, tile):
     assert e_split < 1.5 * e_f32 + 1e-7, (e_split, e_f32)
 
 
+CHAIN_CASES = [  # M, K1, K1b (second operand: the projection form), C1, C2, residual ("inplace" | "separate" | None)
+    (64082, 64, 0, 256, 64, "inplace"),      # layer1.1 conv3 -> layer1.2 conv1 at 713^2 (B = 2)
+    (64082, 64, 128, 256, 64, None),         # layer1.0 conv3 + downsample -> layer1.1 conv1
+    (16200, 128, 0, 512, 128, "inplace"),    # layer2.1 conv3 -> layer2.2 conv1
+    (16200, 128, 256, 512, 128, None),       # layer2.0 conv3 + downsample (stride folded away: dense rows here) -> layer2.1 conv1
+    (16200, 128, 0, 512, 256, "separate"),   # layer2.3 conv3 -> layer3.0 conv1
+    (333, 64, 0, 96, 40, "separate"),        # ragged: rows, columns of both convs not multiples of any tile
+    (1, 32, 32, 32, 32, None),
+]
+
+
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 6])
+@pytest.mark.parametrize("case", CHAIN_CASES)
+def test_conv_chain_is_bit_identical_to_its_two_launches(case, tile):
+    """Round 5: conv3 (+ shortcut) of a bottleneck and conv1 of the next one in ONE launch (fs_conv_chain_nhwc; every workgroup
+    multiplies the pixel rows it has just stored by the second filter bank, re-reading them through L2).  Against the two
+    fs_conv2d_nhwc_split launches it replaces: BOTH outputs bit for bit, every tile shape, the in-place shortcut (conv3 overwrites
+    the map it adds), the concatenated-K projection form, ragged shapes; and against a float64 evaluation."""
+    m, k1, k1b, c1, c2, res = case
+    g = torch.Generator().manual_seed(m + k1 + c1 + c2)
+    x = torch.randn(m, k1, generator=g)
+    x2 = torch.randn(m, k1b, generator=g) if k1b else None
+    w1 = torch.randn(c1, k1 + k1b, generator=g) * (2.0 / (k1 + k1b)) ** 0.5
+    w2 = torch.randn(c2, c1, generator=g) * (2.0 / c1) ** 0.5
+    sc1, sh1 = (None if k1b else torch.rand(c1, generator=g) + 0.5), torch.randn(c1, generator=g) * 0.1
+    sc2, sh2 = torch.rand(c2, generator=g) + 0.5, torch.randn(c2, generator=g) * 0.1
+    r = torch.randn(m, c1, generator=g) if res else None
+    cu = lambda t: None if t is None else t.to(DEV)  # noqa: E731
+    xa = torch.cat([x, x2], 1) if k1b else x
+    # the two launches (1x1 convs over an [M, 1] "image")
+    as_img = lambda t: t.t().reshape(1, t.shape[1], t.shape[0], 1)  # noqa: E731  [M, C] -> logical NCHW [1, C, M, 1]
+    from_img = lambda t: t.permute(0, 2, 3, 1).reshape(t.shape[2], t.shape[1])  # noqa: E731
+    mid_ref = ops.conv2d_nhwc(cu(as_img(xa)), cu(w1.view(c1, -1, 1, 1)), cu(sc1), cu(sh1), cu(as_img(r)) if res else None, 1, 0, 1, True, 0, split=True)
+    out_ref = ops.conv2d_nhwc(mid_ref, cu(w2.view(c2, c1, 1, 1)), cu(sc2), cu(sh2), None, 1, 0, 1, True, 0, split=True)
+    rd = cu(r)
+    mid_buf = rd.clone() if res == "inplace" else None
+    mid, out = ops.conv_chain(cu(x), cu(w1), cu(w2), cu(sc1), cu(sh1), mid_buf if res == "inplace" else rd, cu(x2), True, cu(sc2), cu(sh2), True, tile,
+                              mid=mid_buf)
+    assert torch.equal(mid, from_img(mid_ref)) and torch.equal(out, from_img(out_ref))
+    if res == "separate":
+        assert torch.equal(rd, cu(r))  # a separate shortcut is read-only
+    m64 = xa.double() @ w1.double().t() * (1.0 if sc1 is None else sc1.double()) + sh1.double() + (r.double() if res else 0.0)
+    o64 = (m64.relu() @ w2.double().t() * sc2.double() + sh2.double()).relu()
+    assert note(f"conv_chain_vs_f64_tile{tile}_m{m}_c2{c2}", rel(out.double().cpu(), o64)) < CONV_TOL
+
+
 @pytest.mark.parametrize("relu", [False, True])
 def test_conv_non_finite_operands(relu):
     """What include/floodseg.h promises about +-inf, NaN and finite values beyond the largest bf16 (3.3895e38) on both arithmetic

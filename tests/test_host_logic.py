@@ -144,8 +144,8 @@ def test_hip_options_come_from_hparams_not_from_the_environment(monkeypatch):
         hip_no_winograd, hip_winograd_tile = True, 6
     monkeypatch.setenv("FS_NO_FUSED_HEAD", "1")  # a round-1 knob: must be ignored now
     net = FlowPSPNet(O())
-    assert hip_options(O()) == dict(no_winograd=True, no_fused_winograd=False, no_split_bf16=False, plane_operands=False, no_fused_head=False,
-                                    no_fused_shortcut=False, winograd_tile=6)
+    assert hip_options(O()) == dict(no_winograd=True, no_fused_winograd=False, no_split_bf16=False, plane_operands=False, chain=False,
+                                    no_fused_head=False, no_fused_shortcut=False, winograd_tile=6)
     assert net._hip_net.flags == _lib.OPT_NO_WINOGRAD and net._hip_net.winograd_tile == 6
     assert FlowPSPNet(HP())._hip_net.flags == 0
 
@@ -156,6 +156,10 @@ def test_hip_options_come_from_hparams_not_from_the_environment(monkeypatch):
     class PNP(HP):
         hip_plane_operands = True  # round 4 A/B route: the Winograd input transform writes bf16 planes, GEMMs on gemm_planes_bf16x3
     assert FlowPSPNet(PNP())._hip_net.flags == _lib.OPT_PLANE_OPERANDS
+
+    class PNC(HP):
+        hip_chain = True  # round 5 A/B route: conv3 of block i and conv1 of block i + 1 as one chained launch
+    assert FlowPSPNet(PNC())._hip_net.flags == _lib.OPT_CHAIN
 
 
 def test_model_representation_eval_is_pass_through():
