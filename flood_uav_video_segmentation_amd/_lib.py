@@ -34,6 +34,8 @@ OPT_NO_FUSED_WINOGRAD = 8  # FS_OPT_NO_FUSED_WINOGRAD
 OPT_NO_SPLIT_BF16 = 16  # FS_OPT_NO_SPLIT_BF16
 OPT_PLANE_OPERANDS = 32  # FS_OPT_PLANE_OPERANDS
 OPT_CHAIN = 64  # FS_OPT_CHAIN
+OPT_NO_RES_TOUCH = 128  # FS_OPT_NO_RES_TOUCH
+OPT_NO_FUSED_POOL = 256  # FS_OPT_NO_FUSED_POOL
 CONV_CHUNK_MAJOR = 0x400  # FS_CONV_CHUNK_MAJOR
 
 # name -> (restype, argtypes); must list every symbol of include/floodseg.h
@@ -94,6 +96,7 @@ _SIGNATURES = {
     "fs_conv3x3_winograd_nhwc": (c_int, [c_void, c_int, c_void, c_void, c_void, c_void, c_int] + [c_int] * 8 + [c_void, c_void]),
     "fs_winograd_fused_workspace_floats": (ctypes.c_size_t, [c_int, c_int]),
     "fs_conv3x3_winograd_fused_nhwc": (c_int, [c_void, c_int, c_void, c_void, c_void, c_void, c_int] + [c_int] * 7 + [c_void, c_void]),
+    "fs_conv3x3_winograd_fused_pool_nhwc": (c_int, [c_void, c_int, c_void, c_void, c_void, c_void] + [c_int] * 5 + [c_void, c_void]),
     "fs_stem_conv_nchw": (c_int, [c_void, c_void, c_void, c_void, c_void] + [c_int] * 8 + [c_void]),
     "fs_maxpool3x3s2_nhwc": (c_int, [c_void, c_void, c_int, c_int, c_int, c_int, c_void]),
     "fs_adaptive_avgpool_nhwc": (c_int, [c_void, c_int, c_void, c_int, c_int, c_int, c_int, c_int, c_void]),

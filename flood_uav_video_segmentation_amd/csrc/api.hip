@@ -428,6 +428,13 @@ FS_API int fs_conv3x3_winograd_fused_nhwc(const float* in, int ld_in, const floa
     if (int rc = fs::launch_wino4_filter_packed(wgt_oihw, workspace, Cout, Cin, S(stream))) return rc;
     return fs::launch_wino4_fused(in, ld_in, workspace, scale, shift, out, ld_out, B, H, W, Cin, Cout, relu, S(stream), variant);
 }
+FS_API int fs_conv3x3_winograd_fused_pool_nhwc(const float* in, int ld_in, const float* wgt_oihw, const float* scale, const float* shift, float* pool,
+                                               int B, int H, int W, int Cin, int Cout, float* workspace, fs_stream stream) {
+    if (!in || !wgt_oihw || !pool || !workspace || B < 1 || H < 1 || W < 1 || !fs::wino_fused_supported(Cin, Cout, 3, 3, 1, 1, 1))
+        return fs::fail("fs_conv3x3_winograd_fused_pool_nhwc: bad arguments (Cin %% 32 == 0, 32 <= Cin <= 256, Cout %% 64 == 0)");
+    if (int rc = fs::launch_wino4_filter_packed(wgt_oihw, workspace, Cout, Cin, S(stream))) return rc;
+    return fs::launch_wino4_fused_pool(in, ld_in, workspace, scale, shift, pool, Cout, B, H, W, Cin, Cout, S(stream));
+}
 FS_API int fs_stem_conv_nchw(const float* in_nchw, const float* wgt_hwio, const float* scale, const float* shift,
                              float* out_nhwc, int B, int H, int W, int Cout, int KH, int KW, int stride, int pad,
                              fs_stream stream) {

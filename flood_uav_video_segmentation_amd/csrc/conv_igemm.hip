@@ -360,6 +360,9 @@ __device__ __forceinline__ void conv_tile(ConvParams p, const int m0, const int 
 #pragma unroll
                 for (int pl = 0; pl < 3; ++pl) A3[i][pl] = __builtin_bit_cast(bf16x8, ah[i][pl]);
         }
+        unsigned touch0 = 0, touch1 = 0;
+        int touch_kc = (!DUAL && p.res && p.res_touch) ? max(nchunks - 2, 0) : -1;  // the chunk after whose barrier the residual lines are touched
+        asm volatile("" : "+s"(touch_kc));  // opaque: the loop is not to be versioned on it
         for (int kc = 0; kc < nchunks; ++kc) {
             FS_READ3(cur, 1, araw, B3n)
             __builtin_amdgcn_sched_barrier(0);
@@ -370,6 +373,17 @@ __device__ __forceinline__ void conv_tile(ConvParams p, const int m0, const int 
                 FS_DMA_ALL(cur)
                 FS_DMA_ADVANCE()
             }
+            if (kc == touch_kc) {
+                // the residual tile is BM rows x BN * 4 / 128 lines; thread t touches lines (t & 1) * 2 + {0, 1} of row t >> 1 (+ 128 per pass)
+                const __amdgpu_buffer_rsrc_t t_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.res, 0, (unsigned)((long long)M * p.ld_res * 4), 0x00020000);
+                constexpr int LPR = BN / 32;  // lines per row
+                const int tl = t * 2;
+                const int trow = tl / LPR, tline = tl % LPR;
+                const bool ok = trow < BM && n0 + tline * 32 < p.Cout;
+                const unsigned vo = ok ? (unsigned)((m0 + trow) * p.ld_res + n0 + tline * 32) * 4u : 0x80000000u;
+                touch0 = __builtin_amdgcn_raw_buffer_load_b32(t_rsrc, vo, 0, 0);
+                touch1 = __builtin_amdgcn_raw_buffer_load_b32(t_rsrc, (ok && n0 + (tline + 1) * 32 < p.Cout && LPR > 1) ? vo + 128u : 0x80000000u, 0, 0);
+            }
             __builtin_amdgcn_sched_barrier(0);
             FS_READ3(cur ^ 1, 0, araw, B3)  // (after the last chunk: a stale stage, read and never used)
             __builtin_amdgcn_sched_barrier(0);
@@ -377,6 +391,7 @@ __device__ __forceinline__ void conv_tile(ConvParams p, const int m0, const int 
             __builtin_amdgcn_sched_barrier(0);
             cur ^= 1;
         }
+        asm volatile("" ::"v"(touch0), "v"(touch1));  // keeps the two dead loads (and their registers) alive to here
         if (!DUAL && p.res) igemm_load_residual(rv, p, M, em_base, en_base);
 #undef FS_READ3
 #undef FS_STEP3

@@ -32,6 +32,9 @@ struct ConvParams {
     const float* in2;   int ld_in2;
     int Cin2, stride2, H2, W2;
     int relu;  // epilogue activation: 0 none, 1 ReLU, 2 GELU (erf)
+    int res_touch;  // split route (round 5): != 0 -> after the barrier of the last-but-one chunk every lane touches two 128-B lines of the
+                    // residual tile (dead loads), so that the epilogue's 64 residual loads per lane find them in L2: -3 % on layer3 /
+                    // layer4 conv3, -7 % on layer1 / layer2 conv3 (profiles/r05_experiments.txt section 3); same results bit for bit
     int korder;  // weight k order: 0 = (r, s, c) ; 1 = (c/32, r, s, c%32)
     // grouped GEMM (Winograd: one GEMM per transform position): group g uses in + g*g_in, wgt + g*g_wgt, out + g*g_out
     int groups;  // 0 or 1 = plain
@@ -355,5 +358,11 @@ int launch_wino4_filter_packed(const float* w, float* U, int O, int I, hipStream
 // workgroups per CU), 3 = 16 x 64 warp-specialised (4 MFMA waves + 4 transform waves); bit-identical results
 int launch_wino4_fused(const float* in, int ld_in, const float* U, const float* scale, const float* shift, float* out, int ld_out, int B, int H,
                        int W, int Cin, int Cout, int relu, hipStream_t s, int variant = 0);
+
+// Round 5: the same conv + BatchNorm + ReLU with MaxPool2d(3, stride 2, padding 1) fused into the epilogue (model/resnet.py:114-117:
+// layer0.6 -> layer0.8 -> maxpool): pool = [B][(H-1)/2+1][(W-1)/2+1][ld_pool], zeroed by the launcher; the full-resolution map is
+// never written.  Bit-identical to launch_wino4_fused followed by launch_maxpool3x3s2.
+int launch_wino4_fused_pool(const float* in, int ld_in, const float* U, const float* scale, const float* shift, float* pool, int ld_pool, int B,
+                            int H, int W, int Cin, int Cout, hipStream_t s);
 
 }  // namespace fs

@@ -329,6 +329,7 @@ ConvParams conv_params(const fs_net* h, const ConvBN& c, const float* in, int ld
     p.dil = c.dil;
     p.relu = c.relu;
     p.korder = c.korder;
+    p.res_touch = res != nullptr && h->res_touch;
     split_use(h, p);
     return p;
 }
@@ -402,7 +403,7 @@ int net_create(const fs_config* cfg, fs_handle* out) {
                "fs_create: layers must be 50, 101 or 152");
     FS_REQUIRE(cfg->classes >= 1 && cfg->classes <= 255, "fs_create: classes out of range");
     FS_REQUIRE((cfg->flags & ~(FS_OPT_NO_WINOGRAD | FS_OPT_NO_FUSED_HEAD | FS_OPT_NO_FUSED_SHORTCUT | FS_OPT_NO_FUSED_WINOGRAD | FS_OPT_NO_SPLIT_BF16 |
-                               FS_OPT_PLANE_OPERANDS | FS_OPT_CHAIN)) == 0,
+                               FS_OPT_PLANE_OPERANDS | FS_OPT_CHAIN | FS_OPT_NO_RES_TOUCH | FS_OPT_NO_FUSED_POOL)) == 0,
                "fs_create: unknown option bits 0x%x", cfg->flags);
     FS_REQUIRE(cfg->winograd_tile == 0 || cfg->winograd_tile == 4 || cfg->winograd_tile == 6, "fs_create: winograd_tile must be 0, 4 or 6");
     fs_net* h = new fs_net();
@@ -415,6 +416,8 @@ int net_create(const fs_config* cfg, fs_handle* out) {
     h->use_split = !(cfg->flags & FS_OPT_NO_SPLIT_BF16);
     h->use_plane_operands = h->use_split && (cfg->flags & FS_OPT_PLANE_OPERANDS);
     h->use_chain = h->use_split && (cfg->flags & FS_OPT_CHAIN);
+    h->res_touch = !(cfg->flags & FS_OPT_NO_RES_TOUCH);
+    h->use_fused_pool = !(cfg->flags & FS_OPT_NO_FUSED_POOL);
     if (hipGetDevice(&h->device) != hipSuccess) {
         delete h;
         return fail("fs_create: no HIP device");
@@ -772,12 +775,26 @@ int encoder_core(fs_handle h, const FrameSrc& src, int B, int H, int W, float* o
         FS_TRY(prof_end(h, s));
     }
     int C = h->stem[0].Cout;
+    bool pooled = false;
     if (h->deep_stem) {
         FS_TRY(run_conv(h, h->stem[1], X, C, B, g.H1, g.W1, F1, h->stem[1].Cout, nullptr, 0, s));
-        FS_TRY(run_conv(h, h->stem[2], F1, h->stem[1].Cout, B, g.H1, g.W1, X, h->stem[2].Cout, nullptr, 0, s));
-        C = h->stem[2].Cout;
+        const ConvBN& c = h->stem[2];
+        // Round 5: layer0.6 + BN + ReLU + the max-pool behind it as ONE launch whenever the conv takes the one-kernel Winograd (decided
+        // per image geometry like that route itself): the 357 x 357 x 128 map -- the largest tensor of the network -- is never written
+        pooled = h->use_fused_pool && c.relu == 1 && c.scale && takes_fused_winograd(h, c, B, g.H1, g.W1, h->stem[1].Cout, c.Cout, false) &&
+                 g.H2 == (g.H1 - 1) / 2 + 1 && g.W2 == (g.W1 - 1) / 2 + 1;
+        if (pooled) {
+            const double tiles = (double)B * cdiv(g.H1, 4) * cdiv(g.W1, 4);
+            FS_TRY(prof_begin(h, c.name + "+maxpool", "wino_fused_pool", 2.0 * 36.0 * tiles * c.Cin * c.Cout,
+                              4.0 * ((double)B * g.H1 * g.W1 * c.Cin + 2.0 * (double)B * g.H2 * g.W2 * c.Cout + 36.0 * c.Cin * c.Cout), s));
+            FS_TRY(launch_wino4_fused_pool(F1, h->stem[1].Cout, c.wf, c.scale, c.shift, X, c.Cout, B, g.H1, g.W1, c.Cin, c.Cout, s));
+            FS_TRY(prof_end(h, s));
+        } else {
+            FS_TRY(run_conv(h, c, F1, h->stem[1].Cout, B, g.H1, g.W1, X, c.Cout, nullptr, 0, s));
+        }
+        C = c.Cout;
     }
-    {
+    if (!pooled) {
         const double M = (double)B * g.H2 * g.W2;
         FS_TRY(prof_begin(h, "maxpool", "maxpool3x3s2", 0, 4.0 * ((double)B * g.H1 * g.W1 * C + M * C), s));
         FS_TRY(launch_maxpool3x3s2(X, C, F1, C, B, g.H1, g.W1, C, g.H2, g.W2, s));

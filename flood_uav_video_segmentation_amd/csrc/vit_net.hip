@@ -108,6 +108,7 @@ int run_linear(fs_net* h, const Linear& l, const float* in, int rows, float* out
     p.pad = 0;
     p.dil = 1;
     p.relu = act;
+    p.res_touch = res != nullptr && h->res_touch;
     split_use(h, p);
     const double flops = 2.0 * rows * (double)l.in * l.out;
     FS_TRY(prof_begin(h, l.name, conv_igemm_tile_name(p), flops, 4.0 * ((double)rows * (l.in + l.out) + (double)l.in * l.out), s));

@@ -102,6 +102,10 @@ struct WinoFusedParams {
     int ld_out;
     int B, H, W, Cin, Cout, relu;
     int th, tw, T;       // tiles per column / row of one image, total tiles
+    // POOL form (round 5): MaxPool2d(3, stride 2, padding 1) of the ReLU output fused into the epilogue (model/resnet.py:116-117):
+    // `out` is not written; pool[b][pr][pc][c] (zero-initialised by the launcher) receives the maxima.  Workgroups own 4 x 4 BLOCKS of tiles.
+    float* pool;
+    int ld_pool, Hp, Wp, nby, nbx;
 };
 
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -147,9 +151,90 @@ __device__ __forceinline__ void wino4_epilogue(const f32x4 (&acc)[36], const Win
         }
     }
 }
+
+// Epilogue of the POOL form.  A workgroup owns a 4 x 4 block of tiles = 16 x 16 conv outputs; lane (n, q) holds the four tiles of
+// tile row q (ix = r = 0..3, left to right), channel n.  conv -> BN -> ReLU exactly as above, then MaxPool2d(3, 2, 1): pooled row
+// i covers conv rows 2i-1 .. 2i+1, so a tile row (4 conv rows, first one even) feeds pooled rows 2q (rows 0, 1), 2q + 1 (rows
+// 1, 2, 3: complete) and 2q + 2 (row 3), block-local; columns alike with a carry from tile to tile.  Rows 2q + 2 are completed with
+// the neighbouring lane group's first slot (one cross-lane read); what is left incomplete is the block's rim -- local pooled rows
+// and columns 0 and 8 -- which neighbouring workgroups also contribute to: those 32 of 81 cells go out as integer atomic max
+// (every value is >= +0 after the ReLU and the map starts at +0, so signed-integer order IS float order, and a maximum does not
+// depend on the order of its operands: the result is bit-identical to conv -> store -> maxpool, run to run), the 49 inner ones as
+// plain stores.  Conv outputs outside the image contribute 0 = the identity here (MaxPool2d pads with -inf; the values are >= 0).
+__device__ __forceinline__ void wino4_epilogue_pool(const f32x4 (&acc)[36], const WinoFusedParams& p, int tb, int q, int n, int lane) {
+    const float sc = p.scale ? p.scale[n] : 1.f, sh = p.shift ? p.shift[n] : 0.f;
+    const int bx = tb % p.nbx, by = (tb / p.nbx) % p.nby, b = tb / (p.nbx * p.nby);
+    const int R0 = 16 * by + 4 * q;      // first conv row of this lane's tile row
+    float h[3][9];                       // [row slot][block-local pooled column]
+    float carry[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float half[4][6];
+#pragma unroll
+        for (int x = 0; x < 6; ++x) {
+            float col[6], y4[4];
+#pragma unroll
+            for (int y = 0; y < 6; ++y) col[y] = acc[y * 6 + x][r];
+            wf_at(col, y4);
+#pragma unroll
+            for (int y = 0; y < 4; ++y) half[y][x] = y4[y];
+        }
+        const int C0 = 16 * bx + 4 * r;  // first conv column of this tile
+        float o[4][4];
+#pragma unroll
+        for (int y = 0; y < 4; ++y) {
+            float o4[4];
+            wf_at(half[y], o4);
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+                float v = __builtin_fmaf(o4[x], sc, sh);
+                v = fmaxf(v, 0.f);
+                o[y][x] = (R0 + y < p.H && C0 + x < p.W) ? v : 0.f;
+            }
+        }
+        float rp[3][4];  // vertical part: rows {0,1}, {1,2,3}, {3}
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+            rp[0][x] = fmaxf(o[0][x], o[1][x]);
+            rp[1][x] = fmaxf(fmaxf(o[1][x], o[2][x]), o[3][x]);
+            rp[2][x] = o[3][x];
+        }
+#pragma unroll
+        for (int sl = 0; sl < 3; ++sl) {  // horizontal part: local pooled column 2r = {carry, 0, 1}, 2r + 1 = {1, 2, 3}, carry = 3
+            h[sl][2 * r] = fmaxf(fmaxf(carry[sl], rp[sl][0]), rp[sl][1]);
+            h[sl][2 * r + 1] = fmaxf(fmaxf(rp[sl][1], rp[sl][2]), rp[sl][3]);
+            carry[sl] = rp[sl][3];
+        }
+    }
+#pragma unroll
+    for (int sl = 0; sl < 3; ++sl) h[sl][8] = carry[sl];
+    // local pooled row 2q + 2 = this tile row's slot 2 and the next tile row's slot 0 (lane + 16); the last tile row keeps its own
+#pragma unroll
+    for (int j = 0; j < 9; ++j) {
+        const float below = __shfl_down(h[0][j], 16, 64);
+        if (q < 3) h[2][j] = fmaxf(h[2][j], below);
+    }
+    int* pool = reinterpret_cast<int*>(p.pool);
+#pragma unroll
+    for (int sl = 0; sl < 3; ++sl) {
+        if (sl == 0 && q != 0) continue;  // row 2q is the previous tile row's combined slot 2
+        const int li = 2 * q + sl;        // block-local pooled row 0..8
+        const int pr = 8 * by + li;
+        const bool row_rim = li == 0 || li == 8;
+#pragma unroll
+        for (int j = 0; j < 9; ++j) {
+            const int pc = 8 * bx + j;
+            if (pr >= p.Hp || pc >= p.Wp) continue;
+            const int off = ((b * p.Hp + pr) * p.Wp + pc) * p.ld_pool + n;
+            const int bits = __builtin_bit_cast(int, h[sl][j]);
+            if (row_rim || j == 0 || j == 8) atomicMax(pool + off, bits);
+            else pool[off] = bits;
+        }
+    }
+}
 #endif
 
-template <int WM, int WN>
+template <int WM, int WN, bool POOL = false>
 __global__ __launch_bounds__(64 * WM * WN, 2) void wino4_fused_kernel(WinoFusedParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int NT = 16 * WM, NC = 16 * WN, NTHR = 64 * WM * WN;
@@ -172,10 +257,21 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void wino4_fused_kernel(WinoFusedP
 #pragma unroll
     for (int it = 0; it < ITEMS; ++it) {
         const int item = t + it * NTHR;
-        const int tile = tb * NT + (item >> 4);
-        const bool tv = tile < p.T;
-        const int tt = tv ? tile : 0;
-        const int tx = tt % p.tw, ty = (tt / p.tw) % p.th, b = tt / (p.tw * p.th);
+        int tx, ty, b;
+        bool tv;
+        if (POOL) {  // tile (item >> 4) = (iy, ix) of the 4 x 4 block tb = (b, by, bx)
+            const int li = item >> 4;
+            tx = 4 * (tb % p.nbx) + (li & 3);
+            ty = 4 * ((tb / p.nbx) % p.nby) + (li >> 2);
+            b = tb / (p.nbx * p.nby);
+            tv = tx < p.tw && ty < p.th;
+            if (!tv) tx = ty = 0;
+        } else {
+            const int tile = tb * NT + (item >> 4);
+            tv = tile < p.T;
+            const int tt = tv ? tile : 0;
+            tx = tt % p.tw, ty = (tt / p.tw) % p.th, b = tt / (p.tw * p.th);
+        }
         const int y0 = 4 * ty - 1, x0 = 4 * tx - 1;
 #pragma unroll
         for (int k = 0; k < 6; ++k) {
@@ -257,7 +353,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void wino4_fused_kernel(WinoFusedP
         multiply(s, s & 1);
     }
 
-    wino4_epilogue(acc, p, tb * NT + wm * 16 + 4 * q4, n0 + wn * 16 + m16);
+    if constexpr (POOL) wino4_epilogue_pool(acc, p, tb, q4, n0 + wn * 16 + m16, lane);
+    else wino4_epilogue(acc, p, tb * NT + wm * 16 + 4 * q4, n0 + wn * 16 + m16);
 #endif
 }
 
@@ -489,6 +586,28 @@ int launch_wino4_fused(const float* in, int ld_in, const float* U, const float* 
     }
     else if (variant == 1) hipLaunchKernelGGL((wino4_fused_kernel<2, 4>), dim3(cdiv(p.T, 32) * ncb), dim3(512), 0, s, p);
     else hipLaunchKernelGGL((wino4_fused_kernel<1, 4>), dim3(cdiv(p.T, 16) * ncb), dim3(256), 0, s, p);
+    FS_HIP(hipGetLastError());
+    return 0;
+}
+
+// The same convolution + BatchNorm + ReLU followed by MaxPool2d(3, stride 2, padding 1) in ONE kernel (the deep stem's layer0.6 and
+// the max-pool behind it, model/resnet.py:114-117): the full-resolution map is never written.  pool: [B][Hp][Wp][ld_pool] with
+// Hp = (H - 1) / 2 + 1; it is zeroed here (the rim cells of every 16 x 16 block are integer atomic maxima against +0).
+int launch_wino4_fused_pool(const float* in, int ld_in, const float* U, const float* scale, const float* shift, float* pool, int ld_pool, int B,
+                            int H, int W, int Cin, int Cout, hipStream_t s) {
+    FS_REQUIRE(wino_fused_supported(Cin, Cout, 3, 3, 1, 1, 1), "wino_fused_pool: unsupported shape (Cin=%d Cout=%d)", Cin, Cout);
+    FS_REQUIRE(ld_in >= Cin && ld_pool >= Cout && ((uintptr_t)U & 15) == 0 && ((uintptr_t)in & 3) == 0 && ((uintptr_t)pool & 3) == 0, "wino_fused_pool: bad strides / alignment");
+    const int Hp = (H - 1) / 2 + 1, Wp = (W - 1) / 2 + 1;
+    FS_REQUIRE((int64_t)B * H * W * ld_in * 4 < (int64_t)1 << 30 && (int64_t)B * Hp * Wp * ld_pool * 4 < (int64_t)1 << 31,
+               "wino_fused_pool: input map must be smaller than 1 GiB, pooled map smaller than 2 GiB");
+    WinoFusedParams p{};
+    p.in = in; p.ld_in = ld_in; p.U = U; p.scale = scale; p.shift = shift; p.out = nullptr; p.ld_out = 0;
+    p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.relu = 1;
+    p.th = cdiv(H, 4); p.tw = cdiv(W, 4);
+    p.T = B * p.th * p.tw;
+    p.pool = pool; p.ld_pool = ld_pool; p.Hp = Hp; p.Wp = Wp; p.nby = cdiv(p.th, 4); p.nbx = cdiv(p.tw, 4);
+    FS_HIP(hipMemsetAsync(pool, 0, (size_t)B * Hp * Wp * ld_pool * sizeof(float), s));
+    hipLaunchKernelGGL((wino4_fused_kernel<1, 4, true>), dim3((unsigned)(B * p.nby * p.nbx * (Cout / 64))), dim3(256), 0, s, p);
     FS_HIP(hipGetLastError());
     return 0;
 }

@@ -70,11 +70,17 @@ enum {
                                  once) and the position GEMMs run on fs_gemm_bf16x3_planes instead of splitting fp32 rows in registers
                                  inside the GEMM.  Measured slower end to end (1.5x the V bytes, profiles/r04_experiments.txt), so it
                                  is not the default; ignored with FS_OPT_NO_SPLIT_BF16 */
-    FS_OPT_CHAIN = 64          /* round 5, opt-in A/B route: conv3 (+ shortcut) of a layer1 / layer2 bottleneck and conv1 of the NEXT block as
+    FS_OPT_CHAIN = 64,         /* round 5, opt-in A/B route: conv3 (+ shortcut) of a layer1 / layer2 bottleneck and conv1 of the NEXT block as
                                  ONE chained launch (conv_chain_dma_f32: a workgroup multiplies the pixel rows it has just stored by the
                                  next filters) instead of two.  Bit-identical results either way.  Measured equal in layer1 and slower
                                  in layer2 (profiles/r05_experiments.txt), so it is not the default; needs the split-operand route
                                  (ignored with FS_OPT_NO_SPLIT_BF16) */
+    FS_OPT_NO_FUSED_POOL = 256, /* round 5 A/B switch: the deep stem's last conv (layer0.6) and the max-pool behind it (model/resnet.py:114-117) as two
+                                 launches instead of one (the one-kernel Winograd with MaxPool2d(3, 2, 1) in its epilogue: the 357 x 357 x 128 map
+                                 is never written).  Bit-identical results either way */
+    FS_OPT_NO_RES_TOUCH = 128  /* round 5 A/B switch: without it the split-operand conv kernels touch the lines of a bottleneck's shortcut tile
+                                 (dead loads) before the last K chunk of their main loop, so that the epilogue's residual loads hit in L2.
+                                 Same results bit for bit either way */
 };
 
 int fs_version(void);
@@ -286,6 +292,10 @@ int fs_conv3x3_winograd_fused_nhwc(const float* in, int ld_in, const float* wgt_
 /* wgt_hwio: [KH][KW][3][Cout] (weight.permute(2,3,1,0)) */
 int fs_stem_conv_nchw(const float* in_nchw, const float* wgt_hwio, const float* scale, const float* shift, float* out_nhwc,
                       int B, int H, int W, int Cout, int KH, int KW, int stride, int pad, fs_stream stream);
+/* Round 5: fs_conv3x3_winograd_fused_nhwc (+ BatchNorm + ReLU) followed by MaxPool2d(3, stride 2, padding 1) as ONE launch (the
+ * deep stem's layer0.6 + max-pool): pool = [B][(H-1)/2+1][(W-1)/2+1][Cout]; bit-identical to the two calls it replaces. */
+int fs_conv3x3_winograd_fused_pool_nhwc(const float* in, int ld_in, const float* wgt_oihw, const float* scale, const float* shift, float* pool,
+                                        int B, int H, int W, int Cin, int Cout, float* workspace, fs_stream stream);
 int fs_maxpool3x3s2_nhwc(const float* in, float* out, int B, int H, int W, int C, fs_stream stream);
 int fs_adaptive_avgpool_nhwc(const float* in, int ld_in, float* out, int B, int H, int W, int C, int bin, fs_stream stream);
 int fs_nchw_to_nhwc(const float* in, float* out, int B, int C, int HW, fs_stream stream);

@@ -261,6 +261,8 @@ def test_pspnet_r101_713_against_the_reference():
                                   dict(hip_no_split_bf16=True),  # the fp32-MFMA kernels (round 2's arithmetic)
                                   dict(hip_plane_operands=True),  # round 4 A/B route: V as bf16 planes, position GEMMs on gemm_planes_bf16x3
                                   dict(hip_chain=True),           # round 5 A/B route: conv3 / next conv1 as one chained launch
+                                  dict(hip_no_fused_pool=True),   # round 5 A/B switch: layer0.6 and the max-pool as two launches again
+                                  dict(hip_no_res_touch=True),    # round 5 A/B switch: no L2 touch of the shortcut tile before the epilogue
                                   dict(hip_no_split_bf16=True, hip_no_winograd=True),
                                   dict(hip_no_winograd=True, hip_no_fused_head=True, hip_no_fused_shortcut=True)])
 def test_every_shipped_option_matches_the_reference_golden_at_713(psp, opts):
@@ -301,6 +303,26 @@ def test_chained_bottleneck_boundaries_are_bit_identical_to_separate_launches(ps
     rows = {r[0]: r[1] for r in _profile_rows(chained, x)}
     assert sum(" -> " in k for k in rows) == (7 if layers == 50 else 7) and all(v.startswith("chain") for k, v in rows.items() if " -> " in k)
     assert not any(" -> " in r[0] for r in _profile_rows(plain, x))
+
+
+@pytest.mark.parametrize("size,b", [((713, 713), 2), ((713, 713), 1), ((257, 323), 3), ((129, 161), 2), ((65, 65), 1)])
+def test_fused_stem_maxpool_and_residual_touch_are_bit_identical_to_the_plain_routes(psp, size, b):
+    """Round 5: layer0.6 + max-pool as one launch (default), and the residual-touch experiment: whole-network outputs BIT-identical
+    to the two-launch stem / the untouched epilogue.  (Below 500 tiles per image -- 129 x 161 and 65 x 65 frames -- the stem conv does
+    not take the one-kernel Winograd: the pooled form must step aside with it.)"""
+    _, state = psp
+    nets = [FlowPSPNet(HP(**o)).eval() for o in (dict(), dict(hip_no_fused_pool=True), dict(hip_no_res_touch=True))]
+    for n in nets:
+        n.load_state_dict(state)
+    x = synth.make_clip(b, size, seed=57).cuda()
+    outs = [n.segment(x) for n in nets]
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    kernels = [r[1] for r in _profile_rows(nets[0], x)]
+    h1, w1 = (size[0] - 1) // 2 + 1, (size[1] - 1) // 2 + 1
+    fused = -(-h1 // 4) * -(-w1 // 4) >= 500
+    assert ("wino_fused_pool" in kernels) == fused and ("maxpool3x3s2" in kernels) == (not fused)
+    assert "wino_fused_pool" not in [r[1] for r in _profile_rows(nets[1], x)]
+    assert torch.equal(nets[0].segment(x), outs[0])  # run to run
 
 
 def _profile_rows(net, x):

@@ -581,6 +581,43 @@ def test_winograd_fused_conv3x3(case, variant):
         assert torch.equal(base, out)
 
 
+@pytest.mark.parametrize("case", [
+    # b, h, w, cin, cout
+    (2, 357, 357, 64, 128),   # the deep stem's layer0.6 + max-pool of a 713x713 key-frame pair
+    (1, 16, 16, 64, 64),      # exactly one 4 x 4 block of tiles
+    (2, 23, 29, 64, 128),     # ragged: blocks, tiles and pooling windows cut by the map's edge; odd sizes
+    (1, 5, 3, 32, 64),
+    (3, 70, 66, 32, 192),     # even sizes (the last pooling window has no right / bottom neighbour), three channel blocks
+    (1, 33, 17, 128, 64),
+])
+def test_winograd_fused_conv3x3_with_maxpool_is_bit_identical_to_conv_then_pool(case):
+    """Round 5: conv3x3 + BatchNorm + ReLU + MaxPool2d(3, 2, 1) in ONE kernel (the one-kernel Winograd with the pooling in its epilogue:
+    inner cells of every 16 x 16 block as plain stores, rim cells as integer atomic maxima against a zeroed map).  A maximum is exact
+    and order-independent: the pooled map must equal fs_conv3x3_winograd_fused_nhwc -> fs_maxpool3x3s2_nhwc BIT for bit, run after run;
+    and torch's max_pool2d of the torch convolution within the Winograd tolerance."""
+    lib = _lib.load()
+    b, h, w, cin, cout = case
+    g = torch.Generator().manual_seed(h * 100 + cin + cout + 1)
+    x = torch.randn(b, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (cin * 9)) ** 0.5
+    sc, sh = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.1 - 0.2
+    ref = F.max_pool2d((F.conv2d(x, wt, None, 1, 1, 1) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)).relu(), 3, 2, 1)
+    hp, wp = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    assert ref.shape == (b, cout, hp, wp)
+    xd = ops.as_nhwc(x.to(DEV))
+    ws = torch.empty(lib.fs_winograd_fused_workspace_floats(cin, cout), device=DEV)
+    wd, scd, shd = wt.to(DEV), sc.to(DEV), sh.to(DEV)
+    full = torch.empty((b, h, w, cout), device=DEV)
+    check(lib.fs_conv3x3_winograd_fused_nhwc(ptr(xd), cin, ptr(wd), ptr(scd), ptr(shd), ptr(full), cout, b, h, w, cin, cout, 1, 2, ptr(ws), stream_ptr()))
+    two = torch.empty((b, hp, wp, cout), device=DEV)
+    check(lib.fs_maxpool3x3s2_nhwc(ptr(full), ptr(two), b, h, w, cout, stream_ptr()))
+    for _ in range(3):
+        one = torch.full((b, hp, wp, cout), float("nan"), device=DEV)  # the launcher zeroes the map itself
+        check(lib.fs_conv3x3_winograd_fused_pool_nhwc(ptr(xd), cin, ptr(wd), ptr(scd), ptr(shd), ptr(one), b, h, w, cin, cout, ptr(ws), stream_ptr()))
+        assert torch.equal(one, two)
+    assert note(f"winograd_fused_pool_{h}x{w}x{cin}x{cout}", rel(one.permute(0, 3, 1, 2), ref)) < WINO_FUSED_TOL
+
+
 @pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5])
 @pytest.mark.parametrize("shape", [
     # b, h, w, cin, cout, k, pad, res  -- the layer shapes of a 713x713 window, where every CU holds 2-5 workgroups at once

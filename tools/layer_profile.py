@@ -15,7 +15,8 @@ class HP:
     def __init__(self, layers):
         self.layers, self.classes, self.pretrained = layers, 5, False
         for opt in sys.argv[3:]:
-            setattr(self, opt, True)
+            name, _, val = opt.partition("=")
+            setattr(self, name, int(val) if val else True)
 
 
 def main():
