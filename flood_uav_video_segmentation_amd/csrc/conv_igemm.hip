@@ -559,7 +559,7 @@ const char* conv_igemm_tile_name(const ConvParams& p, int tile) {
     if (tile <= 0 || tile > 5) tile = pick_tile(p);
     if (p.in2 && p.wgt3) return tile == 2 ? "split128x64cat" : "split128x128cat";
     if (p.in2) return tile == 2 ? "igemm128x64cat" : "igemm128x128cat";  // the concatenated-K instantiations are kernels of their own
-    if (p.wgt3) return tile == 1 ? "split128x128" : tile == 2 ? "split128x64" : "split64x64";
+    if (p.wgt3) return tile == 1 ? "split128x128" : tile == 2 ? "split128x64" : tile == 4 ? "split64x128" : "split64x64";
     return kTiles[tile].name;
 }
 
@@ -658,13 +658,16 @@ int launch_conv_igemm(const ConvParams& p, hipStream_t s, int tile) {
             case 1: hipLaunchKernelGGL((conv_igemm_dma_f32<128, 128, 4, 1, false, true>), grid, block, 0, s, p, tm, tn); break;
             case 2: hipLaunchKernelGGL((conv_igemm_dma_f32<128, 64, 4, 1, false, true>), grid, block, 0, s, p, tm, tn); break;
             case 3: hipLaunchKernelGGL((conv_igemm_dma_f32<64, 64, 2, 2, false, true>), grid, block, 0, s, p, tm, tn); break;
+            // round 5: 64 rows x 128 columns, 2 x 2 waves of 32 x 64 (3 split instructions per MFMA against 6 in the 64 x 64 tile): the
+            // shape for GEMMs with few rows and many columns (the Segmenter's Linears: 4052 token rows)
+            case 4: hipLaunchKernelGGL((conv_igemm_dma_f32<64, 128, 2, 2, false, true>), grid, block, 0, s, p, tm, tn); break;
 #ifdef FS_DEV
             // experiment (tools/tile256_bench.py, profiles/r04_experiments.txt section 9): a 256 x 128 tile, 4 x 1 waves of 64 x 128, one
             // workgroup per CU with the accumulators in AGPRs -- 41 % fewer LDS read bytes per MFMA at the same VALU count per MFMA (every
             // filter fragment feeds two row blocks).  Bit-identical; EQUAL to two 128 x 128 workgroups per CU at K = 2048, slower below.
             case 5: hipLaunchKernelGGL((conv_igemm_dma_f32<256, 128, 4, 1, false, true>), grid, block, 0, s, p, tm, tn); break;
 #endif
-            default: return fail("conv_igemm: the split-operand route has tiles 1, 2 and 3");
+            default: return fail("conv_igemm: the split-operand route has tiles 1, 2, 3 and 4");
         }
         FS_HIP(hipGetLastError());
         return 0;

@@ -54,7 +54,7 @@ def test_conv_igemm(case, tile):
     assert rel(got, ref) < CONV_TOL
 
 
-@pytest.mark.parametrize("tile", [0, 1, 2, 3])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4])
 @pytest.mark.parametrize("case", CONV_CASES)
 def test_conv_igemm_split_operands(case, tile):
     """The split-operand kernel (round 3, the networks' default): every fp32 pixel / filter value as the exact sum of three bf16
