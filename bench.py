@@ -73,9 +73,14 @@ ARITHMETIC = ("fp32 tensors; in the implicit-GEMM kernels every fp32 operand is 
               "fp32-MFMA kernel (variants.fps_fp32_mfma_kernels_no_split)")
 
 
+HIP_OPTS = {}  # development A/B only (--hip-opt): explicit fs_config options of the library, e.g. hip_chain, hip_no_fused_pool
+
+
 class HP:
     def __init__(self, layers=50):
         self.layers, self.classes, self.pretrained = layers, CLASSES, False
+        for k, v in HIP_OPTS.items():
+            setattr(self, k, v)
 
 
 def build_id():
@@ -427,6 +432,9 @@ def main():
                     help="multi-rank rehearsal on a 1-GPU box: every rank uses cuda:0 and the reduction runs over gloo")
     ap.add_argument("--lib", default=None,
                     help="development A/B only: load this build of the library instead of the in-tree libfloodseg.so (recorded in the JSON line)")
+    ap.add_argument("--hip-opt", action="append", default=[], metavar="NAME[=INT]",
+                    help="development A/B only: set this explicit library option (hparams attribute, e.g. hip_chain, hip_no_res_touch) on every network "
+                         "the run builds; recorded in the JSON line")
     ap.add_argument("--launch-check", action="store_true",
                     help="no GPU, no measurement: the N ranks rendezvous over gloo, build their shard of the configs[4] schedule, run the "
                          "end-of-run collectives and rank 0 prints a line WITHOUT a metric (rehearses the N-rank launch on CPU)")
@@ -437,6 +445,9 @@ def main():
         sys.exit(spawn_ranks(args.gpus))  # launcher only: no torch, no GPU in this process
     if args.launch_check:
         return launch_check(args)
+    for o in args.hip_opt:
+        name, _, val = o.partition("=")
+        HIP_OPTS[name] = int(val) if val else True
     if args.lib:
         from flood_uav_video_segmentation_amd import _lib as _l
         _l.LIB_PATH = os.path.abspath(args.lib)
@@ -534,6 +545,7 @@ def main():
                         "collectives": "end-of-run all_reduce of int64 frame count + float64 seconds (and int64[3,K] histograms in tools/predict_video.py); "
                                        "none inside the timed loop"},
         "build_id": build_id() if not args.lib else f"--lib {os.path.basename(args.lib)} (not the in-tree build)",
+        "hip_options": dict(HIP_OPTS) or None,  # null = the shipped defaults (what the driver runs)
         "reference_claim_fps_other_hw": 76.85,
     }
 

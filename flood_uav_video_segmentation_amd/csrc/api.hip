@@ -10,7 +10,7 @@
 
 static inline hipStream_t S(fs_stream s) { return reinterpret_cast<hipStream_t>(s); }
 
-FS_API int fs_version(void) { return 400; }
+FS_API int fs_version(void) { return 500; }
 FS_API const char* fs_last_error(void) { return fs::last_error().c_str(); }
 
 FS_API int fs_create(const fs_config* cfg, fs_handle* out) { return fs::net_create(cfg, out); }

@@ -819,7 +819,9 @@ int encoder_core(fs_handle h, const FrameSrc& src, int B, int H, int W, float* o
         c3.relu = 1;  // ReLU after the residual add (model/resnet.py:93-94)
         // Round 5, opt-in (FS_OPT_CHAIN): in layer1 / layer2 (bottleneck width <= 128: short-K, bandwidth- and ramp-bound launches) conv3 +
         // shortcut of this block and conv1 of the NEXT block run as ONE launch (conv_chain_dma_f32).  Decided on the layer shapes alone.
-        const ConvBN* nc1 = (!last && h->use_chain && blk.c3.Cin <= 128 && blk.c3.KH == 1) ? &h->blocks[bi + 1].c1 : nullptr;
+        // (only where 128-row workgroups still fill the chip twice -- layer1 at 713^2: the 64-row form of layer2's 16 200-pixel maps
+        //  measured 20-45 % slower than the two launches, profiles/r05_experiments.txt section 1; decided per image, not per batch)
+        const ConvBN* nc1 = (!last && h->use_chain && blk.c3.Cin <= 128 && blk.c3.KH == 1 && cdiv(oH * oW, 128) >= 192) ? &h->blocks[bi + 1].c1 : nullptr;
         if (nc1 && !(nc1->KH == 1 && nc1->KW == 1 && nc1->stride == 1 && nc1->pad == 0 && nc1->Cin == Cn && nc1->Cin % 32 == 0)) nc1 = nullptr;
         if (blk.has_ds && blk.c3ds.w && h->use_fused_shortcut) {
             // conv3 and the projection shortcut as one launch over the concatenated K: the shortcut map is never written
@@ -928,8 +930,9 @@ int net_segment(fs_handle h, const FrameSrc& src, int B, int H, int W, float* ou
     FS_TRY(ensure_workspace(h, std::max(encoder_buf_elems(h, B, H, W), ppm_term_scratch_floats(B, fh, h->cls_main.Cout)), small_elems_for(B)));
     float* feat = nullptr;
     FS_TRY(encoder_core(h, src, B, H, W, nullptr, &feat, s));
-    // (Running the pyramid branch -- pool, four tiny 1x1 convs, the Z GEMM, ~0.12 ms -- on a side stream under the head's
-    //  Winograd GEMM was measured: +0.2 %, not worth a second stream in the handle.)
+    // (Running the pyramid branch -- pool, four tiny 1x1 convs, the Z GEMM, ~0.08 ms -- on a side stream under the head's
+    //  Winograd GEMM was measured twice: +0.2 % in round 3, -2 % in round 5 (profiles/r05_experiments.txt section 5): the branch's
+    //  kernels are bandwidth- and latency-bound and take memory slots from the GEMM they were meant to hide under.)
     hipStream_t ps = s;
     FS_TRY(pyramid_reduce(h, feat, 2048, B, fh, fw, ps));
     // free workspace buffers now: every h->buf[] except `feat`
