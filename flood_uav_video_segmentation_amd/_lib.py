@@ -98,6 +98,7 @@ _SIGNATURES = {
     "fs_conv3x3_winograd_fused_nhwc": (c_int, [c_void, c_int, c_void, c_void, c_void, c_void, c_int] + [c_int] * 7 + [c_void, c_void]),
     "fs_conv3x3_winograd_fused_pool_nhwc": (c_int, [c_void, c_int, c_void, c_void, c_void, c_void] + [c_int] * 5 + [c_void, c_void]),
     "fs_stem_conv_nchw": (c_int, [c_void, c_void, c_void, c_void, c_void] + [c_int] * 8 + [c_void]),
+    "fs_stem_conv_nchw_split": (c_int, [c_void, c_void, c_void, c_void, c_void] + [c_int] * 8 + [c_void]),
     "fs_maxpool3x3s2_nhwc": (c_int, [c_void, c_void, c_int, c_int, c_int, c_int, c_void]),
     "fs_adaptive_avgpool_nhwc": (c_int, [c_void, c_int, c_void, c_int, c_int, c_int, c_int, c_int, c_void]),
     "fs_nchw_to_nhwc": (c_int, [c_void, c_void, c_int, c_int, c_int, c_void]),

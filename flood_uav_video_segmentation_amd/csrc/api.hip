@@ -435,9 +435,20 @@ FS_API int fs_conv3x3_winograd_fused_pool_nhwc(const float* in, int ld_in, const
     if (int rc = fs::launch_wino4_filter_packed(wgt_oihw, workspace, Cout, Cin, S(stream))) return rc;
     return fs::launch_wino4_fused_pool(in, ld_in, workspace, scale, shift, pool, Cout, B, H, W, Cin, Cout, S(stream));
 }
+static int stem_entry(const float* in_nchw, const float* wgt_hwio, const float* scale, const float* shift, float* out_nhwc, int B, int H, int W, int Cout,
+                      int KH, int KW, int stride, int pad, int split, fs_stream stream);
 FS_API int fs_stem_conv_nchw(const float* in_nchw, const float* wgt_hwio, const float* scale, const float* shift,
                              float* out_nhwc, int B, int H, int W, int Cout, int KH, int KW, int stride, int pad,
                              fs_stream stream) {
+    return stem_entry(in_nchw, wgt_hwio, scale, shift, out_nhwc, B, H, W, Cout, KH, KW, stride, pad, 0, stream);
+}
+FS_API int fs_stem_conv_nchw_split(const float* in_nchw, const float* wgt_hwio, const float* scale, const float* shift,
+                                   float* out_nhwc, int B, int H, int W, int Cout, int KH, int KW, int stride, int pad,
+                                   fs_stream stream) {
+    return stem_entry(in_nchw, wgt_hwio, scale, shift, out_nhwc, B, H, W, Cout, KH, KW, stride, pad, 1, stream);
+}
+static int stem_entry(const float* in_nchw, const float* wgt_hwio, const float* scale, const float* shift, float* out_nhwc, int B, int H, int W, int Cout,
+                      int KH, int KW, int stride, int pad, int split, fs_stream stream) {
     if (!in_nchw || !wgt_hwio || !scale || !shift || !out_nhwc || B < 1) return fs::fail("fs_stem_conv_nchw: bad arguments");
     fs::StemParams p{};
     p.src = fs::frames_plain(in_nchw, nullptr, B);
@@ -456,6 +467,7 @@ FS_API int fs_stem_conv_nchw(const float* in_nchw, const float* wgt_hwio, const 
     p.KW = KW;
     p.stride = stride;
     p.pad = pad;
+    p.split = split;
     return fs::launch_stem_conv(p, S(stream));
 }
 FS_API int fs_maxpool3x3s2_nhwc(const float* in, float* out, int B, int H, int W, int C, fs_stream stream) {

@@ -470,7 +470,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_dma_f32(ConvParams 
 #ifdef FS_TRACE
     // experiment: de-phase the workgroups that share a CU (dispatch order puts bid and bid + 256 on the same CU)
     if ((p.dbg & 32) && ((bid >> 8) & 1))
-        for (int i = 0; i < (p.dbg >> 8); ++i) __builtin_amdgcn_s_sleep(16);  // 1024 cycles each
+        for (int i = 0; i < (p.dbg >> 8); ++i) __builtin_amdgcn_s_sleep(4);  // 256 cycles each
 #endif
     const int q = nblk >> 3, rr = nblk & 7, xcd = bid & 7;
     const int lid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (bid >> 3);

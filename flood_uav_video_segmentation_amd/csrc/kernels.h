@@ -46,7 +46,7 @@ struct ConvParams {
     unsigned plane_bytes;
 #ifdef FS_TRACE  // tools/probe_conv_trace.hip builds only -- the field does not exist in libfloodseg.so
     int dbg;     // timing experiments (results are wrong when != 0): 2 = one block per CU, 16 = skip the epilogue,
-                 // 32 | n << 8 = start workgroups bid+256.. n*1024 cycles late
+                 // 32 | n << 8 = start workgroups bid+256.. n*256 cycles late
 #endif
 };
 // tile: 0 = heuristic, 1 = 128x128, 2 = 128x64, 3 = 64x64, 4 = 64x128
@@ -109,6 +109,7 @@ struct StemParams {
     const float* scale; const float* shift;
     float* out; int ld_out;  // NHWC [B,Ho,Wo,Cout]
     int B, H, W, Ho, Wo, Cout, KH, KW, stride, pad;
+    int split;  // != 0: the split-operand route (three bf16 terms per fp32 value, bf16 matrix cores, fp32 accumulation), round 5
 };
 int launch_stem_conv(const StemParams& p, hipStream_t s);
 

@@ -769,8 +769,9 @@ int encoder_core(fs_handle h, const FrameSrc& src, int B, int H, int W, float* o
         p.KW = c.KW;
         p.stride = c.stride;
         p.pad = c.pad;
+        p.split = h->use_split;
         const double M = (double)B * g.H1 * g.W1;
-        FS_TRY(prof_begin(h, c.name, "stem_conv", 2.0 * M * c.Cout * c.KH * c.KW * 3, 4.0 * (B * 3.0 * H * W + M * c.Cout), s));
+        FS_TRY(prof_begin(h, c.name, h->use_split ? "stem_conv_split" : "stem_conv", 2.0 * M * c.Cout * c.KH * c.KW * 3, 4.0 * (B * 3.0 * H * W + M * c.Cout), s));
         FS_TRY(launch_stem_conv(p, s));
         FS_TRY(prof_end(h, s));
     }

@@ -164,6 +164,134 @@ __global__ __launch_bounds__(256) void stem_conv_mfma_kernel(StemParams p, int k
     }
 }
 
+// -------------------------------------------------------------------------------------------
+// (round 5) The same implicit GEMM on the bf16 matrix cores with SPLIT operands, the arithmetic of conv_igemm_dma_f32<SPLIT>: every
+// fp32 pixel and filter value as the exact sum of three bf16 terms, six of the nine cross products on v_mfma_f32_32x32x16_bf16 with
+// fp32 accumulation (the dropped ones are <= 2^-23 of a product).  Why here: five waves per SIMD shared the fp32 matrix pipe for
+// 32 x 64 cycles each and a wave lived 29.7 k cycles for its ONE tile (r04_experiments.txt section 4); the split form needs 12 x NT MFMAs
+// of 32 cycles per 16 taps instead of 8 x NT of 64 -- 2.7x less matrix time per tile -- and requests the NEXT step's taps before it
+// multiplies the current ones.  A lane (i = l & 31, h = l >> 5) owns taps 16 s + 8 h .. + 7 of pixel i in step s; the filter bank is
+// split once per workgroup into LDS as ready-made B fragments [plane][step][h][Cout][8 bf16].
+// -------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8s __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2s __attribute__((ext_vector_type(2)));
+typedef float f32x2s __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4s __attribute__((ext_vector_type(4)));
+
+template <int NT /* 32-channel sub-tiles */>
+__global__ __launch_bounds__(256) void stem_conv_split_kernel(StemParams p, int nsteps) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int taps = p.KH * p.KW * 3, kpad = 16 * nsteps;
+    u32x4s* wl = reinterpret_cast<u32x4s*>(smem);                              // [(pl * nsteps + s) * 2 + h][Cout] x 8 bf16
+    int* koff = reinterpret_cast<int*>(smem) + 3 * (kpad / 2) * p.Cout;        // [kpad]: element offset of tap k from the patch origin
+    int* kyx = koff + kpad;                                                    // [kpad]: ky << 16 | kx
+    const int rowW = p.src.ncrops ? p.src.FW : p.W;
+    const long long plane = p.src.ncrops ? (long long)p.src.FH * p.src.FW : (long long)p.H * p.W;
+    for (int idx = threadIdx.x; idx < nsteps * 2 * p.Cout; idx += 256) {
+        const int n = idx % p.Cout, sh_ = idx / p.Cout, hh = sh_ & 1, st = sh_ >> 1;
+        u32x4s q[3];
+#pragma unroll
+        for (int e = 0; e < 8; e += 2) {
+            float w[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int k = 16 * st + 8 * hh + e + u;
+                w[u] = k < taps ? p.wgt[k * p.Cout + n] : 0.f;  // padding taps carry zero weights
+            }
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+                const unsigned pk = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2s){w[0], w[1]}, bf16x2s));
+                q[pl][e >> 1] = pk;
+                w[0] -= __builtin_bit_cast(float, pk << 16);
+                w[1] -= __builtin_bit_cast(float, pk & 0xffff0000u);
+            }
+        }
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) wl[((pl * nsteps + st) * 2 + hh) * p.Cout + n] = q[pl];
+    }
+    for (int k = threadIdx.x; k < kpad; k += 256) {
+        const int kk = k < taps ? k : 0;  // k = (ky*KW + kx)*3 + ci
+        const int ci = kk % 3, kx = (kk / 3) % p.KW, ky = kk / (3 * p.KW);
+        koff[k] = (int)(ci * plane + (long long)ky * rowW + kx);
+        kyx[k] = k < taps ? (ky << 16 | kx) : (0x7fff << 16);  // padding taps: a row index no image has
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 31, h = lane >> 5;
+    const int M = p.B * p.Ho * p.Wo, hw = p.Ho * p.Wo;
+    const int tiles = (M + 31) / 32;
+    for (int tile = blockIdx.x * 4 + wave; tile < tiles; tile += gridDim.x * 4) {
+        const int m = tile * 32 + i;
+        const bool mok = m < M;
+        const int mm = mok ? m : 0;
+        const int b = mm / hw, rem = mm - b * hw;
+        const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+        const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;
+        const float* inb;
+        if (p.src.ncrops) {
+            const int c = b < p.src.ncrops ? b : b - p.src.ncrops;
+            inb = (b < p.src.ncrops ? p.src.in : p.src.in2) + (size_t)p.src.cy[c] * rowW + p.src.cx[c];
+        } else {
+            inb = b < p.src.B1 ? p.src.in + (size_t)b * 3 * plane : p.src.in2 + (size_t)(b - p.src.B1) * 3 * plane;
+        }
+        const float* origin = inb + (long long)iy0 * rowW + ix0;  // may point before the frame: only dereferenced for in-range taps
+        f32x16 acc[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+        auto gather = [&](int st, float (&av)[8]) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int k = 16 * st + 8 * h + e;
+                const int yx = kyx[k];
+                const int iy = iy0 + (yx >> 16), ix = ix0 + (yx & 0xffff);
+                const bool ok = mok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+                av[e] = ok ? origin[koff[k]] : 0.f;
+            }
+        };
+        float cur[8], nxt[8];
+        gather(0, cur);
+        for (int st = 0; st < nsteps; ++st) {
+            if (st + 1 < nsteps) gather(st + 1, nxt);  // in flight under this step's split + MFMAs
+            u32x4s a3[3];
+#pragma unroll
+            for (int e = 0; e < 8; e += 2) {
+                float x0 = cur[e], x1 = cur[e + 1];
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) {
+                    const unsigned pk = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2s){x0, x1}, bf16x2s));
+                    a3[pl][e >> 1] = pk;
+                    x0 -= __builtin_bit_cast(float, pk << 16);
+                    x1 -= __builtin_bit_cast(float, pk & 0xffff0000u);
+                }
+            }
+            // the six products of order <= 2^-16, smallest first: l h', h l', m m', m h', h m', h h'
+            constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+            for (int term = 0; term < 6; ++term)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8s, a3[PA[term]]),
+                                                                     __builtin_bit_cast(bf16x8s, wl[((PB[term] * nsteps + st) * 2 + h) * p.Cout + j * 32 + i]), acc[j], 0, 0, 0);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) cur[e] = nxt[e];
+        }
+        // D layout: col n = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * h: every store instruction writes two 128-B channel runs
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int n = j * 32 + i;
+            const float sc = p.scale[n], sh = p.shift[n];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int mr = tile * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                if (mr < M) p.out[(size_t)mr * p.ld_out + n] = fmaxf(acc[j][e] * sc + sh, 0.f);
+            }
+        }
+    }
+#endif
+}
+
 int launch_stem_conv(const StemParams& p, hipStream_t s) {
     FS_REQUIRE(p.Cout >= 16 && p.Cout <= 256 && p.Cout % 16 == 0, "stem_conv: unsupported Cout=%d", p.Cout);
     FS_REQUIRE(p.ld_out % 4 == 0, "stem_conv: ld_out must be a multiple of 4");
@@ -178,6 +306,29 @@ int launch_stem_conv(const StemParams& p, hipStream_t s) {
     }
     const int M = p.B * p.Ho * p.Wo;
     const int taps = p.KH * p.KW * 3;
+    if (p.split && p.Cout % 32 == 0 && p.Cout <= 128 && p.KH < 0x7fff) {  // split-operand route: bf16 matrix cores, fp32 accuracy
+        const int nsteps = cdiv(taps, 16);
+        const size_t lds = (size_t)3 * 16 * nsteps * p.Cout * 2 + (size_t)2 * 16 * nsteps * sizeof(int);
+        FS_REQUIRE(lds <= 150 * 1024, "stem_conv: filter planes %zu B exceed the LDS budget", lds);
+        FS_REQUIRE((long long)3 * (f.ncrops ? (long long)f.FH * f.FW : (long long)p.H * p.W) < (1ll << 31), "stem_conv: frame too large for 32-bit tap offsets");
+        const int tiles = cdiv(M, 32);
+        const dim3 grid((unsigned)std::min(cdiv(tiles, 4), 256 * 8));
+#define FS_STEM_SPLIT(NT_)                                                                                                       \
+    {                                                                                                                            \
+        if (lds > 64 * 1024)                                                                                                     \
+            FS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_conv_split_kernel<NT_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL((stem_conv_split_kernel<NT_>), grid, dim3(256), lds, s, p, nsteps);                                   \
+    }
+        switch (p.Cout / 32) {
+            case 1: FS_STEM_SPLIT(1) break;
+            case 2: FS_STEM_SPLIT(2) break;
+            case 3: FS_STEM_SPLIT(3) break;
+            default: FS_STEM_SPLIT(4) break;
+        }
+#undef FS_STEM_SPLIT
+        FS_HIP(hipGetLastError());
+        return 0;
+    }
     if (p.Cout % 32 == 0 && p.Cout <= 128 && p.KH < 0x7fff) {  // matrix-core route
         const int ksteps = cdiv(cdiv(taps, 2), 8) * 8;  // whole batches of 8 MFMA k-steps; the padding taps carry zero weights
         const size_t lds = (size_t)2 * ksteps * (p.Cout + 2) * sizeof(float);

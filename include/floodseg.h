@@ -292,6 +292,10 @@ int fs_conv3x3_winograd_fused_nhwc(const float* in, int ld_in, const float* wgt_
 /* wgt_hwio: [KH][KW][3][Cout] (weight.permute(2,3,1,0)) */
 int fs_stem_conv_nchw(const float* in_nchw, const float* wgt_hwio, const float* scale, const float* shift, float* out_nhwc,
                       int B, int H, int W, int Cout, int KH, int KW, int stride, int pad, fs_stream stream);
+/* Round 5: the same stem convolution with split operands (three bf16 terms per fp32 value, six cross products on the bf16 matrix cores,
+ * fp32 accumulation: the arithmetic of fs_conv2d_nhwc_split); what the network handles run unless FS_OPT_NO_SPLIT_BF16.  Cout % 32 == 0, <= 128. */
+int fs_stem_conv_nchw_split(const float* in_nchw, const float* wgt_hwio, const float* scale, const float* shift, float* out_nhwc,
+                      int B, int H, int W, int Cout, int KH, int KW, int stride, int pad, fs_stream stream);
 /* Round 5: fs_conv3x3_winograd_fused_nhwc (+ BatchNorm + ReLU) followed by MaxPool2d(3, stride 2, padding 1) as ONE launch (the
  * deep stem's layer0.6 + max-pool): pool = [B][(H-1)/2+1][(W-1)/2+1][Cout]; bit-identical to the two calls it replaces. */
 int fs_conv3x3_winograd_fused_pool_nhwc(const float* in, int ld_in, const float* wgt_oihw, const float* scale, const float* shift, float* pool,

@@ -291,6 +291,19 @@ def test_stem_conv(k, stride, pad, cout):
     xd, wd, scd, shd = x.to(DEV), wt.permute(2, 3, 1, 0).contiguous().to(DEV), sc.to(DEV), sh.to(DEV)
     check(lib.fs_stem_conv_nchw(ptr(xd), ptr(wd), ptr(scd), ptr(shd), ptr(out), 2, 65, 71, cout, k, k, stride, pad, stream_ptr()))
     assert rel(out.permute(0, 3, 1, 2), ref) < CONV_TOL
+    if cout % 32 == 0:
+        # round 5: the split-operand form (bf16 matrix cores, three bf16 terms per fp32 value): what the networks run.  Same tolerance,
+        # and against a float64 convolution of the same fp32 inputs its error is within 1.5x of the fp32-MFMA kernel's
+        out3 = torch.empty_like(out)
+        check(lib.fs_stem_conv_nchw_split(ptr(xd), ptr(wd), ptr(scd), ptr(shd), ptr(out3), 2, 65, 71, cout, k, k, stride, pad, stream_ptr()))
+        assert rel(out3.permute(0, 3, 1, 2), ref) < CONV_TOL
+        ref64 = (F.conv2d(x.double(), wt.double(), None, stride, pad) * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1)).relu()
+        e3, e1 = rel(out3.permute(0, 3, 1, 2).double(), ref64), rel(out.permute(0, 3, 1, 2).double(), ref64)
+        note(f"stem_split_vs_f64_k{k}_s{stride}_c{cout}", e3)
+        assert e3 < 1.5 * e1 + 1e-7, (e3, e1)
+        again = torch.empty_like(out)
+        check(lib.fs_stem_conv_nchw_split(ptr(xd), ptr(wd), ptr(scd), ptr(shd), ptr(again), 2, 65, 71, cout, k, k, stride, pad, stream_ptr()))
+        assert torch.equal(again, out3)
 
 
 def test_maxpool_and_adaptive_avgpool():

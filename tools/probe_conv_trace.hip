@@ -69,6 +69,17 @@ int main(int argc, char** argv) {
     const int warm = getenv("FS_WARM") ? atoi(getenv("FS_WARM")) : 20;  // launches before the traced one (a long run shows the clock the card SUSTAINS)
     for (int i = 0; i < warm; ++i) if (fs::launch_conv_igemm(p, 0, tile)) return 4;
     hipDeviceSynchronize();
+    if (getenv("FS_AVG")) {  // average of N back-to-back launches instead of one traced launch (A/B of a dbg setting); no timeline dump
+        const int n = atoi(getenv("FS_AVG"));
+        hipEventRecord(e0, 0);
+        for (int i = 0; i < n; ++i) if (fs::launch_conv_igemm(p, 0, tile)) return 4;
+        hipEventRecord(e1, 0);
+        hipDeviceSynchronize();
+        float t = 0;
+        hipEventElapsedTime(&t, e0, e1);
+        printf("avg %.2f us over %d launches (dbg=%d)\n", 1e3 * t / n, n, p.dbg);
+        return 0;
+    }
     hipEventRecord(e0, 0);
     if (fs::launch_conv_igemm(p, 0, tile)) return 4;
     hipEventRecord(e1, 0);
