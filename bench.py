@@ -711,6 +711,13 @@ def variants(args, dev, rdev, net, state, fm, windows, dl, dr, host_masks, host_
             host_ring[(w % 4) * N_DELTA:(w % 4 + 1) * N_DELTA].copy_(masks, non_blocking=True)  # every window's masks go to the host
         torch.cuda.current_stream().synchronize()
     run("fps_keyframe_cache_lookahead_long_clip", step_long, long_steps, LONG_WINDOWS * N_DELTA, warm=1)
+
+    # ... and with FOUR new key frames per network pass (predict_clip(keys_per_pass=4): three windows of look-ahead)
+    def step_long4(i):
+        for w, masks in enumerate(pclip.predict_clip(long_items, to_host=False, keys_per_pass=4)):
+            host_ring[(w % 4) * N_DELTA:(w % 4 + 1) * N_DELTA].copy_(masks, non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+    run("fps_keyframe_cache_lookahead_long_clip_4_keys_per_pass", step_long4, long_steps, LONG_WINDOWS * N_DELTA, warm=1)
     out["long_clip"] = {"windows": LONG_WINDOWS, "key_frames_segmented": LONG_WINDOWS + 1, "frames": LONG_WINDOWS * N_DELTA, "clips_timed": long_steps,
                         "note": "FlowPredictor.predict_clip: key-frame cache + one window of look-ahead; masks of every window copied to the host; "
                                 "bit-identical to the uncached windows (tests/test_gpu_fullsize.py)"}

@@ -77,7 +77,7 @@ class FlowPredictor:
                     self.hist = ops.iou_hist(masks[p], prev, self.classes, self.ignore_index, self.hist)
             self.last_output = masks[n - 1].clone()
 
-    def predict_clip(self, items, profiler=None, to_host=True):
+    def predict_clip(self, items, profiler=None, to_host=True, keys_per_pass=2):
         """A clip's consecutive windows (dicts as PredictWindows yields them: frame_prev, frame_next, mvs_left, mvs_right,
         key_ids) with the key-frame cache AND look-ahead: key frames go through the network two at a time (each exactly once),
         and a window is emitted as soon as both of its key frames are there -- every key frame at the efficiency of a full batch
@@ -88,13 +88,19 @@ class FlowPredictor:
         windows' frames (and three key frames' low-resolution logits) are alive at once, however long the clip -- a lazily
         loading iterable such as PredictWindows streams.  Segmentation mode (whole frame or sliding crops); feature mode, a
         network without a fused `segment`, or a window without key_ids take predict_window with a cache that lives for this
-        clip only (the predictor's own cache, when it has one)."""
+        clip only (the predictor's own cache, when it has one).
+
+        keys_per_pass (round 5; whole-frame route): how many NEW key frames go through the network per pass.  2 = one window of
+        look-ahead.  4 or 6 trade latency (that many windows are pulled ahead) for throughput: a pass over four frames costs 8 % less per
+        frame than two passes over two (11 % at six; profiles/r05_experiments.txt section 9) -- every launch of layers 1-3 is short enough
+        to be bound by its fixed cost.  Masks stay bit-identical (a frame's network output does not depend on its batch)."""
         from collections import deque
 
         from .model import KeyframeCache, _region
 
         fm = self.model
         lookahead = not getattr(fm, "feature_based", True) and hasattr(fm.model, "segment") and hasattr(fm.model, "encode_frames")
+        group = max(2, int(keys_per_pass)) if self.crop is None else 2  # the sliding-crop route batches the crops of TWO frames
         local_cache = self.key_cache if self.key_cache is not None else KeyframeCache()
         store = {}         # frame id -> decoder logits of that key frame ([1,K,fh,fw]; [ncrops,K,fh,fw] on the sliding-crop route)
         queue = []         # key frames not segmented yet, in order of first use: (frame id, tensor)
@@ -103,7 +109,7 @@ class FlowPredictor:
         it = iter(items)
         exhausted = False
 
-        def run(frames):  # one or two key frames through the network as ONE batch
+        def run(frames):  # the queued key frames (up to `group`) through the network as ONE batch
             with _region(profiler, "predict_encoder"), _region(profiler, "predict_decoder"):
                 if self.crop is None:
                     lows = fm._segment(*frames)
@@ -132,7 +138,7 @@ class FlowPredictor:
 
         while True:
             plain = None  # a window that cannot take the look-ahead route (no key_ids / feature mode / foreign network)
-            while len(queue) < 2 and not exhausted and plain is None:
+            while len(queue) < group and not exhausted and plain is None:
                 if pending and not queue and all(k in store for k in pending[0]["key_ids"]):
                     break  # nothing to wait for: emit before pulling more
                 try:
@@ -147,9 +153,9 @@ class FlowPredictor:
                 for fid, t in zip(w["key_ids"], (w["frame_prev"], w["frame_next"])):
                     if fid not in store and all(fid != q for q, _ in queue):
                         queue.append((fid, t))
-            # segment what is queued: pairs while there are pairs; a lone frame only when nothing can join it any more
-            while len(queue) >= 2 or (queue and (exhausted or plain is not None)):
-                pair, queue = queue[:2], queue[2:]
+            # segment what is queued: full groups while there are full groups; a smaller one only when nothing can join it any more
+            while len(queue) >= group or (queue and (exhausted or plain is not None)):
+                pair, queue = queue[:group], queue[group:]
                 for (fid, _), lo in zip(pair, run([t for _, t in pair])):
                     store[fid] = lo
             while pending and all(k in store for k in pending[0]["key_ids"]):

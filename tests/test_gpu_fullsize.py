@@ -777,6 +777,10 @@ def test_predict_clip_lookahead_batches_new_key_frames_and_is_bit_identical(psp,
             net._hip_net.segment_crops = real
     assert len(got) == nwin and all(torch.equal(g, w) for g, w in zip(got, want))
     assert torch.equal(look.hist, plain.hist)
+    if crop is None:  # r5: four new key frames per pass (three windows of look-ahead): the same masks, bit for bit
+        look4 = FlowPredictor(fm, 5, plain.out_size, crop=crop)
+        got4 = list(look4.predict_clip(items, to_host=False, keys_per_pass=4))
+        assert len(got4) == nwin and all(torch.equal(g, w) for g, w in zip(got4, want)) and torch.equal(look4.hist, plain.hist)
     chunks = 1 if crop is None else -(-len(crops.crop_windows(size[0], size[1], crop[0], crop[1])) // 8)  # crop batches per frame pair
     assert sum(calls) == (nwin + 1) * chunks  # every key frame once ...
     assert calls.count(2) == (nwin + 1) // 2 * chunks and calls.count(1) == (nwin + 1) % 2 * chunks  # ... two at a time
