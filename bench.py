@@ -233,19 +233,20 @@ STEADY_MIN_TIMED_S = 0.5   # a timed region shorter than this gets a steady-stat
 STEADY_BLOCK_S = 0.8       # ... of at least this long
 
 
-def steady_state_block(step, est_step_s, torch):
+def steady_state_block(step, torch):
     """A caller's `--steps K` may time well under a second (the driver: 20 windows = 0.08 s), and on this chip the clock a card
     holds depends on what ran in the last tens of milliseconds (profiles/r04_experiments.txt section 1).  So next to -- never instead
     of -- such a headline, the same step looped for >= 0.8 s right after the timed region, with per-step stamps and the card's
     shader clock sampled meanwhile: a box that had not reached its held clock in the timed region shows up as a gap between the two."""
-    n = max(20, min(20000, int(STEADY_BLOCK_S / max(est_step_s, 1e-5)) + 1))
     cs = ClockSampler(torch, 0.004)
     per = []
     torch.cuda.synchronize()
     with cs:
         t0 = tp = time.perf_counter()
-        for i in range(n):
-            step(i)
+        n = 0
+        while n < 20 or (tp - t0 < STEADY_BLOCK_S and n < 200000):  # by the clock, not by an estimate: the block IS at least 0.8 s long
+            step(n)
+            n += 1
             tn = time.perf_counter()
             per.append(tn - tp)
             tp = tn
@@ -509,7 +510,7 @@ def main():
     per_rank = shard.gather_floats([elapsed / args.steps * 1e3, median(step_s) * 1e3, marks["first_timed_step"] - t_ref], rdev)
     # a short timed region says little about the clock the card settles at: the same step for >= 0.8 s right behind it (every rank
     # runs it, so the ranks stay symmetric; rank 0 reports its own)
-    steady = steady_state_block(step_native, elapsed / args.steps, torch) if elapsed < STEADY_MIN_TIMED_S else None
+    steady = steady_state_block(step_native, torch) if elapsed < STEADY_MIN_TIMED_S else None
 
     result = {
         "metric": "segmentation FPS @713x713 (PSPNet-ResNet50 keyframe + linear interp, frame_delta=5)",

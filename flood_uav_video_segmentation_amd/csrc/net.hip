@@ -82,7 +82,7 @@ int to_host(const RawTensor& t, std::vector<float>& v) {
 namespace {
 
 bool wino_eligible(const ConvBN& c, bool hwio) {
-    return !hwio && c.KH == 3 && c.KW == 3 && c.stride == 1 && c.pad == c.dil && c.Cin >= 256 && c.Cin % 32 == 0 && c.Cout % 4 == 0;
+    return !hwio && c.KH == 3 && c.KW == 3 && c.stride == 1 && c.pad == c.dil && c.Cin >= 128 && c.Cin % 32 == 0 && c.Cout % 4 == 0;
 }
 
 // The F(mt x mt, 3x3) filter bank of a Winograd-eligible conv, transformed (in double, rounded once) from the direct kernel's
@@ -274,6 +274,11 @@ int run_conv_winograd(fs_net* h, const ConvBN& c, const float* in, int ld_in, in
 // tile-edge / lattice-phase waste (large dilations on a small map leave mostly-empty tiles): 36*T < 0.8 * 9*M
 bool takes_winograd(const fs_net* h, const ConvBN& c, int B, int H, int W, bool has_res) {
     if (!(c.wino && h->use_winograd && !has_res)) return false;
+    // Round 5: the 128-channel convs (conv2 of layer2) have both Winograd forms.  The one-kernel form (wino_fused.hip) is a serial chain of
+    // Cin / 16 stages per workgroup: while one image gives it >= 1500 4x4 tiles it fills the chip several rounds deep and wins; on layer2's
+    // 90 x 90 map (529 tiles per image: 134 workgroups for a key-frame pair, 8 stages each) the three-launch form is faster -- 34 vs 38 us
+    // at B = 2, 26 vs 37 us at B = 1 (profiles/r05_experiments.txt section 10).  Decided on ONE image's geometry, never on the batch.
+    if (c.Cin < 256 && c.wf && h->use_fused_winograd && (long)cdiv(H, 4) * cdiv(W, 4) >= 1500) return false;
     const int mt = h->wino_force_m ? h->wino_force_m : winograd_pick_m(B, H, W, c.dil);
     const double wino_rows = (double)(mt + 2) * (mt + 2) * winograd_tiles(B, H, W, c.dil, mt);
     const double direct_rows = 9.0 * (double)B * c.out_size(H) * c.out_size(W);
