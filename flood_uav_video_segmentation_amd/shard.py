@@ -17,17 +17,27 @@ def world():
     return int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
 
 
+def init_group(backend, rank, local_rank, size):
+    """dist.init_process_group for this path.  RCCL ("nccl"): the rank's GPU is made current first AND named as `device_id`, which
+    binds the process group to that device and creates its communicator eagerly -- every later collective and barrier runs on
+    this GPU without any device guessing, and an IPC / RCCL set-up failure surfaces HERE, before any work (what bench.py's
+    launcher looks for on stderr), not inside the first collective at the end of the run."""
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29511")
+    if backend == "nccl":
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend=backend, rank=rank, world_size=size, device_id=torch.device("cuda", local_rank))
+    else:
+        dist.init_process_group(backend=backend, rank=rank, world_size=size)
+
+
 def init(backend=None):
     """Initialise torch.distributed when launched with WORLD_SIZE > 1; returns (rank, local_rank, world_size)."""
     rank, local_rank, size = world()
     if size > 1 and not dist.is_initialized():
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29511")
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
-        if backend == "nccl":
-            torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend=backend, rank=rank, world_size=size)
+        init_group(backend, rank, local_rank, size)
     return rank, local_rank, size
 
 

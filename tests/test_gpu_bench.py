@@ -120,9 +120,8 @@ sys.path.insert(0, %r)
 os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=%r)
 import torch.distributed as dist
 from flood_uav_video_segmentation_amd import shard
-torch.cuda.set_device(0)
-dist.init_process_group(backend="nccl", rank=0, world_size=1)
-assert shard.describe() == ("nccl", 1)
+shard.init_group("nccl", 0, 0, 1)   # the call an N > 1 rank makes: GPU made current, device_id bound, communicator created eagerly
+assert shard.describe() == ("nccl", 1) and torch.cuda.current_device() == 0
 dev = torch.device("cuda", 0)
 shard.barrier(dev)
 hist, frames, sec = shard.reduce_run(torch.arange(15).view(3, 5), 20, 1.5, dev)
