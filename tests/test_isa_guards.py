@@ -56,3 +56,25 @@ def test_conv_kernel_waits_for_its_lds_dma_before_every_barrier(tmp_path):
     assert checked - attention - planes >= 10, f"expected the fp32 and the split-operand tile instantiations, found {checked - attention - planes}"
     assert planes >= 2, f"expected the 256 x 128 and 256 x 64 instantiations of gemm_planes_bf16x3, found {planes}"
     assert attention == 4, f"expected attention_dma_kernel and attention_bf16x3_kernel, key split / no split each, found {attention}"
+
+
+def test_no_float_atomics_anywhere_and_the_fused_maxpool_uses_integer_max(tmp_path):
+    """Bit-repeatability rests on this: the library contains NO floating-point atomic (their result depends on the order of
+    arrival).  The one atomic it has (round 5) is the signed-integer max of the stem's fused max-pool -- exact and order-independent
+    on values that are >= +0 -- and it lives in wino4_fused_kernel<1, 4, true> only."""
+    dis = _device_disassembly(str(tmp_path))
+    kernels = re.split(r"\n(?=[0-9a-f]+ <[^>]+>:)", dis)
+    with_atomics = {}
+    for k in kernels:
+        head = k.split("\n", 1)[0]
+        ops = [l.split("\t", 1)[-1].strip() for l in k.splitlines()[1:] if "\t" in l]
+        atomics = sorted({o.split()[0] for o in ops if "atomic" in o.split()[0]})
+        if atomics:
+            with_atomics[head] = atomics
+    floaty = {h: a for h, a in with_atomics.items() if any(re.search(r"f32|f64|f16|bf16|fadd|fmin|fmax", x) for x in a)}
+    assert not floaty, f"floating-point atomics found: {floaty}"
+    pool = [h for h in with_atomics if "wino4_fused_kernel" in h and "Lb1E" in h]
+    assert pool and all(any("smax" in x for x in with_atomics[h]) for h in pool), with_atomics
+    # every other atomic in the library is an integer one as well (histograms: iou_hist / mv_to_grids)
+    for h, a in with_atomics.items():
+        assert all(re.search(r"atomic_(add|smax|umax|umin|smin|inc|or|and|cmpswap|swap)(_x2)?(_u32|_u64|_i32|_b32|_b64)?$", x) for x in a), (h, a)
