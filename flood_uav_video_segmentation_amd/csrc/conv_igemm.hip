@@ -64,10 +64,17 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // [0] start, [1] first stage landed, [2] main loop done, [3] epilogue done (shader clock, s_memtime),
 // [4] cycles spent in the per-chunk wait+barrier, [5] HW_ID | XCC_ID << 32, [6] start (100 MHz wall clock), [7] end (wall)
 __device__ unsigned long long fs_trace_buf[8 * 65536];
-#define FS_TRACE_DECL unsigned long long tr_start = __builtin_readcyclecounter(), tr_wall = wall_clock64(), tr_ready = 0, tr_loop = 0, tr_wait = 0;
+// round 5: end-of-chunk stamps of the first 8 K chunks of the split main loop (scalar registers; written out by lane 0 at the end)
+__device__ unsigned long long fs_trace_chunks[8 * 65536];
+#define FS_TRACE_DECL unsigned long long tr_start = __builtin_readcyclecounter(), tr_wall = wall_clock64(), tr_ready = 0, tr_loop = 0, tr_wait = 0; \
+    unsigned long long tr_c0 = 0, tr_c1 = 0, tr_c2 = 0, tr_c3 = 0, tr_c4 = 0, tr_c5 = 0, tr_c6 = 0, tr_c7 = 0;
+#define FS_TRACE_CHUNK(KC_) { const unsigned long long tc_ = __builtin_readcyclecounter(); \
+    if ((KC_) == 0) tr_c0 = tc_; else if ((KC_) == 1) tr_c1 = tc_; else if ((KC_) == 2) tr_c2 = tc_; else if ((KC_) == 3) tr_c3 = tc_; \
+    else if ((KC_) == 4) tr_c4 = tc_; else if ((KC_) == 5) tr_c5 = tc_; else if ((KC_) == 6) tr_c6 = tc_; else if ((KC_) == 7) tr_c7 = tc_; }
 #define FS_TRACE_SYNC() { const unsigned long long tw = __builtin_readcyclecounter(); FS_DMA_PUBLISH() tr_wait += __builtin_readcyclecounter() - tw; }
 #else
 #define FS_TRACE_DECL
+#define FS_TRACE_CHUNK(KC_)
 #define FS_TRACE_SYNC() FS_DMA_PUBLISH()
 #endif
 // A wave's buffer_load...lds writes are complete when ITS vmcnt reaches 0; the other waves may read them only after that.
@@ -82,8 +89,10 @@ __device__ unsigned long long fs_trace_buf[8 * 65536];
 // map with its own pixel stride / conv stride.  A separate instantiation (no residual input: the shortcut IS the second
 // operand), so the plain kernel's register budget -- 252 of the 256 VGPRs that let two workgroups share a CU -- is untouched.
 // LDS floats of one workgroup: two stages of (pixel tile + filter tile)
-template <int BM, int BN, bool SPLIT>
-constexpr int conv_tile_lds_floats() { return 2 * (BM * 32 + (SPLIT ? 3 * BN * 16 : BN * 32)); }
+// (split filters are staged in whole 16-row groups per wave: a 96-column tile stages 128 rows, the last 32 of them zeros)
+constexpr int conv_split_rows(int BN, int waves) { return (BN / 16 + waves - 1) / waves * waves * 16; }
+template <int BM, int BN, bool SPLIT, int WAVES = 4>
+constexpr int conv_tile_lds_floats() { return 2 * (BM * 32 + (SPLIT ? 3 * conv_split_rows(BN, WAVES) * 16 : BN * 32)); }
 
 // One BM x BN output tile at (m0, n0): prologue, main loop, epilogue.  `lds` = conv_tile_lds_floats() floats, 1 KiB aligned; every
 // wave of the workgroup calls it with the same arguments.  A_AUX: cache-policy bits of the PIXEL operand's DMA loads (16 = sc1,
@@ -97,10 +106,11 @@ __device__ __forceinline__ void conv_tile(ConvParams p, const int m0, const int 
     constexpr int WM = BM / WGM, WN = BN / WGN;
     constexpr int TM = WM / 32, TN = WN / 32;
     // SPLIT: a filter row of a chunk is 3 planes x 32 bf16 = 3 x 64 B; one DMA wave-instruction covers 16 rows of one plane
-    constexpr int BPL = BN * 16;  // floats of LDS per filter plane and stage
-    constexpr int RA = BM / RSTEP, RB = SPLIT ? 3 * (BN / 16) / (NT / 64) : BN / RSTEP;
-    constexpr int RB1 = SPLIT ? (BN / 16) / (NT / 64) : RB;  // of them per plane
-    static_assert(!SPLIT || (BN / 16) % (NT / 64) == 0, "split filters: every wave stages whole 16-row groups");
+    constexpr int BNL = SPLIT ? conv_split_rows(BN, NT / 64) : BN;  // filter rows staged (>= BN: every wave stages whole 16-row groups)
+    constexpr int BPL = BNL * 16;  // floats of LDS per filter plane and stage
+    constexpr int RA = BM / RSTEP, RB = SPLIT ? 3 * (BNL / 16) / (NT / 64) : BN / RSTEP;
+    constexpr int RB1 = SPLIT ? (BNL / 16) / (NT / 64) : RB;  // of them per plane
+    static_assert(BN % 32 == 0 && WN % 32 == 0 && (SPLIT || BN % RSTEP == 0), "tile columns: whole 32-column MFMA blocks per wave");
     constexpr int STAGE = BM * BK + (SPLIT ? 3 * BPL : BN * BK);
     FS_TRACE_DECL
 
@@ -180,7 +190,7 @@ __device__ __forceinline__ void conv_tile(ConvParams p, const int m0, const int 
         for (int j = 0; j < RB1; ++j) {
             const int row = 16 * (wv + (NT / 64) * j) + (lane >> 2);
             const int n = n0 + row;
-            b_voff[j] = n < p.Cout ? (unsigned)(n * ldw * 2 + (((lane & 3) ^ ((row >> 2) & 3)) * 16)) : SENT;
+            b_voff[j] = (n < p.Cout && row < BN) ? (unsigned)(n * ldw * 2 + (((lane & 3) ^ ((row >> 2) & 3)) * 16)) : SENT;
         }
     } else {
 #pragma unroll
@@ -262,9 +272,25 @@ __device__ __forceinline__ void conv_tile(ConvParams p, const int m0, const int 
             _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                        \
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(A_[i][e], B_[j][e], acc[i][j], 0, 0, 0);
 
+    // Round 5: BOTH stages are requested before the first wait.  The per-chunk stamps of the trace build (profiles/r05_experiments.txt
+    // section 12) showed what a tile's first chunk cost: 7.9 k cycles against 3.0 k in the steady state -- the second stage used to be
+    // requested only after the first had landed, so its whole memory latency (cold, with every workgroup of the launch starting at
+    // once) stood behind half a chunk of MFMAs.  A wave's vector-memory operations complete in order, so "all but the RA + RB youngest"
+    // = "this wave's stage-0 tiles have landed" (tests/test_isa_guards.py checks that exactly RA + RB LDS-DMAs sit between).
     FS_DMA_ALL(0)
     FS_DMA_ADVANCE()
-    FS_DMA_PUBLISH()  // stage 0 has landed for every wave
+    if (nchunks > 1) {
+        FS_DMA_ALL(1)
+        FS_DMA_ADVANCE()
+        constexpr int NV = RA + RB;  // vmcnt is split over bits [3:0] and [15:14] of the s_waitcnt immediate; expcnt (6:4) = no wait, lgkmcnt (11:8) = 0
+        static_assert(NV < 64, "stage DMA count must fit the vmcnt field");
+        __builtin_amdgcn_s_waitcnt((NV & 15) | ((NV >> 4) << 14) | 0x0070);
+        __builtin_amdgcn_s_barrier();  // stage 0 has landed for every wave; stage 1 stays in flight (a bare s_barrier: __syncthreads()'s
+                                        // release fence would make the compiler wait for vmcnt(0) again)
+        __builtin_amdgcn_sched_barrier(0);
+    } else {
+        FS_DMA_PUBLISH()  // stage 0 has landed for every wave
+    }
 #ifdef FS_TRACE
     tr_ready = __builtin_readcyclecounter();
 #endif
@@ -281,10 +307,6 @@ __device__ __forceinline__ void conv_tile(ConvParams p, const int m0, const int 
         const int n = en_base + j * 32;
         sc_n[j] = (n < p.Cout && p.scale) ? p.scale[n] : 1.f;
         sh_n[j] = (n < p.Cout && p.shift) ? p.shift[n] : 0.f;
-    }
-    if (nchunks > 1) {
-        FS_DMA_ALL(1)
-        FS_DMA_ADVANCE()
     }
     if constexpr (SPLIT) {
         // Split operands: every fp32 value x is the exact sum h + m + l of three bf16 terms (h = bf16(x), m = bf16(x - h),
@@ -382,13 +404,14 @@ __device__ __forceinline__ void conv_tile(ConvParams p, const int m0, const int 
                 const bool ok = trow < BM && n0 + tline * 32 < p.Cout;
                 const unsigned vo = ok ? (unsigned)((m0 + trow) * p.ld_res + n0 + tline * 32) * 4u : 0x80000000u;
                 touch0 = __builtin_amdgcn_raw_buffer_load_b32(t_rsrc, vo, 0, 0);
-                touch1 = __builtin_amdgcn_raw_buffer_load_b32(t_rsrc, (ok && n0 + (tline + 1) * 32 < p.Cout && LPR > 1) ? vo + 128u : 0x80000000u, 0, 0);
+                touch1 = __builtin_amdgcn_raw_buffer_load_b32(t_rsrc, (ok && tline + 1 < LPR && n0 + (tline + 1) * 32 < p.Cout) ? vo + 128u : 0x80000000u, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
             FS_READ3(cur ^ 1, 0, araw, B3)  // (after the last chunk: a stale stage, read and never used)
             __builtin_amdgcn_sched_barrier(0);
             FS_STEP3(A3n, B3n, araw, A3)
             __builtin_amdgcn_sched_barrier(0);
+            FS_TRACE_CHUNK(kc)
             cur ^= 1;
         }
         asm volatile("" ::"v"(touch0), "v"(touch1));  // keeps the two dead loads (and their registers) alive to here
@@ -456,6 +479,8 @@ __device__ __forceinline__ void conv_tile(ConvParams p, const int m0, const int 
         o[0] = tr_start; o[1] = tr_ready; o[2] = tr_loop; o[3] = __builtin_readcyclecounter(); o[4] = tr_wait;
         o[5] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
         o[6] = tr_wall; o[7] = wall_clock64();
+        unsigned long long* c = fs_trace_chunks + 8 * (size_t)(bid & 65535);
+        c[0] = tr_c0; c[1] = tr_c1; c[2] = tr_c2; c[3] = tr_c3; c[4] = tr_c4; c[5] = tr_c5; c[6] = tr_c6; c[7] = tr_c7;
     }
 #endif
 #endif
@@ -465,7 +490,7 @@ template <int BM, int BN, int WGM = 2, int WGN = 2, bool DUAL = false, bool SPLI
 __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_dma_f32(ConvParams p, int tiles_m, int tiles_n) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int PM = 8;  // m-tiles per raster panel (panels sized to the ~64 tiles co-resident on an XCD: same time, +3 % L2 misses)
-    __shared__ __attribute__((aligned(1024))) float lds[conv_tile_lds_floats<BM, BN, SPLIT>()];
+    __shared__ __attribute__((aligned(1024))) float lds[conv_tile_lds_floats<BM, BN, SPLIT, WGM * WGN>()];
     const int nblk = gridDim.x, bid = blockIdx.x;
 #ifdef FS_TRACE
     // experiment: de-phase the workgroups that share a CU (dispatch order puts bid and bid + 256 on the same CU)
@@ -531,18 +556,23 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_chain_dma_f32(ConvParams 
 
 namespace {
 struct TileCfg { int bm, bn; const char* name; };
-const TileCfg kTiles[6] = {{0, 0, "auto"}, {128, 128, "igemm128x128"}, {128, 64, "igemm128x64"},
-                           {64, 64, "igemm64x64"}, {64, 128, "igemm64x128"}, {256, 128, "igemm256x128"}};
+const TileCfg kTiles[7] = {{0, 0, "auto"}, {128, 128, "igemm128x128"}, {128, 64, "igemm128x64"},
+                           {64, 64, "igemm64x64"}, {64, 128, "igemm64x128"}, {256, 128, "igemm256x128"}, {128, 96, "split128x96"}};
 
 int pick_tile(const ConvParams& p) {
     // Cost model fitted to the MI355X tile sweeps (profiles/r01_conv_tile_sweep*.txt): per-tile MFMA efficiency by tile
     // shape; a CU that hosts a single workgroup runs at ~0.8 of the rate it reaches with two or more co-resident ones;
     // the launch takes as long as its most loaded CU (ceil(tiles / 256) workgroups).
     const int M = p.B * p.Ho * p.Wo;
-    const double eff[5] = {0, 1.00, 0.92, 0.80, 0.92};
+    // Tile 6 (128 x 96, split route, round 5) is a candidate only where 96 divides the columns: the Segmenter's Linears (d_model 384 / 768
+    // and their multiples) -- 4052 token rows x 1536 columns are exactly 512 such tiles, two per CU, where 128 x 64 leaves 768 (1.5 per
+    // slot).  No PSPNet / DeepLab layer qualifies (their channel counts are powers of two), so their choices are untouched.
+    const double eff[7] = {0, 1.00, 0.92, 0.80, 0.92, 0, 0.97};
     int best = 1;
     double best_t = 1e300;
-    for (int c = 1; c <= (p.in2 ? 2 : p.wgt3 ? 3 : 4); ++c) {
+    const int last = p.in2 ? 2 : p.wgt3 ? 3 : 4;
+    for (int c = 1; c <= 6; ++c) {
+        if (c > last && !(c == 6 && p.wgt3 && !p.in2 && p.Cout % 96 == 0)) continue;
         const int bm = kTiles[c].bm, bn = kTiles[c].bn;
         if (p.Cout < bn && bn > 64) continue;
         const long tiles = (long)cdiv(M, bm) * cdiv(p.Cout, bn) * (p.groups > 1 ? p.groups : 1);
@@ -556,10 +586,10 @@ int pick_tile(const ConvParams& p) {
 
 const char* conv_igemm_tile_name(const ConvParams& p, int tile) {
     tile &= 0xff;
-    if (tile <= 0 || tile > 5) tile = pick_tile(p);
+    if (tile <= 0 || tile > 6) tile = pick_tile(p);
     if (p.in2 && p.wgt3) return tile == 2 ? "split128x64cat" : "split128x128cat";
     if (p.in2) return tile == 2 ? "igemm128x64cat" : "igemm128x128cat";  // the concatenated-K instantiations are kernels of their own
-    if (p.wgt3) return tile == 1 ? "split128x128" : tile == 2 ? "split128x64" : tile == 4 ? "split64x128" : "split64x64";
+    if (p.wgt3) return tile == 1 ? "split128x128" : tile == 2 ? "split128x64" : tile == 4 ? "split64x128" : tile == 6 ? "split128x96" : "split64x64";
     return kTiles[tile].name;
 }
 
@@ -624,7 +654,8 @@ int check_conv_params(const ConvParams& p) {
 int launch_conv_igemm(const ConvParams& p, hipStream_t s, int tile) {
     FS_TRY(check_conv_params(p));
     tile &= 0xff;
-    if (tile <= 0 || tile > 5) tile = pick_tile(p);
+    if (tile <= 0 || tile > 6) tile = pick_tile(p);
+    FS_REQUIRE(tile != 6 || (p.wgt3 && !p.in2), "conv_igemm: tile 6 (128 x 96) exists on the split-operand route only");
     const int M = p.B * p.Ho * p.Wo;
     const int bm = kTiles[tile].bm, bn = kTiles[tile].bn;
     const int tm = cdiv(M, bm), tn = cdiv(p.Cout, bn);
@@ -661,13 +692,15 @@ int launch_conv_igemm(const ConvParams& p, hipStream_t s, int tile) {
             // round 5: 64 rows x 128 columns, 2 x 2 waves of 32 x 64 (3 split instructions per MFMA against 6 in the 64 x 64 tile): the
             // shape for GEMMs with few rows and many columns (the Segmenter's Linears: 4052 token rows)
             case 4: hipLaunchKernelGGL((conv_igemm_dma_f32<64, 128, 2, 2, false, true>), grid, block, 0, s, p, tm, tn); break;
+            // round 5: 128 rows x 96 columns (4 x 1 waves of 32 x 96), for column counts that are multiples of 96 -- see pick_tile
+            case 6: hipLaunchKernelGGL((conv_igemm_dma_f32<128, 96, 4, 1, false, true>), grid, block, 0, s, p, tm, tn); break;
 #ifdef FS_DEV
             // experiment (tools/tile256_bench.py, profiles/r04_experiments.txt section 9): a 256 x 128 tile, 4 x 1 waves of 64 x 128, one
             // workgroup per CU with the accumulators in AGPRs -- 41 % fewer LDS read bytes per MFMA at the same VALU count per MFMA (every
             // filter fragment feeds two row blocks).  Bit-identical; EQUAL to two 128 x 128 workgroups per CU at K = 2048, slower below.
             case 5: hipLaunchKernelGGL((conv_igemm_dma_f32<256, 128, 4, 1, false, true>), grid, block, 0, s, p, tm, tn); break;
 #endif
-            default: return fail("conv_igemm: the split-operand route has tiles 1, 2, 3 and 4");
+            default: return fail("conv_igemm: the split-operand route has tiles 1, 2, 3, 4 and 6");
         }
         FS_HIP(hipGetLastError());
         return 0;

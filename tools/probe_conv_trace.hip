@@ -92,6 +92,27 @@ int main(int argc, char** argv) {
     if (hipMemcpyFromSymbol(tr.data(), HIP_SYMBOL(fs::fs_trace_buf), tr.size() * 8) != hipSuccess) return 5;
     printf("# %s M=%d N=%d K=%d  %.4f ms  %.1f TFLOP/s (single launch incl. launch overhead)\n", fs::conv_igemm_tile_name(p, tile), M, Cout,
            K * K * Cin, ms, gf / ms);
+    if (getenv("FS_CHUNKS")) {  // round 5: per-chunk durations of the first 8 chunks (median / p10 / p90 over workgroups), split kernel only
+        std::vector<unsigned long long> ch(8 * 65536);
+        if (hipMemcpyFromSymbol(ch.data(), HIP_SYMBOL(fs::fs_trace_chunks), ch.size() * 8) != hipSuccess) return 5;
+        std::vector<long long> d[9];
+        for (int b = 0; b < 65536; ++b) {
+            const unsigned long long* o = &tr[8 * (size_t)b];
+            const unsigned long long* c = &ch[8 * (size_t)b];
+            if (o[3] == 0 || c[0] == 0) continue;
+            d[0].push_back((long long)(c[0] - o[1]));
+            for (int k = 1; k < 8; ++k) if (c[k]) d[k].push_back((long long)(c[k] - c[k - 1]));
+            d[8].push_back((long long)(o[1] - o[0]));
+        }
+        auto pr = [&](const char* nm, std::vector<long long>& v) {
+            if (v.empty()) return;
+            std::sort(v.begin(), v.end());
+            printf("  %-22s n=%zu  p10 %7lld  p50 %7lld  p90 %7lld\n", nm, v.size(), v[v.size() / 10], v[v.size() / 2], v[v.size() * 9 / 10]);
+        };
+        pr("prologue -> stage 0", d[8]);
+        for (int k = 0; k < 8; ++k) { char nm[32]; snprintf(nm, sizeof nm, "chunk %d", k); pr(nm, d[k]); }
+        return 0;
+    }
     printf("bid,start,ready,loop,end,wait,hwid,xcc,wall0,wall1\n");
     for (int b = 0; b < 65536; ++b) {
         const unsigned long long* o = &tr[8 * (size_t)b];
