@@ -272,25 +272,11 @@ __device__ __forceinline__ void conv_tile(ConvParams p, const int m0, const int 
             _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                        \
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(A_[i][e], B_[j][e], acc[i][j], 0, 0, 0);
 
-    // Round 5: BOTH stages are requested before the first wait.  The per-chunk stamps of the trace build (profiles/r05_experiments.txt
-    // section 12) showed what a tile's first chunk cost: 7.9 k cycles against 3.0 k in the steady state -- the second stage used to be
-    // requested only after the first had landed, so its whole memory latency (cold, with every workgroup of the launch starting at
-    // once) stood behind half a chunk of MFMAs.  A wave's vector-memory operations complete in order, so "all but the RA + RB youngest"
-    // = "this wave's stage-0 tiles have landed" (tests/test_isa_guards.py checks that exactly RA + RB LDS-DMAs sit between).
+    // (Round 5 measured the alternative -- both stages requested before the first wait, a counted vmcnt in between: the first stage
+    //  lands 700 cycles later, the first chunk ends 800 cycles earlier, nothing end to end: profiles/r05_experiments.txt section 12.)
     FS_DMA_ALL(0)
     FS_DMA_ADVANCE()
-    if (nchunks > 1) {
-        FS_DMA_ALL(1)
-        FS_DMA_ADVANCE()
-        constexpr int NV = RA + RB;  // vmcnt is split over bits [3:0] and [15:14] of the s_waitcnt immediate; expcnt (6:4) = no wait, lgkmcnt (11:8) = 0
-        static_assert(NV < 64, "stage DMA count must fit the vmcnt field");
-        __builtin_amdgcn_s_waitcnt((NV & 15) | ((NV >> 4) << 14) | 0x0070);
-        __builtin_amdgcn_s_barrier();  // stage 0 has landed for every wave; stage 1 stays in flight (a bare s_barrier: __syncthreads()'s
-                                        // release fence would make the compiler wait for vmcnt(0) again)
-        __builtin_amdgcn_sched_barrier(0);
-    } else {
-        FS_DMA_PUBLISH()  // stage 0 has landed for every wave
-    }
+    FS_DMA_PUBLISH()  // stage 0 has landed for every wave
 #ifdef FS_TRACE
     tr_ready = __builtin_readcyclecounter();
 #endif
@@ -307,6 +293,10 @@ __device__ __forceinline__ void conv_tile(ConvParams p, const int m0, const int 
         const int n = en_base + j * 32;
         sc_n[j] = (n < p.Cout && p.scale) ? p.scale[n] : 1.f;
         sh_n[j] = (n < p.Cout && p.shift) ? p.shift[n] : 0.f;
+    }
+    if (nchunks > 1) {
+        FS_DMA_ALL(1)
+        FS_DMA_ADVANCE()
     }
     if constexpr (SPLIT) {
         // Split operands: every fp32 value x is the exact sum h + m + l of three bf16 terms (h = bf16(x), m = bf16(x - h),
