@@ -36,6 +36,27 @@ __device__ __forceinline__ void igemm_load_residual(float (&rv)[TM][TN][16], con
     }
 }
 
+// erf for the GELU epilogue (nn.GELU, erf form: segm/model/blocks.py:16-28).  Branch-free: erf(|x|) = 1 - 2^(-|x| P(|x|)), P = the degree-10
+// fit of -log2(erfc(x)) / x on [0, 4] (beyond 4, erfc < 2^-25: the result is 1 in fp32), 11 FMAs + one v_exp_f32 against the ~35
+// instructions of the library erff, whose two argument ranges a wave executes one after the other.  Absolute error <= 1.0e-7 (the library's:
+// 6e-8); in 0.5 v (1 + erf(v / sqrt 2)) that is below the rounding of the sum: measured against float64 the GELU's error is the same
+// (tests/test_gpu_ops.py::test_gelu_epilogue_against_float64).  Round 5: the Segmenter's fc1 launches 41.6 -> 3x us, profiles/r05_experiments.txt 15.
+__device__ __forceinline__ float gelu_erf(float x) {
+    const float a = fminf(fabsf(x), 4.f);  // (a NaN becomes 4 here; the caller's product with v keeps it a NaN)
+    float q = -1.434946029e-07f;
+    q = fmaf(q, a, 3.633772167e-06f);
+    q = fmaf(q, a, -4.095856275e-05f);
+    q = fmaf(q, a, 2.688578097e-04f);
+    q = fmaf(q, a, -1.106124604e-03f);
+    q = fmaf(q, a, 2.616208512e-03f);
+    q = fmaf(q, a, -3.566103114e-04f);
+    q = fmaf(q, a, -2.759680524e-02f);
+    q = fmaf(q, a, 1.482741833e-01f);
+    q = fmaf(q, a, 9.184474349e-01f);
+    q = fmaf(q, a, 1.627907038e+00f);
+    return copysignf(1.f - __builtin_amdgcn_exp2f(-(q * a)), x);
+}
+
 template <int ACT, bool RES, int TM, int TN>
 __device__ __forceinline__ void igemm_epilogue(const f32x16 (&acc)[TM][TN], const float (&rv)[TM][TN][16], const float (&sc)[TN],
                                                const float (&sh)[TN], const ConvParams& p, int M, int m_base, int n_base) {
@@ -55,7 +76,7 @@ __device__ __forceinline__ void igemm_epilogue(const f32x16 (&acc)[TM][TN], cons
                 float v = acc[i][j][e] * sc[j] + sh[j];
                 if (RES) v += rv[i][j][e];
                 if (ACT == 1) v = fmaxf(v, 0.f);
-                else if (ACT == 2) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752f));  // nn.GELU (erf form)
+                else if (ACT == 2) v = 0.5f * v * (1.f + gelu_erf(v * 0.70710678118654752f));  // nn.GELU (erf form)
                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), o_rsrc, vo + (unsigned)((e & 3) + 8 * (e >> 2)) * row_o, 0, 0);
             }
         }

@@ -86,6 +86,25 @@ def test_conv_igemm_split_operands(case, tile):
     assert e_split < 1.5 * e_f32 + 1e-7, (e_split, e_f32)
 
 
+def test_gelu_epilogue_against_float64():
+    """relu = 2: nn.GELU (erf form, segm/model/blocks.py:16-28) in the conv epilogue, with the library's own branch-free erf
+    (csrc/igemm_epilogue.h::gelu_erf).  An identity 1x1 conv hands the epilogue 400 k values from -12 to 12 (dense around 0 and around
+    the |v| / sqrt 2 = 4 clamp); against float64 the error stays within what rounding 0.5 v (1 + erf) to fp32 costs anyway."""
+    n, c = 12500, 32
+    v = torch.cat([torch.linspace(-12, 12, n * c // 2), torch.linspace(-1e-3, 1e-3, n * c // 4), torch.linspace(5.5, 5.8, n * c // 8),
+                   -torch.linspace(5.5, 5.8, n * c // 8)]).view(1, n, 1, c).permute(0, 3, 1, 2).contiguous()
+    eye = torch.eye(c).view(c, c, 1, 1)
+    ref = 0.5 * v.double() * (1 + torch.erf(v.double() / 2 ** 0.5))
+    for split in (False, True):
+        got = ops.conv2d_nhwc(v.to(DEV), eye.to(DEV), None, None, None, 1, 0, 1, 2, 0, split=split).cpu().double()
+        err = (got - ref).abs()
+        bound = 2.5e-7 * v.abs().double().clamp_min(1.0)  # half an ulp of the result + 0.5 |v| x the erf's 1e-7
+        assert (err <= bound).all(), (split, float(err.max()), float(v.flatten()[err.argmax()]))
+        note(f"gelu_epilogue_max_abs_err_{'split' if split else 'fp32'}", float(err.max()))
+    assert torch.equal(ops.conv2d_nhwc(torch.full((1, c, 1, 1), float("nan")).to(DEV), eye.to(DEV), None, None, None, 1, 0, 1, 2).isnan().cpu(),
+                       torch.ones(1, c, 1, 1, dtype=torch.bool))
+
+
 CHAIN_CASES = [  # M, K1, K1b (second operand: the projection form), C1, C2, residual ("inplace" | "separate" | None)
     (64082, 64, 0, 256, 64, "inplace"),      # layer1.1 conv3 -> layer1.2 conv1 at 713^2 (B = 2)
     (64082, 64, 128, 256, 64, None),         # layer1.0 conv3 + downsample -> layer1.1 conv1
