@@ -52,8 +52,12 @@ int linear_splits(const Linear& l, int rows_per_image, int act) {
     // decided on ONE image's rows (for the usual batch of two key frames: ~768 workgroups), never on the batch: a frame's
     // result must not depend on the batch it is computed in (the key-frame cache relies on it)
     if (act != 0 || l.in < 768) return 0;
-    const long tiles = (long)cdiv(rows_per_image, 64) * cdiv(l.out, 64);
-    int split = (int)std::min<long>(4, (384 + tiles / 2) / std::max<long>(tiles, 1));
+    // the tile the launch will get (conv_igemm.hip::pick_tile): 128 x 96 where 96 divides the columns, else 64 x 64; aim at two
+    // workgroups per CU for a pair of images
+    const bool t96 = l.out % 96 == 0;
+    const long tiles = t96 ? (long)cdiv(rows_per_image, 128) * (l.out / 96) : (long)cdiv(rows_per_image, 64) * cdiv(l.out, 64);
+    const long want = t96 ? 256 : 384;
+    int split = (int)std::min<long>(4, (want + tiles / 2) / std::max<long>(tiles, 1));
     while (split >= 2 && (l.in % (32 * split) != 0 || l.in / split < 384)) --split;
     return split >= 2 ? split : 0;
 }
