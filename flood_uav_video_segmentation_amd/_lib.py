@@ -36,6 +36,7 @@ OPT_PLANE_OPERANDS = 32  # FS_OPT_PLANE_OPERANDS
 OPT_CHAIN = 64  # FS_OPT_CHAIN
 OPT_NO_RES_TOUCH = 128  # FS_OPT_NO_RES_TOUCH
 OPT_NO_FUSED_POOL = 256  # FS_OPT_NO_FUSED_POOL
+OPT_ATT_PIPELINED = 512  # FS_OPT_ATT_PIPELINED
 CONV_CHUNK_MAJOR = 0x400  # FS_CONV_CHUNK_MAJOR
 
 # name -> (restype, argtypes); must list every symbol of include/floodseg.h

@@ -333,7 +333,7 @@ FS_API int fs_attention(const float* qkv, float* out, int B, int N, int heads, f
     if (!split_operands) return fs::launch_attention_f32(qkv, out, B, N, heads, scale, scratch, S(stream));
     float* planes = workspace + sc;
     planes += (64 - ((uintptr_t)planes / 4) % 64) % 64;  // 256-B aligned
-    return fs::launch_attention_split(qkv, out, B, N, heads, scale, scratch, planes, S(stream));
+    return fs::launch_attention_split(qkv, out, B, N, heads, scale, scratch, planes, S(stream), split_operands == 2);
 }
 FS_API size_t fs_winograd_workspace_floats(int B, int H, int W, int Cin, int Cout, int dil, int tile_m) {
     if (B < 1 || H < 1 || W < 1 || dil < 1 || !(tile_m == 0 || tile_m == 4 || tile_m == 6)) return 0;

@@ -279,7 +279,7 @@ int launch_attention_f32(const float* qkv, float* out, int B, int N, int heads, 
 // the same on the bf16 matrix cores with split operands (three bf16 terms per fp32 value, fp32 accumulate: vit_ops.hip);
 // planes: attention_split_floats(B, N, heads) floats of workspace for the K / V^T planes
 size_t attention_split_floats(int B, int N, int heads);
-int launch_attention_split(const float* qkv, float* out, int B, int N, int heads, float scale, float* scratch, float* planes, hipStream_t s);
+int launch_attention_split(const float* qkv, float* out, int B, int N, int heads, float scale, float* scratch, float* planes, hipStream_t s, bool pipelined = false);
 // masks[b][k][i] = LayerNorm_K( <pp[b][i]/|pp|, cc[b][N+k]/|cc|> )  (segm/model/decoder.py:90-100), NCHW out
 // out[r][c] = sum_s part[s][r][c] + bias[c] (+ res[r][c]): merges the split-K partial products of a Linear
 int launch_splitk_combine(const float* part, int nsplit, const float* bias, const float* res, float* out, int rows, int N, hipStream_t s);

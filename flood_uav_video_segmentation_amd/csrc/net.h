@@ -136,6 +136,7 @@ struct fs_net {
     bool use_fused_winograd = true;  // !(flags & FS_OPT_NO_FUSED_WINOGRAD)
     bool use_split = true;           // !(flags & FS_OPT_NO_SPLIT_BF16): the implicit-GEMM launches take the split-operand kernel
     bool use_chain = false;          // flags & FS_OPT_CHAIN: conv3 of block i + conv1 of block i + 1 as one launch in layer1 / layer2
+    bool att_pipelined = false;      // flags & FS_OPT_ATT_PIPELINED: Segmenter attention on attention_bf16x3_pipe_kernel
     bool use_fused_pool = true;      // !(flags & FS_OPT_NO_FUSED_POOL): layer0.6 + maxpool as one launch (deep stem, one-kernel Winograd route)
     bool res_touch = true;           // !(flags & FS_OPT_NO_RES_TOUCH): the conv kernels touch a shortcut tile's lines into L2 before their last K chunk
     bool use_plane_operands = false;  // flags & FS_OPT_PLANE_OPERANDS: the Winograd input transform writes the row operand's bf16 planes (gemm_planes.hip)

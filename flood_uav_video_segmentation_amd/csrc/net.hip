@@ -408,7 +408,7 @@ int net_create(const fs_config* cfg, fs_handle* out) {
                "fs_create: layers must be 50, 101 or 152");
     FS_REQUIRE(cfg->classes >= 1 && cfg->classes <= 255, "fs_create: classes out of range");
     FS_REQUIRE((cfg->flags & ~(FS_OPT_NO_WINOGRAD | FS_OPT_NO_FUSED_HEAD | FS_OPT_NO_FUSED_SHORTCUT | FS_OPT_NO_FUSED_WINOGRAD | FS_OPT_NO_SPLIT_BF16 |
-                               FS_OPT_PLANE_OPERANDS | FS_OPT_CHAIN | FS_OPT_NO_RES_TOUCH | FS_OPT_NO_FUSED_POOL)) == 0,
+                               FS_OPT_PLANE_OPERANDS | FS_OPT_CHAIN | FS_OPT_NO_RES_TOUCH | FS_OPT_NO_FUSED_POOL | FS_OPT_ATT_PIPELINED)) == 0,
                "fs_create: unknown option bits 0x%x", cfg->flags);
     FS_REQUIRE(cfg->winograd_tile == 0 || cfg->winograd_tile == 4 || cfg->winograd_tile == 6, "fs_create: winograd_tile must be 0, 4 or 6");
     fs_net* h = new fs_net();
@@ -423,6 +423,7 @@ int net_create(const fs_config* cfg, fs_handle* out) {
     h->use_chain = h->use_split && (cfg->flags & FS_OPT_CHAIN);
     h->res_touch = !(cfg->flags & FS_OPT_NO_RES_TOUCH);
     h->use_fused_pool = !(cfg->flags & FS_OPT_NO_FUSED_POOL);
+    h->att_pipelined = h->use_split && (cfg->flags & FS_OPT_ATT_PIPELINED);
     if (hipGetDevice(&h->device) != hipSuccess) {
         delete h;
         return fail("fs_create: no HIP device");

@@ -163,7 +163,7 @@ int run_block(fs_net* h, const VitBlock& blk, const VitWs& ws, int B, int tokens
     FS_TRY(run_linear(h, blk.qkv, ws.Xn, rows, ws.QKV, nullptr, 0, s));
     const double aflops = 4.0 * B * heads * (double)tokens * tokens * 64;
     FS_TRY(prof_begin(h, blk.qkv.name + ".attention", ws.kv ? "attention_split" : "attention_f32", aflops, 4.0 * rows * 4.0 * D, s));
-    if (ws.kv) FS_TRY(launch_attention_split(ws.QKV, ws.A, B, tokens, heads, 0.125f, ws.att, ws.kv, s));
+    if (ws.kv) FS_TRY(launch_attention_split(ws.QKV, ws.A, B, tokens, heads, 0.125f, ws.att, ws.kv, s, h->att_pipelined));
     else FS_TRY(launch_attention_f32(ws.QKV, ws.A, B, tokens, heads, 0.125f, ws.att, s));
     FS_TRY(prof_end(h, s));
     FS_TRY(run_linear(h, blk.proj, ws.A, rows, ws.X, ws.X, 0, s, ws.part, tokens));  // x = x + proj(attn)

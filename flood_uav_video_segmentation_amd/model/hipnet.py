@@ -15,7 +15,8 @@ from .._lib import check, one_device, ptr, stream_ptr
 def hip_options(hparams):
     """Explicit A/B options of the library (include/floodseg.h: fs_config.flags / .winograd_tile), taken from optional
     attributes of the reference-style `hparams` object: `hip_no_winograd`, `hip_no_fused_head`, `hip_no_fused_shortcut`,
-    `hip_no_fused_winograd`, `hip_no_split_bf16`, `hip_plane_operands`, `hip_chain`, `hip_no_res_touch`, `hip_no_fused_pool`, `hip_winograd_tile`."""
+    `hip_no_fused_winograd`, `hip_no_split_bf16`, `hip_plane_operands`, `hip_chain`, `hip_no_res_touch`, `hip_no_fused_pool`, `hip_att_pipelined`,
+    `hip_winograd_tile`."""
     return dict(no_winograd=bool(getattr(hparams, "hip_no_winograd", False)),
                 no_fused_winograd=bool(getattr(hparams, "hip_no_fused_winograd", False)),
                 no_split_bf16=bool(getattr(hparams, "hip_no_split_bf16", False)),
@@ -23,6 +24,7 @@ def hip_options(hparams):
                 chain=bool(getattr(hparams, "hip_chain", False)),
                 no_res_touch=bool(getattr(hparams, "hip_no_res_touch", False)),
                 no_fused_pool=bool(getattr(hparams, "hip_no_fused_pool", False)),
+                att_pipelined=bool(getattr(hparams, "hip_att_pipelined", False)),
                 no_fused_head=bool(getattr(hparams, "hip_no_fused_head", False)),
                 no_fused_shortcut=bool(getattr(hparams, "hip_no_fused_shortcut", False)),
                 winograd_tile=int(getattr(hparams, "hip_winograd_tile", 0)))
@@ -31,13 +33,14 @@ def hip_options(hparams):
 class HipNet:
     def __init__(self, arch, layers, classes, patch=0, d_model=0, n_layers=0, dec_layers=0, image_size=0, no_winograd=False,
                  no_fused_head=False, no_fused_shortcut=False, winograd_tile=0, no_fused_winograd=False, no_split_bf16=False,
-                 plane_operands=False, chain=False, no_res_touch=False, no_fused_pool=False):
+                 plane_operands=False, chain=False, no_res_touch=False, no_fused_pool=False, att_pipelined=False):
         self.arch, self.layers, self.classes = arch, int(layers), int(classes)
         self.vit = (int(patch), int(d_model), int(n_layers), int(dec_layers), int(image_size))
         self.flags = ((_lib.OPT_NO_WINOGRAD if no_winograd else 0) | (_lib.OPT_NO_FUSED_HEAD if no_fused_head else 0)
                       | (_lib.OPT_NO_FUSED_SHORTCUT if no_fused_shortcut else 0) | (_lib.OPT_NO_FUSED_WINOGRAD if no_fused_winograd else 0)
                       | (_lib.OPT_NO_SPLIT_BF16 if no_split_bf16 else 0) | (_lib.OPT_PLANE_OPERANDS if plane_operands else 0)
-                      | (_lib.OPT_CHAIN if chain else 0) | (_lib.OPT_NO_RES_TOUCH if no_res_touch else 0) | (_lib.OPT_NO_FUSED_POOL if no_fused_pool else 0))
+                      | (_lib.OPT_CHAIN if chain else 0) | (_lib.OPT_NO_RES_TOUCH if no_res_touch else 0) | (_lib.OPT_NO_FUSED_POOL if no_fused_pool else 0)
+                      | (_lib.OPT_ATT_PIPELINED if att_pipelined else 0))
         self.winograd_tile = int(winograd_tile)
         self._h = None
         self.ready = False

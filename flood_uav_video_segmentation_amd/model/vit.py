@@ -30,7 +30,7 @@ class VITSegmentModel(HipSegNet):
         self.d_model = d_model
         # hip_no_split_bf16=True (keyword; library A/B option, include/floodseg.h FS_OPT_NO_SPLIT_BF16): the Linears on the fp32-MFMA kernel
         self._hip_net = HipNet(self.ARCH, 0, num_classes, patch_size, d_model, n_layers, dec_layers, image_size,
-                               no_split_bf16=bool(kwargs.get("hip_no_split_bf16", False)))
+                               no_split_bf16=bool(kwargs.get("hip_no_split_bf16", False)), att_pipelined=bool(kwargs.get("hip_att_pipelined", False)))
         self.encoder = HipStage(self._hip_net.encode, "encoder")  # [B,3,H,W] -> [B, D, gh, gw], stored as [B, gh*gw, D]
         self.decoder = HipStage(self._decode_map, "decoder")
 

@@ -381,7 +381,8 @@ def conv_chain(x, w1, w2, scale1=None, shift1=None, residual=None, x2=None, relu
 
 def attention(qkv, heads, split_operands=True):
     """softmax(q k^T / 8) v per head (segm/model/blocks.py:39-66) for qkv [B, N, 3 * heads * 64] -> [B, N, heads * 64].
-    split_operands: the bf16-matrix-core route with three bf16 terms per fp32 value (the networks' default) or the fp32-MFMA one."""
+    split_operands: True / 1 the bf16-matrix-core route with three bf16 terms per fp32 value (the networks' default), False / 0 the fp32-MFMA
+    one, 2 the split-operand route on the software-pipelined kernel with the balanced grid (FS_OPT_ATT_PIPELINED in the networks)."""
     lib = _lib.load()
     with torch.cuda.device(one_device(qkv, what="floodseg.attention")):
         qkv = _f32c(qkv)

@@ -78,6 +78,8 @@ enum {
     FS_OPT_NO_FUSED_POOL = 256, /* round 5 A/B switch: the deep stem's last conv (layer0.6) and the max-pool behind it (model/resnet.py:114-117) as two
                                  launches instead of one (the one-kernel Winograd with MaxPool2d(3, 2, 1) in its epilogue: the 357 x 357 x 128 map
                                  is never written).  Bit-identical results either way */
+    FS_OPT_ATT_PIPELINED = 512, /* round 5, opt-in A/B route (Segmenter): the split-operand attention software-pipelined inside a wave on a balanced
+                                 grid (fs_attention mode 2) instead of the stage-serial kernel with equal key splits (mode 1) */
     FS_OPT_NO_RES_TOUCH = 128  /* round 5 A/B switch: without it the split-operand conv kernels touch the lines of a bottleneck's shortcut tile
                                  (dead loads) before the last K chunk of their main loop, so that the epilogue's residual loads hit in L2.
                                  Same results bit for bit either way */
@@ -240,7 +242,10 @@ int fs_conv2d_nhwc(const float* in, int ld_in, const float* wgt_ohwi, const floa
 /* Multi-head attention of the Segmenter (segm/model/blocks.py:39-66): out[b][n][h*64 + d] = softmax_keys(q k^T * scale) v for
  * qkv = [B][N][3 * heads * 64] (q | k | v, head-major inside each third), head_dim 64.  split_operands = 0: fp32 matrix cores;
  * 1: the split-operand route (three bf16 terms per fp32 value of q, k, v and of the probabilities, bf16 matrix cores, fp32
- * accumulation and softmax).  workspace: fs_attention_workspace_floats(B, N, heads, split_operands) floats. */
+ * accumulation and softmax); 2: the same route software-pipelined inside a wave (round 5 experiment: the matrix cores compute the
+ * scores of the next 32 keys while the vector ALU does the softmax of the current ones; bit-identical outputs; its stage loop runs
+ * 1.5x faster but it needs 198 registers, i.e. two workgroups per CU instead of three, and loses that on the grid of 768 workgroups:
+ * profiles/r05_experiments.txt section 16).  workspace: fs_attention_workspace_floats(B, N, heads, split_operands) floats. */
 size_t fs_attention_workspace_floats(int B, int N, int heads, int split_operands);
 int fs_attention(const float* qkv, float* out, int B, int N, int heads, float scale, int split_operands, float* workspace, fs_stream stream);
 int fs_split_bf16x3(const float* w, int64_t n, void* planes, fs_stream stream);

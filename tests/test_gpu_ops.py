@@ -691,8 +691,9 @@ def test_attention_both_routes_against_float64(shape):
     q, k, v = [t.view(b, n, heads, 64).permute(0, 2, 1, 3).double() for t in qkv.split(heads * 64, dim=2)]
     ref = (torch.softmax(q @ k.transpose(-1, -2) * 0.125, dim=-1) @ v).permute(0, 2, 1, 3).reshape(b, n, heads * 64)
     e = {}
-    for split in (False, True):
+    for split in (False, True, 2):  # 2: the software-pipelined split kernel on its balanced grid (round 5, opt-in in the networks)
         got = ops.attention(qkv.to(DEV), heads, split_operands=split)
-        e[split] = note(f"attention_{'split' if split else 'fp32'}_{b}x{n}x{heads}", rel(got.double(), ref))
+        e[split] = note(f"attention_{ {False: 'fp32', True: 'split', 2: 'split_pipelined'}[split]}_{b}x{n}x{heads}", rel(got.double(), ref))
         assert e[split] < 2e-5, (split, e[split])
-    assert e[True] < 2.0 * e[False] + 2e-7, e  # the split route is as accurate as the fp32-MFMA one
+        assert torch.equal(got, ops.attention(qkv.to(DEV), heads, split_operands=split))  # and repeatable bit for bit
+    assert e[True] < 2.0 * e[False] + 2e-7 and e[2] < 2.0 * e[False] + 2e-7, e  # the split routes are as accurate as the fp32-MFMA one

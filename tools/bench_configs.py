@@ -125,13 +125,13 @@ def main():
         rows.append(("configs[2] DeepLabv3-R101 keyframe + logit warp", N / t, t * 1e3))
         del dl3
     if want("cfg3"):
-        vit = VITSegmentModel(5, 704, patch_size=16, d_model=384, n_layers=12, dec_layers=2).eval()
+        vit = VITSegmentModel(5, 704, patch_size=16, d_model=384, n_layers=12, dec_layers=2, **{w: True for w in HP.OPTIONS}).eval()
         vit.load_state_dict(synth.make_vit_state(5, 704, 16, 384, 12, 2, seed=0))
         t = timeit(window(FlowModel(vit, feature_based=True, no_warp=False).eval(), (wl, wr)), st)
         rows.append(("configs[3] Segmenter ViT-S/16 keyframe + feature flow (extension)", N / t, t * 1e3))
         del vit
     if want("vitb"):
-        vitb = VITSegmentModel(5, 704).eval()
+        vitb = VITSegmentModel(5, 704, **{w: True for w in HP.OPTIONS}).eval()
         vitb.load_state_dict(synth.make_vit_state(5, 704, seed=0))
 
         def vit_single(i):
