@@ -144,7 +144,7 @@ def test_hip_options_come_from_hparams_not_from_the_environment(monkeypatch):
         hip_no_winograd, hip_winograd_tile = True, 6
     monkeypatch.setenv("FS_NO_FUSED_HEAD", "1")  # a round-1 knob: must be ignored now
     net = FlowPSPNet(O())
-    assert hip_options(O()) == dict(no_winograd=True, no_fused_winograd=False, no_split_bf16=False, plane_operands=False, chain=False, no_res_touch=False, no_fused_pool=False,
+    assert hip_options(O()) == dict(no_winograd=True, no_fused_winograd=False, no_split_bf16=False, plane_operands=False, chain=False, no_res_touch=False, no_fused_pool=False, att_pipelined=False,
                                     no_fused_head=False, no_fused_shortcut=False, winograd_tile=6)
     assert net._hip_net.flags == _lib.OPT_NO_WINOGRAD and net._hip_net.winograd_tile == 6
     assert FlowPSPNet(HP())._hip_net.flags == 0
