@@ -214,8 +214,15 @@ __device__ __forceinline__ void conv_tile(ConvParams p, const int m0, const int 
     unsigned b_soff = 0;               // its byte offset along k in the packed filters
 
     // One DMA row (A rows first, then B rows): ROW_ in [0, RA+RB).
+#ifdef FS_TRACE  // elimination experiments (results invalid, timing only; profiles/r05_experiments.txt section 17): dbg & 64 no pixel-row DMAs,
+                 // & 128 (below) no pixel-fragment LDS reads, & 256 no filter-row DMAs
+#define FS_DMA_SKIP(ROW_) (((ROW_) < RA && (p.dbg & 64)) || ((ROW_) >= RA && (p.dbg & 256)))
+#else
+#define FS_DMA_SKIP(ROW_) false
+#endif
 #define FS_DMA_ROW(STG, ROW_)                                                                                     \
-    if ((ROW_) < RA) {                                                                                            \
+    if (FS_DMA_SKIP(ROW_)) {                                                                                      \
+    } else if ((ROW_) < RA) {                                                                                     \
         const int j = (ROW_) < RA ? (ROW_) : 0;                                                                   \
         if (DUAL && second) {                                                                                     \
             const unsigned vo = (a_mask[j] & 1u) ? a2_voff[DUAL ? j : 0] : SENT;                                  \
@@ -307,15 +314,30 @@ __device__ __forceinline__ void conv_tile(ConvParams p, const int m0, const int 
         // A chunk of 32 k = two MFMA steps of 16 k; lane (i, hh) owns k = 16 s + 8 hh .. + 7 of row i in both operands.
         bf16x8 A3[TM][3], B3[TN][3], A3n[TM][3], B3n[TN][3];
         f32x4 araw[TM][2];
+#ifdef FS_TRACE
+        const bool FS_NO_A_READ = (p.dbg & 128) != 0;  // elimination experiment: the pixel fragments are not read from LDS
+        f32x4 fake_a = {1.f + lane, 2.f, 3.f, 4.f};
+        asm volatile("" : "+v"(fake_a));
+#define FS_FAKE_A_OPAQUE() asm volatile("" : "+v"(fake_a));
+#else
+        constexpr bool FS_NO_A_READ = false;
+        const f32x4 fake_a = {0.f, 0.f, 0.f, 0.f};
+#define FS_FAKE_A_OPAQUE()
+#endif
         u32x4 ah[TM][3];
 #define FS_READ3(STG, S_, RAW_, B_)                                                                               \
     {                                                                                                             \
         const float* a_src = lds + (STG) * STAGE;                                                                 \
         const float* b_src = a_src + BM * BK;                                                                     \
         const int c0 = (4 * (S_) + 2 * hh) ^ sw;                                                                  \
+        if (FS_NO_A_READ) {                                                                                       \
+            FS_FAKE_A_OPAQUE()  /* per use: the split of the fake fragments is not to be hoisted out of the loop */ \
+            _Pragma("unroll") for (int i = 0; i < TM; ++i) { RAW_[i][0] = fake_a; RAW_[i][1] = fake_a; }          \
+        } else {                                                                                                  \
         _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                                          \
             RAW_[i][0] = *reinterpret_cast<const f32x4*>(&a_src[(wm * WM + i * 32 + l31) * BK + 4 * c0]);         \
             RAW_[i][1] = *reinterpret_cast<const f32x4*>(&a_src[(wm * WM + i * 32 + l31) * BK + 4 * (c0 ^ 1)]);   \
+        }                                                                                                         \
         }                                                                                                         \
         const int bslot = (2 * (S_) + hh) ^ ((l31 >> 2) & 3);                                                     \
         _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                            \
@@ -408,6 +430,7 @@ __device__ __forceinline__ void conv_tile(ConvParams p, const int m0, const int 
         if (!DUAL && p.res) igemm_load_residual(rv, p, M, em_base, en_base);
 #undef FS_READ3
 #undef FS_STEP3
+#undef FS_FAKE_A_OPAQUE
     } else {
     if (!DUAL && p.res && nchunks <= 2) igemm_load_residual(rv, p, M, em_base, en_base);
     FS_FRAGS(0, 0, a0, b0)
@@ -447,6 +470,7 @@ __device__ __forceinline__ void conv_tile(ConvParams p, const int m0, const int 
 #undef FS_DMA_ROW
 #undef FS_DMA_ADVANCE
 #undef FS_DMA_ALL
+#undef FS_DMA_SKIP
 #undef FS_FRAGS
 #undef FS_MMA
 
