@@ -121,7 +121,8 @@ def kernel_symbol(label):
         return f"conv_chain_dma_f32<{m.group(1)}, {m.group(2)}, {'4, 1' if m.group(1) == '128' else '2, 2'}, "
     m = re.match(r"(igemm|split)(\d+)x(\d+)(cat)?$", label)
     split, bm, bn, cat = m.group(1) == "split", int(m.group(2)), int(m.group(3)), bool(m.group(4))
-    waves = "4, 2" if bm == 256 else "4, 1" if split and bm == 128 else "2, 2"  # (split64x128, round 5: 2 x 2 waves like the 64 x 64 tile)
+    # (split64x128, round 5: 2 x 2 waves like the 64 x 64 tile; split256x128, round 5: eight waves 8 x 1; igemm256x128: the fp32 route's 4 x 2)
+    waves = ("8, 1" if split else "4, 2") if bm == 256 else "4, 1" if split and bm == 128 else "2, 2"
     return f"conv_igemm_dma_f32<{bm}, {bn}, {waves}, {'true' if cat else 'false'}, {'true' if split else 'false'}>"
 
 

@@ -286,9 +286,10 @@ static int conv2d_entry(const float* in, int ld_in, const float* wgt_ohwi, const
     p.Ho = (H + 2 * pad - dil * (KH - 1) - 1) / stride + 1;
     p.Wo = (W + 2 * pad - dil * (KW - 1) - 1) / stride + 1;
     if (p.Ho < 1 || p.Wo < 1) return fs::fail("fs_conv2d_nhwc: empty output");
-    // tile = workgroup tile id 0..6 (6: split route only), optionally | FS_CONV_CHUNK_MAJOR; anything else is refused (no hidden experiment bits)
-    if ((tile & ~FS_CONV_CHUNK_MAJOR) < 0 || (tile & ~FS_CONV_CHUNK_MAJOR) > 6)
-        return fs::fail("fs_conv2d_nhwc: tile must be 0..6, optionally | FS_CONV_CHUNK_MAJOR (got 0x%x)", tile);
+    // tile = workgroup tile id 0..7 (6, 7: split route only), optionally | FS_CONV_CHUNK_MAJOR; anything else is refused (no hidden experiment bits)
+    constexpr int kMaxTile = 7;
+    if ((tile & ~FS_CONV_CHUNK_MAJOR) < 0 || (tile & ~FS_CONV_CHUNK_MAJOR) > kMaxTile)
+        return fs::fail("fs_conv2d_nhwc: tile must be 0..7, optionally | FS_CONV_CHUNK_MAJOR (got 0x%x)", tile);
     p.korder = (tile & FS_CONV_CHUNK_MAJOR) ? 1 : 0;
     return fs::launch_conv_igemm(p, S(stream), tile & ~FS_CONV_CHUNK_MAJOR);
 }

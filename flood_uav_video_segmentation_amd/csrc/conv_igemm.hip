@@ -570,8 +570,9 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_chain_dma_f32(ConvParams 
 
 namespace {
 struct TileCfg { int bm, bn; const char* name; };
-const TileCfg kTiles[7] = {{0, 0, "auto"}, {128, 128, "igemm128x128"}, {128, 64, "igemm128x64"},
-                           {64, 64, "igemm64x64"}, {64, 128, "igemm64x128"}, {256, 128, "igemm256x128"}, {128, 96, "split128x96"}};
+const TileCfg kTiles[8] = {{0, 0, "auto"}, {128, 128, "igemm128x128"}, {128, 64, "igemm128x64"},
+                           {64, 64, "igemm64x64"}, {64, 128, "igemm64x128"}, {256, 128, "igemm256x128"}, {128, 96, "split128x96"},
+                           {256, 128, "split256x128"}};
 
 int pick_tile(const ConvParams& p) {
     // Cost model fitted to the MI355X tile sweeps (profiles/r01_conv_tile_sweep*.txt): per-tile MFMA efficiency by tile
@@ -581,6 +582,8 @@ int pick_tile(const ConvParams& p) {
     // Tile 6 (128 x 96, split route, round 5) is a candidate only where 96 divides the columns: the Segmenter's Linears (d_model 384 / 768
     // and their multiples) -- 4052 token rows x 1536 columns are exactly 512 such tiles, two per CU, where 128 x 64 leaves 768 (1.5 per
     // slot).  No PSPNet / DeepLab layer qualifies (their channel counts are powers of two), so their choices are untouched.
+    // (Round 5, profiles/r05_experiments.txt section 18: tile 7 -- 256 x 128 on eight waves -- as a candidate for single-round launches and the
+    //  64 x 64 tile re-priced at 0.70 won 3-12 % on isolated launches and nothing in a window; the model stays as fitted.)
     const double eff[7] = {0, 1.00, 0.92, 0.80, 0.92, 0, 0.97};
     int best = 1;
     double best_t = 1e300;
@@ -600,10 +603,10 @@ int pick_tile(const ConvParams& p) {
 
 const char* conv_igemm_tile_name(const ConvParams& p, int tile) {
     tile &= 0xff;
-    if (tile <= 0 || tile > 6) tile = pick_tile(p);
+    if (tile <= 0 || tile > 7) tile = pick_tile(p);
     if (p.in2 && p.wgt3) return tile == 2 ? "split128x64cat" : "split128x128cat";
     if (p.in2) return tile == 2 ? "igemm128x64cat" : "igemm128x128cat";  // the concatenated-K instantiations are kernels of their own
-    if (p.wgt3) return tile == 1 ? "split128x128" : tile == 2 ? "split128x64" : tile == 4 ? "split64x128" : tile == 6 ? "split128x96" : "split64x64";
+    if (p.wgt3) return tile == 1 ? "split128x128" : tile == 2 ? "split128x64" : tile == 4 ? "split64x128" : tile == 6 ? "split128x96" : tile == 7 ? "split256x128" : "split64x64";
     return kTiles[tile].name;
 }
 
@@ -668,8 +671,8 @@ int check_conv_params(const ConvParams& p) {
 int launch_conv_igemm(const ConvParams& p, hipStream_t s, int tile) {
     FS_TRY(check_conv_params(p));
     tile &= 0xff;
-    if (tile <= 0 || tile > 6) tile = pick_tile(p);
-    FS_REQUIRE(tile != 6 || (p.wgt3 && !p.in2), "conv_igemm: tile 6 (128 x 96) exists on the split-operand route only");
+    if (tile <= 0 || tile > 7) tile = pick_tile(p);
+    FS_REQUIRE(tile < 6 || (p.wgt3 && !p.in2), "conv_igemm: tiles 6 (128 x 96) and 7 (256 x 128, eight waves) exist on the split-operand route only");
     const int M = p.B * p.Ho * p.Wo;
     const int bm = kTiles[tile].bm, bn = kTiles[tile].bn;
     const int tm = cdiv(M, bm), tn = cdiv(p.Cout, bn);
@@ -708,13 +711,19 @@ int launch_conv_igemm(const ConvParams& p, hipStream_t s, int tile) {
             case 4: hipLaunchKernelGGL((conv_igemm_dma_f32<64, 128, 2, 2, false, true>), grid, block, 0, s, p, tm, tn); break;
             // round 5: 128 rows x 96 columns (4 x 1 waves of 32 x 96), for column counts that are multiples of 96 -- see pick_tile
             case 6: hipLaunchKernelGGL((conv_igemm_dma_f32<128, 96, 4, 1, false, true>), grid, block, 0, s, p, tm, tn); break;
+            // round 5: 256 x 128 on EIGHT waves of 32 x 128 (8 x 1, 512 threads, one workgroup per CU) -- what two co-resident 128 x 128
+            // workgroups do, as ONE workgroup that stages the filter tile once for both halves (56 KB of DMA per chunk instead of 2 x 40; the
+            // elimination runs of profiles/r05_experiments.txt section 17 price that traffic).  Bit-identical to every other tile.  Alone it wins
+            // 3 % where the launch is ONE round of it (<= 256 tiles: layer4's conv1) and loses where a CU runs several in sequence; in a window: nothing
+            // (section 18).  Forced tile only (tests, sweeps).
+            case 7: hipLaunchKernelGGL((conv_igemm_dma_f32<256, 128, 8, 1, false, true>), grid, dim3(512), 0, s, p, tm, tn); break;
 #ifdef FS_DEV
             // experiment (tools/tile256_bench.py, profiles/r04_experiments.txt section 9): a 256 x 128 tile, 4 x 1 waves of 64 x 128, one
             // workgroup per CU with the accumulators in AGPRs -- 41 % fewer LDS read bytes per MFMA at the same VALU count per MFMA (every
             // filter fragment feeds two row blocks).  Bit-identical; EQUAL to two 128 x 128 workgroups per CU at K = 2048, slower below.
             case 5: hipLaunchKernelGGL((conv_igemm_dma_f32<256, 128, 4, 1, false, true>), grid, block, 0, s, p, tm, tn); break;
 #endif
-            default: return fail("conv_igemm: the split-operand route has tiles 1, 2, 3, 4 and 6");
+            default: return fail("conv_igemm: the split-operand route has tiles 1, 2, 3, 4, 6 and 7");
         }
         FS_HIP(hipGetLastError());
         return 0;

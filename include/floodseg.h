@@ -229,8 +229,8 @@ int fs_conv2d_nhwc(const float* in, int ld_in, const float* wgt_ohwi, const floa
  * terms (round-to-nearest residues) and the six cross products of order <= 2^-16 run on the bf16 matrix cores with fp32
  * accumulation (the three dropped ones are <= 2^-23 of the product: below the rounding of one fp32 add).  fs_split_bf16x3 writes
  * the three planes (3 * n bf16, n % 8 == 0) of a packed filter bank; fs_conv2d_nhwc_split takes them in place of wgt_ohwi
- * (tiles 0..4 and 6; 4 = 64x128 has no fp32-route twin of the same wave layout; 6 = 128x96 exists on this route only: the cost
- * model considers it where 96 divides Cout -- the Segmenter's Linears).
+ * (tiles 0..4, 6 and 7; 4 = 64x128 has no fp32-route twin of the same wave layout; 6 = 128x96 and 7 = 256x128 on eight waves exist on
+ * this route only: the cost model considers 6 where 96 divides Cout -- the Segmenter's Linears; 7 is a forced tile (sweeps)).
  * Non-finite and out-of-range operands (tests/test_gpu_ops.py::test_conv_non_finite_operands): the split is exact for every
  * finite fp32 value up to the largest bf16, |x| <= 3.3895e38 (and flushes nothing above 2^-110: the low-order term of a smaller
  * value may be a bf16 denormal).  An operand that is +-inf, NaN, or finite with 3.3895e38 < |x| <= FLT_MAX makes EVERY output it

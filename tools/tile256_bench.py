@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""DEV experiment (make DEV=1 library): the split-operand kernel with a 256 x 128 workgroup tile, 4 x 1 waves of 64 x 128 (one
-workgroup per CU, accumulators in AGPRs) against the shipped 128 x 128 tile (two workgroups per CU) on the long-K layer shapes.
+"""DEV experiment (make DEV=1 library): the split-operand kernel with a 256 x 128 workgroup tile -- 4 x 1 waves of 64 x 128 (tile 5, one
+workgroup per CU, accumulators in AGPRs) and, round 5, 8 x 1 waves of 32 x 128 (tile 7, 512 threads) -- against the shipped 128 x 128 tile (two workgroups per CU) on the long-K layer shapes.
 Candidates interleaved, medians of REPS blocks of ITERS launches.  usage: tile256_bench.py [iters] [reps]"""
 import os
 import statistics
@@ -21,6 +21,8 @@ SHAPES = {  # b, h, w, cin, cout, residual
     "layer3.conv3 256->1024 +res": (2, 90, 90, 256, 1024, True),
     "layer4.0.conv1 1024->512": (2, 90, 90, 1024, 512, False),
     "aspp 1x1 2048->256 (128x64 default)": (2, 90, 90, 2048, 256, False),
+    "layer3.conv1 1024->256": (2, 90, 90, 1024, 256, False),
+    "layer2.conv3 128->512 +res": (2, 90, 90, 128, 512, True),
 }
 
 
@@ -54,7 +56,7 @@ def main():
         ref = ((ref + r.double()) if res else ref).relu()
         flops = 2.0 * b * h * w * cout * cin
         outs, fns = {}, {}
-        for tile in (0, 1, 5):
+        for tile in (0, 1, 5, 7):
             outs[tile] = torch.empty(b, h, w, cout, device="cuda")
 
             def fn(tile=tile):
@@ -70,7 +72,7 @@ def main():
             ms = statistics.median(times[t])
             err = ((outs[t].double() - ref).abs().max() / ref.abs().max()).item()
             same = "" if t == 0 else ("  bit-identical to tile 0" if torch.equal(outs[t], outs[0]) else "  differs from tile 0")
-            print(f"{name:38s} {({0: 'auto', 1: '128x128', 5: '256x128 dev'})[t]:>12s} {ms * 1e3:8.1f} {flops / ms / 1e9:8.1f} {err:9.2e}{same}")
+            print(f"{name:38s} {({0: 'auto', 1: '128x128', 5: '256x128 4w', 7: '256x128 8w'})[t]:>12s} {ms * 1e3:8.1f} {flops / ms / 1e9:8.1f} {err:9.2e}{same}")
 
 
 if __name__ == "__main__":
