@@ -67,6 +67,8 @@ _SIGNATURES = {
     "fs_blend": (c_int, [c_void, c_f32, c_void, c_f32, c_void, c_i64, c_void]),
     "fs_seg_tail": (c_int, [c_void, c_void, ctypes.POINTER(c_void), ctypes.POINTER(c_void), c_int, c_int, c_int, c_int, c_int,
                             c_int, c_int, c_int, c_int, c_void, c_void, c_void, c_void]),
+    "fs_feat_tail": (c_int, [c_void, c_void, c_int, c_int, c_int, ctypes.POINTER(c_void), ctypes.POINTER(c_void), c_int, c_int, c_void, c_int, c_int,
+                             c_int, c_int, c_void, c_void, c_void]),
     "fs_seg_tail_accumulate": (c_int, [c_void, c_void, ctypes.POINTER(c_void), ctypes.POINTER(c_void), c_int, c_int, c_int, c_int, c_int,
                                        c_int, c_int, c_int, c_int, c_void, c_void, c_int, c_int, c_int, c_int, c_void, c_void]),
     "fs_canvas_resize_argmax": (c_int, [c_void, c_int, c_int, c_int, c_int, c_void, c_int, c_int, c_void]),

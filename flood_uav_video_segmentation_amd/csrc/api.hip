@@ -118,6 +118,30 @@ FS_API int fs_seg_tail(const float* lo_prev, const float* lo_next, const float* 
     return fs::launch_seg_tail(p, S(stream));
 }
 
+FS_API int fs_feat_tail(const float* f_prev, const float* f_next, int C, int fh, int fw, const float* const* grids_left,
+                        const float* const* grids_right, int Hg, int Wg, const float* grid0, int H0, int W0, int n, int no_warp, float* stack,
+                        float* scratch, fs_stream stream) {
+    if (!f_prev || !stack || C < 1 || fh < 1 || fw < 1) return fs::fail("fs_feat_tail: bad arguments");
+    fs::FeatTailParams p{};
+    p.f_prev = f_prev;
+    p.f_next = f_next;
+    p.grids_left = grids_left;
+    p.grids_right = grids_right;
+    p.grid0 = grid0;
+    p.C = C;
+    p.fh = fh;
+    p.fw = fw;
+    p.Hg = Hg;
+    p.Wg = Wg;
+    p.H0 = H0;
+    p.W0 = W0;
+    p.n = n;
+    p.no_warp = no_warp;
+    p.stack = stack;
+    p.scratch = scratch;
+    return fs::launch_feat_tail(p, S(stream));
+}
+
 FS_API int fs_seg_tail_accumulate(const float* lo_prev, const float* lo_next, const float* const* grids_left,
                                   const float* const* grids_right, int K, int h, int w, int Hg, int Wg, int H, int W, int n, int no_warp,
                                   double* canvas, double* count, int cH, int cW, int y0, int x0, float* scratch, fs_stream stream) {

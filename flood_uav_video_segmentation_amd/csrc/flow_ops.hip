@@ -10,6 +10,7 @@
 namespace fs {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // The flat element index of these kernels is decomposed with divisions by run-time sizes: as a 64-bit value that is ~100 instructions
 // per division, several times the interpolation itself.  Every kernel is a template on the index type and runs on unsigned 32-bit
@@ -48,6 +49,25 @@ int launch_grid_sample_nchw(const float* in, int B, int C, int Hi, int Wi, const
     return 0;
 }
 
+// The four taps of one grid_sample output for four channels of an NHWC map (`base` = the map + the channel offset).  All four loads are
+// issued unconditionally from clamped, always valid addresses and the out-of-image taps are zeroed afterwards: written as
+// `ok ? load : 0` the compiler has to branch around each load and waits for one before it issues the next (four serial round trips).
+__device__ __forceinline__ f32x4 gs_gather_nhwc(const float* __restrict__ base, int Wi, int ld, const GsTaps& t) {
+    const int x1 = t.x1ok ? t.x0 + 1 : t.x0, y1 = t.y1ok ? t.y0 + 1 : t.y0;
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    const f32x4 vnw = *reinterpret_cast<const f32x4*>(base + ((size_t)t.y0 * Wi + t.x0) * ld);
+    f32x4 vne = *reinterpret_cast<const f32x4*>(base + ((size_t)t.y0 * Wi + x1) * ld);
+    f32x4 vsw = *reinterpret_cast<const f32x4*>(base + ((size_t)y1 * Wi + t.x0) * ld);
+    f32x4 vse = *reinterpret_cast<const f32x4*>(base + ((size_t)y1 * Wi + x1) * ld);
+    vne = t.x1ok ? vne : z;
+    vsw = t.y1ok ? vsw : z;
+    vse = (t.x1ok && t.y1ok) ? vse : z;
+    f32x4 r;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) r[q] = gs_combine(vnw[q], vne[q], vsw[q], vse[q], t);
+    return r;
+}
+
 // ------------------------------------------------------------------ grid_sample, NHWC (C % 4 == 0)
 // One wave-sized group of float4 lanes sweeps the channels of one output pixel: every tap is a
 // contiguous C*4-byte run, so the gather is fully coalesced.
@@ -62,17 +82,8 @@ __global__ __launch_bounds__(256) void grid_sample_nhwc_kernel(const float* __re
         const int b = (int)(m / ((I)Hg * Wg));
         const float gx = grid[m * 2 + 0], gy = grid[m * 2 + 1];
         const GsTaps t = gs_taps(gx, gy, Wi, Hi, ac);
-        const int x1 = t.x1ok ? t.x0 + 1 : t.x0, y1 = t.y1ok ? t.y0 + 1 : t.y0;
         const float* base = in + (size_t)b * Hi * Wi * ld_in + c4 * 4;
-        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-        const f32x4 vnw = *reinterpret_cast<const f32x4*>(base + ((size_t)t.y0 * Wi + t.x0) * ld_in);
-        const f32x4 vne = t.x1ok ? *reinterpret_cast<const f32x4*>(base + ((size_t)t.y0 * Wi + x1) * ld_in) : z;
-        const f32x4 vsw = t.y1ok ? *reinterpret_cast<const f32x4*>(base + ((size_t)y1 * Wi + t.x0) * ld_in) : z;
-        const f32x4 vse = (t.x1ok && t.y1ok) ? *reinterpret_cast<const f32x4*>(base + ((size_t)y1 * Wi + x1) * ld_in) : z;
-        f32x4 r;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) r[e] = gs_combine(vnw[e], vne[e], vsw[e], vse[e], t);
-        *reinterpret_cast<f32x4*>(out + (size_t)m * ld_out + c4 * 4) = r;
+        *reinterpret_cast<f32x4*>(out + (size_t)m * ld_out + c4 * 4) = gs_gather_nhwc(base, Wi, ld_in, t);
     }
 }
 
@@ -385,6 +396,331 @@ int launch_seg_tail(const SegTailParams& p, hipStream_t s) {
         else { if (canvas) FS_SEG_FUSE(32, false, true); else FS_SEG_FUSE(32, false, false); }
     }
 #undef FS_SEG_FUSE
+    FS_HIP(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------ fused predict_feature tail (flow/model.py:131-171)
+// Everything FlowModel.predict_feature does between the encoder and the ONE batched decoder call, on NHWC feature maps:
+//   warp chains   w_1 = warp(f, g_0), w_j = warp(w_{j-1}, g_{j-1})  kept at GRID resolution [Hg][Wg][C]         (:135-151)
+//   stack[0]    = up(grid_sample(f, default grid [H0][W0], align_corners=True))                                 (:154-159)
+//   stack[p]    = (n-p)/n * up(fwd[p-1]) + p/n * up(bwd[n-p-1]),  up = bilinear align_corners=True to fh x fw   (:166-171)
+// The reference (and the op-by-op route) materialises the eight upsampled maps and the H0 x W0 resample; here the steps of a
+// chain are one launch for both directions and ONE launch writes every map of the decoder's batch straight from the low-resolution
+// chains.  Same operations in the same order per element (gs_combine, bilerp, separate mul / add roundings): bit-identical to
+// fs_grid_sample_nhwc -> fs_resize_bilinear_nhwc -> fs_blend.
+__global__ __launch_bounds__(256) void feat_warp_step_kernel(const float* __restrict__ src_f, const float* __restrict__ src_b, int Hs, int Ws,
+                                                             const float* __restrict__ grid_f, const float* __restrict__ grid_b,
+                                                             float* __restrict__ dst_f, float* __restrict__ dst_b, int C4, unsigned total, int S) {
+    const int dir = blockIdx.y;
+    const float* __restrict__ src = dir ? src_b : src_f;
+    const float* __restrict__ grid = dir ? grid_b : grid_f;
+    float* __restrict__ dst = dir ? dst_b : dst_f;
+    const int ld = C4 * 4;
+    {
+        // channel slab per XCD, cells in raster order (see feat_fuse_kernel): the four taps of neighbouring cells meet in one L2
+        const unsigned xcd = blockIdx.x & 7u;
+        const unsigned e = (blockIdx.x >> 3) * 256u + threadIdx.x;
+        const unsigned m = e / (unsigned)S;
+        const int c4 = (int)(xcd * (unsigned)S + (e - m * (unsigned)S));
+        if (m >= total || c4 >= C4) return;   // total = cells of the grid
+        const float gx = grid[m * 2 + 0], gy = grid[m * 2 + 1];
+        const GsTaps t = gs_taps(gx, gy, Ws, Hs, 0);
+        *reinterpret_cast<f32x4*>(dst + (size_t)m * ld + c4 * 4) = gs_gather_nhwc(src + c4 * 4, Ws, ld, t);
+    }
+}
+
+struct FeatFuseArgs {
+    const float* f_prev;   // [fh][fw][C]
+    const float* f_next;   // [fh][fw][C] (no_warp) or nullptr
+    const float* chains;   // warp: [2][n-1][Hg][Wg][C] forward maps then backward maps
+    const float* grid0;    // warp: [H0][W0][2]
+    float* stack;          // [nmaps][fh][fw][C]
+    int C4, fh, fw, Hg, Wg, H0, W0, n;
+    int same_g, same_0;    // the chain / identity maps already have the feature size: the reference skips the resize (:138, :158)
+    float sy_g, sx_g, sy_0, sx_0;
+};
+
+// Two launches write every map of the decoder's batch.  What bounds them is not HBM but the CUs' vector-memory path: with one float4 of
+// one pixel per thread a warped map costs 8 tap loads + 1 store per output (6 GB through the L1s for 0.66 GB written: 430-440 us
+// measured, with or without L2 locality).  So:
+//   * maps 1..n-1 (feat_fuse_warp_kernel): a thread owns ONE float4 of channels and a RUN of FEAT_RUN consecutive output pixels of a
+//     row; the two low-resolution columns it interpolates between stay in registers and shift as the run advances (an upsample by
+//     90 / 44 moves on by one column every other pixel): ~2.4 loads per output instead of 8;
+//   * map 0 (feat_fuse_key_kernel): the key-frame map through the H0 x W0 default grid (4 cells x 4 taps per output), the cells'
+//     coordinate arithmetic shared by four float4s of channels per thread;
+//   * XCD-aware split in both parts: XCD x = blockIdx % 8 owns the channel slab [x * S, (x + 1) * S) float4s of every pixel and walks
+//     the pixels in raster order, so all readers of a tap share one L2 and follow each other closely.
+// Same loads, same operations in the same order per element as the op-by-op route: bit-identical.
+#ifndef FS_FEAT_RUN
+#define FS_FEAT_RUN 10
+#endif
+constexpr int FEAT_RUN = FS_FEAT_RUN;
+
+// One cell of the default grid as the key-map kernel uses it: the four taps as element offsets into the key frame's map, the four
+// weights, and which taps lie inside the image -- computed ONCE per thread and applied to FEAT_KEY_CH float4s of channels (the
+// coordinate arithmetic of four cells is ~180 vector instructions; per float4 of channels it was three quarters of the kernel's work).
+struct GsCell {
+    unsigned nw, ne, sw, se;
+    float wnw, wne, wsw, wse;
+    bool all_in;
+    bool x1ok, y1ok;
+};
+
+__device__ __forceinline__ GsCell feat_cell(const FeatFuseArgs& a, int gy, int gx) {
+    const size_t m = (size_t)gy * a.W0 + gx;
+    const float2 g = *reinterpret_cast<const float2*>(a.grid0 + m * 2);
+    const GsTaps t = gs_taps(g.x, g.y, a.fw, a.fh, 1);
+    const int x1 = t.x1ok ? t.x0 + 1 : t.x0, y1 = t.y1ok ? t.y0 + 1 : t.y0;  // clamped: every address is valid, outside taps are zeroed
+    const unsigned ld = (unsigned)a.C4 * 4u;
+    GsCell c;
+    c.nw = (unsigned)(t.y0 * a.fw + t.x0) * ld;
+    c.ne = (unsigned)(t.y0 * a.fw + x1) * ld;
+    c.sw = (unsigned)(y1 * a.fw + t.x0) * ld;
+    c.se = (unsigned)(y1 * a.fw + x1) * ld;
+    c.wnw = t.nw; c.wne = t.ne; c.wsw = t.sw; c.wse = t.se;
+    c.x1ok = t.x1ok; c.y1ok = t.y1ok;
+    c.all_in = t.x1ok && t.y1ok;
+    return c;
+}
+
+// gs_combine over four channels as channel pairs on the packed fp32 instructions (same products, same order of additions)
+__device__ __forceinline__ f32x4 feat_cell_value(const float* __restrict__ cbase, const GsCell& c) {
+    const f32x4 vnw = *reinterpret_cast<const f32x4*>(cbase + c.nw);
+    f32x4 vne = *reinterpret_cast<const f32x4*>(cbase + c.ne);
+    f32x4 vsw = *reinterpret_cast<const f32x4*>(cbase + c.sw);
+    f32x4 vse = *reinterpret_cast<const f32x4*>(cbase + c.se);
+    if (__builtin_amdgcn_ballot_w64(!c.all_in) != 0) {  // a tap beyond the last row / column (whole waves skip this: border cells only)
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        vne = c.x1ok ? vne : z;
+        vsw = c.y1ok ? vsw : z;
+        vse = c.all_in ? vse : z;
+    }
+    const f32x2 wnw = {c.wnw, c.wnw}, wne = {c.wne, c.wne}, wsw = {c.wsw, c.wsw}, wse = {c.wse, c.wse};
+    f32x4 r;
+    r.lo = ((vnw.lo * wnw + vne.lo * wne) + vsw.lo * wsw) + vse.lo * wse;
+    r.hi = ((vnw.hi * wnw + vne.hi * wne) + vsw.hi * wsw) + vse.hi * wse;
+    return r;
+}
+
+constexpr int FEAT_KEY_CH = 4;   // float4s of channels per thread of the key-map kernel
+
+__global__ __launch_bounds__(256) void feat_fuse_key_kernel(FeatFuseArgs a, unsigned npix, int S, int LP) {
+    const int ld = a.C4 * 4;
+    // ---- map 0: LP = ceil(S / FEAT_KEY_CH) lanes per pixel inside the XCD's slab; lane l owns float4s l, l + LP, l + 2 LP, ...
+    const unsigned xcd = blockIdx.x & 7u;
+    const unsigned e = (blockIdx.x >> 3) * 256u + threadIdx.x;
+    const unsigned m = e / (unsigned)LP;
+    const int l = (int)(e - m * (unsigned)LP);
+    if (m >= npix) return;
+    const int oy = (int)(m / (unsigned)a.fw), ox = (int)(m - (unsigned)oy * (unsigned)a.fw);
+    LinCoord cy, cx;
+    if (a.same_0) {
+        cy.i0 = cy.i1 = oy; cx.i0 = cx.i1 = ox;
+        cy.w0 = cx.w0 = 1.f; cy.w1 = cx.w1 = 0.f;
+    } else {
+        cy = lin_coord(oy, a.H0, a.sy_0, 1);
+        cx = lin_coord(ox, a.W0, a.sx_0, 1);
+    }
+    const GsCell c00 = feat_cell(a, cy.i0, cx.i0);
+    GsCell c01 = c00, c10 = c00, c11 = c00;
+    if (!a.same_0) {
+        c01 = feat_cell(a, cy.i0, cx.i1);
+        c10 = feat_cell(a, cy.i1, cx.i0);
+        c11 = feat_cell(a, cy.i1, cx.i1);
+    }
+    const f32x2 wx0 = {cx.w0, cx.w0}, wx1 = {cx.w1, cx.w1}, wy0 = {cy.w0, cy.w0}, wy1 = {cy.w1, cy.w1};
+#pragma unroll 1
+    for (int k = 0; k < FEAT_KEY_CH; ++k) {
+        const int cc = l + k * LP;
+        const int c4 = (int)xcd * S + cc;
+        if (cc >= S || c4 >= a.C4) break;
+        const float* cbase = a.f_prev + c4 * 4;
+        f32x4 r;
+        if (a.same_0) {
+            r = feat_cell_value(cbase, c00);   // the default grid has the feature size: no resize (flow/model.py:158)
+        } else {
+            const f32x4 v00 = feat_cell_value(cbase, c00), v01 = feat_cell_value(cbase, c01);
+            const f32x4 v10 = feat_cell_value(cbase, c10), v11 = feat_cell_value(cbase, c11);
+            r.lo = wy0 * (wx0 * v00.lo + wx1 * v01.lo) + wy1 * (wx0 * v10.lo + wx1 * v11.lo);   // bilerp, channel pairs
+            r.hi = wy0 * (wx0 * v00.hi + wx1 * v01.hi) + wy1 * (wx0 * v10.hi + wx1 * v11.hi);
+        }
+        *reinterpret_cast<f32x4*>(a.stack + (size_t)m * ld + c4 * 4) = r;
+    }
+}
+
+// ---- maps 1..n-1: (map, row, run) per thread, S float4 lanes of the XCD's slab side by side.  Its own kernel: 6 waves per SIMD (the
+// key-map kernel holds 16 taps in registers), since what this loop waits for is the latency of its 4-load groups.
+#ifndef FS_FEAT_WAVES
+#define FS_FEAT_WAVES 6
+#endif
+__global__ __launch_bounds__(256, FS_FEAT_WAVES) void feat_fuse_warp_kernel(FeatFuseArgs a, int S, int nruns) {
+    const int ld = a.C4 * 4;
+    const size_t map = (size_t)a.fh * a.fw * ld;
+    const unsigned bid = blockIdx.x;
+    const unsigned xcd = bid & 7u;
+    const unsigned e = (bid >> 3) * 256u + threadIdx.x;
+    const unsigned item = e / (unsigned)S;
+    const int c4 = (int)(xcd * (unsigned)S + (e - item * (unsigned)S));
+    const unsigned rowid = item / (unsigned)nruns;
+    const int run = (int)(item - rowid * (unsigned)nruns);
+    const int p = 1 + (int)(rowid / (unsigned)a.fh);
+    const int oy = (int)(rowid - (unsigned)(p - 1) * (unsigned)a.fh);
+    if (p >= a.n || c4 >= a.C4) return;
+    const float wa = (float)((double)(a.n - p) / (double)a.n);
+    const float wb = (float)((double)p / (double)a.n);
+    const size_t cmap = (size_t)a.Hg * a.Wg * ld;
+    const float* pf = a.chains + (size_t)(p - 1) * cmap + c4 * 4;                  // forward map p-1
+    const float* pb = a.chains + (size_t)(a.n - 1 + a.n - p - 1) * cmap + c4 * 4;  // backward map n-p-1
+    float* dst = a.stack + (size_t)p * map + ((size_t)oy * a.fw) * ld + c4 * 4;
+    const int x0 = run * FEAT_RUN, x1 = min(a.fw, x0 + FEAT_RUN);
+    if (a.same_g) {
+        for (int ox = x0; ox < x1; ++ox) {
+            const f32x4 va = *reinterpret_cast<const f32x4*>(pf + ((size_t)oy * a.Wg + ox) * ld);
+            const f32x4 vb = *reinterpret_cast<const f32x4*>(pb + ((size_t)oy * a.Wg + ox) * ld);
+            f32x4 r;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) r[q] = __fadd_rn(__fmul_rn(wa, va[q]), __fmul_rn(wb, vb[q]));
+            *reinterpret_cast<f32x4*>(dst + (size_t)ox * ld) = r;
+        }
+        return;
+    }
+    const LinCoord cy = lin_coord(oy, a.Hg, a.sy_g, 1);
+    const float* f0 = pf + (size_t)cy.i0 * a.Wg * ld;
+    const float* f1 = pf + (size_t)cy.i1 * a.Wg * ld;
+    const float* b0 = pb + (size_t)cy.i0 * a.Wg * ld;
+    const float* b1 = pb + (size_t)cy.i1 * a.Wg * ld;
+    // Two register sets A / B hold the two low-resolution columns an output interpolates between (rows i0 / i1 of the forward and of
+    // the backward map).  When the run moves on by a column only the set that fell behind is reloaded and the two sets swap roles --
+    // no register moves: a + b == b + a bit for bit, so wx_left * left + wx_right * right is evaluated as wxA * A + wxB * B with the
+    // weights following the roles.  Channel pairs go through the packed fp32 instructions (v_pk_mul_f32 / v_pk_add_f32: separate
+    // roundings, like the scalar form).
+    int colA = -1, colB = -1;
+    f32x4 Af0, Af1, Ab0, Ab1, Bf0, Bf1, Bb0, Bb1;
+    Af0 = Af1 = Ab0 = Ab1 = Bf0 = Bf1 = Bb0 = Bb1 = f32x4{0.f, 0.f, 0.f, 0.f};
+#define FS_FEAT_LOAD(S_, col_)                                        \
+    do {                                                              \
+        const size_t o_ = (size_t)(col_) * ld;                        \
+        S_##f0 = *reinterpret_cast<const f32x4*>(f0 + o_);            \
+        S_##f1 = *reinterpret_cast<const f32x4*>(f1 + o_);            \
+        S_##b0 = *reinterpret_cast<const f32x4*>(b0 + o_);            \
+        S_##b1 = *reinterpret_cast<const f32x4*>(b1 + o_);            \
+    } while (0)
+    const f32x2 wy0 = {cy.w0, cy.w0}, wy1 = {cy.w1, cy.w1}, wa2 = {wa, wa}, wb2 = {wb, wb};
+    for (int ox = x0; ox < x1; ++ox) {
+        const LinCoord cx = lin_coord(ox, a.Wg, a.sx_g, 1);
+        if (!((colA == cx.i0 && colB == cx.i1) || (colA == cx.i1 && colB == cx.i0))) {
+            if (colA == cx.i0) { FS_FEAT_LOAD(B, cx.i1); colB = cx.i1; }
+            else if (colB == cx.i0) { FS_FEAT_LOAD(A, cx.i1); colA = cx.i1; }
+            else if (colA == cx.i1) { FS_FEAT_LOAD(B, cx.i0); colB = cx.i0; }
+            else if (colB == cx.i1) { FS_FEAT_LOAD(A, cx.i0); colA = cx.i0; }
+            else { FS_FEAT_LOAD(A, cx.i0); FS_FEAT_LOAD(B, cx.i1); colA = cx.i0; colB = cx.i1; }
+        }
+        const bool a_left = (colA == cx.i0 && colB == cx.i1);
+        const float wA = a_left ? cx.w0 : cx.w1, wB = a_left ? cx.w1 : cx.w0;
+        const f32x2 wxA = {wA, wA}, wxB = {wB, wB};
+        f32x4 r;
+#define FS_FEAT_HALF(h_)                                                                      \
+    do {                                                                                      \
+        const f32x2 tf = wxA * Af0.h_ + wxB * Bf0.h_, bf = wxA * Af1.h_ + wxB * Bf1.h_;       \
+        const f32x2 tb = wxA * Ab0.h_ + wxB * Bb0.h_, bb = wxA * Ab1.h_ + wxB * Bb1.h_;       \
+        const f32x2 va = wy0 * tf + wy1 * bf, vb = wy0 * tb + wy1 * bb;                       \
+        r.h_ = wa2 * va + wb2 * vb;                                                           \
+    } while (0)
+        FS_FEAT_HALF(lo);
+        FS_FEAT_HALF(hi);
+#undef FS_FEAT_HALF
+        *reinterpret_cast<f32x4*>(dst + (size_t)ox * ld) = r;
+    }
+#undef FS_FEAT_LOAD
+}
+
+// no_warp: every map is a blend of the two key-frame maps -- each float4 of f_prev / f_next is read ONCE and all n maps written from it
+// (a launch per map, or a map per blockIdx.y, re-reads 2 x 133 MB per map: 1.9 GB moved for 0.66 GB written).
+__global__ __launch_bounds__(256) void feat_fuse_nowarp_kernel(const float* __restrict__ f_prev, const float* __restrict__ f_next,
+                                                               float* __restrict__ stack, unsigned total4, int n, int nmaps) {
+    const unsigned i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= total4) return;
+    const f32x4 x = reinterpret_cast<const f32x4*>(f_prev)[i];
+    f32x4 r;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) r[q] = __fmul_rn(1.f, x[q]);  // the op-by-op route's copy is fs_blend(f, 1.0)
+    reinterpret_cast<f32x4*>(stack)[i] = r;
+    if (nmaps == 1) return;
+    const f32x4 y = reinterpret_cast<const f32x4*>(f_next)[i];
+    for (int p = 1; p < n; ++p) {
+        const float wa = (float)((double)(n - p) / (double)n);
+        const float wb = (float)((double)p / (double)n);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) r[q] = __fadd_rn(__fmul_rn(wa, x[q]), __fmul_rn(wb, y[q]));
+        reinterpret_cast<f32x4*>(stack)[(size_t)p * total4 + i] = r;
+    }
+}
+
+int launch_feat_tail(const FeatTailParams& p, hipStream_t s) {
+    FS_REQUIRE(p.f_prev && p.stack && p.C >= 4 && p.C % 4 == 0 && p.fh >= 1 && p.fw >= 1, "feat_tail: bad arguments (C %% 4 == 0, NHWC maps)");
+    FS_REQUIRE(p.n >= 1, "feat_tail: n must be >= 1");
+    FS_REQUIRE((((uintptr_t)p.f_prev | (uintptr_t)p.f_next | (uintptr_t)p.stack | (uintptr_t)p.scratch) & 15) == 0, "feat_tail: maps must be 16-byte aligned");
+    const int C4 = p.C / 4;
+    const int64_t total = (int64_t)p.fh * p.fw * C4;
+    FS_REQUIRE(total < ((int64_t)1 << 31), "feat_tail: feature map of at most 2^31 float4 elements");
+    const bool warp = !p.no_warp;
+    const int nmaps = p.f_next ? p.n : 1;
+    FeatFuseArgs a{};
+    a.f_prev = p.f_prev;
+    a.f_next = p.f_next;
+    a.stack = p.stack;
+    a.C4 = C4;
+    a.fh = p.fh;
+    a.fw = p.fw;
+    a.n = p.n;
+    a.Hg = a.Wg = a.H0 = a.W0 = 1;
+    if (warp) {
+        FS_REQUIRE(p.grid0 && p.H0 >= 1 && p.W0 >= 1, "feat_tail: warp mode needs the default grid");
+        a.grid0 = p.grid0;
+        a.H0 = p.H0;
+        a.W0 = p.W0;
+        a.same_0 = (p.H0 == p.fh && p.W0 == p.fw);
+        a.sy_0 = resize_scale(p.H0, p.fh, 1);
+        a.sx_0 = resize_scale(p.W0, p.fw, 1);
+        if (nmaps > 1) {
+            FS_REQUIRE(p.scratch && p.grids_left && p.grids_right && p.Hg >= 1 && p.Wg >= 1, "feat_tail: warp mode needs grids and scratch");
+            const int64_t gtotal = (int64_t)p.Hg * p.Wg * C4;
+            FS_REQUIRE(gtotal < ((int64_t)1 << 31), "feat_tail: grid too large");
+            const size_t cmap = (size_t)p.Hg * p.Wg * p.C;
+            float* fwd = p.scratch;
+            float* bwd = p.scratch + (size_t)(p.n - 1) * cmap;
+            const int Sg = cdiv(C4, 8);
+            const unsigned blocks = 8u * (unsigned)cdiv64((int64_t)p.Hg * p.Wg * Sg, 256);
+            for (int j = 0; j < p.n - 1; ++j) {
+                hipLaunchKernelGGL(feat_warp_step_kernel, dim3(blocks, 2), dim3(256), 0, s, j ? fwd + (size_t)(j - 1) * cmap : p.f_prev,
+                                   j ? bwd + (size_t)(j - 1) * cmap : p.f_next, j ? p.Hg : p.fh, j ? p.Wg : p.fw, p.grids_left[j], p.grids_right[j],
+                                   fwd + (size_t)j * cmap, bwd + (size_t)j * cmap, C4, (unsigned)(p.Hg * p.Wg), Sg);
+            }
+            a.chains = p.scratch;
+            a.Hg = p.Hg;
+            a.Wg = p.Wg;
+            a.same_g = (p.Hg == p.fh && p.Wg == p.fw);
+            a.sy_g = resize_scale(p.Hg, p.fh, 1);
+            a.sx_g = resize_scale(p.Wg, p.fw, 1);
+        }
+    }
+    if (!warp) {
+        hipLaunchKernelGGL(feat_fuse_nowarp_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, s, p.f_prev, p.f_next, p.stack, (unsigned)total, p.n,
+                           nmaps);
+        FS_HIP(hipGetLastError());
+        return 0;
+    }
+    const int S = cdiv(C4, 8);  // float4s of a pixel per XCD
+    const int64_t npix = (int64_t)p.fh * p.fw;
+    const int nruns = cdiv(p.fw, FEAT_RUN);
+    const int64_t items = (int64_t)(nmaps - 1) * p.fh * nruns;  // (map, row, run) triples of maps 1..n-1
+    FS_REQUIRE(npix * S < ((int64_t)1 << 28) && items * S < ((int64_t)1 << 28), "feat_tail: feature map too large");
+    const unsigned blocks1 = 8u * (unsigned)cdiv64(items * S, 256);
+    const int LP = cdiv(S, FEAT_KEY_CH);
+    const unsigned blocks0 = 8u * (unsigned)cdiv64(npix * LP, 256);
+    hipLaunchKernelGGL(feat_fuse_key_kernel, dim3(blocks0), dim3(256), 0, s, a, (unsigned)npix, S, LP);
+    if (blocks1) hipLaunchKernelGGL(feat_fuse_warp_kernel, dim3(blocks1), dim3(256), 0, s, a, S, nruns);
     FS_HIP(hipGetLastError());
     return 0;
 }

@@ -205,6 +205,19 @@ struct SegTailParams {
 };
 int launch_seg_tail(const SegTailParams& p, hipStream_t s);
 
+// Fused predict_feature tail (flow/model.py:131-171): warp chains at grid resolution + every map of the decoder's batch in one launch.
+struct FeatTailParams {
+    const float* f_prev;    // NHWC [fh][fw][C] encoder features of the previous key frame
+    const float* f_next;    // the next key frame's, or nullptr (single frame: stack holds one map)
+    const float* const* grids_left;   // n-1 device pointers [Hg,Wg,2] (ignored when no_warp)
+    const float* const* grids_right;
+    const float* grid0;     // [H0,W0,2] the default (identity) grid the key-frame map is resampled through (warp mode)
+    int C, fh, fw, Hg, Wg, H0, W0, n, no_warp;
+    float* stack;           // NHWC [n | 1][fh][fw][C]: the decoder's batch
+    float* scratch;         // >= 2*(n-1)*Hg*Wg*C floats when warping with two key frames
+};
+int launch_feat_tail(const FeatTailParams& p, hipStream_t s);
+
 // Sliding crops in one pass (flow/base.py:182-209 after the network): every pixel of the full frame from the crops covering it.
 struct CropsFuseParams {
     const float* lo_prev;   // [nc, K, h, w] per-crop decoder logits of the previous key frame

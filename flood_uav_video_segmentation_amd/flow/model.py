@@ -89,6 +89,9 @@ class FlowModel(nn.Module):
         self.no_interpolation_percentage = no_interpolation_percentage
         # plain attribute (not a buffer), moved to the device lazily -- as the reference does (:32, :155-156)
         self.default_motion_vector = torch.from_numpy(get_default_grid()).float().unsqueeze(0)
+        # extension (A/B switch, not a constructor argument of the reference): predict_feature's tail as fs_feat_tail (True) or
+        # op by op as the reference issues it (False); the two give the same bits
+        self.fused_feature_tail = True
 
     # ------------------------------------------------------------------------------------ helpers
     def _encode(self, *frames):
@@ -236,6 +239,16 @@ class FlowModel(nn.Module):
         # the n maps the decoder sees are produced straight into ONE batch tensor (the reference stacks them with torch.cat, :173-176)
         nmaps = n if f_next is not None else 1
         nhwc = ops.is_channels_last_dense(f) and f.shape[1] > 1 and not f.is_contiguous()
+        if self.fused_feature_tail and nhwc and f.shape[0] == 1 and f.shape[1] % 4 == 0 and f.dtype == torch.float32:
+            # the HIP mirrors' NHWC features: warp chains at grid resolution + ONE launch that writes every map of the decoder's batch
+            # (fs_feat_tail) -- bit-identical to the op-by-op route below, without its eight upsampled maps and 67x120 resample
+            if not self.no_warp and self.default_motion_vector.device != f.device:
+                self.default_motion_vector = self.default_motion_vector.to(device=f.device)
+            with _region(profiler, "predict_warp"), _region(profiler, "predict_fusion"):
+                stack = ops.feat_tail(f, f_next, mvs_left, mvs_right, n, self.no_warp, None if self.no_warp else self.default_motion_vector)
+            with _region(profiler, "predict_decoder"):
+                out = self._fit_out(self.model.decoder(stack), h, w)
+            return {"pred": out, "mask": ops.argmax_u8(out)} if with_mask else {"pred": out}
         stack = (ops.empty_nhwc(nmaps, f.shape[1], f_h, f_w, f.device) if nhwc else
                  torch.empty((nmaps, f.shape[1], f_h, f_w), dtype=torch.float32, device=f.device))
         fwd, bwd = [], []

@@ -165,6 +165,52 @@ def seg_tail(lo_prev, lo_next, grids_left, grids_right, n, out_hw, no_warp, want
     return logits, mask
 
 
+def feat_tail(f_prev, f_next, grids_left, grids_right, n, no_warp, default_grid=None):
+    """Fused predict_feature tail (flow/model.py:131-171 between the encoder and the batched decoder call): f_prev / f_next
+    [1,C,fh,fw] stored channels_last; grids: lists of n-1 [1,Hg,Wg,2]; default_grid [1,H0,W0,2] (warp mode).  Returns the decoder's
+    batch [n,C,fh,fw] ([1,C,fh,fw] when f_next is None), channels_last -- bit-identical to the op-by-op route."""
+    lib = _lib.load()
+    warp = not no_warp
+    grids = list(grids_left) + list(grids_right) if (warp and f_next is not None) else []
+    dev = one_device(f_prev, f_next, default_grid if warp else None, *grids, what="floodseg.feat_tail")
+    for t in (f_prev, f_next):
+        if t is not None and not (t.dim() == 4 and t.shape[0] == 1 and t.dtype == torch.float32 and is_channels_last_dense(t)):
+            raise RuntimeError("floodseg.feat_tail: feature maps must be float32 [1,C,fh,fw] stored channels_last")
+    _, c, fh, fw = f_prev.shape
+    if c % 4 != 0:
+        raise RuntimeError("floodseg.feat_tail: C must be a multiple of 4")
+    if f_next is not None and f_next.shape != f_prev.shape:
+        raise RuntimeError("floodseg.feat_tail: f_prev / f_next shapes differ")
+    with torch.cuda.device(dev):
+        nmaps = n if f_next is not None else 1
+        stack = empty_nhwc(nmaps, c, fh, fw, dev)
+        gl = gr = None
+        hg = wg = h0 = w0 = 1
+        scratch = g0 = None
+        keep = []
+        if warp:
+            if default_grid is None:
+                raise RuntimeError("floodseg.feat_tail: warp mode needs the default grid")
+            g0 = _f32c(default_grid, "default_grid")
+            if g0.dim() != 4 or g0.shape[0] != 1 or g0.shape[3] != 2:
+                raise RuntimeError("floodseg.feat_tail: default grid must be [1,H0,W0,2]")
+            h0, w0 = g0.shape[1], g0.shape[2]
+            if f_next is not None and n > 1:
+                if len(grids_left) != n - 1 or len(grids_right) != n - 1:
+                    raise RuntimeError("floodseg.feat_tail: need n-1 grids per direction")
+                keep = [_f32c(g, "grid") for g in grids]
+                hg, wg = keep[0].shape[1], keep[0].shape[2]
+                for g in keep:
+                    if tuple(g.shape) != (1, hg, wg, 2):
+                        raise RuntimeError("floodseg.feat_tail: all grids must be [1,Hg,Wg,2] of one size")
+                gl = _ptr_array(keep[: n - 1])
+                gr = _ptr_array(keep[n - 1:])
+                scratch = torch.empty(2 * (n - 1) * hg * wg * c, dtype=torch.float32, device=dev)
+        check(lib.fs_feat_tail(ptr(f_prev), ptr(f_next), c, fh, fw, gl, gr, hg, wg, ptr(g0), h0, w0, int(n), int(bool(no_warp)), ptr(stack),
+                               ptr(scratch), stream_ptr()))
+    return stack
+
+
 def seg_tail_accumulate(lo_prev, lo_next, grids_left, grids_right, n, crop_hw, no_warp, canvas, count, y0, x0):
     """The same tail feeding the sliding-crop canvas (flow/base.py:204-205, 226-234): softmax over K of every output frame
     of this crop is ADDED to canvas [n,K,H,W] (float64) at (y0, x0), count[H,W] += 1 over the crop -- in place."""

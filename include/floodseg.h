@@ -165,6 +165,18 @@ int fs_seg_tail(const float* lo_prev, const float* lo_next, const float* const* 
                 const float* const* grids_right, int K, int h, int w, int Hg, int Wg, int H, int W, int n, int no_warp,
                 float* out_logits, uint8_t* out_mask, float* scratch, fs_stream stream);
 
+/* Fused tail of FlowModel.predict_feature between the encoder and its one batched decoder call (flow/model.py:131-171), on the
+ * NHWC feature maps fs_encoder_forward returns (C % 4 == 0, one image per key frame):
+ *   warp chains at grid resolution (:135-151), stack[0] = up(grid_sample(f_prev, grid0 [H0,W0,2], align_corners=True)) (:154-159),
+ *   stack[p] = (n-p)/n * up(fwd[p-1]) + p/n * up(bwd[n-p-1]) (:166-171), up = bilinear align_corners=True to fh x fw, skipped when the
+ *   map already has that size (:138,:149,:158);  no_warp: stack[0] = f_prev, stack[p] = (n-p)/n * f_prev + p/n * f_next.
+ * stack: NHWC [n][fh][fw][C] ([1][fh][fw][C] when f_next is NULL) = the decoder's batch; the upsampled chain maps and the H0 x W0
+ * resample are never materialised.  Bit-identical to fs_grid_sample_nhwc -> fs_resize_bilinear_nhwc -> fs_blend per map.
+ * grids_left / grids_right: host arrays of n-1 device pointers [Hg,Wg,2]; scratch: >= 2*(n-1)*Hg*Wg*C floats (warp mode, f_next given). */
+int fs_feat_tail(const float* f_prev, const float* f_next, int C, int fh, int fw, const float* const* grids_left,
+                 const float* const* grids_right, int Hg, int Wg, const float* grid0, int H0, int W0, int n, int no_warp, float* stack,
+                 float* scratch, fs_stream stream);
+
 /* The same tail feeding the sliding-crop canvas instead of returning logits: compute_predict_crop's softmax over K
  * (flow/base.py:226-234) of every output frame is added to canvas[n,K,cH,cW] (float64) at the crop's offset (y0, x0) and
  * count[cH,cW] += 1 over the crop (flow/base.py:204-205) -- fs_seg_tail + fs_softmax_accumulate without the [n,K,H,W] logits

@@ -139,6 +139,13 @@ def test_pspnet_feature_based_against_oracle(psp_flow, nw, profiler):
     ref = flow_oracle.predict_feature(enc, dec, clip[0:1], clip[1:2], mvl, mvr, n, nw)["pred"]
     assert out.shape == ref.shape == (3, 5, 129, 129)
     assert note(f"pspnet_feature_129_nw{int(nw)}_vs_oracle", rel_err(out.cpu(), ref)) < NET_TOL
+    assert {"predict_warp", "predict_fusion"} <= set(profiler.names)
+    fm.fused_feature_tail = False  # the op-by-op route (one HIP launch per torch op of flow/model.py:131-171): same bits
+    assert torch.equal(fm.predict(clip[0:1].cuda(), clip[1:2].cuda(), cu(mvl), cu(mvr), n, None)["pred"], out)
+    one = FlowModel(net, feature_based=True, no_warp=nw).eval()
+    single = one.predict(clip[0:1].cuda(), None, cu(mvl), cu(mvr), n, None)["pred"]  # frame_next=None (:127): one map
+    one.fused_feature_tail = False
+    assert single.shape == (1, 5, 129, 129) and torch.equal(one.predict(clip[0:1].cuda(), None, cu(mvl), cu(mvr), n, None)["pred"], single)
 
 
 def test_sliding_crop_inference_against_oracle_parity_unpinned():

@@ -210,6 +210,9 @@ def test_pspnet_feature_based_713_against_oracle(psp):
     fm = FlowModel(net, feature_based=True, no_warp=False).eval()
     got = fm.predict(prev.cuda(), nxt.cuda(), cu(mvl), cu(mvr), N, None)["pred"]
     assert note("a2_pspnet_feature_713_warp_logits_vs_reference", rel_err(got[:, :, ::16, ::16].cpu(), z["warp_logits_sub"])) < LOGIT_TOL
+    fm.fused_feature_tail = False  # fs_feat_tail against the op-by-op route it replaces: bit-identical at the BASELINE size
+    assert torch.equal(fm.predict(prev.cuda(), nxt.cuda(), cu(mvl), cu(mvr), N, None)["pred"], got)
+    fm.fused_feature_tail = True
     assert note("a2_pspnet_feature_713_warp_mask_disagreement_vs_reference",
                 1 - (ops.argmax_u8(got)[:, ::2, ::2].cpu().numpy() == z["warp_mask_sub"]).mean()) < 1 - MASK_MIN
     enc = memo(lambda x: pspnet_oracle.encoder(x, state, 50))

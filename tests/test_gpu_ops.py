@@ -412,6 +412,82 @@ def test_blend_is_bit_exact():
         ops.blend(big_a, 1.0, out=torch.empty(2, 5, 16, 8, device=DEV))            # wrong shape
 
 
+def _feature_tail_op_by_op(f, f_next, mvl, mvr, n, no_warp, g0):
+    """predict_feature's tail as the reference issues it (flow/model.py:131-171), one HIP op per torch op."""
+    fh, fw = f.shape[2:]
+    fit = lambda t: t if t.shape[2:] == (fh, fw) else ops.resize_bilinear(t, (fh, fw), align_corners=True)  # noqa: E731
+    fwd, bwd = [], []
+    if f_next is not None and not no_warp:
+        cur = f
+        for m in mvl:
+            cur = ops.grid_sample(cur, m, align_corners=False)
+            fwd.append(fit(cur))
+        cur = f_next
+        for m in mvr:
+            cur = ops.grid_sample(cur, m, align_corners=False)
+            bwd.append(fit(cur))
+    maps = [fit(ops.grid_sample(f, g0, align_corners=True)) if not no_warp else ops.blend(f, 1.0)]
+    if f_next is not None:
+        for p in range(1, n):
+            maps.append(ops.blend(f, (n - p) / n, f_next, p / n) if no_warp else ops.blend(fwd[p - 1], (n - p) / n, bwd[n - p - 1], p / n))
+    return torch.cat(maps, 0)
+
+
+@pytest.mark.parametrize("case", [
+    # C, fh, fw, Hg, Wg, H0, W0, n
+    (64, 17, 13, 8, 6, 9, 15, 5),     # everything resized, odd sizes
+    (96, 12, 12, 12, 12, 7, 9, 3),    # grids already at the feature size: the chain maps are used as they are (flow/model.py:138)
+    (128, 9, 11, 5, 4, 9, 11, 4),     # default grid at the feature size: no resize of the key-frame map (:158)
+    (68, 6, 5, 3, 3, 4, 4, 2),        # n = 2: one map between the keys, C not a multiple of 64
+    (384, 45, 45, 44, 44, 67, 120, 5),   # the Segmenter's token map at 713^2 (configs[3])
+])
+@pytest.mark.parametrize("no_warp", [False, True])
+@pytest.mark.parametrize("single", [False, True])
+def test_feat_tail_is_bit_identical_to_the_op_by_op_route(case, no_warp, single):
+    """fs_feat_tail (the fused predict_feature tail) against grid_sample -> resize -> blend per map: same bits, including grid
+    coordinates outside [-1, 1] (border clamp)."""
+    C, fh, fw, Hg, Wg, H0, W0, n = case
+    g = torch.Generator().manual_seed(C + fh + n)
+    f = (torch.randn(1, C, fh, fw, generator=g) * 3).to(DEV).contiguous(memory_format=torch.channels_last)
+    f_next = None if single else (torch.randn(1, C, fh, fw, generator=g) * 3).to(DEV).contiguous(memory_format=torch.channels_last)
+    mk = lambda: (torch.rand(1, Hg, Wg, 2, generator=g) * 2.6 - 1.3).to(DEV)  # noqa: E731
+    mvl, mvr = [mk() for _ in range(n - 1)], [mk() for _ in range(n - 1)]
+    g0 = (torch.rand(1, H0, W0, 2, generator=g) * 2.2 - 1.1).to(DEV)
+    got = ops.feat_tail(f, f_next, mvl, mvr, n, no_warp, None if no_warp else g0)
+    want = _feature_tail_op_by_op(f, f_next, mvl, mvr, n, no_warp, g0)
+    assert got.shape == want.shape == (1 if single else n, C, fh, fw) and ops.is_channels_last_dense(got)
+    assert torch.equal(got, want)
+    if not no_warp and not single:  # and against torch's own ops on the CPU (same formulas, un-contracted)
+        fc, nc = f.cpu(), f_next.cpu()
+        up = lambda t: t if t.shape[2:] == (fh, fw) else F.interpolate(t, (fh, fw), mode="bilinear", align_corners=True)  # noqa: E731
+        cur, ref_f = fc, []
+        for m in mvl:
+            cur = F.grid_sample(cur, m.cpu(), mode="bilinear", padding_mode="border", align_corners=False)
+            ref_f.append(up(cur))
+        cur, ref_b = nc, []
+        for m in mvr:
+            cur = F.grid_sample(cur, m.cpu(), mode="bilinear", padding_mode="border", align_corners=False)
+            ref_b.append(up(cur))
+        ref = [up(F.grid_sample(fc, g0.cpu(), mode="bilinear", padding_mode="border", align_corners=True))]
+        ref += [(n - p) / n * ref_f[p - 1] + p / n * ref_b[n - p - 1] for p in range(1, n)]
+        assert rel(got, torch.cat(ref, 0)) < INTERP_TOL
+
+
+def test_feat_tail_refuses_what_it_cannot_address():
+    f = torch.randn(1, 64, 8, 8, device=DEV).contiguous(memory_format=torch.channels_last)
+    g = [torch.zeros(1, 4, 4, 2, device=DEV)]
+    with pytest.raises(RuntimeError, match="channels_last"):
+        ops.feat_tail(torch.randn(1, 64, 8, 8, device=DEV), None, [], [], 1, True)          # NCHW storage
+    with pytest.raises(RuntimeError, match="multiple of 4"):
+        ops.feat_tail(torch.randn(1, 6, 8, 8, device=DEV).contiguous(memory_format=torch.channels_last), None, [], [], 1, True)
+    with pytest.raises(RuntimeError, match="default grid"):
+        ops.feat_tail(f, f, g, g, 2, False, None)
+    with pytest.raises(RuntimeError, match="n-1 grids"):
+        ops.feat_tail(f, f, g, g, 3, False, torch.zeros(1, 3, 3, 2, device=DEV))
+    with pytest.raises(RuntimeError, match="GPU"):
+        ops.feat_tail(f.cpu(), None, [], [], 1, True)
+
+
 def test_argmax_resize_argmax_and_iou_hist():
     g = torch.Generator().manual_seed(11)
     x = torch.randn(3, 5, 40, 44, generator=g)

@@ -50,6 +50,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--opt", action="append", default=[], help="hip_no_split_bf16 | hip_no_winograd | hip_plane_operands | ... (repeatable)")
     ap.add_argument("--lib", default=None, help="development A/B: load this build of the library instead of the in-tree one")
+    ap.add_argument("--feat-op-by-op", action="store_true", help="A/B: predict_feature's tail op by op instead of fs_feat_tail (feat, cfg3)")
     ap.add_argument("--json", action="store_true", help="also print one JSON line {value, unit, ms_per_step, steps} of the last config run")
     args = ap.parse_args()
     HP.OPTIONS = tuple(args.opt)
@@ -65,6 +66,8 @@ def main():
     wl, wr = [[g.to(dev) for g in gs] for gs in synth.make_grids(N, 44, 44, seed=2000)]
 
     def window(fm, grids):
+        fm.fused_feature_tail = not args.feat_op_by_op
+
         def step(i):
             out = fm.predict(keys[i % 4:i % 4 + 1], keys[i % 4 + 1:i % 4 + 2], grids[0], grids[1], N, None)["pred"]
             host.copy_(ops.argmax_u8(out), non_blocking=True)
