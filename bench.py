@@ -73,7 +73,7 @@ ARITHMETIC = ("fp32 tensors; in the implicit-GEMM kernels every fp32 operand is 
               "fp32-MFMA kernel (variants.fps_fp32_mfma_kernels_no_split)")
 
 
-HIP_OPTS = {}  # development A/B only (--hip-opt): explicit fs_config options of the library, e.g. hip_chain, hip_no_fused_pool
+HIP_OPTS = {}  # development A/B only (--hip-opt): explicit fs_config options of the library, e.g. hip_no_res_touch, hip_no_fused_pool (unknown names are refused: model/hipnet.py::HIP_OPTIONS)
 
 
 class HP:
@@ -89,7 +89,7 @@ def build_id():
     h = hashlib.sha256()
     csrc = os.path.join(ROOT, "flood_uav_video_segmentation_amd", "csrc")
     files = sorted(glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.h")) + [os.path.join(csrc, "Makefile")])
-    for f in files + [os.path.join(ROOT, "include", "floodseg.h")]:
+    for f in files + [os.path.join(ROOT, "include", "floodseg.h"), os.path.join(ROOT, "include", "floodseg_test.h")]:
         h.update(os.path.basename(f).encode())
         h.update(open(f, "rb").read())
     return h.hexdigest()[:16]
@@ -113,16 +113,10 @@ def newest_pmc_summary():
 
 def kernel_symbol(label):
     """HIP-event label of the library's profile (split128x128, igemm128x64cat, ...) -> the kernel symbol rocprofv3 reports."""
-    m = re.match(r"planes256x(\d+)$", label)
-    if m:
-        return f"gemm_planes_bf16x3<{m.group(1)}>"
-    m = re.match(r"chain(\d+)x(\d+)$", label)
-    if m:  # round 5: conv3 + next conv1 in one launch (both the residual and the concatenated-K form carry this label)
-        return f"conv_chain_dma_f32<{m.group(1)}, {m.group(2)}, {'4, 1' if m.group(1) == '128' else '2, 2'}, "
     m = re.match(r"(igemm|split)(\d+)x(\d+)(cat)?$", label)
     split, bm, bn, cat = m.group(1) == "split", int(m.group(2)), int(m.group(3)), bool(m.group(4))
-    # (split64x128, round 5: 2 x 2 waves like the 64 x 64 tile; split256x128, round 5: eight waves 8 x 1; igemm256x128: the fp32 route's 4 x 2)
-    waves = ("8, 1" if split else "4, 2") if bm == 256 else "4, 1" if split and bm == 128 else "2, 2"
+    # (split64x128: 2 x 2 waves like the 64 x 64 tile)
+    waves = "4, 1" if split and bm == 128 else "2, 2"
     return f"conv_igemm_dma_f32<{bm}, {bn}, {waves}, {'true' if cat else 'false'}, {'true' if split else 'false'}>"
 
 
@@ -435,7 +429,7 @@ def main():
     ap.add_argument("--lib", default=None,
                     help="development A/B only: load this build of the library instead of the in-tree libfloodseg.so (recorded in the JSON line)")
     ap.add_argument("--hip-opt", action="append", default=[], metavar="NAME[=INT]",
-                    help="development A/B only: set this explicit library option (hparams attribute, e.g. hip_chain, hip_no_res_touch) on every network "
+                    help="development A/B only: set this explicit library option (hparams attribute, e.g. hip_no_res_touch; unknown names are refused) on every network "
                          "the run builds; recorded in the JSON line")
     ap.add_argument("--launch-check", action="store_true",
                     help="no GPU, no measurement: the N ranks rendezvous over gloo, build their shard of the configs[4] schedule, run the "
@@ -580,9 +574,9 @@ def main():
             d["ms"] += ms
             d["flops"] += flops
             d["launches"] += 1
-        conv = {k: v for k, v in per.items() if k.startswith(("igemm", "split", "planes", "chain"))}  # the implicit-GEMM launches (direct convs, Winograd position GEMMs, Linears)
+        conv = {k: v for k, v in per.items() if k.startswith(("igemm", "split"))}  # the implicit-GEMM launches (direct convs, Winograd position GEMMs, Linears)
         dom_name, dom = max(conv.items(), key=lambda kv: kv[1]["ms"])
-        is_split = dom_name.startswith(("split", "planes", "chain"))
+        is_split = dom_name.startswith("split")
         # split-operand kernel: the matrix cores execute 6 bf16 MFMA FLOPs per algorithmic (fp32) FLOP; the roofline is the bf16 pipe's
         alg = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
         ach = alg * (SPLIT_TERMS if is_split else 1)
@@ -829,7 +823,7 @@ def variants(args, dev, rdev, net, state, fm, windows, dl, dr, host_masks, host_
 
     # (viii) BASELINE configs[3]: Segmenter ViT-S/16 key frames + feature propagation (our extension: the reference has none)
     from flood_uav_video_segmentation_amd.model.vit import VITSegmentModel
-    vit = VITSegmentModel(CLASSES, 704, patch_size=16, d_model=384, n_layers=12, dec_layers=2).eval()
+    vit = VITSegmentModel(CLASSES, 704, patch_size=16, d_model=384, n_layers=12, dec_layers=2, **HIP_OPTS).eval()
     vit.load_state_dict(synth.make_vit_state(CLASSES, 704, 16, 384, 12, 2, seed=0))
     fmv = FlowModel(vit, feature_based=True, no_warp=False).eval()
 

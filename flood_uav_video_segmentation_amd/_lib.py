@@ -32,14 +32,12 @@ OPT_NO_FUSED_HEAD = 2    # FS_OPT_NO_FUSED_HEAD
 OPT_NO_FUSED_SHORTCUT = 4  # FS_OPT_NO_FUSED_SHORTCUT
 OPT_NO_FUSED_WINOGRAD = 8  # FS_OPT_NO_FUSED_WINOGRAD
 OPT_NO_SPLIT_BF16 = 16  # FS_OPT_NO_SPLIT_BF16
-OPT_PLANE_OPERANDS = 32  # FS_OPT_PLANE_OPERANDS
-OPT_CHAIN = 64  # FS_OPT_CHAIN
 OPT_NO_RES_TOUCH = 128  # FS_OPT_NO_RES_TOUCH
 OPT_NO_FUSED_POOL = 256  # FS_OPT_NO_FUSED_POOL
-OPT_ATT_PIPELINED = 512  # FS_OPT_ATT_PIPELINED
+OPT_NO_FUSED_QKV = 1024  # FS_OPT_NO_FUSED_QKV
 CONV_CHUNK_MAJOR = 0x400  # FS_CONV_CHUNK_MAJOR
 
-# name -> (restype, argtypes); must list every symbol of include/floodseg.h
+# name -> (restype, argtypes); must list every symbol of include/floodseg.h (+ fs_test_hooks of include/floodseg_test.h)
 _SIGNATURES = {
     "fs_version": (c_int, []),
     "fs_last_error": (ctypes.c_char_p, []),
@@ -83,30 +81,56 @@ _SIGNATURES = {
     "fs_mv_to_grids": (c_int, [c_void, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void, c_void, c_void, c_void]),
     "fs_softmax_accumulate": (c_int, [c_void, c_int, c_int, c_int, c_int, c_void, c_void, c_int, c_int, c_int, c_int, c_void]),
     "fs_canvas_finish": (c_int, [c_void, c_void, c_int, c_int, c_i64, c_void, c_void]),
-    "fs_pack_conv_weight": (c_int, [c_void, c_void, c_int, c_int, c_int, c_int, c_void]),
-    "fs_conv2d_nhwc": (c_int, [c_void, c_int, c_void, c_void, c_void, c_void, c_int, c_void, c_int] + [c_int] * 12 + [c_void]),
-    "fs_attention_workspace_floats": (ctypes.c_size_t, [c_int] * 4),
-    "fs_attention": (c_int, [c_void, c_void, c_int, c_int, c_int, c_f32, c_int, c_void, c_void]),
-    "fs_split_bf16x3": (c_int, [c_void, c_i64, c_void, c_void]),
-    "fs_conv2d_nhwc_split": (c_int, [c_void, c_int, c_void, c_void, c_void, c_void, c_int, c_void, c_int] + [c_int] * 12 + [c_void]),
-    "fs_conv_chain_nhwc": (c_int, [c_void, c_int, c_void, c_int, c_void, c_void, c_void, c_void, c_void, c_int, c_int, c_void, c_void, c_void, c_void,
-                                   c_int, c_int, c_int, c_int, c_void]),
-    "fs_gemm_bf16x3_planes": (c_int, [c_void, c_i64, c_int, c_void, c_i64, c_int, c_void, c_void, c_void, c_int, c_int, c_int, c_int, c_int, c_int,
-                                      c_i64, c_i64, c_i64, c_int, c_void]),
-    "fs_winograd_planes_workspace_floats": (ctypes.c_size_t, [c_int] * 7),
-    "fs_conv3x3_winograd_planes_nhwc": (c_int, [c_void, c_int, c_void, c_void, c_void, c_void, c_int] + [c_int] * 8 + [c_void, c_void]),
-    "fs_winograd_workspace_floats": (ctypes.c_size_t, [c_int] * 7),
-    "fs_conv3x3_winograd_nhwc": (c_int, [c_void, c_int, c_void, c_void, c_void, c_void, c_int] + [c_int] * 8 + [c_void, c_void]),
-    "fs_winograd_fused_workspace_floats": (ctypes.c_size_t, [c_int, c_int]),
-    "fs_conv3x3_winograd_fused_nhwc": (c_int, [c_void, c_int, c_void, c_void, c_void, c_void, c_int] + [c_int] * 7 + [c_void, c_void]),
-    "fs_conv3x3_winograd_fused_pool_nhwc": (c_int, [c_void, c_int, c_void, c_void, c_void, c_void] + [c_int] * 5 + [c_void, c_void]),
-    "fs_stem_conv_nchw": (c_int, [c_void, c_void, c_void, c_void, c_void] + [c_int] * 8 + [c_void]),
-    "fs_stem_conv_nchw_split": (c_int, [c_void, c_void, c_void, c_void, c_void] + [c_int] * 8 + [c_void]),
-    "fs_maxpool3x3s2_nhwc": (c_int, [c_void, c_void, c_int, c_int, c_int, c_int, c_void]),
-    "fs_adaptive_avgpool_nhwc": (c_int, [c_void, c_int, c_void, c_int, c_int, c_int, c_int, c_int, c_void]),
-    "fs_nchw_to_nhwc": (c_int, [c_void, c_void, c_int, c_int, c_int, c_void]),
-    "fs_nhwc_to_nchw": (c_int, [c_void, c_void, c_int, c_int, c_int, c_void]),
+    "fs_test_hooks": (c_void, []),
 }
+
+# members of fs_test_api (include/floodseg_test.h), in declaration order after `size`: name -> (restype, argtypes).  Reached as
+# load().fs_<name>(...) like any exported function -- tests and tools do not care that they come from the table fs_test_hooks() returns.
+_HOOKS = [
+    ("pack_conv_weight", c_int, [c_void, c_void, c_int, c_int, c_int, c_int, c_void]),
+    ("conv2d_nhwc", c_int, [c_void, c_int, c_void, c_void, c_void, c_void, c_int, c_void, c_int] + [c_int] * 12 + [c_void]),
+    ("split_bf16x3", c_int, [c_void, c_i64, c_void, c_void]),
+    ("conv2d_nhwc_split", c_int, [c_void, c_int, c_void, c_void, c_void, c_void, c_int, c_void, c_int] + [c_int] * 12 + [c_void]),
+    ("attention_workspace_floats", ctypes.c_size_t, [c_int] * 4),
+    ("attention", c_int, [c_void, c_void, c_int, c_int, c_int, c_f32, c_int, c_void, c_void]),
+    ("winograd_workspace_floats", ctypes.c_size_t, [c_int] * 7),
+    ("conv3x3_winograd_nhwc", c_int, [c_void, c_int, c_void, c_void, c_void, c_void, c_int] + [c_int] * 8 + [c_void, c_void]),
+    ("winograd_fused_workspace_floats", ctypes.c_size_t, [c_int, c_int]),
+    ("conv3x3_winograd_fused_nhwc", c_int, [c_void, c_int, c_void, c_void, c_void, c_void, c_int] + [c_int] * 7 + [c_void, c_void]),
+    ("conv3x3_winograd_fused_pool_nhwc", c_int, [c_void, c_int, c_void, c_void, c_void, c_void] + [c_int] * 5 + [c_void, c_void]),
+    ("stem_conv_nchw", c_int, [c_void, c_void, c_void, c_void, c_void] + [c_int] * 8 + [c_void]),
+    ("stem_conv_nchw_split", c_int, [c_void, c_void, c_void, c_void, c_void] + [c_int] * 8 + [c_void]),
+    ("maxpool3x3s2_nhwc", c_int, [c_void, c_void, c_int, c_int, c_int, c_int, c_void]),
+    ("adaptive_avgpool_nhwc", c_int, [c_void, c_int, c_void, c_int, c_int, c_int, c_int, c_int, c_void]),
+    ("nchw_to_nhwc", c_int, [c_void, c_void, c_int, c_int, c_int, c_void]),
+    ("nhwc_to_nchw", c_int, [c_void, c_void, c_int, c_int, c_int, c_void]),
+]
+
+
+class FsTestApi(ctypes.Structure):
+    _fields_ = [("size", ctypes.c_size_t)] + [(name, ctypes.CFUNCTYPE(res, *args)) for name, res, args in _HOOKS]
+
+
+class _Library:
+    """The loaded library: exported functions as attributes (ctypes), and the op-level test hooks of fs_test_hooks() under the names
+    fs_<member> (so `lib.fs_conv2d_nhwc(...)` works whether a symbol is exported or lives in the table)."""
+
+    def __init__(self, cdll):
+        self._cdll = cdll
+        self._hooks = None
+
+    def __getattr__(self, name):
+        if name.startswith("fs_") and name != "fs_test_hooks" and any(name == "fs_" + h[0] for h in _HOOKS):
+            if self._hooks is None:
+                table = ctypes.cast(self._cdll.fs_test_hooks(), ctypes.POINTER(FsTestApi)).contents
+                if table.size < ctypes.sizeof(FsTestApi):
+                    raise RuntimeError(f"floodseg: the library's test-hook table ({table.size} B) is older than this binding ({ctypes.sizeof(FsTestApi)} B)")
+                self._hooks = table
+            fn = getattr(self._hooks, name[3:])
+            setattr(self, name, fn)
+            return fn
+        return getattr(self._cdll, name)
+
 
 _lib = None
 ALLOW_MISSING = False  # development A/B against an OLDER build only (bench.py --lib): symbols it lacks are skipped, not an error
@@ -128,12 +152,17 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
-    _lib = lib
-    return lib
+    _lib = _Library(lib)
+    return _lib
 
 
 def exported_symbols():
     return sorted(_SIGNATURES)
+
+
+def hook_names():
+    """Members of fs_test_api after `size`, in declaration order."""
+    return [h[0] for h in _HOOKS]
 
 
 def check(rc):

@@ -10,7 +10,7 @@
 
 static inline hipStream_t S(fs_stream s) { return reinterpret_cast<hipStream_t>(s); }
 
-FS_API int fs_version(void) { return 500; }
+FS_API int fs_version(void) { return 600; }
 FS_API const char* fs_last_error(void) { return fs::last_error().c_str(); }
 
 FS_API int fs_create(const fs_config* cfg, fs_handle* out) { return fs::net_create(cfg, out); }
@@ -275,239 +275,3 @@ FS_API int fs_crops_fuse(const float* lo_prev, const float* lo_next, const float
     return fs::launch_crops_fuse(p, crop_grids, scratch, S(stream));
 }
 
-FS_API int fs_pack_conv_weight(const float* oihw, float* ohwi, int O, int I, int KH, int KW, fs_stream stream) {
-    if (!oihw || !ohwi || O < 1 || I < 1 || KH < 1 || KW < 1) return fs::fail("fs_pack_conv_weight: bad arguments");
-    return fs::launch_pack_oihw_to_ohwi(oihw, ohwi, O, I, KH, KW, S(stream));
-}
-static int conv2d_entry(const float* in, int ld_in, const float* wgt_ohwi, const void* wgt3, const float* scale, const float* shift,
-                        const float* res, int ld_res, float* out, int ld_out, int B, int H, int W, int Cin, int Cout, int KH,
-                        int KW, int stride, int pad, int dil, int relu, int tile, fs_stream stream) {
-    if (!in || (!wgt_ohwi && !wgt3) || !out || B < 1 || H < 1 || W < 1 || stride < 1 || dil < 1 || pad < 0)
-        return fs::fail("fs_conv2d_nhwc: bad arguments");
-    fs::ConvParams p{};
-    p.in = in;
-    p.ld_in = ld_in;
-    p.wgt = wgt_ohwi;
-    p.wgt3 = wgt3;
-    p.plane_bytes = (unsigned)((size_t)Cout * KH * KW * Cin * 2);
-    p.scale = scale;
-    p.shift = shift;
-    p.res = res;
-    p.ld_res = ld_res;
-    p.out = out;
-    p.ld_out = ld_out;
-    p.B = B;
-    p.H = H;
-    p.W = W;
-    p.Cin = Cin;
-    p.Cout = Cout;
-    p.KH = KH;
-    p.KW = KW;
-    p.stride = stride;
-    p.pad = pad;
-    p.dil = dil;
-    p.relu = relu;
-    p.Ho = (H + 2 * pad - dil * (KH - 1) - 1) / stride + 1;
-    p.Wo = (W + 2 * pad - dil * (KW - 1) - 1) / stride + 1;
-    if (p.Ho < 1 || p.Wo < 1) return fs::fail("fs_conv2d_nhwc: empty output");
-    // tile = workgroup tile id 0..7 (6, 7: split route only), optionally | FS_CONV_CHUNK_MAJOR; anything else is refused (no hidden experiment bits)
-    constexpr int kMaxTile = 7;
-    if ((tile & ~FS_CONV_CHUNK_MAJOR) < 0 || (tile & ~FS_CONV_CHUNK_MAJOR) > kMaxTile)
-        return fs::fail("fs_conv2d_nhwc: tile must be 0..7, optionally | FS_CONV_CHUNK_MAJOR (got 0x%x)", tile);
-    p.korder = (tile & FS_CONV_CHUNK_MAJOR) ? 1 : 0;
-    return fs::launch_conv_igemm(p, S(stream), tile & ~FS_CONV_CHUNK_MAJOR);
-}
-FS_API int fs_conv2d_nhwc(const float* in, int ld_in, const float* wgt_ohwi, const float* scale, const float* shift,
-                          const float* res, int ld_res, float* out, int ld_out, int B, int H, int W, int Cin, int Cout, int KH,
-                          int KW, int stride, int pad, int dil, int relu, int tile, fs_stream stream) {
-    return conv2d_entry(in, ld_in, wgt_ohwi, nullptr, scale, shift, res, ld_res, out, ld_out, B, H, W, Cin, Cout, KH, KW, stride, pad, dil, relu,
-                        tile, stream);
-}
-FS_API int fs_split_bf16x3(const float* w, int64_t n, void* planes, fs_stream stream) { return fs::launch_split_bf16x3(w, n, planes, S(stream)); }
-FS_API int fs_conv2d_nhwc_split(const float* in, int ld_in, const void* wgt_planes, const float* scale, const float* shift,
-                                const float* res, int ld_res, float* out, int ld_out, int B, int H, int W, int Cin, int Cout, int KH,
-                                int KW, int stride, int pad, int dil, int relu, int tile, fs_stream stream) {
-    if (!wgt_planes) return fs::fail("fs_conv2d_nhwc_split: bad arguments");
-    return conv2d_entry(in, ld_in, nullptr, wgt_planes, scale, shift, res, ld_res, out, ld_out, B, H, W, Cin, Cout, KH, KW, stride, pad, dil,
-                        relu, tile, stream);
-}
-FS_API int fs_conv_chain_nhwc(const float* in, int K1, const float* in2, int K1b, const void* w1_planes, const float* scale1, const float* shift1,
-                              const float* res, float* mid, int C1, int relu1, const void* w2_planes, const float* scale2, const float* shift2,
-                              float* out, int C2, int relu2, int M, int tile, fs_stream stream) {
-    if (!in || !w1_planes || !mid || !w2_planes || !out || M < 1 || K1 < 32 || C1 < 1 || C2 < 1 || (in2 != nullptr) != (K1b > 0) || (in2 && res))
-        return fs::fail("fs_conv_chain_nhwc: bad arguments");
-    if (!(tile == 0 || tile == 1 || tile == 2 || tile == 3 || tile == 6)) return fs::fail("fs_conv_chain_nhwc: tile must be 0, 1, 2, 3 or 6 (got %d)", tile);
-    fs::ConvParams a{}, b{};
-    a.in = in; a.ld_in = K1; a.wgt = (const float*)w1_planes; a.wgt3 = w1_planes; a.plane_bytes = (unsigned)((size_t)C1 * (K1 + K1b) * 2);
-    a.scale = scale1; a.shift = shift1; a.res = res; a.ld_res = C1; a.out = mid; a.ld_out = C1;
-    a.B = 1; a.H = M; a.W = 1; a.Cin = K1; a.Ho = M; a.Wo = 1; a.Cout = C1; a.KH = a.KW = 1; a.stride = 1; a.dil = 1; a.relu = relu1;
-    if (in2) { a.in2 = in2; a.ld_in2 = K1b; a.Cin2 = K1b; a.stride2 = 1; a.H2 = M; a.W2 = 1; }
-    b.in = mid; b.ld_in = C1; b.wgt = (const float*)w2_planes; b.wgt3 = w2_planes; b.plane_bytes = (unsigned)((size_t)C2 * C1 * 2);
-    b.scale = scale2; b.shift = shift2; b.out = out; b.ld_out = C2;
-    b.B = 1; b.H = M; b.W = 1; b.Cin = C1; b.Ho = M; b.Wo = 1; b.Cout = C2; b.KH = b.KW = 1; b.stride = 1; b.dil = 1; b.relu = relu2;
-    return fs::launch_conv_chain(a, b, S(stream), tile);
-}
-FS_API size_t fs_attention_workspace_floats(int B, int N, int heads, int split_operands) {
-    if (B < 1 || N < 1 || heads < 1) return 0;
-    return fs::attention_scratch_floats(B, N, heads) + (split_operands ? fs::attention_split_floats(B, N, heads) + 64 : 0) + 64;
-}
-FS_API int fs_attention(const float* qkv, float* out, int B, int N, int heads, float scale, int split_operands, float* workspace, fs_stream stream) {
-    if (!qkv || !out || !workspace || B < 1 || N < 1 || heads < 1) return fs::fail("fs_attention: bad arguments");
-    const size_t sc = fs::attention_scratch_floats(B, N, heads);
-    float* scratch = sc ? workspace : nullptr;
-    if (!split_operands) return fs::launch_attention_f32(qkv, out, B, N, heads, scale, scratch, S(stream));
-    float* planes = workspace + sc;
-    planes += (64 - ((uintptr_t)planes / 4) % 64) % 64;  // 256-B aligned
-    return fs::launch_attention_split(qkv, out, B, N, heads, scale, scratch, planes, S(stream), split_operands == 2);
-}
-FS_API size_t fs_winograd_workspace_floats(int B, int H, int W, int Cin, int Cout, int dil, int tile_m) {
-    if (B < 1 || H < 1 || W < 1 || dil < 1 || !(tile_m == 0 || tile_m == 4 || tile_m == 6)) return 0;
-    const int mt = tile_m ? tile_m : fs::winograd_pick_m(B, H, W, dil);
-    const size_t G = (size_t)(mt + 2) * (mt + 2), T = (size_t)fs::winograd_tiles(B, H, W, dil, mt);
-    return G * T * ((size_t)Cin + (size_t)Cout) + G * (size_t)Cout * Cin;
-}
-FS_API int fs_conv3x3_winograd_nhwc(const float* in, int ld_in, const float* wgt_oihw, const float* scale, const float* shift,
-                                    float* out, int ld_out, int B, int H, int W, int Cin, int Cout, int dil, int relu, int tile_m,
-                                    float* workspace, fs_stream stream) {
-    if (!in || !wgt_oihw || !out || !workspace || B < 1 || H < 1 || W < 1 || dil < 1 || Cin % 32 != 0 || Cout % 4 != 0 ||
-        !(tile_m == 0 || tile_m == 4 || tile_m == 6))
-        return fs::fail("fs_conv3x3_winograd_nhwc: bad arguments (Cin %% 32, Cout %% 4, tile_m in {0, 4, 6} required)");
-    const int mt = tile_m ? tile_m : fs::winograd_pick_m(B, H, W, dil);
-    const size_t G = (size_t)(mt + 2) * (mt + 2), T = (size_t)fs::winograd_tiles(B, H, W, dil, mt);
-    float* U = workspace;
-    float* V = U + G * (size_t)Cout * Cin;
-    float* Mb = V + G * T * Cin;
-    if (int rc = fs::launch_winograd_filter(wgt_oihw, U, Cout, Cin, mt, S(stream))) return rc;
-    if (int rc = fs::launch_winograd_input(in, ld_in, V, B, H, W, Cin, dil, mt, S(stream))) return rc;
-    fs::ConvParams p{};
-    p.in = V;
-    p.ld_in = Cin;
-    p.wgt = U;
-    p.out = Mb;
-    p.ld_out = Cout;
-    p.B = 1;
-    p.H = (int)T;
-    p.W = 1;
-    p.Cin = Cin;
-    p.Ho = (int)T;
-    p.Wo = 1;
-    p.Cout = Cout;
-    p.KH = p.KW = 1;
-    p.stride = 1;
-    p.dil = 1;
-    p.groups = (int)G;
-    p.g_wgt = (long long)Cout * Cin;
-    fs::winograd_gemm_params(p, mt, (int)T, Cin, Cout);
-    if (int rc = fs::launch_conv_igemm(p, S(stream))) return rc;
-    return fs::launch_winograd_output(Mb, scale, shift, out, ld_out, B, H, W, Cout, relu, dil, mt, S(stream));
-}
-FS_API int fs_gemm_bf16x3_planes(const void* a_planes, int64_t a_plane_elems, int ld_a, const void* b_planes, int64_t b_plane_elems, int ld_b,
-                                 const float* scale, const float* shift, float* out, int ld_out, int M, int N, int K, int relu, int groups,
-                                 int64_t g_a, int64_t g_b, int64_t g_out, int bn, fs_stream stream) {
-    if (!a_planes || !b_planes || !out || a_plane_elems < 1 || b_plane_elems < 1 || a_plane_elems * 2 >= ((int64_t)1 << 31) ||
-        b_plane_elems * 2 >= ((int64_t)1 << 31) || !((bn & 0xff) == 0 || (bn & 0xff) == 64 || (bn & 0xff) == 128) || bn < 0 || relu < 0 || relu > 2)
-        return fs::fail("fs_gemm_bf16x3_planes: bad arguments (planes below 2 GiB, bn in {0, 64, 128}, relu in {0, 1, 2})");
-    fs::PlaneGemmParams p{};
-    p.a3 = a_planes; p.a_plane_bytes = (unsigned)(a_plane_elems * 2); p.ld_a = ld_a;
-    p.b3 = b_planes; p.b_plane_bytes = (unsigned)(b_plane_elems * 2); p.ld_b = ld_b;
-    p.scale = scale; p.shift = shift; p.out = out; p.ld_out = ld_out;
-    p.M = M; p.N = N; p.K = K; p.relu = relu;
-    p.groups = groups; p.g_a = g_a; p.g_b = g_b; p.g_out = g_out;
-    return fs::launch_gemm_planes(p, S(stream), bn);
-}
-FS_API size_t fs_winograd_planes_workspace_floats(int B, int H, int W, int Cin, int Cout, int dil, int tile_m) {
-    if (B < 1 || H < 1 || W < 1 || dil < 1 || Cin < 1 || Cout < 1 || !(tile_m == 0 || tile_m == 4 || tile_m == 6)) return 0;
-    const int mt = tile_m ? tile_m : fs::winograd_pick_m(B, H, W, dil);
-    const size_t G = (size_t)(mt + 2) * (mt + 2), T = (size_t)fs::winograd_tiles(B, H, W, dil, mt);
-    // U (fp32) + its planes + the planes of V + M (fp32); every block a multiple of 8 floats
-    return G * (size_t)Cout * Cin * 5 / 2 + G * T * (size_t)Cin * 3 / 2 + G * T * (size_t)Cout + 64;
-}
-FS_API int fs_conv3x3_winograd_planes_nhwc(const float* in, int ld_in, const float* wgt_oihw, const float* scale, const float* shift,
-                                           float* out, int ld_out, int B, int H, int W, int Cin, int Cout, int dil, int relu, int tile_m,
-                                           float* workspace, fs_stream stream) {
-    if (!in || !wgt_oihw || !out || !workspace || B < 1 || H < 1 || W < 1 || dil < 1 || Cin % 32 != 0 || Cout % 4 != 0 ||
-        !(tile_m == 0 || tile_m == 4 || tile_m == 6))
-        return fs::fail("fs_conv3x3_winograd_planes_nhwc: bad arguments (Cin %% 32, Cout %% 4, tile_m in {0, 4, 6} required)");
-    const int mt = tile_m ? tile_m : fs::winograd_pick_m(B, H, W, dil);
-    const size_t G = (size_t)(mt + 2) * (mt + 2), T = (size_t)fs::winograd_tiles(B, H, W, dil, mt);
-    const size_t u_elems = G * (size_t)Cout * Cin, v_elems = G * T * (size_t)Cin;
-    float* U = workspace;
-    float* U3 = U + u_elems;
-    float* V3 = U3 + (3 * u_elems + 1) / 2 + 8 - ((3 * u_elems + 1) / 2) % 8;
-    float* Mb = V3 + (3 * v_elems + 1) / 2 + 8 - ((3 * v_elems + 1) / 2) % 8;
-    if (int rc = fs::launch_winograd_filter(wgt_oihw, U, Cout, Cin, mt, S(stream))) return rc;
-    if (int rc = fs::launch_split_bf16x3(U, (long long)u_elems, U3, S(stream))) return rc;
-    if (int rc = fs::launch_winograd_input_planes(in, ld_in, V3, (long long)v_elems, B, H, W, Cin, dil, mt, S(stream))) return rc;
-    fs::PlaneGemmParams p{};
-    if (int rc = fs::winograd_plane_gemm_params(p, mt, (int)T, Cin, Cout, V3, U3, Mb)) return rc;
-    if (int rc = fs::launch_gemm_planes(p, S(stream))) return rc;
-    return fs::launch_winograd_output(Mb, scale, shift, out, ld_out, B, H, W, Cout, relu, dil, mt, S(stream));
-}
-FS_API size_t fs_winograd_fused_workspace_floats(int Cin, int Cout) { return fs::wino_fused_bank_floats(Cin, Cout); }
-FS_API int fs_conv3x3_winograd_fused_nhwc(const float* in, int ld_in, const float* wgt_oihw, const float* scale, const float* shift,
-                                          float* out, int ld_out, int B, int H, int W, int Cin, int Cout, int relu, int variant,
-                                          float* workspace, fs_stream stream) {
-    if (!in || !wgt_oihw || !out || !workspace || B < 1 || H < 1 || W < 1 || variant < 0 || variant > 3 ||
-        !fs::wino_fused_supported(Cin, Cout, 3, 3, 1, 1, 1))
-        return fs::fail("fs_conv3x3_winograd_fused_nhwc: bad arguments (Cin %% 32 == 0, 32 <= Cin <= 256, Cout %% 64 == 0, variant 0..3)");
-    if (int rc = fs::launch_wino4_filter_packed(wgt_oihw, workspace, Cout, Cin, S(stream))) return rc;
-    return fs::launch_wino4_fused(in, ld_in, workspace, scale, shift, out, ld_out, B, H, W, Cin, Cout, relu, S(stream), variant);
-}
-FS_API int fs_conv3x3_winograd_fused_pool_nhwc(const float* in, int ld_in, const float* wgt_oihw, const float* scale, const float* shift, float* pool,
-                                               int B, int H, int W, int Cin, int Cout, float* workspace, fs_stream stream) {
-    if (!in || !wgt_oihw || !pool || !workspace || B < 1 || H < 1 || W < 1 || !fs::wino_fused_supported(Cin, Cout, 3, 3, 1, 1, 1))
-        return fs::fail("fs_conv3x3_winograd_fused_pool_nhwc: bad arguments (Cin %% 32 == 0, 32 <= Cin <= 256, Cout %% 64 == 0)");
-    if (int rc = fs::launch_wino4_filter_packed(wgt_oihw, workspace, Cout, Cin, S(stream))) return rc;
-    return fs::launch_wino4_fused_pool(in, ld_in, workspace, scale, shift, pool, Cout, B, H, W, Cin, Cout, S(stream));
-}
-static int stem_entry(const float* in_nchw, const float* wgt_hwio, const float* scale, const float* shift, float* out_nhwc, int B, int H, int W, int Cout,
-                      int KH, int KW, int stride, int pad, int split, fs_stream stream);
-FS_API int fs_stem_conv_nchw(const float* in_nchw, const float* wgt_hwio, const float* scale, const float* shift,
-                             float* out_nhwc, int B, int H, int W, int Cout, int KH, int KW, int stride, int pad,
-                             fs_stream stream) {
-    return stem_entry(in_nchw, wgt_hwio, scale, shift, out_nhwc, B, H, W, Cout, KH, KW, stride, pad, 0, stream);
-}
-FS_API int fs_stem_conv_nchw_split(const float* in_nchw, const float* wgt_hwio, const float* scale, const float* shift,
-                                   float* out_nhwc, int B, int H, int W, int Cout, int KH, int KW, int stride, int pad,
-                                   fs_stream stream) {
-    return stem_entry(in_nchw, wgt_hwio, scale, shift, out_nhwc, B, H, W, Cout, KH, KW, stride, pad, 1, stream);
-}
-static int stem_entry(const float* in_nchw, const float* wgt_hwio, const float* scale, const float* shift, float* out_nhwc, int B, int H, int W, int Cout,
-                      int KH, int KW, int stride, int pad, int split, fs_stream stream) {
-    if (!in_nchw || !wgt_hwio || !scale || !shift || !out_nhwc || B < 1) return fs::fail("fs_stem_conv_nchw: bad arguments");
-    fs::StemParams p{};
-    p.src = fs::frames_plain(in_nchw, nullptr, B);
-    p.wgt = wgt_hwio;
-    p.scale = scale;
-    p.shift = shift;
-    p.out = out_nhwc;
-    p.ld_out = Cout;
-    p.B = B;
-    p.H = H;
-    p.W = W;
-    p.Ho = (H + 2 * pad - KH) / stride + 1;
-    p.Wo = (W + 2 * pad - KW) / stride + 1;
-    p.Cout = Cout;
-    p.KH = KH;
-    p.KW = KW;
-    p.stride = stride;
-    p.pad = pad;
-    p.split = split;
-    return fs::launch_stem_conv(p, S(stream));
-}
-FS_API int fs_maxpool3x3s2_nhwc(const float* in, float* out, int B, int H, int W, int C, fs_stream stream) {
-    if (!in || !out || B < 1 || H < 1 || W < 1) return fs::fail("fs_maxpool3x3s2_nhwc: bad arguments");
-    return fs::launch_maxpool3x3s2(in, C, out, C, B, H, W, C, (H + 2 - 3) / 2 + 1, (W + 2 - 3) / 2 + 1, S(stream));
-}
-FS_API int fs_adaptive_avgpool_nhwc(const float* in, int ld_in, float* out, int B, int H, int W, int C, int bin, fs_stream stream) {
-    if (!in || !out || B < 1 || H < 1 || W < 1 || bin < 1) return fs::fail("fs_adaptive_avgpool_nhwc: bad arguments");
-    return fs::launch_adaptive_avgpool(in, ld_in, out, B, H, W, C, bin, S(stream));
-}
-FS_API int fs_nchw_to_nhwc(const float* in, float* out, int B, int C, int HW, fs_stream stream) {
-    if (!in || !out || B < 1 || C < 1 || HW < 1) return fs::fail("fs_nchw_to_nhwc: bad arguments");
-    return fs::launch_nchw_to_nhwc(in, out, C, B, C, HW, S(stream));
-}
-FS_API int fs_nhwc_to_nchw(const float* in, float* out, int B, int C, int HW, fs_stream stream) {
-    if (!in || !out || B < 1 || C < 1 || HW < 1) return fs::fail("fs_nhwc_to_nchw: bad arguments");
-    return fs::launch_nhwc_to_nchw(in, C, out, B, C, HW, S(stream));
-}

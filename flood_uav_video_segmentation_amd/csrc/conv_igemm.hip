@@ -478,6 +478,15 @@ __device__ __forceinline__ void conv_tile(ConvParams p, const int m0, const int 
 #ifdef FS_TRACE
     if ((p.dbg & 16) && p.ld_out >= 0) return;  // timing experiment: skip the epilogue (the test keeps the main loop alive)
 #endif
+    if constexpr (SPLIT && !DUAL && BN == 96 && TM == 1) {
+        // the Segmenter's qkv Linear: K / V column tiles leave as the attention's operand planes (ConvParams::kv_k, igemm_epilogue.h)
+        const int Dm = p.kv_heads * 64;
+        if (p.kv_k && n0 >= Dm) {
+            const int kind = n0 >= 2 * Dm ? 2 : 1;
+            igemm_epilogue_kv<TN>(acc, sc_n, sh_n, p, kind, em_base, en_base - kind * Dm, en_base < p.Cout, lane);
+            return;
+        }
+    }
     if (!DUAL && p.res) {
         if (p.relu == 1) igemm_epilogue<1, true>(acc, rv, sc_n, sh_n, p, M, em_base, en_base);
         else if (p.relu == 2) igemm_epilogue<2, true>(acc, rv, sc_n, sh_n, p, M, em_base, en_base);
@@ -524,55 +533,15 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_igemm_dma_f32(ConvParams 
     p.wgt += (long long)grp * p.g_wgt;
     if (SPLIT) p.wgt3 = (const char*)p.wgt3 + (long long)grp * p.g_wgt * 2;  // the group's rows inside every plane
     p.out += (long long)grp * p.g_out;
+    p.kv_b = grp;
     conv_tile<BM, BN, WGM, WGN, DUAL, SPLIT>(p, m0, n0, lds, bid);
-#endif
-}
-
-// ---------------------------------------------------------------------------------------------------------
-// conv_chain_dma_f32 (round 5): TWO dependent 1x1 convolutions of a bottleneck boundary in one launch --
-//   phase 1  X' = relu(bn3(conv3(f)) + x)           (or, DUAL: relu(bn3(conv3(f)) + bn_ds(downsample(x))), concatenated K)
-//   phase 2  g  = relu(bn1'(conv1'(X')))             the NEXT block's conv1 (model/resnet.py:76-96, two consecutive Bottlenecks)
-// A workgroup owns BM pixel rows: it computes ALL Cout1 / BN column tiles of phase 1 for them (the pixel operand is re-staged per
-// tile: L2 hits), stores X' (the next block's shortcut needs it in memory anyway), and then multiplies those same BM rows of X'
-// by the next conv1's filters.  The rows it reads in phase 2 are rows IT wrote: no other workgroup's data is involved, so the
-// only ordering needed is inside the workgroup -- every wave's stores complete (s_waitcnt vmcnt(0)) before the barrier that ends
-// a tile -- plus phase-2 pixel loads that do not trust this CU's L1 (sc1: conv3 may run in place over the shortcut, whose lines
-// the L1 may hold from the residual read).  What it saves against two launches: one launch ramp and tail per boundary, and the
-// 2 x M x Cout1 x 4 B re-read of X' from memory (it is read back from L2 microseconds after it was written).
-// ---------------------------------------------------------------------------------------------------------
-template <int BM, int BN, int WGM, int WGN, bool DUAL>
-__global__ __launch_bounds__(64 * WGM * WGN) void conv_chain_dma_f32(ConvParams pa, ConvParams pb, int tiles_m) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    __shared__ __attribute__((aligned(1024))) float lds[conv_tile_lds_floats<BM, BN, true>()];
-    // blocks b, b + 8, ... share an XCD (L2): give every XCD a contiguous run of m-tiles
-    const int nblk = gridDim.x, bid = blockIdx.x;
-    const int q = nblk >> 3, rr = nblk & 7, xcd = bid & 7;
-    const int lid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (bid >> 3);
-    if (lid >= tiles_m) return;
-    const int m0 = lid * BM;
-    const int tn_a = (pa.Cout + BN - 1) / BN, tn_b = (pb.Cout + BN - 1) / BN;
-    // (m0 is laundered through an empty asm per tile: otherwise the per-lane row offsets, invariant across the column tiles, are
-    //  hoisted out of the loops and kept in ~50 VGPRs, which costs the 128 x 128 form its second workgroup per CU)
-    for (int j = 0; j < tn_a; ++j) {
-        int m0j = m0;
-        asm volatile("" : "+s"(m0j));
-        conv_tile<BM, BN, WGM, WGN, DUAL, true>(pa, m0j, j * BN, lds, bid);
-        FS_DMA_PUBLISH()  // this tile's stores have completed, every wave is done with the LDS stages
-    }
-    for (int j = 0; j < tn_b; ++j) {
-        int m0j = m0;
-        asm volatile("" : "+s"(m0j));
-        conv_tile<BM, BN, WGM, WGN, false, true, 16>(pb, m0j, j * BN, lds, bid);
-        if (j + 1 < tn_b) FS_DMA_PUBLISH()
-    }
 #endif
 }
 
 namespace {
 struct TileCfg { int bm, bn; const char* name; };
-const TileCfg kTiles[8] = {{0, 0, "auto"}, {128, 128, "igemm128x128"}, {128, 64, "igemm128x64"},
-                           {64, 64, "igemm64x64"}, {64, 128, "igemm64x128"}, {256, 128, "igemm256x128"}, {128, 96, "split128x96"},
-                           {256, 128, "split256x128"}};
+const TileCfg kTiles[7] = {{0, 0, "auto"}, {128, 128, "igemm128x128"}, {128, 64, "igemm128x64"},
+                           {64, 64, "igemm64x64"}, {64, 128, "igemm64x128"}, {0, 0, "(retired)"}, {128, 96, "split128x96"}};
 
 int pick_tile(const ConvParams& p) {
     // Cost model fitted to the MI355X tile sweeps (profiles/r01_conv_tile_sweep*.txt): per-tile MFMA efficiency by tile
@@ -582,8 +551,8 @@ int pick_tile(const ConvParams& p) {
     // Tile 6 (128 x 96, split route, round 5) is a candidate only where 96 divides the columns: the Segmenter's Linears (d_model 384 / 768
     // and their multiples) -- 4052 token rows x 1536 columns are exactly 512 such tiles, two per CU, where 128 x 64 leaves 768 (1.5 per
     // slot).  No PSPNet / DeepLab layer qualifies (their channel counts are powers of two), so their choices are untouched.
-    // (Round 5, profiles/r05_experiments.txt section 18: tile 7 -- 256 x 128 on eight waves -- as a candidate for single-round launches and the
-    //  64 x 64 tile re-priced at 0.70 won 3-12 % on isolated launches and nothing in a window; the model stays as fitted.)
+    // (Rounds 4-5, profiles/r04_experiments.txt section 9, r05_experiments.txt section 18: 256 x 128 tiles -- four waves of 64 x 128, or eight of
+    //  32 x 128 -- won 3-12 % on isolated single-round launches and nothing in a window; removed in round 6, the model stays as fitted.)
     const double eff[7] = {0, 1.00, 0.92, 0.80, 0.92, 0, 0.97};
     int best = 1;
     double best_t = 1e300;
@@ -603,10 +572,10 @@ int pick_tile(const ConvParams& p) {
 
 const char* conv_igemm_tile_name(const ConvParams& p, int tile) {
     tile &= 0xff;
-    if (tile <= 0 || tile > 7) tile = pick_tile(p);
+    if (tile <= 0 || tile > 6 || tile == 5) tile = pick_tile(p);
     if (p.in2 && p.wgt3) return tile == 2 ? "split128x64cat" : "split128x128cat";
     if (p.in2) return tile == 2 ? "igemm128x64cat" : "igemm128x128cat";  // the concatenated-K instantiations are kernels of their own
-    if (p.wgt3) return tile == 1 ? "split128x128" : tile == 2 ? "split128x64" : tile == 4 ? "split64x128" : tile == 6 ? "split128x96" : tile == 7 ? "split256x128" : "split64x64";
+    if (p.wgt3) return tile == 1 ? "split128x128" : tile == 2 ? "split128x64" : tile == 4 ? "split64x128" : tile == 6 ? "split128x96" : "split64x64";
     return kTiles[tile].name;
 }
 
@@ -635,7 +604,7 @@ int launch_split_bf16x3(const float* w, long long n, void* planes, hipStream_t s
 }
 
 namespace {
-// argument checks shared by launch_conv_igemm and launch_conv_chain
+// argument checks of launch_conv_igemm
 int check_conv_params(const ConvParams& p) {
     FS_REQUIRE(p.Cin % 32 == 0, "conv_igemm: Cin=%d must be a multiple of 32", p.Cin);
     if (p.in2) {
@@ -671,14 +640,23 @@ int check_conv_params(const ConvParams& p) {
 int launch_conv_igemm(const ConvParams& p, hipStream_t s, int tile) {
     FS_TRY(check_conv_params(p));
     tile &= 0xff;
-    if (tile <= 0 || tile > 7) tile = pick_tile(p);
-    FS_REQUIRE(tile < 6 || (p.wgt3 && !p.in2), "conv_igemm: tiles 6 (128 x 96) and 7 (256 x 128, eight waves) exist on the split-operand route only");
+    if (tile <= 0 || tile > 6 || tile == 5) tile = pick_tile(p);
+    FS_REQUIRE(tile < 6 || (p.wgt3 && !p.in2), "conv_igemm: tile 6 (128 x 96) exists on the split-operand route only");
     const int M = p.B * p.Ho * p.Wo;
     const int bm = kTiles[tile].bm, bn = kTiles[tile].bn;
     const int tm = cdiv(M, bm), tn = cdiv(p.Cout, bn);
     const int groups = p.groups > 1 ? p.groups : 1;
     FS_REQUIRE(groups == 1 || p.res == nullptr, "conv_igemm: grouped GEMM has no residual input");
     const dim3 grid(tm * tn * groups), block(256);
+    if (p.kv_k) {
+        const int Dm = p.kv_heads * 64;
+        FS_REQUIRE(tile == 6 && p.wgt3 && !p.in2 && !p.res && p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0 && p.relu == 0,
+                   "conv_igemm: the K / V plane epilogue belongs to a plain Linear on the 128 x 96 split tile");
+        FS_REQUIRE(p.kv_vt && p.kv_heads >= 1 && Dm % 96 == 0 && p.Cout == 3 * Dm && p.kv_N == M && p.kv_Npad % 32 == 0 && p.kv_Npad >= M &&
+                       p.kv_Npad <= tm * bm && (int64_t)3 * p.kv_plane_bytes < (int64_t)1 << 31 &&
+                       (int64_t)p.kv_plane_bytes == (int64_t)groups * p.kv_heads * p.kv_Npad * 128 && (((uintptr_t)p.kv_k | (uintptr_t)p.kv_vt) & 15) == 0,
+                   "conv_igemm: bad K / V plane geometry (heads %d, tokens %d, padded %d)", p.kv_heads, p.kv_N, p.kv_Npad);
+    }
     if (p.wgt3) {
         FS_REQUIRE(((uintptr_t)p.wgt3 & 15) == 0 && p.plane_bytes % 16 == 0 && (int64_t)3 * p.plane_bytes < (int64_t)1 << 31 && ldw_ok(p),
                    "conv_igemm: bad split filter bank (plane_bytes=%u)", p.plane_bytes);
@@ -711,25 +689,8 @@ int launch_conv_igemm(const ConvParams& p, hipStream_t s, int tile) {
             case 4: hipLaunchKernelGGL((conv_igemm_dma_f32<64, 128, 2, 2, false, true>), grid, block, 0, s, p, tm, tn); break;
             // round 5: 128 rows x 96 columns (4 x 1 waves of 32 x 96), for column counts that are multiples of 96 -- see pick_tile
             case 6: hipLaunchKernelGGL((conv_igemm_dma_f32<128, 96, 4, 1, false, true>), grid, block, 0, s, p, tm, tn); break;
-            // round 5: 256 x 128 on EIGHT waves of 32 x 128 (8 x 1, 512 threads, one workgroup per CU) -- what two co-resident 128 x 128
-            // workgroups do, as ONE workgroup that stages the filter tile once for both halves (56 KB of DMA per chunk instead of 2 x 40; the
-            // elimination runs of profiles/r05_experiments.txt section 17 price that traffic).  Bit-identical to every other tile.  Alone it wins
-            // 3 % where the launch is ONE round of it (<= 256 tiles: layer4's conv1) and loses where a CU runs several in sequence; in a window: nothing
-            // (section 18).  Forced tile only (tests, sweeps).
-            case 7: hipLaunchKernelGGL((conv_igemm_dma_f32<256, 128, 8, 1, false, true>), grid, dim3(512), 0, s, p, tm, tn); break;
-#ifdef FS_DEV
-            // experiment (tools/tile256_bench.py, profiles/r04_experiments.txt section 9): a 256 x 128 tile, 4 x 1 waves of 64 x 128, one
-            // workgroup per CU with the accumulators in AGPRs -- 41 % fewer LDS read bytes per MFMA at the same VALU count per MFMA (every
-            // filter fragment feeds two row blocks).  Bit-identical; EQUAL to two 128 x 128 workgroups per CU at K = 2048, slower below.
-            case 5: hipLaunchKernelGGL((conv_igemm_dma_f32<256, 128, 4, 1, false, true>), grid, block, 0, s, p, tm, tn); break;
-#endif
-            default: return fail("conv_igemm: the split-operand route has tiles 1, 2, 3, 4, 6 and 7");
+            default: return fail("conv_igemm: the split-operand route has tiles 1, 2, 3, 4 and 6");
         }
-        FS_HIP(hipGetLastError());
-        return 0;
-    }
-    if (tile == 5) {  // 8-wave workgroup, one per CU
-        hipLaunchKernelGGL((conv_igemm_dma_f32<256, 128, 4, 2>), grid, dim3(512), 0, s, p, tm, tn);
         FS_HIP(hipGetLastError());
         return 0;
     }
@@ -750,61 +711,5 @@ int launch_conv_igemm(const ConvParams& p, hipStream_t s, int tile) {
     return 0;
 }
 
-
-namespace {
-int check_split_bank(const ConvParams& p) {
-    FS_REQUIRE(p.wgt3 && ((uintptr_t)p.wgt3 & 15) == 0 && p.plane_bytes % 16 == 0 && (int64_t)3 * p.plane_bytes < (int64_t)1 << 31 && ldw_ok(p),
-               "conv_igemm: bad split filter bank (plane_bytes=%u)", p.plane_bytes);
-    return 0;
-}
-const TileCfg kChainTiles[7] = {{0, 0, "auto"}, {128, 128, "chain128x128"}, {128, 64, "chain128x64"}, {64, 64, "chain64x64"}, {0, 0, ""}, {0, 0, ""},
-                                {64, 128, "chain64x128"}};
-// Row tile by the number of workgroups it leaves (one per row tile): 128 rows while that still gives every CU about two
-// workgroups; column tile 64 only when neither conv has more than 64 output channels to fill a wider one.
-int pick_chain_tile(const ConvParams& pa, const ConvParams& pb) {
-    const int M = pa.B * pa.Ho * pa.Wo;
-    const bool wide = pb.Cout > 64;
-    if (cdiv(M, 128) >= 384) return wide ? 1 : 2;
-    return wide ? 6 : 3;
-}
-}  // namespace
-
-const char* conv_chain_tile_name(const ConvParams& pa, const ConvParams& pb, int tile) {
-    if (!(tile == 1 || tile == 2 || tile == 3 || tile == 6)) tile = pick_chain_tile(pa, pb);
-    return kChainTiles[tile].name;
-}
-
-// Two dependent 1x1 convolutions over the same pixel rows in one launch (conv_chain_dma_f32): pa = block i's conv3 with its
-// shortcut (residual input, or the concatenated-K projection form), pb = block i + 1's conv1 reading pa's output in place.
-int launch_conv_chain(const ConvParams& pa, const ConvParams& pb, hipStream_t s, int tile) {
-    FS_TRY(check_conv_params(pa));
-    FS_TRY(check_conv_params(pb));
-    FS_TRY(check_split_bank(pa));
-    FS_TRY(check_split_bank(pb));
-    for (const ConvParams* p : {&pa, &pb})
-        FS_REQUIRE(p->KH == 1 && p->KW == 1 && p->stride == 1 && p->pad == 0 && p->groups <= 1 && p->korder == 0 && p->ld_wgt == 0,
-                   "conv_chain: both convolutions must be plain 1x1 stride-1 convs");
-    FS_REQUIRE(pb.in == pa.out && pb.ld_in == pa.ld_out && pb.Cin == pa.Cout && pb.B * pb.Ho * pb.Wo == pa.B * pa.Ho * pa.Wo,
-               "conv_chain: the second conv must read the first one's output in place (Cin %d vs Cout %d)", pb.Cin, pa.Cout);
-    FS_REQUIRE(pb.res == nullptr && pb.in2 == nullptr && pb.out != pa.out && pb.out != pa.in, "conv_chain: the second conv takes no shortcut and writes its own buffer");
-    if (!(tile == 1 || tile == 2 || tile == 3 || tile == 6)) tile = pick_chain_tile(pa, pb);
-    const int M = pa.B * pa.Ho * pa.Wo;
-    const int bm = kChainTiles[tile].bm;
-    const int tm = cdiv(M, bm);
-    const dim3 grid(tm), block(256);
-    const bool dual = pa.in2 != nullptr;
-#define FS_CHAIN_LAUNCH(BM_, BN_, WGM_, WGN_)                                                                                  \
-    if (dual) hipLaunchKernelGGL((conv_chain_dma_f32<BM_, BN_, WGM_, WGN_, true>), grid, block, 0, s, pa, pb, tm);             \
-    else hipLaunchKernelGGL((conv_chain_dma_f32<BM_, BN_, WGM_, WGN_, false>), grid, block, 0, s, pa, pb, tm);
-    switch (tile) {
-        case 1: FS_CHAIN_LAUNCH(128, 128, 4, 1) break;
-        case 2: FS_CHAIN_LAUNCH(128, 64, 4, 1) break;
-        case 3: FS_CHAIN_LAUNCH(64, 64, 2, 2) break;
-        default: FS_CHAIN_LAUNCH(64, 128, 2, 2) break;
-    }
-#undef FS_CHAIN_LAUNCH
-    FS_HIP(hipGetLastError());
-    return 0;
-}
 
 }  // namespace fs

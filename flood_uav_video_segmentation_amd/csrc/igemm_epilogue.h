@@ -82,6 +82,83 @@ __device__ __forceinline__ void igemm_epilogue(const f32x16 (&acc)[TM][TN], cons
         }
     }
 }
+
+// ---- the Segmenter's qkv Linear: K / V column tiles written as the attention's operand planes (ConvParams::kv_k)
+typedef unsigned ep_u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 ep_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float ep_f32x2 __attribute__((ext_vector_type(2)));
+
+// (x0, x1) -> the three bf16 terms of each (x = h + m + l exactly, round-to-nearest residues), packed {x0 term, x1 term}
+__device__ __forceinline__ void ep_split_pair(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
+    h = __builtin_bit_cast(unsigned, __builtin_convertvector((ep_f32x2){x0, x1}, ep_bf16x2));
+    const float r0 = x0 - __builtin_bit_cast(float, h << 16), r1 = x1 - __builtin_bit_cast(float, h & 0xffff0000u);
+    m = __builtin_bit_cast(unsigned, __builtin_convertvector((ep_f32x2){r0, r1}, ep_bf16x2));
+    const float q0 = r0 - __builtin_bit_cast(float, m << 16), q1 = r1 - __builtin_bit_cast(float, m & 0xffff0000u);
+    l = __builtin_bit_cast(unsigned, __builtin_convertvector((ep_f32x2){q0, q1}, ep_bf16x2));
+}
+
+// kind 1: K tile, kind 2: V tile.  m_base = first row of this lane's rows (block base + 4 * hh), n_rel = this lane's first column relative to
+// the start of K (resp. V) inside the qkv row.  Row r of the 32-row block is key kb + r of image p.kv_b; a lane holds rows
+// (e & 3) + 8 * (e >> 2) + 4 * hh of one column (channel d of one head) per 32-column block.
+//   K  [bh][key][d]:   rows e, e + 1 are consecutive keys; lanes d, d + 1 exchange one of them (DPP), so every lane stores dwords (two
+//                      channels of one key) -- a store instruction covers four 64-B runs.
+//   V^T [bh][d][pos]:  inside 16 keys the position is (k & 3) + 4 (k >> 3) + 8 ((k >> 2) & 1): a lane's registers 8 g .. 8 g + 7 ARE
+//                      positions 8 hh .. 8 hh + 7 of key group 2 (kb / 32) + g in that order -- one 16-B store per plane and group.
+template <int TN>
+__device__ __forceinline__ void igemm_epilogue_kv(const f32x16 (&acc)[1][TN], const float (&sc)[TN], const float (&sh)[TN], const ConvParams& p, int kind,
+                                                  int m_base, int n_rel, bool col_ok, int lane) {
+    constexpr unsigned SENT = 0x80000000u;
+    const int hh = lane >> 5, odd = lane & 1;
+    const int N = p.kv_N, Npad = p.kv_Npad;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(kind == 1 ? p.kv_k : p.kv_vt), 0, 3u * p.kv_plane_bytes, 0x00020000);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n_rel + j * 32;
+        const int bh = p.kv_b * p.kv_heads + (n >> 6), d = n & 63;
+        if (kind == 1) {
+#pragma unroll
+            for (int ep = 0; ep < 8; ++ep) {
+                const int e0 = 2 * ep, key0 = m_base + (e0 & 3) + 8 * (e0 >> 2);
+                const float v0 = key0 < N ? acc[0][j][e0] * sc[j] + sh[j] : 0.f;
+                const float v1 = key0 + 1 < N ? acc[0][j][e0 + 1] * sc[j] + sh[j] : 0.f;
+                unsigned H, Mm, L;
+                ep_split_pair(v0, v1, H, Mm, L);  // low halves: key0, high halves: key0 + 1, channel d
+                // even lanes keep key0 and receive the neighbour's (channel d + 1); odd lanes keep key0 + 1 and receive channel d - 1's
+                const unsigned send_hm = odd ? ((H & 0xffffu) | (Mm << 16)) : ((H >> 16) | (Mm & 0xffff0000u));
+                const unsigned send_l = odd ? (L & 0xffffu) : (L >> 16);
+                const unsigned recv_hm = (unsigned)__builtin_amdgcn_mov_dpp((int)send_hm, 0xB1, 0xf, 0xf, true);  // quad_perm [1, 0, 3, 2]
+                const unsigned recv_l = (unsigned)__builtin_amdgcn_mov_dpp((int)send_l, 0xB1, 0xf, 0xf, true);
+                const unsigned oH = odd ? ((recv_hm & 0xffffu) | (H & 0xffff0000u)) : ((H & 0xffffu) | (recv_hm << 16));
+                const unsigned oM = odd ? ((recv_hm >> 16) | (Mm & 0xffff0000u)) : ((Mm & 0xffffu) | (recv_hm & 0xffff0000u));
+                const unsigned oL = odd ? ((recv_l & 0xffffu) | (L & 0xffff0000u)) : ((L & 0xffffu) | (recv_l << 16));
+                const int key = key0 + odd;
+                const unsigned vo = (col_ok && key < Npad) ? (unsigned)(((bh * Npad + key) * 64 + (d & ~1)) * 2) : SENT;
+                __builtin_amdgcn_raw_buffer_store_b32(oH, rsrc, vo, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(oM, rsrc, vo, (int)p.kv_plane_bytes, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(oL, rsrc, vo, (int)(2u * p.kv_plane_bytes), 0);
+            }
+        } else {
+            const int kb = m_base - 4 * hh;  // first key of the 32-row block (a multiple of 32)
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                ep_u32x4 H, Mm, L;
+#pragma unroll
+                for (int t2 = 0; t2 < 4; ++t2) {
+                    const int e0 = 8 * g + 2 * t2, key0 = m_base + (e0 & 3) + 8 * (e0 >> 2);
+                    const float v0 = key0 < N ? acc[0][j][e0] * sc[j] + sh[j] : 0.f;
+                    const float v1 = key0 + 1 < N ? acc[0][j][e0 + 1] * sc[j] + sh[j] : 0.f;
+                    unsigned h, m, l;
+                    ep_split_pair(v0, v1, h, m, l);
+                    H[t2] = h; Mm[t2] = m; L[t2] = l;
+                }
+                const unsigned vo = (col_ok && kb < Npad) ? (unsigned)(((bh * 64 + d) * Npad + kb + 16 * g + 8 * hh) * 2) : SENT;
+                __builtin_amdgcn_raw_buffer_store_b128(H, rsrc, vo, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(Mm, rsrc, vo, (int)p.kv_plane_bytes, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(L, rsrc, vo, (int)(2u * p.kv_plane_bytes), 0);
+            }
+        }
+    }
+}
 #endif
 
 

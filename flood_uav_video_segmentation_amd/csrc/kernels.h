@@ -44,6 +44,16 @@ struct ConvParams {
     // nullptr = the fp32-MFMA kernel.  plane_bytes = bytes of one plane.
     const void* wgt3;
     unsigned plane_bytes;
+    // Segmenter qkv Linear (round 6, 128 x 96 tile of the split route only): kv_k != nullptr -> the launch is grouped by IMAGE (groups = B,
+    // M = the tokens of one image, so a tile's rows are keys of one image and 32-row blocks are aligned with the attention's 16-key groups)
+    // and the epilogue of the K and V column tiles writes the attention kernel's operand planes -- K as three bf16 planes [bh][Npad][64],
+    // V transposed as three planes [bh][64][Npad] in the key order of the S^T accumulator (vit_ops.hip::attention_split_kv_kernel, whose
+    // work this is), keys N .. Npad-1 as zeros -- instead of fp32 rows; the Q columns are stored as usual.  Cout = 3 * kv_heads * 64.
+    unsigned short* kv_k;
+    unsigned short* kv_vt;
+    int kv_N, kv_Npad, kv_heads;
+    unsigned kv_plane_bytes;   // bytes of one plane of K (= of V^T): B * heads * Npad * 64 * 2
+    int kv_b;                  // image of this workgroup's group (set by the kernel)
 #ifdef FS_TRACE  // tools/probe_conv_trace.hip builds only -- the field does not exist in libfloodseg.so
     int dbg;     // timing experiments (results are wrong when != 0): 2 = one block per CU, 16 = skip the epilogue,
                  // 32 | n << 8 = start workgroups bid+256.. n*256 cycles late
@@ -52,32 +62,9 @@ struct ConvParams {
 // tile: 0 = heuristic, 1 = 128x128, 2 = 128x64, 3 = 64x64, 4 = 64x128
 int launch_conv_igemm(const ConvParams& p, hipStream_t s, int tile = 0);
 const char* conv_igemm_tile_name(const ConvParams& p, int tile = 0);
-// Round 5: two dependent 1x1 convolutions of a bottleneck boundary in ONE launch (conv_chain_dma_f32): pa = block i's conv3 with
-// its shortcut (residual, or the concatenated-K projection form), pb = block i + 1's conv1 with pb.in == pa.out.  Split-operand
-// route only (both need wgt3).  tile: 0 = by row count, 1 = 128x128, 2 = 128x64, 3 = 64x64, 6 = 64x128.  Results are bit-identical
-// to the two launches (same tile arithmetic per output: a tile's k order does not depend on its shape).
-int launch_conv_chain(const ConvParams& pa, const ConvParams& pb, hipStream_t s, int tile = 0);
-const char* conv_chain_tile_name(const ConvParams& pa, const ConvParams& pb, int tile = 0);
 // planes[t][i] (t = 0, 1, 2; bf16) with w[i] == planes[0][i] + planes[1][i] + planes[2][i] exactly (ConvParams::wgt3)
 int launch_split_bf16x3(const float* w, long long n, void* planes, hipStream_t s);
 
-// ---------------------------------------------------------------------------------
-// Split-operand GEMM with a PRE-SPLIT row operand (gemm_planes.hip): out[m][n] = act(scale[n] * sum_k A[m][k] * W[n][k] + shift[n]),
-// A and W both given as three bf16 planes whose sum is the fp32 operand exactly (launch_split_bf16x3 / a producer's epilogue).
-// Element (plane t, row r, column k) of an operand lives at base + t * plane_bytes + (r * ld + k) * 2; group g (Winograd: one GEMM
-// per transform position) adds g * g_a / g_b elements inside every plane and g * g_out floats to the output.
-// ---------------------------------------------------------------------------------
-struct PlaneGemmParams {
-    const void* a3; unsigned a_plane_bytes; int ld_a;   // row operand [M][K]
-    const void* b3; unsigned b_plane_bytes; int ld_b;   // filters [N][K]
-    const float* scale; const float* shift;             // [N] or nullptr
-    float* out; int ld_out;                             // fp32 [M][N]
-    int M, N, K;                                        // K % 32 == 0
-    int relu;                                           // 0 none, 1 ReLU, 2 GELU (erf)
-    int groups; long long g_a, g_b, g_out;
-};
-// bn: 128 or 64 output columns per workgroup (0 = by N); the row tile is 256
-int launch_gemm_planes(const PlaneGemmParams& p, hipStream_t s, int bn = 0);
 
 // ---------------------------------------------------------------------------------
 // Stem convolution with Cin = 3 read straight from the caller's NCHW frame
@@ -292,7 +279,7 @@ int launch_attention_f32(const float* qkv, float* out, int B, int N, int heads, 
 // the same on the bf16 matrix cores with split operands (three bf16 terms per fp32 value, fp32 accumulate: vit_ops.hip);
 // planes: attention_split_floats(B, N, heads) floats of workspace for the K / V^T planes
 size_t attention_split_floats(int B, int N, int heads);
-int launch_attention_split(const float* qkv, float* out, int B, int N, int heads, float scale, float* scratch, float* planes, hipStream_t s, bool pipelined = false);
+int launch_attention_split(const float* qkv, float* out, int B, int N, int heads, float scale, float* scratch, float* planes, hipStream_t s, bool planes_ready = false);
 // masks[b][k][i] = LayerNorm_K( <pp[b][i]/|pp|, cc[b][N+k]/|cc|> )  (segm/model/decoder.py:90-100), NCHW out
 // out[r][c] = sum_s part[s][r][c] + bias[c] (+ res[r][c]): merges the split-K partial products of a Linear
 int launch_splitk_combine(const float* part, int nsplit, const float* bias, const float* res, float* out, int rows, int N, hipStream_t s);
@@ -318,10 +305,6 @@ int launch_winograd_filter(const float* w, float* U /*[(m+2)^2][O][I]*/, int O, 
 // tiles are enumerated (b, py, px, ty, tx).
 int launch_winograd_input(const float* in, int ld_in, float* V /*[(m+2)^2][T][C]*/, int B, int H, int W, int C, int dil, int mt,
                           hipStream_t s);
-// the same transform written as the three bf16 planes of V (same element order inside every plane; plane t starts t * plane_elems
-// bf16 after V3): the row operand of launch_gemm_planes, split once here instead of once per 128 output channels in the GEMM
-int launch_winograd_input_planes(const float* in, int ld_in, void* V3, long long plane_elems, int B, int H, int W, int C, int dil, int mt,
-                                 hipStream_t s);
 int launch_winograd_output(const float* M /*[(m+2)^2][T][N]*/, const float* scale, const float* shift, float* out, int ld_out, int B,
                            int H, int W, int N, int relu, int dil, int mt, hipStream_t s);
 // element (position xi, tile t, channel c) of V (C = Cin) / M (C = Cout) lives at xi * s_pos + t * s_tile + c
@@ -334,18 +317,6 @@ static inline void winograd_gemm_params(ConvParams& p, int mt, int T, int Cin, i
     p.g_in = a.s_pos;
     p.ld_out = (int)o.s_tile;
     p.g_out = o.s_pos;
-}
-// the same grouped GEMM on gemm_planes.hip: V3 / U3 = the three bf16 planes of V (launch_winograd_input_planes) and of the filter
-// bank U[(m+2)^2][Cout][Cin] (launch_split_bf16x3), Mb = fp32 output in M's layout
-static inline int winograd_plane_gemm_params(PlaneGemmParams& p, int mt, int T, int Cin, int Cout, const void* V3, const void* U3, float* Mb) {
-    const long long G = (long long)(mt + 2) * (mt + 2);
-    const WinoLayout a = winograd_layout(mt, T, Cin), o = winograd_layout(mt, T, Cout);
-    if (G * T * Cin * 2 >= (1ll << 31) || G * Cout * Cin * 2 >= (1ll << 31)) return fail("winograd: operand planes beyond 2 GiB");
-    p.a3 = V3; p.a_plane_bytes = (unsigned)(G * T * Cin * 2); p.ld_a = (int)a.s_tile; p.g_a = a.s_pos;
-    p.b3 = U3; p.b_plane_bytes = (unsigned)(G * Cout * Cin * 2); p.ld_b = Cin; p.g_b = (long long)Cout * Cin;
-    p.out = Mb; p.ld_out = (int)o.s_tile; p.g_out = o.s_pos;
-    p.M = T; p.N = Cout; p.K = Cin; p.groups = (int)G;
-    return 0;
 }
 static inline int winograd_tiles(int B, int H, int W, int dil, int mt) {
     return B * dil * dil * ((cdiv(H, dil) + mt - 1) / mt) * ((cdiv(W, dil) + mt - 1) / mt);

@@ -135,11 +135,9 @@ struct fs_net {
     bool use_fused_shortcut = true;  // !(flags & FS_OPT_NO_FUSED_SHORTCUT)
     bool use_fused_winograd = true;  // !(flags & FS_OPT_NO_FUSED_WINOGRAD)
     bool use_split = true;           // !(flags & FS_OPT_NO_SPLIT_BF16): the implicit-GEMM launches take the split-operand kernel
-    bool use_chain = false;          // flags & FS_OPT_CHAIN: conv3 of block i + conv1 of block i + 1 as one launch in layer1 / layer2
-    bool att_pipelined = false;      // flags & FS_OPT_ATT_PIPELINED: Segmenter attention on attention_bf16x3_pipe_kernel
+    bool use_fused_qkv = true;       // !(flags & FS_OPT_NO_FUSED_QKV): the Segmenter's qkv Linear writes the attention's K / V^T planes in its epilogue
     bool use_fused_pool = true;      // !(flags & FS_OPT_NO_FUSED_POOL): layer0.6 + maxpool as one launch (deep stem, one-kernel Winograd route)
     bool res_touch = true;           // !(flags & FS_OPT_NO_RES_TOUCH): the conv kernels touch a shortcut tile's lines into L2 before their last K chunk
-    bool use_plane_operands = false;  // flags & FS_OPT_PLANE_OPERANDS: the Winograd input transform writes the row operand's bf16 planes (gemm_planes.hip)
     // fp32 filter bank -> its three bf16 planes (split_bf16x3), keyed by the bank's first float; value = (planes, floats in the bank)
     std::map<const float*, std::pair<void*, size_t>> split_banks;
     int device = 0;              // HIP device the handle's memory lives on (current device at fs_create)

@@ -202,13 +202,9 @@ int prof_end(fs_net* h, hipStream_t s) {
 
 namespace {
 
-// Winograd workspace: V (fp32; on the opt-in plane-operand route three bf16 planes = 1.5x the floats) followed by M (fp32)
-bool wino_planes(const fs_net* h, size_t v_elems, int Cin) { return h->use_plane_operands && Cin % 32 == 0 && (long long)v_elems * 2 < (1ll << 31); }
-size_t wino_v_floats(const fs_net* h, size_t G, size_t T, int Cin) {
-    const size_t v = G * T * Cin;
-    return ((wino_planes(h, v, Cin) ? v * 3 / 2 : v) + 7) / 8 * 8;
-}
-size_t wino_ws_floats(const fs_net* h, size_t G, size_t T, int Cin, int Cout) { return wino_v_floats(h, G, T, Cin) + G * T * Cout; }
+// Winograd workspace: V followed by M (fp32)
+size_t wino_v_floats(size_t G, size_t T, int Cin) { return (G * T * Cin + 7) / 8 * 8; }
+size_t wino_ws_floats(size_t G, size_t T, int Cin, int Cout) { return wino_v_floats(G, T, Cin) + G * T * Cout; }
 
 // 3x3 s1 p1 conv as Winograd F(4x4,3x3): input transform -> 36 grouped GEMMs -> output transform (+BN, ReLU)
 int run_conv_winograd(fs_net* h, const ConvBN& c, const float* in, int ld_in, int B, int H, int W, float* out, int ld_out,
@@ -219,9 +215,9 @@ int run_conv_winograd(fs_net* h, const ConvBN& c, const float* in, int ld_in, in
     const float* U = nullptr;
     FS_TRY(wino_bank(h, c, mt, s, &U));
     const size_t v_elems = (size_t)G * T * c.Cin, m_elems = (size_t)G * T * c.Cout;
-    FS_TRY(ws_grow(h, &h->wino_ws, &h->wino_ws_elems, wino_ws_floats(h, G, T, c.Cin, c.Cout), false));
+    FS_TRY(ws_grow(h, &h->wino_ws, &h->wino_ws_elems, wino_ws_floats(G, T, c.Cin, c.Cout), false));
     float* V = h->wino_ws;
-    float* Mb = h->wino_ws + wino_v_floats(h, G, T, c.Cin);
+    float* Mb = h->wino_ws + wino_v_floats(G, T, c.Cin);
     ConvParams p{};
     p.in = V;
     p.ld_in = c.Cin;
@@ -243,28 +239,12 @@ int run_conv_winograd(fs_net* h, const ConvBN& c, const float* in, int ld_in, in
     winograd_gemm_params(p, mt, T, c.Cin, c.Cout);  // V / M are tile-major when that fits a buffer descriptor (winograd.hip)
     split_use(h, p);
     const double flops = 2.0 * G * (double)T * c.Cin * c.Cout;
-    // Round 4, opt-in (FS_OPT_PLANE_OPERANDS): the input transform writes V as its three bf16 planes (each value split ONCE) and the
-    // position GEMMs run on gemm_planes_bf16x3, whose main loop is DMA + fragment reads + MFMAs only (gemm_planes.hip)
-    const bool planes = p.wgt3 && wino_planes(h, v_elems, c.Cin);
-    if (planes) {
-        FS_TRY(prof_begin(h, c.name + ".wino_in", "winograd_input_planes", 0, 4.0 * (double)B * H * W * c.Cin + 6.0 * (double)v_elems, s));
-        FS_TRY(launch_winograd_input_planes(in, ld_in, V, (long long)v_elems, B, H, W, c.Cin, c.dil, mt, s));
-        FS_TRY(prof_end(h, s));
-        PlaneGemmParams q{};
-        FS_TRY(winograd_plane_gemm_params(q, mt, T, c.Cin, c.Cout, V, p.wgt3, Mb));
-        q.b_plane_bytes = p.plane_bytes;  // the registered bank's plane size (the bank may hold more than this conv's U)
-        FS_TRY(prof_begin(h, c.name + ".wino_gemm", c.Cout <= 64 ? "planes256x64" : "planes256x128", flops,
-                          6.0 * ((double)v_elems + (double)G * c.Cout * c.Cin) + 4.0 * (double)m_elems, s));
-        FS_TRY(launch_gemm_planes(q, s));
-        FS_TRY(prof_end(h, s));
-    } else {
-        FS_TRY(prof_begin(h, c.name + ".wino_in", "winograd_input", 0, 4.0 * ((double)B * H * W * c.Cin + (double)v_elems), s));
-        FS_TRY(launch_winograd_input(in, ld_in, V, B, H, W, c.Cin, c.dil, mt, s));
-        FS_TRY(prof_end(h, s));
-        FS_TRY(prof_begin(h, c.name + ".wino_gemm", conv_igemm_tile_name(p), flops, 4.0 * ((double)v_elems + (double)G * c.Cout * c.Cin + (double)m_elems), s));
-        FS_TRY(launch_conv_igemm(p, s));
-        FS_TRY(prof_end(h, s));
-    }
+    FS_TRY(prof_begin(h, c.name + ".wino_in", "winograd_input", 0, 4.0 * ((double)B * H * W * c.Cin + (double)v_elems), s));
+    FS_TRY(launch_winograd_input(in, ld_in, V, B, H, W, c.Cin, c.dil, mt, s));
+    FS_TRY(prof_end(h, s));
+    FS_TRY(prof_begin(h, c.name + ".wino_gemm", conv_igemm_tile_name(p), flops, 4.0 * ((double)v_elems + (double)G * c.Cout * c.Cin + (double)m_elems), s));
+    FS_TRY(launch_conv_igemm(p, s));
+    FS_TRY(prof_end(h, s));
     FS_TRY(prof_begin(h, c.name + ".wino_out", "winograd_output", 0, 4.0 * ((double)m_elems + (double)B * H * W * c.Cout), s));
     FS_TRY(launch_winograd_output(Mb, c.scale, c.shift, out, ld_out, B, H, W, c.Cout, c.relu, c.dil, mt, s));
     return prof_end(h, s);
@@ -292,7 +272,7 @@ int reserve_conv(fs_net* h, const ConvBN& c, int B, int H, int W, hipStream_t s,
     if (!takes_winograd(h, c, B, H, W, false)) return 0;
     const int mt = h->wino_force_m ? h->wino_force_m : winograd_pick_m(B, H, W, c.dil);
     const size_t G = (size_t)(mt + 2) * (mt + 2), T = (size_t)winograd_tiles(B, H, W, c.dil, mt);
-    *need = std::max(*need, wino_ws_floats(h, G, T, c.Cin, c.Cout));
+    *need = std::max(*need, wino_ws_floats(G, T, c.Cin, c.Cout));
     const float* U = nullptr;
     return wino_bank(h, c, mt, s, &U);
 }
@@ -408,7 +388,7 @@ int net_create(const fs_config* cfg, fs_handle* out) {
                "fs_create: layers must be 50, 101 or 152");
     FS_REQUIRE(cfg->classes >= 1 && cfg->classes <= 255, "fs_create: classes out of range");
     FS_REQUIRE((cfg->flags & ~(FS_OPT_NO_WINOGRAD | FS_OPT_NO_FUSED_HEAD | FS_OPT_NO_FUSED_SHORTCUT | FS_OPT_NO_FUSED_WINOGRAD | FS_OPT_NO_SPLIT_BF16 |
-                               FS_OPT_PLANE_OPERANDS | FS_OPT_CHAIN | FS_OPT_NO_RES_TOUCH | FS_OPT_NO_FUSED_POOL | FS_OPT_ATT_PIPELINED)) == 0,
+                               FS_OPT_NO_RES_TOUCH | FS_OPT_NO_FUSED_POOL | FS_OPT_NO_FUSED_QKV)) == 0,
                "fs_create: unknown option bits 0x%x", cfg->flags);
     FS_REQUIRE(cfg->winograd_tile == 0 || cfg->winograd_tile == 4 || cfg->winograd_tile == 6, "fs_create: winograd_tile must be 0, 4 or 6");
     fs_net* h = new fs_net();
@@ -419,11 +399,9 @@ int net_create(const fs_config* cfg, fs_handle* out) {
     h->use_fused_shortcut = !(cfg->flags & FS_OPT_NO_FUSED_SHORTCUT);
     h->use_fused_winograd = !(cfg->flags & (FS_OPT_NO_FUSED_WINOGRAD | FS_OPT_NO_WINOGRAD));
     h->use_split = !(cfg->flags & FS_OPT_NO_SPLIT_BF16);
-    h->use_plane_operands = h->use_split && (cfg->flags & FS_OPT_PLANE_OPERANDS);
-    h->use_chain = h->use_split && (cfg->flags & FS_OPT_CHAIN);
     h->res_touch = !(cfg->flags & FS_OPT_NO_RES_TOUCH);
     h->use_fused_pool = !(cfg->flags & FS_OPT_NO_FUSED_POOL);
-    h->att_pipelined = h->use_split && (cfg->flags & FS_OPT_ATT_PIPELINED);
+    h->use_fused_qkv = h->use_split && !(cfg->flags & FS_OPT_NO_FUSED_QKV);
     if (hipGetDevice(&h->device) != hipSuccess) {
         delete h;
         return fail("fs_create: no HIP device");
@@ -811,25 +789,17 @@ int encoder_core(fs_handle h, const FrameSrc& src, int B, int H, int W, float* o
     // ---- residual stages.  X holds the block input; F1..F3 are free.
     int curH = g.H2, curW = g.W2;
     const int nblocks = (int)h->blocks.size();
-    bool c1_done = false;  // this block's conv1 output is already in F1: the previous block's chained launch wrote it
     for (int bi = 0; bi < nblocks; ++bi) {
         const Bottleneck& blk = h->blocks[bi];
         const bool last = bi == nblocks - 1;
         const int oH = blk.c2.out_size(curH), oW = blk.c2.out_size(curW);
-        if (!c1_done) FS_TRY(run_conv(h, blk.c1, X, C, B, curH, curW, F1, blk.c1.Cout, nullptr, 0, s));
-        c1_done = false;
+        FS_TRY(run_conv(h, blk.c1, X, C, B, curH, curW, F1, blk.c1.Cout, nullptr, 0, s));
         FS_TRY(run_conv(h, blk.c2, F1, blk.c1.Cout, B, curH, curW, F2, blk.c2.Cout, nullptr, 0, s));
         const int Cn = blk.c3.Cout;
         float* dst = last ? (fused ? F1 : out) : nullptr;  // F1 (conv1's output) is free again once conv2 has run
         const int ld_dst = last && !fused ? h->feat_channels() : Cn;
         ConvBN c3 = blk.c3;
         c3.relu = 1;  // ReLU after the residual add (model/resnet.py:93-94)
-        // Round 5, opt-in (FS_OPT_CHAIN): in layer1 / layer2 (bottleneck width <= 128: short-K, bandwidth- and ramp-bound launches) conv3 +
-        // shortcut of this block and conv1 of the NEXT block run as ONE launch (conv_chain_dma_f32).  Decided on the layer shapes alone.
-        // (only where 128-row workgroups still fill the chip twice -- layer1 at 713^2: the 64-row form of layer2's 16 200-pixel maps
-        //  measured 20-45 % slower than the two launches, profiles/r05_experiments.txt section 1; decided per image, not per batch)
-        const ConvBN* nc1 = (!last && h->use_chain && blk.c3.Cin <= 128 && blk.c3.KH == 1 && cdiv(oH * oW, 128) >= 192) ? &h->blocks[bi + 1].c1 : nullptr;
-        if (nc1 && !(nc1->KH == 1 && nc1->KW == 1 && nc1->stride == 1 && nc1->pad == 0 && nc1->Cin == Cn && nc1->Cin % 32 == 0)) nc1 = nullptr;
         if (blk.has_ds && blk.c3ds.w && h->use_fused_shortcut) {
             // conv3 and the projection shortcut as one launch over the concatenated K: the shortcut map is never written
             if (!dst) dst = F3;
@@ -841,16 +811,8 @@ int encoder_core(fs_handle h, const FrameSrc& src, int B, int H, int W, float* o
             split_use(h, p);
             const double M = (double)B * oH * oW;
             const double fl = 2.0 * M * Cn * (p.Cin + p.Cin2), by = 4.0 * (M * p.Cin + (double)B * curH * curW * p.Cin2 + (double)Cn * (p.Cin + p.Cin2) + M * Cn);
-            ConvParams pb = nc1 ? conv_params(h, *nc1, dst, ld_dst, B, oH, oW, F1, nc1->Cout, nullptr, 0) : ConvParams{};
-            if (nc1 && p.wgt3 && pb.wgt3) {
-                FS_TRY(prof_begin(h, blk.c3ds.name + " -> " + nc1->name, conv_chain_tile_name(p, pb), fl + 2.0 * M * Cn * nc1->Cout,
-                                  by + 4.0 * ((double)Cn * nc1->Cout + M * nc1->Cout), s));
-                FS_TRY(launch_conv_chain(p, pb, s));
-                c1_done = true;
-            } else {
-                FS_TRY(prof_begin(h, blk.c3ds.name, conv_igemm_tile_name(p), fl, by, s));
-                FS_TRY(launch_conv_igemm(p, s));
-            }
+            FS_TRY(prof_begin(h, blk.c3ds.name, conv_igemm_tile_name(p), fl, by, s));
+            FS_TRY(launch_conv_igemm(p, s));
             FS_TRY(prof_end(h, s));
             if (!last) std::swap(X, F3);
         } else if (blk.has_ds) {
@@ -860,18 +822,7 @@ int encoder_core(fs_handle h, const FrameSrc& src, int B, int H, int W, float* o
             if (!last) std::swap(X, F3);
         } else {
             if (!dst) dst = X;  // in place over the identity shortcut
-            ConvParams pa = conv_params(h, c3, F2, blk.c2.Cout, B, oH, oW, dst, ld_dst, X, C);
-            ConvParams pb = nc1 ? conv_params(h, *nc1, dst, ld_dst, B, oH, oW, F1, nc1->Cout, nullptr, 0) : ConvParams{};
-            if (nc1 && pa.wgt3 && pb.wgt3) {
-                const double M = (double)B * oH * oW;
-                FS_TRY(prof_begin(h, c3.name + " -> " + nc1->name, conv_chain_tile_name(pa, pb), 2.0 * M * Cn * (c3.Cin + nc1->Cout),
-                                  4.0 * (M * c3.Cin + 2.0 * M * Cn + M * nc1->Cout + (double)Cn * (c3.Cin + nc1->Cout)), s));
-                FS_TRY(launch_conv_chain(pa, pb, s));
-                FS_TRY(prof_end(h, s));
-                c1_done = true;
-            } else {
-                FS_TRY(run_conv(h, c3, F2, blk.c2.Cout, B, oH, oW, dst, ld_dst, X, C, s));
-            }
+            FS_TRY(run_conv(h, c3, F2, blk.c2.Cout, B, oH, oW, dst, ld_dst, X, C, s));
         }
         C = Cn;
         curH = oH;

@@ -120,6 +120,31 @@ int run_linear(fs_net* h, const Linear& l, const float* in, int rows, float* out
     return prof_end(h, s);
 }
 
+// qkv = in @ W^T + b for B images of `tokens` rows, grouped by image; the Q columns go to out[rows][3D] as fp32, the K and V columns to the
+// attention's operand planes (layout of launch_attention_split: K planes, then V^T planes, keys padded to a multiple of 32)
+int run_linear_qkv(fs_net* h, const Linear& l, const float* in, int B, int tokens, float* out, float* planes, hipStream_t s) {
+    const int D = l.in, heads = D / 64, Npad = (tokens + 31) / 32 * 32;
+    const size_t plane_elems = (size_t)B * heads * Npad * 64;
+    ConvParams p{};
+    p.in = in; p.ld_in = l.in; p.wgt = l.w; p.shift = l.b; p.out = out; p.ld_out = l.out;
+    p.B = 1; p.H = tokens; p.W = 1; p.Cin = l.in; p.Ho = tokens; p.Wo = 1; p.Cout = l.out;
+    p.KH = p.KW = 1; p.stride = 1; p.dil = 1;
+    p.groups = B;
+    p.g_in = (long long)tokens * l.in;
+    p.g_wgt = 0;
+    p.g_out = (long long)tokens * l.out;
+    p.kv_k = reinterpret_cast<unsigned short*>(planes);
+    p.kv_vt = p.kv_k + 3 * plane_elems;
+    p.kv_N = tokens; p.kv_Npad = Npad; p.kv_heads = heads;
+    p.kv_plane_bytes = (unsigned)(plane_elems * 2);
+    split_use(h, p);
+    FS_REQUIRE(p.wgt3, "segmenter: the fused qkv epilogue needs the split filter bank");
+    const double rows = (double)B * tokens;
+    FS_TRY(prof_begin(h, l.name, conv_igemm_tile_name(p, 6), 2.0 * rows * (double)l.in * l.out, 4.0 * (rows * (l.in + l.out) + (double)l.in * l.out), s));
+    FS_TRY(launch_conv_igemm(p, s, 6));
+    return prof_end(h, s);
+}
+
 int run_norm(fs_net* h, const LNorm& n, const float* in, float* out, int rows, int rows_per_batch, int drop_first, hipStream_t s) {
     FS_TRY(prof_begin(h, "layernorm", "layernorm", 0, 8.0 * rows * n.D, s));
     FS_TRY(launch_layernorm(in, n.g, n.b, out, rows, n.D, rows_per_batch, drop_first, s));
@@ -160,10 +185,15 @@ int run_block(fs_net* h, const VitBlock& blk, const VitWs& ws, int B, int tokens
               bool* next_done = nullptr) {
     const int D = h->cfg.d_model, heads = D / 64, rows = B * tokens;
     if (!n1_done) FS_TRY(run_norm(h, blk.n1, ws.X, ws.Xn, rows, tokens, 0, s));
-    FS_TRY(run_linear(h, blk.qkv, ws.Xn, rows, ws.QKV, nullptr, 0, s));
+    // Round 6: the qkv Linear writes the attention's K / V^T operand planes from its epilogue (conv_igemm.hip, ConvParams::kv_k): the
+    // pre-pass that read the fp32 rows back is gone (one launch and 31 MB per block); bit-identical planes.  Needs the split route and
+    // column tiles of 96 that do not straddle q | k | v (d_model % 96 == 0: 384, 768).
+    const bool fused_qkv = h->use_fused_qkv && ws.kv && D % 96 == 0;
+    if (fused_qkv) FS_TRY(run_linear_qkv(h, blk.qkv, ws.Xn, B, tokens, ws.QKV, ws.kv, s));
+    else FS_TRY(run_linear(h, blk.qkv, ws.Xn, rows, ws.QKV, nullptr, 0, s));
     const double aflops = 4.0 * B * heads * (double)tokens * tokens * 64;
     FS_TRY(prof_begin(h, blk.qkv.name + ".attention", ws.kv ? "attention_split" : "attention_f32", aflops, 4.0 * rows * 4.0 * D, s));
-    if (ws.kv) FS_TRY(launch_attention_split(ws.QKV, ws.A, B, tokens, heads, 0.125f, ws.att, ws.kv, s, h->att_pipelined));
+    if (ws.kv) FS_TRY(launch_attention_split(ws.QKV, ws.A, B, tokens, heads, 0.125f, ws.att, ws.kv, s, fused_qkv));
     else FS_TRY(launch_attention_f32(ws.QKV, ws.A, B, tokens, heads, 0.125f, ws.att, s));
     FS_TRY(prof_end(h, s));
     FS_TRY(run_linear(h, blk.proj, ws.A, rows, ws.X, ws.X, 0, s, ws.part, tokens));  // x = x + proj(attn)

@@ -735,307 +735,9 @@ __global__ __launch_bounds__(64 * ATT_NW, 3) void attention_bf16x3_kernel(const 
 #endif
 }
 
-#ifdef FS_ATT_TRACE
-// tools/probe_attention_trace.hip only (never in libfloodseg.so): per wave, cycles (s_memtime) spent [0] in the per-stage wait + barrier,
-// [1] in phase 1 (softmax, with the next stage's S^T MFMAs in the pipelined kernel), [2] in phase 2 (P.V MFMAs), [3] whole kernel, [4] stages
-__device__ unsigned long long fs_att_trace[8 * 65536];
-#define ATT_T(V_) const unsigned long long V_ = __builtin_readcyclecounter();
-#define ATT_TACC(ACC_, A_, B_) ACC_ += (B_) - (A_);
-#else
-#define ATT_T(V_)
-#define ATT_TACC(ACC_, A_, B_)
-#endif
-// ------------------------------------------------------------------ the same attention, software-pipelined INSIDE a wave (round 5)
-// attention_bf16x3_kernel above runs a stage as S^T MFMAs -> softmax (VALU) -> split of P (VALU) -> P.V MFMAs, strictly in that order
-// per wave, and counts on the other two waves of its SIMD to fill the matrix pipe meanwhile.  They do not: the three workgroups of a
-// CU are dispatched together, run the same code and meet at a barrier every stage, so their phases coincide -- the pipe idles while
-// all of them do softmax and all of them queue for it afterwards (43 % matrix-pipe time on ViT-S/16).  Here one wave overlaps the two
-// kinds of work itself: while the matrix pipe computes S^T of stage s + 1 (24 MFMAs, one every 32 cycles), the vector ALU does the
-// softmax of stage s, the rescale of O and the split of the first 16 probabilities, a few instructions behind each MFMA in program
-// order (the slots are fenced with sched_barrier: an MFMA issues, the VALU instructions behind it execute while it runs, the next --
-// dependent -- MFMA is due when they are through).  The P.V MFMAs of stage s then hide the split of the other 16 probabilities.
-//   K of stage s + 2 and V^T of stage s + 1 are requested at the top of iteration s (their LDS buffers were last read in iteration
-//   s - 1); one s_waitcnt vmcnt(0) + barrier per stage, as before; same LDS (48 KB), same grid, same key splits and merge.
-// Every value is produced by the same operations in the same order as in attention_bf16x3_kernel (the accumulation chains of S^T and
-// of the two O^T blocks are untouched; O is multiplied by alpha also when alpha is 1): the outputs are bit-identical
-// (tests/test_gpu_ops.py::test_attention_pipelined_is_bit_identical_to_the_stage_serial_kernel).
-template <bool SPLIT>
-__global__ __launch_bounds__(64 * ATT_NW, 2) void attention_bf16x3_pipe_kernel(const float* __restrict__ qkv, const unsigned short* __restrict__ Kp,
-                                                                             const unsigned short* __restrict__ Vtp, float* __restrict__ out,
-                                                                             float* __restrict__ part_o, float* __restrict__ part_ml, int N, int Npad,
-                                                                             int heads, float scale, int nslot, unsigned plane_bytes, int qtiles, int S,
-                                                                             int L) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    constexpr int ST = 32;     // keys per stage
-    constexpr int PL = 1024;   // floats of LDS per plane and stage
-    __shared__ __attribute__((aligned(1024))) float Ks[2][3 * PL];
-    __shared__ __attribute__((aligned(1024))) float Vs[2][3 * PL];
-    const int D = heads * ATT_DH, ld = 3 * D;
-    const int b = blockIdx.z;
-    const int t = threadIdx.x, lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int l31 = lane & 31, hh = lane >> 5;
-    const float scale2 = scale * 1.44269504088896340736f;
-    // This workgroup's run of the image's (tile, stage) sequence -- tile = head * qtiles + query tile, S stages of 32 keys each -- is
-    // [w L, w L + L): at most two tiles (L <= S), each a SEGMENT with its own prologue, stage loop and partial result.
-    const int lin_end = min(((int)blockIdx.x + 1) * L, heads * qtiles * S);
-    for (int lin = (int)blockIdx.x * L; lin < lin_end;) {
-    const int tile = lin / S, s0 = lin - tile * S, s1 = min(S, s0 + (lin_end - lin));
-    lin += s1 - s0;
-    const int head = tile / qtiles, qt = tile - head * qtiles, bh = b * heads + head;
-    const int slot = (int)blockIdx.x - (tile * S) / L;  // this segment's place among its tile's partial results (merge order)
-    const int q = qt * (32 * ATT_NW) + wv * 32 + l31;
-    const int qc = min(q, N - 1);
-    f32x16 acc_o[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc_o[i][e] = 0.f;
-    float m_run = -INFINITY, l_run = 0.f;
-
-    const __amdgpu_buffer_rsrc_t k_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)Kp, 0, 3u * plane_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t v_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)Vtp, 0, 3u * plane_bytes, 0x00020000);
-    const int krow = 8 * wv + (lane >> 3), vrow = 16 * wv + (lane >> 2);
-    const unsigned k_voff = (unsigned)((((size_t)bh * Npad + krow) * ATT_DH + 8 * ((lane & 7) ^ ((krow >> 1) & 7))) * 2);
-    const unsigned v_voff = (unsigned)((((size_t)bh * ATT_DH + vrow) * Npad + 8 * ((lane & 3) ^ ((vrow >> 2) & 3))) * 2);
-    auto issue_k = [&](int stage, int buf) {
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(k_rsrc, (__attribute__((address_space(3))) void*)(&Ks[buf][pl * PL + wv * 256]), 16, k_voff,
-                                                     (unsigned)pl * plane_bytes + (unsigned)(stage * ST * ATT_DH * 2), 0, 0);
-    };
-    auto issue_v = [&](int stage, int buf) {
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(v_rsrc, (__attribute__((address_space(3))) void*)(&Vs[buf][pl * PL + wv * 256]), 16, v_voff,
-                                                     (unsigned)pl * plane_bytes + (unsigned)(stage * ST * 2), 0, 0);
-    };
-    const int kx = (l31 >> 1) & 7, vx = (l31 >> 2) & 3;
-    constexpr int TA[6] = {0, 2, 1, 0, 1, 0}, TB[6] = {2, 0, 1, 1, 0, 0};  // h l, l h, m m, h m, m h, h h: the order of attention_bf16x3_kernel
-    // one plane (0 = h, 1 = m, 2 = l) of this lane's K / V^T fragment of MFMA step KS_ (V^T: d-block I_)
-#define ATT_KPLANE(BUF_, KS_, PL_) __builtin_bit_cast(abf16x8, *reinterpret_cast<const au32x4*>(&Ks[BUF_][(PL_) * PL + l31 * 32 + 4 * ((2 * (KS_) + hh) ^ kx)]))
-#define ATT_VPLANE(BUF_, KS_, I_, PL_) __builtin_bit_cast(abf16x8, *reinterpret_cast<const au32x4*>(&Vs[BUF_][(PL_) * PL + ((I_) * 32 + l31) * 16 + 4 * ((2 * (KS_) + hh) ^ vx)]))
-    // A group of six MFMAs takes its row-operand planes in the order h l m h m h (TA): l is free after the second, m after the fifth,
-    // h only after the last -- so the NEXT group's l and m are read into the same registers as soon as they are free and only h is
-    // double-buffered: 16 fragment registers instead of 24 (the kernel has to fit 168 for three workgroups per CU).
-
-#ifdef FS_ATT_TRACE
-    unsigned long long tr_wait = 0, tr_p1 = 0, tr_p2 = 0, tr_pro1 = 0;
-    const unsigned long long tr_begin = __builtin_readcyclecounter();
-#endif
-    // the first stages are requested BEFORE this lane's query is fetched and split: the two latencies overlap
-    if (s0 < s1) {
-        issue_k(s0, 0);
-        issue_v(s0, 0);
-        if (s0 + 1 < s1) issue_k(s0 + 1, 1);
-    }
-    abf16x8 Qp[4][3];
-    {
-        const float* qp = qkv + ((size_t)b * N + qc) * ld + head * ATT_DH + 8 * hh;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            const f32x4 a = *reinterpret_cast<const f32x4*>(qp + 16 * ks), c = *reinterpret_cast<const f32x4*>(qp + 16 * ks + 4);
-            au32x4 h, m, l;
-            const float x[8] = {a[0], a[1], a[2], a[3], c[0], c[1], c[2], c[3]};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                unsigned hu, mu, lu;
-                att_split_pair(x[2 * e] * scale2, x[2 * e + 1] * scale2, hu, mu, lu);
-                h[e] = hu; m[e] = mu; l[e] = lu;
-            }
-            Qp[ks][0] = __builtin_bit_cast(abf16x8, h);
-            Qp[ks][1] = __builtin_bit_cast(abf16x8, m);
-            Qp[ks][2] = __builtin_bit_cast(abf16x8, l);
-        }
-    }
-    ATT_T(tq_)
-    f32x16 sN;  // S^T of the NEXT stage to go through the softmax
-    if (s0 < s1) {
-        __builtin_amdgcn_s_waitcnt(0x0070);
-        __syncthreads();
-        ATT_T(tb_)
-        ATT_TACC(tr_pro1, tq_, tb_)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) sN[e] = 0.f;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            const abf16x8 kf[3] = {ATT_KPLANE(0, ks, 0), ATT_KPLANE(0, ks, 1), ATT_KPLANE(0, ks, 2)};
-#pragma unroll
-            for (int tm = 0; tm < 6; ++tm) sN = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[TA[tm]], Qp[ks][TB[tm]], sN, 0, 0, 0);
-        }
-    }
-#ifdef FS_ATT_TRACE
-    const unsigned long long tr_loop0 = __builtin_readcyclecounter();
-#endif
-    for (int s = s0; s < s1; ++s) {
-        const int buf = (s - s0) & 1;
-        // K of stage s + 1 and V^T of stage s have landed (requested a whole iteration ago); every wave is through iteration s - 1, so
-        // K buffer `buf` (stage s, multiplied already) and V buffer `buf ^ 1` (stage s - 1) may be overwritten
-        ATT_T(t0_)
-        __builtin_amdgcn_s_waitcnt(0x0070);
-        __syncthreads();
-        ATT_T(t1_)
-        ATT_TACC(tr_wait, t0_, t1_)
-        if (s + 2 < s1) issue_k(s + 2, buf);
-        if (s + 1 < s1) issue_v(s + 1, buf ^ 1);
-        f32x16 sT = sN;
-        const int key0 = s * ST;
-        if (key0 + 32 > N) {  // block-uniform: only the last stage has keys to mask
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                if (key0 + (r & 3) + 8 * (r >> 2) + 4 * hh >= N) sT[r] = -INFINITY;
-        }
-        abf16x8 fh[2], fm, fl;  // fragment planes of the running group of six MFMAs (K in phase 1, V^T in phase 2)
-        au32x4 p0[3], p1[3];    // probabilities 0-7 / 8-15 of this lane's 16, as three bf16 planes
-        float m4[4], alpha = 1.f, m_new = 0.f, lsum = 0.f;
-        // ---- phase 1: 24 slots.  Slot j = the vector work listed below, then (if another stage follows) MFMA j of its S^T.
-        //   slots 0-3   partial maxima of four scores each          slot 4      row maximum, alpha
-        //   slots 5-20  one exp + its place in the row sum, two accumulators of O rescaled, each
-        //   slots 14-17 the split of probabilities 0-7 -> p0
-        auto phase1 = [&](auto more_t) {
-            constexpr bool MORE = decltype(more_t)::value;
-            if (MORE) {
-                fh[0] = ATT_KPLANE(buf ^ 1, 0, 0);
-                fl = ATT_KPLANE(buf ^ 1, 0, 2);
-                fm = ATT_KPLANE(buf ^ 1, 0, 1);
-#pragma unroll
-                for (int e = 0; e < 16; ++e) sN[e] = 0.f;
-            }
-#pragma unroll
-            for (int j = 0; j < 24; ++j) {
-                const int ks = j / 6, tm = j % 6;
-                if (j < 4) m4[j] = fmaxf(fmaxf(sT[4 * j], sT[4 * j + 1]), fmaxf(sT[4 * j + 2], sT[4 * j + 3]));
-                if (j == 4) {
-                    // (the same maximum as the serial kernel's left-to-right chain: max is associative and exact)
-                    float mloc = fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3]));
-                    mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
-                    m_new = fmaxf(m_run, mloc);
-                    alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-                }
-                if (j >= 5 && j < 21) {
-                    const int r = j - 5;
-                    sT[r] = __builtin_amdgcn_exp2f(sT[r] - m_new);
-                    lsum += sT[r];
-                    acc_o[r >> 3][2 * (r & 7)] *= alpha;
-                    acc_o[r >> 3][2 * (r & 7) + 1] *= alpha;
-                }
-                if (j >= 20) {  // probabilities 2 e, 2 e + 1 (e = j - 20), as late as phase 2 allows: their three planes take the
-                    const int e = j - 20;  // registers the exponentials they are made from give back
-                    unsigned hu, mu, lu;
-                    att_split_pair(sT[2 * e], sT[2 * e + 1], hu, mu, lu);
-                    p0[0][e] = hu; p0[1][e] = mu; p0[2][e] = lu;
-                }
-                if (j == 21) {
-                    l_run = l_run * alpha + lsum;
-                    m_run = m_new;
-                }
-                if (MORE) {
-                    const abf16x8 a = TA[tm] == 0 ? fh[ks & 1] : TA[tm] == 1 ? fm : fl;
-                    sN = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, Qp[ks][TB[tm]], sN, 0, 0, 0);
-                    if (ks < 3) {  // the next group's planes, each as soon as its registers are free
-                        if (tm == 1) fl = ATT_KPLANE(buf ^ 1, ks + 1, 2);
-                        if (tm == 2) fh[(ks + 1) & 1] = ATT_KPLANE(buf ^ 1, ks + 1, 0);
-                        if (tm == 4) fm = ATT_KPLANE(buf ^ 1, ks + 1, 1);
-                    }
-                }
-                // the first V^T group's planes, as the last K group lets go of the registers (h[0] after slot 17, l after 19, m after 22)
-                if (j == 20) {
-                    fh[0] = ATT_VPLANE(buf, 0, 0, 0);
-                    fl = ATT_VPLANE(buf, 0, 0, 2);
-                }
-                if (j == 23) fm = ATT_VPLANE(buf, 0, 0, 1);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        };
-        if (s + 1 < s1) phase1(std::true_type{});   // block-uniform
-        else phase1(std::false_type{});
-        ATT_T(t2_)
-        ATT_TACC(tr_p1, t1_, t2_)
-        // ---- phase 2: O^T += V^T P^T, 24 MFMAs in four groups (ks, i); the split of probabilities 8-15 rides under the first two
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int ks = g >> 1, i = g & 1;
-#pragma unroll
-            for (int tm = 0; tm < 6; ++tm) {
-                const abf16x8 a = TA[tm] == 0 ? fh[g & 1] : TA[tm] == 1 ? fm : fl;
-                const abf16x8 pb = __builtin_bit_cast(abf16x8, ks == 0 ? p0[TB[tm]] : p1[TB[tm]]);
-                acc_o[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, pb, acc_o[i], 0, 0, 0);
-                if (g < 3) {
-                    if (tm == 1) fl = ATT_VPLANE(buf, (g + 1) >> 1, (g + 1) & 1, 2);
-                    if (tm == 2) fh[(g + 1) & 1] = ATT_VPLANE(buf, (g + 1) >> 1, (g + 1) & 1, 0);
-                    if (tm == 4) fm = ATT_VPLANE(buf, (g + 1) >> 1, (g + 1) & 1, 1);
-                }
-                if (g < 2 && tm < 2) {  // pairs 2 g + tm of the second half: one behind each of the first two MFMAs of groups 0 and 1
-                    const int e = 2 * g + tm;
-                    unsigned hu, mu, lu;
-                    att_split_pair(sT[8 + 2 * e], sT[8 + 2 * e + 1], hu, mu, lu);
-                    p1[0][e] = hu; p1[1][e] = mu; p1[2][e] = lu;
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-        ATT_T(t3_)
-        ATT_TACC(tr_p2, t2_, t3_)
-    }
-#ifdef FS_ATT_TRACE
-    if (lane == 0) {
-        const size_t w = (((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * ATT_NW + wv;
-        unsigned long long* o = fs_att_trace + 8 * (w & 65535);
-        o[0] = tr_wait; o[1] = tr_p1; o[2] = tr_p2; o[3] = __builtin_readcyclecounter() - tr_begin; o[4] = (unsigned long long)(s1 - s0);
-        o[5] = tq_ - tr_begin; o[6] = tr_pro1; o[7] = tr_loop0 - tr_begin;
-    }
-#endif
-#undef ATT_KPLANE
-#undef ATT_VPLANE
-    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-    if (SPLIT) {
-        if (q < N) {
-            const size_t row = ((size_t)bh * nslot + slot) * N + q;
-            float* op = part_o + row * ATT_DH;
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    f32x4 v;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = acc_o[i][4 * g + e];
-                    *reinterpret_cast<f32x4*>(op + i * 32 + 8 * g + 4 * hh) = v;
-                }
-            if (hh == 0) {
-                part_ml[2 * row] = m_run;
-                part_ml[2 * row + 1] = l_tot;
-            }
-        }
-    } else {
-        const float inv = 1.f / l_tot;
-        if (q < N) {
-            float* op = out + ((size_t)b * N + q) * D + head * ATT_DH;
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    f32x4 v;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = acc_o[i][4 * g + e] * inv;
-                    *reinterpret_cast<f32x4*>(op + i * 32 + 8 * g + 4 * hh) = v;
-                }
-        }
-    }
-    // the next segment's first DMAs overwrite the LDS stages: every wave's fragment reads of this one must be done (lgkmcnt(0) only:
-    // the partial-result stores above need not have completed)
-    if (lin < lin_end) {
-        __builtin_amdgcn_s_waitcnt(0xC07F);
-        __builtin_amdgcn_s_barrier();
-    }
-    }  // segments
-#endif
-}
-
 // merge the key splits of one query: O = sum_s e^(m_s - M) O_s / sum_s e^(m_s - M) l_s ; thread = (query row, float4 of dh)
-// sched_S > 0: the partial results come from attention_bf16x3_pipe_kernel's segment schedule -- `nsplit` slots per tile of which tile a
-// (= head * qtiles + q / 128) filled the first floor(((a + 1) S - 1) / L) - floor(a S / L) + 1, in key order
 __global__ __launch_bounds__(256) void attention_combine_kernel(const float* __restrict__ part_o, const float* __restrict__ part_ml,
-                                                                float* __restrict__ out, int B, int N, int heads, int nsplit, int sched_S, int sched_L,
-                                                                int qtiles) {
+                                                                float* __restrict__ out, int B, int N, int heads, int nsplit) {
     const int64_t total = (int64_t)B * heads * N * 16;
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= total) return;
@@ -1044,16 +746,11 @@ __global__ __launch_bounds__(256) void attention_combine_kernel(const float* __r
     const int q = (int)(r % N);
     const int bh = (int)(r / N);
     const int b = bh / heads, head = bh - b * heads;
-    int nseg = nsplit;
-    if (sched_S > 0) {
-        const int a = head * qtiles + q / (32 * ATT_NW);
-        nseg = ((a + 1) * sched_S - 1) / sched_L - (a * sched_S) / sched_L + 1;
-    }
     float M = -INFINITY;
-    for (int sp = 0; sp < nseg; ++sp) M = fmaxf(M, part_ml[2 * (((size_t)bh * nsplit + sp) * N + q)]);
+    for (int sp = 0; sp < nsplit; ++sp) M = fmaxf(M, part_ml[2 * (((size_t)bh * nsplit + sp) * N + q)]);
     float L = 0.f;
     f32x4 o = {0.f, 0.f, 0.f, 0.f};
-    for (int sp = 0; sp < nseg; ++sp) {
+    for (int sp = 0; sp < nsplit; ++sp) {
         const size_t row = ((size_t)bh * nsplit + sp) * N + q;
         const float w = __builtin_amdgcn_exp2f(part_ml[2 * row] - M);   // the partial maxima are in log2 units (see the kernel)
         L += w * part_ml[2 * row + 1];
@@ -1065,22 +762,6 @@ __global__ __launch_bounds__(256) void attention_combine_kernel(const float* __r
 #pragma unroll
     for (int e = 0; e < 4; ++e) o[e] *= inv;
     *reinterpret_cast<f32x4*>(out + ((size_t)b * N + q) * (heads * ATT_DH) + head * ATT_DH + c4 * 4) = o;
-}
-
-// The pipelined kernel's schedule for ONE image (never the batch: the partition of a query's keys is part of its result): the image's
-// qtiles x heads tiles x S stages are cut into runs of L stages, one workgroup each -- L such that an image is 256 workgroups (two per
-// CU for the usual pair of key frames, with equal work: 2026 tokens x 6 heads = 96 tiles x 64 stages = 256 runs of 24), at least 8
-// stages, at most a whole tile.  L == S: every workgroup owns whole tiles' worth -- exactly one tile -- and writes the output itself.
-struct AttSchedule { int qtiles, S, L, W, nslot; };
-static AttSchedule attention_schedule(int N, int heads) {
-    AttSchedule a;
-    a.qtiles = cdiv(N, 32 * ATT_NW);
-    a.S = cdiv(N, 32);
-    const int U = a.qtiles * heads * a.S;
-    a.L = std::min(a.S, std::max(8, cdiv(U, 256)));
-    a.W = cdiv(U, a.L);
-    a.nslot = a.L == a.S ? 1 : cdiv(a.S, a.L) + 1;
-    return a;
 }
 
 int attention_splits(int /*B*/, int N, int heads) {
@@ -1095,7 +776,7 @@ int attention_splits(int /*B*/, int N, int heads) {
 }
 
 size_t attention_scratch_floats(int B, int N, int heads) {
-    const int ns = std::max(attention_splits(B, N, heads), attention_schedule(N, heads).nslot);  // equal key splits / the pipelined kernel's slots
+    const int ns = attention_splits(B, N, heads);
     return ns > 1 ? (size_t)B * heads * ns * N * (ATT_DH + 2) : 0;
 }
 
@@ -1103,40 +784,22 @@ size_t attention_scratch_floats(int B, int N, int heads) {
 size_t attention_split_floats(int B, int N, int heads) { return (size_t)2 * 3 * B * heads * ((N + 31) / 32 * 32) * (ATT_DH / 2); }
 
 // softmax(Q K^T * scale) V with split operands (see attention_bf16x3_kernel).  planes: attention_split_floats(B, N, heads) floats;
-// scratch: as launch_attention_f32 (same key splits, same merge).
-// pipelined: attention_bf16x3_pipe_kernel (round 5 experiment, bit-identical, two workgroups per CU) instead of the shipped stage-serial kernel
-int launch_attention_split(const float* qkv, float* out, int B, int N, int heads, float scale, float* scratch, float* planes, hipStream_t s, bool pipelined) {
+// scratch: as launch_attention_f32 (same key splits, same merge).  planes_ready: the K / V^T planes were already written by the
+// producer of qkv (the qkv Linear's epilogue, conv_igemm.hip) -- the pre-pass is skipped.
+int launch_attention_split(const float* qkv, float* out, int B, int N, int heads, float scale, float* scratch, float* planes, hipStream_t s, bool planes_ready) {
     FS_REQUIRE(B >= 1 && N >= 1 && heads >= 1 && planes, "attention: bad shape");
     const int Npad = (N + 31) / 32 * 32;
     const size_t plane_elems = (size_t)B * heads * Npad * ATT_DH;
     FS_REQUIRE(plane_elems * 2 * 3 < ((size_t)1 << 31) && ((uintptr_t)qkv & 15) == 0 && ((uintptr_t)planes & 15) == 0, "attention: K / V planes too large or unaligned");
     unsigned short* Kp = reinterpret_cast<unsigned short*>(planes);
     unsigned short* Vtp = Kp + 3 * plane_elems;
-    const int64_t total = (int64_t)B * heads * Npad * 8;
-    hipLaunchKernelGGL(attention_split_kv_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, s, qkv, Kp, Vtp, B, N, Npad, heads);
-    FS_HIP(hipGetLastError());
+    if (!planes_ready) {
+        const int64_t total = (int64_t)B * heads * Npad * 8;
+        hipLaunchKernelGGL(attention_split_kv_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, s, qkv, Kp, Vtp, B, N, Npad, heads);
+        FS_HIP(hipGetLastError());
+    }
     const int qtiles = cdiv(N, 32 * ATT_NW);
     const unsigned plane_bytes = (unsigned)(plane_elems * 2);
-    if (pipelined) {
-        const AttSchedule sc = attention_schedule(N, heads);
-        FS_REQUIRE(sc.nslot == 1 || scratch, "attention: the pipelined kernel needs its workspace");
-        if (sc.nslot == 1) {  // one whole tile per workgroup: it normalises and writes the output itself
-            hipLaunchKernelGGL(attention_bf16x3_pipe_kernel<false>, dim3(sc.W, 1, B), dim3(64 * ATT_NW), 0, s, qkv, Kp, Vtp, out, nullptr, nullptr, N, Npad, heads,
-                               scale, 1, plane_bytes, sc.qtiles, sc.S, sc.L);
-            FS_HIP(hipGetLastError());
-            return 0;
-        }
-        float* part_o = scratch;
-        float* part_ml = scratch + (size_t)B * heads * sc.nslot * N * ATT_DH;
-        hipLaunchKernelGGL(attention_bf16x3_pipe_kernel<true>, dim3(sc.W, 1, B), dim3(64 * ATT_NW), 0, s, qkv, Kp, Vtp, out, part_o, part_ml, N, Npad, heads,
-                           scale, sc.nslot, plane_bytes, sc.qtiles, sc.S, sc.L);
-        FS_HIP(hipGetLastError());
-        const int64_t tot = (int64_t)B * heads * N * 16;
-        hipLaunchKernelGGL(attention_combine_kernel, dim3((unsigned)cdiv64(tot, 256)), dim3(256), 0, s, part_o, part_ml, out, B, N, heads, sc.nslot, sc.S, sc.L,
-                           sc.qtiles);
-        FS_HIP(hipGetLastError());
-        return 0;
-    }
     const int ns = scratch ? attention_splits(B, N, heads) : 1;
     if (ns == 1) {
         hipLaunchKernelGGL(attention_bf16x3_kernel<false>, dim3(qtiles, heads, B), dim3(64 * ATT_NW), 0, s, qkv, Kp, Vtp, out, nullptr, nullptr, N, Npad,
@@ -1150,7 +813,7 @@ int launch_attention_split(const float* qkv, float* out, int B, int N, int heads
                        heads, scale, ns, plane_bytes);
     FS_HIP(hipGetLastError());
     const int64_t tot = (int64_t)B * heads * N * 16;
-    hipLaunchKernelGGL(attention_combine_kernel, dim3((unsigned)cdiv64(tot, 256)), dim3(256), 0, s, part_o, part_ml, out, B, N, heads, ns, 0, 0, 0);
+    hipLaunchKernelGGL(attention_combine_kernel, dim3((unsigned)cdiv64(tot, 256)), dim3(256), 0, s, part_o, part_ml, out, B, N, heads, ns);
     FS_HIP(hipGetLastError());
     return 0;
 }
@@ -1176,7 +839,7 @@ int launch_attention_f32(const float* qkv, float* out, int B, int N, int heads, 
                        scale, ns);
     FS_HIP(hipGetLastError());
     const int64_t total = (int64_t)B * heads * N * 16;
-    hipLaunchKernelGGL(attention_combine_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, s, part_o, part_ml, out, B, N, heads, ns, 0, 0, 0);
+    hipLaunchKernelGGL(attention_combine_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, s, part_o, part_ml, out, B, N, heads, ns);
     FS_HIP(hipGetLastError());
     return 0;
 }

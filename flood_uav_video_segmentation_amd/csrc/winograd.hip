@@ -57,14 +57,9 @@ int launch_winograd_filter(const float* w_oihw, float* U, int O, int I, int mt, 
 // which order) is unchanged.
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-
-// PLANES: V is written as the three bf16 terms of every value (x = h + m + l exactly, round-to-nearest residues: the split of
-// conv_igemm.hip's split_bf16x3_kernel), plane t at V + t * plane_elems bf16 -- the row operand of gemm_planes.hip
-template <int MT, bool PLANES>
+template <int MT>
 __global__ __launch_bounds__((MT + 2) * 32) void winograd_input_kernel(const float* __restrict__ in, int ld_in, float* __restrict__ V, int B, int H,
-                                                                       int W, int C4, int th, int tw, int dil, long long s_pos, long long s_tile,
-                                                                       long long plane_elems) {
+                                                                       int W, int C4, int th, int tw, int dil, long long s_pos, long long s_tile) {
     constexpr int A = Wino<MT>::A;
     __shared__ f32x4 tmp[A][A][32];  // [r][x][channel quad]
     // dilation d: the conv splits into d*d independent undilated convs on the pixel lattices (py + d*i, px + d*j);
@@ -102,30 +97,9 @@ __global__ __launch_bounds__((MT + 2) * 32) void winograd_input_kernel(const flo
 #pragma unroll
             for (int x = 0; x < A; ++x) row[x] = tmp[lane_x][x][cq];
             Wino<MT>::bt(row, o);
-            if (cok && !PLANES) {
+            if (cok) {
 #pragma unroll
                 for (int q = 0; q < A; ++q) *reinterpret_cast<f32x4*>(V + (size_t)(lane_x * A + q) * s_pos + (size_t)t * s_tile + (size_t)c4 * 4) = o[q];
-            }
-            if (cok && PLANES) {
-                __bf16* V3 = reinterpret_cast<__bf16*>(V);
-#pragma unroll
-                for (int q = 0; q < A; ++q) {
-                    bf16x4 hi, mid, lo;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float x = o[q][e];
-                        const __bf16 h = (__bf16)x;
-                        const float r = x - (float)h;
-                        const __bf16 m = (__bf16)r;
-                        hi[e] = h;
-                        mid[e] = m;
-                        lo[e] = (__bf16)(r - (float)m);
-                    }
-                    const size_t at = (size_t)(lane_x * A + q) * s_pos + (size_t)t * s_tile + (size_t)c4 * 4;
-                    *reinterpret_cast<bf16x4*>(V3 + at) = hi;
-                    *reinterpret_cast<bf16x4*>(V3 + plane_elems + at) = mid;
-                    *reinterpret_cast<bf16x4*>(V3 + 2 * plane_elems + at) = lo;
-                }
             }
         }
         __syncthreads();  // tmp is reused by the next tile of the grid-stride loop
@@ -145,37 +119,19 @@ WinoLayout winograd_layout(int mt, long long T, int C) {
     return l;
 }
 
-namespace {
-int winograd_input_any(const float* in, int ld_in, void* V, long long plane_elems, int B, int H, int W, int C, int dil, int mt, hipStream_t s) {
+int launch_winograd_input(const float* in, int ld_in, float* V, int B, int H, int W, int C, int dil, int mt, hipStream_t s) {
     FS_REQUIRE(C % 4 == 0 && ld_in % 4 == 0 && dil >= 1, "winograd_input: C must be a multiple of 4");
     FS_REQUIRE(mt == 4 || mt == 6, "winograd: tile size must be 4 or 6");
-    FS_REQUIRE(((uintptr_t)in & 15) == 0 && ((uintptr_t)V & 15) == 0 && plane_elems % 8 == 0, "winograd_input: unaligned operand");
+    FS_REQUIRE(((uintptr_t)in & 15) == 0 && ((uintptr_t)V & 15) == 0, "winograd_input: unaligned operand");
     const int th = (cdiv(H, dil) + mt - 1) / mt, tw = (cdiv(W, dil) + mt - 1) / mt;
     const long long T = (long long)B * dil * dil * th * tw;
-    FS_REQUIRE(plane_elems == 0 || plane_elems >= T * (mt + 2) * (mt + 2) * C, "winograd_input: a plane of %lld elements does not hold V", plane_elems);
     FS_REQUIRE(T < (1ll << 31), "winograd_input: too many tiles");
     const dim3 grid((unsigned)cdiv(C / 4, 32), (unsigned)std::min<long long>(T, 65535));
     const WinoLayout lay = winograd_layout(mt, T, C);
-    float* Vf = reinterpret_cast<float*>(V);
-    if (plane_elems) {
-        if (mt == 4) hipLaunchKernelGGL((winograd_input_kernel<4, true>), grid, dim3(6 * 32), 0, s, in, ld_in, Vf, B, H, W, C / 4, th, tw, dil, lay.s_pos, lay.s_tile, plane_elems);
-        else hipLaunchKernelGGL((winograd_input_kernel<6, true>), grid, dim3(8 * 32), 0, s, in, ld_in, Vf, B, H, W, C / 4, th, tw, dil, lay.s_pos, lay.s_tile, plane_elems);
-    } else {
-        if (mt == 4) hipLaunchKernelGGL((winograd_input_kernel<4, false>), grid, dim3(6 * 32), 0, s, in, ld_in, Vf, B, H, W, C / 4, th, tw, dil, lay.s_pos, lay.s_tile, 0ll);
-        else hipLaunchKernelGGL((winograd_input_kernel<6, false>), grid, dim3(8 * 32), 0, s, in, ld_in, Vf, B, H, W, C / 4, th, tw, dil, lay.s_pos, lay.s_tile, 0ll);
-    }
+    if (mt == 4) hipLaunchKernelGGL((winograd_input_kernel<4>), grid, dim3(6 * 32), 0, s, in, ld_in, V, B, H, W, C / 4, th, tw, dil, lay.s_pos, lay.s_tile);
+    else hipLaunchKernelGGL((winograd_input_kernel<6>), grid, dim3(8 * 32), 0, s, in, ld_in, V, B, H, W, C / 4, th, tw, dil, lay.s_pos, lay.s_tile);
     FS_HIP(hipGetLastError());
     return 0;
-}
-}  // namespace
-
-int launch_winograd_input(const float* in, int ld_in, float* V, int B, int H, int W, int C, int dil, int mt, hipStream_t s) {
-    return winograd_input_any(in, ld_in, V, 0, B, H, W, C, dil, mt, s);
-}
-
-int launch_winograd_input_planes(const float* in, int ld_in, void* V3, long long plane_elems, int B, int H, int W, int C, int dil, int mt, hipStream_t s) {
-    FS_REQUIRE(plane_elems > 0, "winograd_input_planes: plane_elems must be positive");
-    return winograd_input_any(in, ld_in, V3, plane_elems, B, H, W, C, dil, mt, s);
 }
 
 // ---- output transform + scale/shift + activation: pass 1 thread (q, oq) transforms column q of M, pass 2 thread (a, oq), a < m,

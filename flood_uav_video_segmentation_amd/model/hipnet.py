@@ -12,19 +12,31 @@ from .. import _lib, ops
 from .._lib import check, one_device, ptr, stream_ptr
 
 
+HIP_OPTIONS = ("hip_no_winograd", "hip_no_fused_head", "hip_no_fused_shortcut", "hip_no_fused_winograd", "hip_no_split_bf16", "hip_no_res_touch",
+               "hip_no_fused_pool", "hip_no_fused_qkv", "hip_winograd_tile")
+
+
+def check_hip_options(names):
+    """Every hip_* option a caller names must exist: a mistyped or retired one raises instead of silently running the defaults
+    (an A/B script would otherwise compare the defaults with themselves)."""
+    unknown = sorted(n for n in names if n.startswith("hip_") and n not in HIP_OPTIONS)
+    if unknown:
+        raise ValueError(f"floodseg: unknown hip option(s) {unknown}; known: {list(HIP_OPTIONS)}")
+
+
 def hip_options(hparams):
     """Explicit A/B options of the library (include/floodseg.h: fs_config.flags / .winograd_tile), taken from optional
-    attributes of the reference-style `hparams` object: `hip_no_winograd`, `hip_no_fused_head`, `hip_no_fused_shortcut`,
-    `hip_no_fused_winograd`, `hip_no_split_bf16`, `hip_plane_operands`, `hip_chain`, `hip_no_res_touch`, `hip_no_fused_pool`, `hip_att_pipelined`,
-    `hip_winograd_tile`."""
+    attributes of the reference-style `hparams` object (HIP_OPTIONS); any other attribute named hip_* is refused."""
+    names = [n for n in dir(hparams) if not n.startswith("__")]
+    if hasattr(hparams, "keys"):  # dict-like hparams (Lightning's AttributeDict): the options are keys, not attributes
+        names += [str(k) for k in hparams.keys()]
+    check_hip_options(names)
     return dict(no_winograd=bool(getattr(hparams, "hip_no_winograd", False)),
                 no_fused_winograd=bool(getattr(hparams, "hip_no_fused_winograd", False)),
                 no_split_bf16=bool(getattr(hparams, "hip_no_split_bf16", False)),
-                plane_operands=bool(getattr(hparams, "hip_plane_operands", False)),
-                chain=bool(getattr(hparams, "hip_chain", False)),
                 no_res_touch=bool(getattr(hparams, "hip_no_res_touch", False)),
                 no_fused_pool=bool(getattr(hparams, "hip_no_fused_pool", False)),
-                att_pipelined=bool(getattr(hparams, "hip_att_pipelined", False)),
+                no_fused_qkv=bool(getattr(hparams, "hip_no_fused_qkv", False)),
                 no_fused_head=bool(getattr(hparams, "hip_no_fused_head", False)),
                 no_fused_shortcut=bool(getattr(hparams, "hip_no_fused_shortcut", False)),
                 winograd_tile=int(getattr(hparams, "hip_winograd_tile", 0)))
@@ -33,14 +45,13 @@ def hip_options(hparams):
 class HipNet:
     def __init__(self, arch, layers, classes, patch=0, d_model=0, n_layers=0, dec_layers=0, image_size=0, no_winograd=False,
                  no_fused_head=False, no_fused_shortcut=False, winograd_tile=0, no_fused_winograd=False, no_split_bf16=False,
-                 plane_operands=False, chain=False, no_res_touch=False, no_fused_pool=False, att_pipelined=False):
+                 no_res_touch=False, no_fused_pool=False, no_fused_qkv=False):
         self.arch, self.layers, self.classes = arch, int(layers), int(classes)
         self.vit = (int(patch), int(d_model), int(n_layers), int(dec_layers), int(image_size))
         self.flags = ((_lib.OPT_NO_WINOGRAD if no_winograd else 0) | (_lib.OPT_NO_FUSED_HEAD if no_fused_head else 0)
                       | (_lib.OPT_NO_FUSED_SHORTCUT if no_fused_shortcut else 0) | (_lib.OPT_NO_FUSED_WINOGRAD if no_fused_winograd else 0)
-                      | (_lib.OPT_NO_SPLIT_BF16 if no_split_bf16 else 0) | (_lib.OPT_PLANE_OPERANDS if plane_operands else 0)
-                      | (_lib.OPT_CHAIN if chain else 0) | (_lib.OPT_NO_RES_TOUCH if no_res_touch else 0) | (_lib.OPT_NO_FUSED_POOL if no_fused_pool else 0)
-                      | (_lib.OPT_ATT_PIPELINED if att_pipelined else 0))
+                      | (_lib.OPT_NO_SPLIT_BF16 if no_split_bf16 else 0) | (_lib.OPT_NO_RES_TOUCH if no_res_touch else 0)
+                      | (_lib.OPT_NO_FUSED_POOL if no_fused_pool else 0) | (_lib.OPT_NO_FUSED_QKV if no_fused_qkv else 0))
         self.winograd_tile = int(winograd_tile)
         self._h = None
         self.ready = False

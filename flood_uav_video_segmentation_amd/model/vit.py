@@ -15,7 +15,7 @@ never wires ViT into the flow path (flow/base.py:94-103), so that combination is
 from torch import nn
 
 from .. import _lib, ops
-from .hipnet import HipNet, HipSegNet, HipStage
+from .hipnet import HipNet, HipSegNet, HipStage, check_hip_options
 
 
 class VITSegmentModel(HipSegNet):
@@ -28,9 +28,11 @@ class VITSegmentModel(HipSegNet):
         self.num_classes = num_classes
         self.dropout = dropout  # identity in eval
         self.d_model = d_model
-        # hip_no_split_bf16=True (keyword; library A/B option, include/floodseg.h FS_OPT_NO_SPLIT_BF16): the Linears on the fp32-MFMA kernel
+        # library A/B options as keywords (include/floodseg.h): hip_no_split_bf16=True -- Linears and attention on the fp32-MFMA kernels;
+        # hip_no_fused_qkv=True -- the attention's K / V^T planes by a separate pre-pass instead of the qkv Linear's epilogue
+        check_hip_options(kwargs)
         self._hip_net = HipNet(self.ARCH, 0, num_classes, patch_size, d_model, n_layers, dec_layers, image_size,
-                               no_split_bf16=bool(kwargs.get("hip_no_split_bf16", False)), att_pipelined=bool(kwargs.get("hip_att_pipelined", False)))
+                               no_split_bf16=bool(kwargs.get("hip_no_split_bf16", False)), no_fused_qkv=bool(kwargs.get("hip_no_fused_qkv", False)))
         self.encoder = HipStage(self._hip_net.encode, "encoder")  # [B,3,H,W] -> [B, D, gh, gw], stored as [B, gh*gw, D]
         self.decoder = HipStage(self._decode_map, "decoder")
 

@@ -374,6 +374,7 @@ def iou_hist(pred_u8, target_u8, classes, ignore_index=255, hist=None):
 
 
 # ------------------------------------------------------------------------------------------ building blocks
+# (test / bring-up helpers over the op-level hooks of include/floodseg_test.h; nothing on the product path calls them)
 def conv2d_nhwc(x, weight, scale=None, shift=None, residual=None, stride=1, pad=0, dil=1, relu=False, tile=0, out=None, split=False):
     """Conv2d on the matrix cores; x logical NCHW (stored NHWC), weight OIHW. Test/bring-up helper.  split=True: the split-operand
     kernel (three bf16 terms per fp32 value, bf16 MFMA, fp32 accumulate: fs_conv2d_nhwc_split) instead of the fp32-MFMA one."""
@@ -400,35 +401,9 @@ def conv2d_nhwc(x, weight, scale=None, shift=None, residual=None, stride=1, pad=
     return out
 
 
-def conv_chain(x, w1, w2, scale1=None, shift1=None, residual=None, x2=None, relu1=True, scale2=None, shift2=None, relu2=True, tile=0, mid=None):
-    """Two dependent 1x1 convolutions over the same rows in one launch (fs_conv_chain_nhwc): x [M, K1] (+ x2 [M, K1b]), w1 [C1, K1 (+ K1b)],
-    w2 [C2, C1] -> (mid [M, C1], out [M, C2]).  residual [M, C1]; mid=residual runs the first conv in place over its shortcut."""
-    lib = _lib.load()
-    with torch.cuda.device(one_device(x, w1, w2, scale1, shift1, residual, x2, scale2, shift2, mid, what="floodseg.conv_chain")):
-        x, w1, w2 = _f32c(x), _f32c(w1), _f32c(w2)
-        m, k1 = x.shape
-        c1, c2 = w1.shape[0], w2.shape[0]
-        k1b = 0 if x2 is None else x2.shape[1]
-        if w1.shape[1] != k1 + k1b or w2.shape[1] != c1:
-            raise ValueError("floodseg.conv_chain: filter shapes do not match the operands")
-        x2 = _f32c(x2) if x2 is not None else None
-        residual = _f32c(residual) if residual is not None else None
-        p1 = torch.empty(3 * w1.numel(), dtype=torch.bfloat16, device=x.device)
-        p2 = torch.empty(3 * w2.numel(), dtype=torch.bfloat16, device=x.device)
-        check(lib.fs_split_bf16x3(ptr(w1), w1.numel(), ptr(p1), stream_ptr()))
-        check(lib.fs_split_bf16x3(ptr(w2), w2.numel(), ptr(p2), stream_ptr()))
-        if mid is None:
-            mid = torch.empty((m, c1), dtype=torch.float32, device=x.device)
-        out = torch.empty((m, c2), dtype=torch.float32, device=x.device)
-        check(lib.fs_conv_chain_nhwc(ptr(x), k1, ptr(x2), k1b, ptr(p1), ptr(scale1), ptr(shift1), ptr(residual), ptr(mid), c1, int(relu1), ptr(p2),
-                                     ptr(scale2), ptr(shift2), ptr(out), c2, int(relu2), m, tile, stream_ptr()))
-    return mid, out
-
-
 def attention(qkv, heads, split_operands=True):
     """softmax(q k^T / 8) v per head (segm/model/blocks.py:39-66) for qkv [B, N, 3 * heads * 64] -> [B, N, heads * 64].
-    split_operands: True / 1 the bf16-matrix-core route with three bf16 terms per fp32 value (the networks' default), False / 0 the fp32-MFMA
-    one, 2 the split-operand route on the software-pipelined kernel with the balanced grid (FS_OPT_ATT_PIPELINED in the networks)."""
+    split_operands: True the bf16-matrix-core route with three bf16 terms per fp32 value (the networks' default), False the fp32-MFMA one."""
     lib = _lib.load()
     with torch.cuda.device(one_device(qkv, what="floodseg.attention")):
         qkv = _f32c(qkv)

@@ -66,25 +66,21 @@ enum {
     FS_OPT_NO_SPLIT_BF16 = 16, /* implicit-GEMM launches (1x1 / 3x3 convs, Winograd GEMMs, nn.Linear) on the fp32 matrix-core kernel
                                  (v_mfma_f32_32x32x2_f32) instead of the split-operand one: each fp32 operand as the exact sum of three
                                  bf16 terms, six cross products on the bf16 matrix cores, fp32 accumulation (fs_conv2d_nhwc_split) */
-    FS_OPT_PLANE_OPERANDS = 32, /* round 4, opt-in A/B route: the Winograd input transform writes V as three bf16 planes (each value split
-                                 once) and the position GEMMs run on fs_gemm_bf16x3_planes instead of splitting fp32 rows in registers
-                                 inside the GEMM.  Measured slower end to end (1.5x the V bytes, profiles/r04_experiments.txt), so it
-                                 is not the default; ignored with FS_OPT_NO_SPLIT_BF16 */
-    FS_OPT_CHAIN = 64,         /* round 5, opt-in A/B route: conv3 (+ shortcut) of a layer1 / layer2 bottleneck and conv1 of the NEXT block as
-                                 ONE chained launch (conv_chain_dma_f32: a workgroup multiplies the pixel rows it has just stored by the
-                                 next filters) instead of two.  Bit-identical results either way.  Measured equal in layer1 and slower
-                                 in layer2 (profiles/r05_experiments.txt), so it is not the default; needs the split-operand route
-                                 (ignored with FS_OPT_NO_SPLIT_BF16) */
     FS_OPT_NO_FUSED_POOL = 256, /* round 5 A/B switch: the deep stem's last conv (layer0.6) and the max-pool behind it (model/resnet.py:114-117) as two
                                  launches instead of one (the one-kernel Winograd with MaxPool2d(3, 2, 1) in its epilogue: the 357 x 357 x 128 map
                                  is never written).  Bit-identical results either way */
-    FS_OPT_ATT_PIPELINED = 512, /* round 5, opt-in A/B route (Segmenter): the split-operand attention software-pipelined inside a wave on a balanced
-                                 grid (fs_attention mode 2) instead of the stage-serial kernel with equal key splits (mode 1) */
-    FS_OPT_NO_RES_TOUCH = 128  /* round 5 A/B switch: without it the split-operand conv kernels touch the lines of a bottleneck's shortcut tile
+    FS_OPT_NO_RES_TOUCH = 128, /* round 5 A/B switch: without it the split-operand conv kernels touch the lines of a bottleneck's shortcut tile
                                  (dead loads) before the last K chunk of their main loop, so that the epilogue's residual loads hit in L2.
                                  Same results bit for bit either way */
+    FS_OPT_NO_FUSED_QKV = 1024 /* round 6 A/B switch (Segmenter): without it the qkv Linear of every block writes the attention's K planes and
+                                 transposed V planes (three bf16 terms per value) from its epilogue; with it a separate pre-pass reads the fp32
+                                 qkv rows back and writes them.  Same results bit for bit either way.
+                                 (Bits 32, 64 and 512 were the opt-in experiment routes of rounds 4-5 -- pre-split Winograd operands, chained
+                                 bottleneck launches, the wave-pipelined attention kernel; all measured null or slower, removed in round 6:
+                                 fs_create refuses them.) */
 };
 
+/* 600: the handle API and the ops below; additions keep the number, a changed or removed signature raises it. */
 int fs_version(void);
 const char* fs_last_error(void);
 
@@ -226,102 +222,6 @@ int fs_crop_grids(const float* const* grids, int ngrids, int Hg, int Wg, int H, 
 int fs_crops_fuse(const float* lo_prev, const float* lo_next, const float* crop_grids, int ncrops, const int* crop_y, const int* crop_x,
                   int K, int h, int w, int Hg, int Wg, int ch, int cw, int n, int no_warp, double* canvas, uint8_t* mask, int H, int W,
                   float* scratch, fs_stream stream);
-
-/* ---- building blocks (exposed for op-level parity tests and for other host code) ---------------- */
-int fs_pack_conv_weight(const float* oihw, float* ohwi, int O, int I, int KH, int KW, fs_stream stream);
-/* Conv2d (+ per-channel scale/shift, + residual, + ReLU (relu = 1) / GELU (2)) on the fp32 matrix cores; Cin % 32 == 0.
- * in/out/res are NHWC with pixel strides ld_*; wgt_ohwi from fs_pack_conv_weight.  tile: 0 = cost-model choice, 1..5 force the
- * workgroup tile 128x128, 128x64, 64x64, 64x128, 256x128 (tests / sweeps); | FS_CONV_CHUNK_MAJOR = the filters are packed
- * chunk-major ([O][I/32][KH][KW][32]).  Any other bit is refused with a non-zero return. */
-#define FS_CONV_CHUNK_MAJOR 0x400
-int fs_conv2d_nhwc(const float* in, int ld_in, const float* wgt_ohwi, const float* scale, const float* shift,
-                   const float* res, int ld_res, float* out, int ld_out, int B, int H, int W, int Cin, int Cout, int KH,
-                   int KW, int stride, int pad, int dil, int relu, int tile, fs_stream stream);
-/* The same convolution with SPLIT operands: every fp32 filter value and every fp32 pixel is written as the exact sum of three bf16
- * terms (round-to-nearest residues) and the six cross products of order <= 2^-16 run on the bf16 matrix cores with fp32
- * accumulation (the three dropped ones are <= 2^-23 of the product: below the rounding of one fp32 add).  fs_split_bf16x3 writes
- * the three planes (3 * n bf16, n % 8 == 0) of a packed filter bank; fs_conv2d_nhwc_split takes them in place of wgt_ohwi
- * (tiles 0..4, 6 and 7; 4 = 64x128 has no fp32-route twin of the same wave layout; 6 = 128x96 and 7 = 256x128 on eight waves exist on
- * this route only: the cost model considers 6 where 96 divides Cout -- the Segmenter's Linears; 7 is a forced tile (sweeps)).
- * Non-finite and out-of-range operands (tests/test_gpu_ops.py::test_conv_non_finite_operands): the split is exact for every
- * finite fp32 value up to the largest bf16, |x| <= 3.3895e38 (and flushes nothing above 2^-110: the low-order term of a smaller
- * value may be a bf16 denormal).  An operand that is +-inf, NaN, or finite with 3.3895e38 < |x| <= FLT_MAX makes EVERY output it
- * contributes to NaN on this route (its leading bf16 term is infinite and the residue inf - inf); the fp32-MFMA route
- * (fs_conv2d_nhwc, FS_OPT_NO_SPLIT_BF16) follows IEEE like the reference's convolution: +-inf where the sum diverges, NaN for
- * NaN operands and inf - inf.  Outputs the operand does not contribute to are unaffected on both routes.  On BOTH routes the
- * fused ReLU epilogue is max(v, 0) and maps a NaN to 0 (torch's F.relu keeps it): a caller that must detect corrupt frames
- * checks its inputs -- an image normalised from 8-bit pixels and finite trained weights never reach any of these cases. */
-/* Multi-head attention of the Segmenter (segm/model/blocks.py:39-66): out[b][n][h*64 + d] = softmax_keys(q k^T * scale) v for
- * qkv = [B][N][3 * heads * 64] (q | k | v, head-major inside each third), head_dim 64.  split_operands = 0: fp32 matrix cores;
- * 1: the split-operand route (three bf16 terms per fp32 value of q, k, v and of the probabilities, bf16 matrix cores, fp32
- * accumulation and softmax); 2: the same route software-pipelined inside a wave (round 5 experiment: the matrix cores compute the
- * scores of the next 32 keys while the vector ALU does the softmax of the current ones; bit-identical outputs; its stage loop runs
- * 1.5x faster but it needs 198 registers, i.e. two workgroups per CU instead of three, and loses that on the grid of 768 workgroups:
- * profiles/r05_experiments.txt section 16).  workspace: fs_attention_workspace_floats(B, N, heads, split_operands) floats. */
-size_t fs_attention_workspace_floats(int B, int N, int heads, int split_operands);
-int fs_attention(const float* qkv, float* out, int B, int N, int heads, float scale, int split_operands, float* workspace, fs_stream stream);
-int fs_split_bf16x3(const float* w, int64_t n, void* planes, fs_stream stream);
-int fs_conv2d_nhwc_split(const float* in, int ld_in, const void* wgt_planes, const float* scale, const float* shift,
-                         const float* res, int ld_res, float* out, int ld_out, int B, int H, int W, int Cin, int Cout, int KH,
-                         int KW, int stride, int pad, int dil, int relu, int tile, fs_stream stream);
-/* Round 5: two dependent 1x1 convolutions over the same M pixel rows in ONE launch (conv_chain_dma_f32; the networks use it at the
- * layer1 / layer2 bottleneck boundaries of model/resnet.py:76-96: conv3 + shortcut of block i, then conv1 of block i + 1):
- *   mid[M][C1] = act1(scale1 * (in @ W1a^T + in2 @ W1b^T) + shift1 + res)        in [M][K1]; in2 [M][K1b] optional (then no res);
- *   out[M][C2] = act2(scale2 * (mid @ W2^T) + shift2)                            res [M][C1] optional, may BE mid (in place)
- * All tensors dense (pixel stride = channel count).  w1_planes: fs_split_bf16x3 of the [C1][K1 + K1b] filter rows, w2_planes of
- * [C2][C1]; scale* / shift* may be NULL.  tile: 0 = by M, 1 = 128x128, 2 = 128x64, 3 = 64x64, 6 = 64x128 (rows x columns per
- * workgroup).  Every output is bit-identical to the two fs_conv2d_nhwc_split calls it replaces. */
-int fs_conv_chain_nhwc(const float* in, int K1, const float* in2, int K1b, const void* w1_planes, const float* scale1, const float* shift1,
-                       const float* res, float* mid, int C1, int relu1, const void* w2_planes, const float* scale2, const float* shift2,
-                       float* out, int C2, int relu2, int M, int tile, fs_stream stream);
-/* 3x3 stride-1 conv with padding == dilation as Winograd F(m x m,3x3) (transforms + (m+2)^2 grouped MFMA GEMMs); the network
- * uses it for every such conv with Cin >= 256.  tile_m: 4, 6, or 0 = whichever needs fewer GEMM rows for this map (a 90x90
- * map is exactly 15x15 tiles of 6x6).  workspace: fs_winograd_workspace_floats(..., same tile_m) floats of device memory. */
-size_t fs_winograd_workspace_floats(int B, int H, int W, int Cin, int Cout, int dil, int tile_m);
-int fs_conv3x3_winograd_nhwc(const float* in, int ld_in, const float* wgt_oihw, const float* scale, const float* shift, float* out,
-                             int ld_out, int B, int H, int W, int Cin, int Cout, int dil, int relu, int tile_m, float* workspace,
-                             fs_stream stream);
-/* Round 4: the split-operand GEMM whose ROW operand is pre-split as well.  out[m][n] = act(scale[n] * sum_k A[m][k] W[n][k] + shift[n])
- * with A [M][K] and W [N][K] each given as three bf16 planes (fs_split_bf16x3 layout: plane t starts t * plane_elems bf16 after the
- * base; element (r, k) at (r * ld + k) inside a plane; K % 32 == 0, ld % 8 == 0); `groups` > 1: group g adds g * g_a / g_b elements
- * inside every plane and g * g_out floats to out (the Winograd position GEMMs).  bn: 128 or 64 output columns per 256-row workgroup
- * tile, 0 = by N.  Same six cross products in the same order as fs_conv2d_nhwc_split: bit-identical sums for the same operands.
- * With FS_OPT_PLANE_OPERANDS the networks use it for the Winograd GEMMs, whose input transform then writes the planes (split once per
- * value instead of once per 128 output channels inside the GEMM). */
-int fs_gemm_bf16x3_planes(const void* a_planes, int64_t a_plane_elems, int ld_a, const void* b_planes, int64_t b_plane_elems, int ld_b,
-                          const float* scale, const float* shift, float* out, int ld_out, int M, int N, int K, int relu, int groups,
-                          int64_t g_a, int64_t g_b, int64_t g_out, int bn, fs_stream stream);
-/* fs_conv3x3_winograd_nhwc on that route: filter bank split at call time, input transform writes the planes of V. */
-size_t fs_winograd_planes_workspace_floats(int B, int H, int W, int Cin, int Cout, int dil, int tile_m);
-int fs_conv3x3_winograd_planes_nhwc(const float* in, int ld_in, const float* wgt_oihw, const float* scale, const float* shift, float* out,
-                                    int ld_out, int B, int H, int W, int Cin, int Cout, int dil, int relu, int tile_m, float* workspace,
-                                    fs_stream stream);
-/* 3x3 stride-1 pad-1 conv with FEW input channels (32 <= Cin <= 256, Cin % 32 == 0, Cout % 64 == 0) as ONE fused Winograd
- * F(4x4,3x3) kernel: input transform, the 36 position GEMMs on the fp32 matrix cores and the output transform (+ scale/shift,
- * ReLU) without the Winograd-domain tensors ever reaching HBM.  The network uses it for the deep stem's 64-channel convs and
- * conv2 of layer1 / layer2 (model/resnet.py:110-116, 67-69).  workspace: fs_winograd_fused_workspace_floats(Cin, Cout) floats
- * (the packed filter bank, rebuilt by every call of this test entry; the network builds it once at fs_finalize).
- * variant: 0 = by workgroup count, 1 = 32 tiles x 64 channels per workgroup, 2 = 16 tiles x 64 channels (two workgroups per CU),
- * 3 = 16 x 64 warp-specialised (four MFMA waves + four transform waves); all give bit-identical results. */
-size_t fs_winograd_fused_workspace_floats(int Cin, int Cout);
-int fs_conv3x3_winograd_fused_nhwc(const float* in, int ld_in, const float* wgt_oihw, const float* scale, const float* shift, float* out,
-                                   int ld_out, int B, int H, int W, int Cin, int Cout, int relu, int variant, float* workspace,
-                                   fs_stream stream);
-/* wgt_hwio: [KH][KW][3][Cout] (weight.permute(2,3,1,0)) */
-int fs_stem_conv_nchw(const float* in_nchw, const float* wgt_hwio, const float* scale, const float* shift, float* out_nhwc,
-                      int B, int H, int W, int Cout, int KH, int KW, int stride, int pad, fs_stream stream);
-/* Round 5: the same stem convolution with split operands (three bf16 terms per fp32 value, six cross products on the bf16 matrix cores,
- * fp32 accumulation: the arithmetic of fs_conv2d_nhwc_split); what the network handles run unless FS_OPT_NO_SPLIT_BF16.  Cout % 32 == 0, <= 128. */
-int fs_stem_conv_nchw_split(const float* in_nchw, const float* wgt_hwio, const float* scale, const float* shift, float* out_nhwc,
-                      int B, int H, int W, int Cout, int KH, int KW, int stride, int pad, fs_stream stream);
-/* Round 5: fs_conv3x3_winograd_fused_nhwc (+ BatchNorm + ReLU) followed by MaxPool2d(3, stride 2, padding 1) as ONE launch (the
- * deep stem's layer0.6 + max-pool): pool = [B][(H-1)/2+1][(W-1)/2+1][Cout]; bit-identical to the two calls it replaces. */
-int fs_conv3x3_winograd_fused_pool_nhwc(const float* in, int ld_in, const float* wgt_oihw, const float* scale, const float* shift, float* pool,
-                                        int B, int H, int W, int Cin, int Cout, float* workspace, fs_stream stream);
-int fs_maxpool3x3s2_nhwc(const float* in, float* out, int B, int H, int W, int C, fs_stream stream);
-int fs_adaptive_avgpool_nhwc(const float* in, int ld_in, float* out, int B, int H, int W, int C, int bin, fs_stream stream);
-int fs_nchw_to_nhwc(const float* in, float* out, int B, int C, int HW, fs_stream stream);
-int fs_nhwc_to_nchw(const float* in, float* out, int B, int C, int HW, fs_stream stream);
 
 #ifdef __cplusplus
 }

@@ -262,8 +262,6 @@ def test_pspnet_r101_713_against_the_reference():
 @pytest.mark.parametrize("opts", [dict(hip_no_winograd=True), dict(hip_winograd_tile=4), dict(hip_winograd_tile=6),
                                   dict(hip_no_fused_head=True), dict(hip_no_fused_shortcut=True), dict(hip_no_fused_winograd=True),
                                   dict(hip_no_split_bf16=True),  # the fp32-MFMA kernels (round 2's arithmetic)
-                                  dict(hip_plane_operands=True),  # round 4 A/B route: V as bf16 planes, position GEMMs on gemm_planes_bf16x3
-                                  dict(hip_chain=True),           # round 5 A/B route: conv3 / next conv1 as one chained launch
                                   dict(hip_no_fused_pool=True),   # round 5 A/B switch: layer0.6 and the max-pool as two launches again
                                   dict(hip_no_res_touch=True),    # round 5 A/B switch: no L2 touch of the shortcut tile before the epilogue
                                   dict(hip_no_split_bf16=True, hip_no_winograd=True),
@@ -287,27 +285,6 @@ def test_every_shipped_option_matches_the_reference_golden_at_713(psp, opts):
     fm = FlowModel(net, feature_based=False, no_warp=True).eval()
     mask = fm.predict_masks(prev, nxt, cu(dl), cu(dr), N)
     assert note(f"option[{tag}]_713_cfg1_mask_disagreement", 1 - (mask.cpu().numpy() == zp["cfg2_mask"]).mean()) < 1 - MASK_MIN
-
-
-@pytest.mark.parametrize("layers,size,b", [(50, (713, 713), 2), (50, (713, 713), 1), (50, (129, 161), 3), (101, (97, 97), 2)])
-def test_chained_bottleneck_boundaries_are_bit_identical_to_separate_launches(psp, layers, size, b):
-    """Round 5 (opt-in, FS_OPT_CHAIN): in layer1 / layer2 conv3 (+ shortcut) of block i and conv1 of block i + 1 as ONE launch
-    (conv_chain_dma_f32): 7 boundaries in ResNet-50 (two of them the concatenated-K projection form, two crossing into the next
-    stage), fewer launches and no re-read of the block output from memory.  Same multiply-adds in the same order per output: the
-    encoder features and the logits are BIT-identical to the default two-launch route.  The network takes the chained launch where
-    one image's map still gives 192 workgroups of 128 rows (layer1 at 713^2: 3 boundaries); the op-level test covers every tile
-    shape and the layer2 geometries (tests/test_gpu_ops.py::test_conv_chain_is_bit_identical_to_its_two_launches)."""
-    state = psp[1] if layers == 50 else synth.make_pspnet_state(layers, 5, seed=0)
-    chained, plain = FlowPSPNet(HP(layers=layers, hip_chain=True)).eval(), FlowPSPNet(HP(layers=layers)).eval()
-    chained.load_state_dict(state)
-    plain.load_state_dict(state)
-    x = synth.make_clip(b, size, seed=56).cuda()
-    assert torch.equal(chained.segment(x), plain.segment(x))
-    assert torch.equal(chained.encoder(x), plain.encoder(x))
-    rows = {r[0]: r[1] for r in _profile_rows(chained, x)}
-    # the network chains only where one image's map gives >= 192 workgroups of 128 rows: the three layer1 boundaries at 713^2
-    assert sum(" -> " in k for k in rows) == (3 if size[0] == 713 else 0) and all(v.startswith("chain") for k, v in rows.items() if " -> " in k)
-    assert not any(" -> " in r[0] for r in _profile_rows(plain, x))
 
 
 @pytest.mark.parametrize("size,b", [((713, 713), 2), ((713, 713), 1), ((257, 323), 3), ((129, 161), 2), ((65, 65), 1)])

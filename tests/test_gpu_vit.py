@@ -70,13 +70,14 @@ def test_small_segmenters_against_oracle(cfg):
     got32 = net32(x.cuda())["pred"]
     assert rel_err(got32.cpu(), ref) < VIT_TOL
     assert rel_err(got.cpu(), got32.cpu()) < VIT_TOL
-    # ... and with the attention on the software-pipelined kernel (FS_OPT_ATT_PIPELINED: another partition of each query's keys)
-    netp = VITSegmentModel(5, cfg["image_size"], patch_size=cfg["patch"], d_model=cfg["d_model"], n_layers=cfg["n_layers"],
-                           dec_layers=cfg["dec_layers"], hip_att_pipelined=True).eval()
-    netp.load_state_dict(state)
-    gotp = netp(x.cuda())["pred"]
-    assert rel_err(gotp.cpu(), ref) < VIT_TOL
-    assert rel_err(got.cpu(), gotp.cpu()) < VIT_TOL
+    # ... and with the attention's K / V^T planes written by a separate pre-pass instead of the qkv Linear's epilogue (FS_OPT_NO_FUSED_QKV):
+    # the same planes, so the same bits
+    netq = VITSegmentModel(5, cfg["image_size"], patch_size=cfg["patch"], d_model=cfg["d_model"], n_layers=cfg["n_layers"],
+                           dec_layers=cfg["dec_layers"], hip_no_fused_qkv=True).eval()
+    netq.load_state_dict(state)
+    assert torch.equal(netq(x.cuda())["pred"], got)
+    with pytest.raises(ValueError, match="unknown hip option"):
+        VITSegmentModel(5, cfg["image_size"], hip_att_pipelined=True)  # a retired / mistyped option is refused, not ignored
 
 
 def test_vit_feature_flow_extension_against_oracle_parity_unpinned():

@@ -144,7 +144,7 @@ def test_hip_options_come_from_hparams_not_from_the_environment(monkeypatch):
         hip_no_winograd, hip_winograd_tile = True, 6
     monkeypatch.setenv("FS_NO_FUSED_HEAD", "1")  # a round-1 knob: must be ignored now
     net = FlowPSPNet(O())
-    assert hip_options(O()) == dict(no_winograd=True, no_fused_winograd=False, no_split_bf16=False, plane_operands=False, chain=False, no_res_touch=False, no_fused_pool=False, att_pipelined=False,
+    assert hip_options(O()) == dict(no_winograd=True, no_fused_winograd=False, no_split_bf16=False, no_res_touch=False, no_fused_pool=False, no_fused_qkv=False,
                                     no_fused_head=False, no_fused_shortcut=False, winograd_tile=6)
     assert net._hip_net.flags == _lib.OPT_NO_WINOGRAD and net._hip_net.winograd_tile == 6
     assert FlowPSPNet(HP())._hip_net.flags == 0
@@ -153,13 +153,20 @@ def test_hip_options_come_from_hparams_not_from_the_environment(monkeypatch):
         hip_no_split_bf16 = True  # round 3: the implicit GEMMs on the fp32-MFMA kernel instead of the split-operand one
     assert FlowPSPNet(P32())._hip_net.flags == _lib.OPT_NO_SPLIT_BF16
 
-    class PNP(HP):
-        hip_plane_operands = True  # round 4 A/B route: the Winograd input transform writes bf16 planes, GEMMs on gemm_planes_bf16x3
-    assert FlowPSPNet(PNP())._hip_net.flags == _lib.OPT_PLANE_OPERANDS
+    class Retired(HP):
+        hip_chain = True  # a route removed in round 6 (or any mistyped name): refused, never silently the defaults
+    with pytest.raises(ValueError, match="unknown hip option"):
+        FlowPSPNet(Retired())
 
-    class PNC(HP):
-        hip_chain = True  # round 5 A/B route: conv3 of block i and conv1 of block i + 1 as one chained launch
-    assert FlowPSPNet(PNC())._hip_net.flags == _lib.OPT_CHAIN
+    class DictLike(dict):  # Lightning hands hparams over as an AttributeDict: options are keys
+        def __getattr__(self, k):
+            try:
+                return self[k]
+            except KeyError:
+                raise AttributeError(k) from None
+    with pytest.raises(ValueError, match="unknown hip option"):
+        hip_options(DictLike(layers=50, classes=5, hip_res_touch=True))
+    assert hip_options(DictLike(layers=50, classes=5, hip_no_res_touch=True))["no_res_touch"] is True
 
 
 def test_model_representation_eval_is_pass_through():
@@ -308,9 +315,9 @@ def test_bench_quotes_pmc_traffic_only_for_the_running_build(tmp_path, monkeypat
 
     assert bench.kernel_symbol("igemm128x128") == "conv_igemm_dma_f32<128, 128, 2, 2, false, false>"
     assert bench.kernel_symbol("igemm128x64cat") == "conv_igemm_dma_f32<128, 64, 2, 2, true, false>"
-    assert bench.kernel_symbol("igemm256x128") == "conv_igemm_dma_f32<256, 128, 4, 2, false, false>"
     assert bench.kernel_symbol("split128x128") == "conv_igemm_dma_f32<128, 128, 4, 1, false, true>"      # the split-operand instantiations
     assert bench.kernel_symbol("split128x64cat") == "conv_igemm_dma_f32<128, 64, 4, 1, true, true>"
+    assert bench.kernel_symbol("split128x96") == "conv_igemm_dma_f32<128, 96, 4, 1, false, true>"
     prof = tmp_path / "profiles"
     prof.mkdir()
     monkeypatch.setattr(bench, "ROOT", str(tmp_path))

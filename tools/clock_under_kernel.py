@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Why do isolated kernel wins vanish inside a window?  One GEMM launched back to back for ~1.5 s per candidate tile while the card's shader clock
 and socket power are sampled (bench.ClockSampler): time per launch, clock held, power drawn, and time x clock (cycles per launch).
-usage: clock_under_kernel.py [seconds per candidate] [other build of the library, e.g. the make DEV=1 one with tile 5]"""
+usage: clock_under_kernel.py [seconds per candidate] [other build of the library]"""
 import os
 import sys
 import time
@@ -14,11 +14,11 @@ from flood_uav_video_segmentation_amd import _lib  # noqa: E402
 from flood_uav_video_segmentation_amd._lib import check, ptr, stream_ptr  # noqa: E402
 
 SHAPES = {  # rows, cin, cout, tiles to compare
-    "layer4 conv1 16200 x 2048 -> 512": (16200, 2048, 512, (1, 7, 2, 5)),
-    "layer4 conv3 16200 x 512 -> 2048": (16200, 512, 2048, (1, 7, 2, 5)),
+    "layer4 conv1 16200 x 2048 -> 512": (16200, 2048, 512, (1, 2)),
+    "layer4 conv3 16200 x 512 -> 2048": (16200, 512, 2048, (1, 2)),
     "layer3 conv1 16200 x 1024 -> 256": (16200, 1024, 256, (2, 1, 3)),
 }
-NAMES = {1: "128x128", 2: "128x64", 3: "64x64", 5: "256x128 (4 waves)", 7: "256x128 (8 waves)"}
+NAMES = {1: "128x128", 2: "128x64", 3: "64x64"}  # (the 256 x 128 tiles of profiles/r05_experiments.txt section 19 were removed in round 6)
 
 
 def main():
@@ -38,8 +38,6 @@ def main():
         out = torch.empty(1, 1, m, cout, device="cuda")
         for rep in range(2):
             for tile in tiles:
-                if tile == 5 and not dev:
-                    continue
 
                 def fn():
                     check(lib.fs_conv2d_nhwc_split(ptr(x), cin, ptr(pl), ptr(sc), ptr(sh), None, cout, ptr(out), cout, 1, 1, m, cin, cout, 1, 1, 1, 0, 1, 0, tile,
