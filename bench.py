@@ -494,18 +494,36 @@ def main():
         host_masks.copy_(out["mask"], non_blocking=True)
         torch.cuda.current_stream().synchronize()  # masks are on the host when the step ends
 
+    def enqueue_native(i):
+        """step_native without the wait: what the HOST does per window (Python, ctypes, launches, the async copy)."""
+        prev, nxt = windows[i % nwin]
+        host_masks.copy_(fm.predict(prev, nxt, dl, dr, N_DELTA, None, with_mask=True)["mask"], non_blocking=True)
+
     step_s, marks = [], {}
-    elapsed = timed(step_native, args.steps, args.warmup, dev, step_s, marks)
+    cs_timed = ClockSampler(torch, 0.01)  # this rank's card while the timed region runs (one sysfs read per 10 ms)
+    with cs_timed:
+        elapsed = timed(step_native, args.steps, args.warmup, dev, step_s, marks)
     _, frames_total, elapsed_max = shard.reduce_run(torch.zeros(3, CLASSES, dtype=torch.int64), args.steps * N_DELTA, elapsed, rdev)
     fps = frames_total / elapsed_max
     # process start (the launcher's, when bench.py spawned the ranks itself) -> first timed step, per rank: imports, weights, data,
     # workspace, warm-up and the barrier -- what a driver-side timeout on a many-GPU node would have been spent on
     t_ref = float(os.environ.get("FS_BENCH_LAUNCHER_T0", T_PROCESS))
     # every rank's own figures (mean and median step, start-up), so that a straggler is visible in the N > 1 line
-    per_rank = shard.gather_floats([elapsed / args.steps * 1e3, median(step_s) * 1e3, marks["first_timed_step"] - t_ref], rdev)
     # a short timed region says little about the clock the card settles at: the same step for >= 0.8 s right behind it (every rank
     # runs it, so the ranks stay symmetric; rank 0 reports its own)
     steady = steady_state_block(step_native, torch) if elapsed < STEADY_MIN_TIMED_S else None
+    # host time to ENQUEUE one window (no wait; a short burst, so the launch queue never pushes back): with one process per GPU on a
+    # many-GPU node this is what the ranks' share of the host cores has to sustain -- a rank is host-bound once it reaches ms_per_step
+    torch.cuda.synchronize()
+    t_enq = time.perf_counter()
+    for i in range(4):
+        enqueue_native(i)
+    enqueue_ms = (time.perf_counter() - t_enq) / 4 * 1e3
+    torch.cuda.synchronize()
+    # the clock this rank's card held: sampled inside the timed region when that was long enough for a few samples, else in the block above
+    sclk = (sum(cs_timed.clk) / len(cs_timed.clk)) if len(cs_timed.clk) >= 4 else ((steady or {}).get("sclk_mhz_mean") or -1.0)
+    per_rank = shard.gather_floats([elapsed / args.steps * 1e3, median(step_s) * 1e3, marks["first_timed_step"] - t_ref, enqueue_ms, float(sclk),
+                                    float(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))], rdev)
 
     result = {
         "metric": "segmentation FPS @713x713 (PSPNet-ResNet50 keyframe + linear interp, frame_delta=5)",
@@ -531,6 +549,14 @@ def main():
         "distributed": {"backend": backend, "rccl_world_size": dist_world if backend == "nccl" else 0, "world_size": dist_world,
                         "rank_ms_per_step": {"min": round(min(r[0] for r in per_rank), 4), "max": round(max(r[0] for r in per_rank), 4),
                                              "per_rank": [round(r[0], 4) for r in per_rank]},
+                        # what an N = 8 line is read with: the host side of every rank -- time to enqueue one window
+                        # (host-bound when it approaches ms_per_step), the cores the rank may run on, and the clock its card held
+                        "host_enqueue_ms_per_step": {"max": round(max(r[3] for r in per_rank), 4), "per_rank": [round(r[3], 4) for r in per_rank],
+                                                     "what": "host wall time to enqueue one window without waiting (4 windows, after the timed region)"},
+                        "host_cpus": {"cpu_count": os.cpu_count(), "affinity_per_rank": [int(r[5]) for r in per_rank], "ranks": world,
+                                      "cpus_per_rank": round(min(r[5] for r in per_rank) / max(world, 1), 2)},
+                        "sclk_mhz_mean": {"per_rank": [round(r[4], 1) if r[4] > 0 else None for r in per_rank],
+                                          "source": "hwmon freq1_input of each rank's card during its timed region (the steady-state block when that was too short)"},
                         "startup_s": {"max": round(max(r[2] for r in per_rank), 2), "per_rank": [round(r[2], 2) for r in per_rank],
                                       "from": "bench.py launcher start" if "FS_BENCH_LAUNCHER_T0" in os.environ else "this process's start",
                                       "to": "first timed step (after imports, weights, resident inputs, fs_reserve, warm-up, barrier)"},

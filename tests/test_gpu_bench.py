@@ -51,6 +51,13 @@ def test_bench_json_line_has_the_contract_fields():
     assert 0.6 * j["ms_per_step"] < st["ms_per_step"] < 1.4 * j["ms_per_step"] and (st["sclk_mhz_mean"] is None or 500 < st["sclk_mhz_mean"] < 3000)
     su = d["startup_s"]
     assert su["per_rank"] == [su["max"]] and 0 < su["max"] < 600 and su["from"] == "this process's start"
+    # r6: the host side of the line -- enqueue time per window (GPU-bound path: a fraction of the step), cores, the card's clock
+    he = d["host_enqueue_ms_per_step"]
+    assert he["per_rank"] == [he["max"]] and 0.01 < he["max"] < 0.5 * j["ms_per_step"]
+    hc = d["host_cpus"]
+    assert hc["ranks"] == 1 and hc["affinity_per_rank"][0] >= 1 and hc["cpu_count"] >= hc["affinity_per_rank"][0] and hc["cpus_per_rank"] >= 1
+    sc = d["sclk_mhz_mean"]["per_rank"]
+    assert len(sc) == 1 and (sc[0] is None or 500 < sc[0] < 3000)
 
 
 def test_bench_two_ranks_rehearsed_on_one_gpu():
@@ -108,6 +115,39 @@ def test_bench_four_ranks_spawned_by_the_launcher_on_one_gpu():
     su = j["distributed"]["startup_s"]  # launcher start -> first timed step, every rank's own
     assert len(su["per_rank"]) == 4 and su["max"] == max(su["per_rank"]) and su["from"] == "bench.py launcher start" and min(su["per_rank"]) > 1.0
     assert abs(j["value"] - 4 * 5 * 1000.0 / j["ms_per_step"]) < 1e-2 * j["value"]
+    d = j["distributed"]
+    assert len(d["host_enqueue_ms_per_step"]["per_rank"]) == 4 and len(d["sclk_mhz_mean"]["per_rank"]) == 4 and d["host_cpus"]["ranks"] == 4
+
+
+def test_four_ranks_squeezed_onto_four_cores_keep_their_step_time():
+    """The only host-contention evidence a 1-GPU lease can give: the 4-rank rehearsal once with the box's cores and once
+    with the whole process tree pinned to FOUR cores (one per rank: launcher, torchrun agent, ranks, their helper threads).  The ranks
+    share one GPU in both runs, so the difference between the two is the host's.  Per-rank step time must not degrade by 10 %, and
+    the time a rank needs to ENQUEUE a window on its one core must stay far below the 4-ms window of a GPU of its own -- the
+    condition for an 8-rank node with >= 1 core per rank to stay GPU-bound."""
+    cpus = sorted(os.sched_getaffinity(0))
+    if len(cpus) < 8:
+        pytest.skip("needs at least 8 cores to compare a free run with a 4-core one")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "24", "--warmup", "4", "--no-extras", "--no-cpu-baseline",
+           "--rehearse-on-one-gpu"]
+
+    def run(pin):
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, cwd=ROOT, env=env,
+                           preexec_fn=(lambda: os.sched_setaffinity(0, pin)) if pin else None)
+        assert r.returncode == 0, r.stderr[-3000:]
+        return _last_json(r.stdout)
+
+    free, tight = run(None), run(set(cpus[:4]))
+    assert tight["distributed"]["host_cpus"]["affinity_per_rank"] == [4] * 4 and tight["distributed"]["host_cpus"]["cpus_per_rank"] == 1.0
+    assert min(free["distributed"]["host_cpus"]["affinity_per_rank"]) >= 8
+    slow = tight["ms_per_step"] / free["ms_per_step"]
+    from conftest import note
+    note("four_ranks_on_four_cores_step_time_ratio", slow)
+    note("four_ranks_on_four_cores_host_enqueue_ms", tight["distributed"]["host_enqueue_ms_per_step"]["max"])
+    assert slow < 1.10, (free["distributed"]["rank_ms_per_step"], tight["distributed"]["rank_ms_per_step"])
+    # a window of a GPU of its own takes ~4 ms (this run's ranks share one card: ms_per_step / 4 is that window)
+    assert tight["distributed"]["host_enqueue_ms_per_step"]["max"] < 0.5 * tight["ms_per_step"] / 4
 
 
 def test_rccl_code_path_with_a_world_of_one():

@@ -49,7 +49,10 @@ def main():
     lib = _lib.load()
     print(f"B = {b}")
     print(f"{'shape':42s} " + " ".join(f"{NAMES[t]:>10s}" for t in NAMES) + "   best vs auto")
+    only = sys.argv[2] if len(sys.argv) > 2 else ""   # substring filter on the shape names
     for name, (h, w, cin, cout, k, stride, res) in SHAPES.items():
+        if only not in name:
+            continue
         g = torch.Generator(device="cuda").manual_seed(1)
         x = torch.randn(b, h, w, cin, device="cuda", generator=g).relu()
         wt = torch.randn(cout, cin, k, k, device="cuda", generator=g) * (2.0 / (cin * k * k)) ** 0.5

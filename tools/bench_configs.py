@@ -29,8 +29,9 @@ class HP:
 
     def __init__(self, layers):
         self.layers, self.classes, self.pretrained = layers, 5, False
-        for word in HP.OPTIONS:
-            setattr(self, word, True)
+        for word in HP.OPTIONS:  # NAME or NAME=INT
+            name, _, val = word.partition("=")
+            setattr(self, name, int(val) if val else True)
 
 
 def timeit(fn, steps=10, warmup=2):
@@ -48,7 +49,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="", help="cfg0 | cfg1 | cfg4 | feat | crops | crops_cached | cfg2 | cfg3 | vitb")
     ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--opt", action="append", default=[], help="hip_no_split_bf16 | hip_no_winograd | hip_plane_operands | ... (repeatable)")
+    ap.add_argument("--opt", action="append", default=[], help="hip_no_split_bf16 | hip_no_winograd | hip_winograd_tile=4 | ... (repeatable; model/hipnet.py::HIP_OPTIONS)")
     ap.add_argument("--lib", default=None, help="development A/B: load this build of the library instead of the in-tree one")
     ap.add_argument("--feat-op-by-op", action="store_true", help="A/B: predict_feature's tail op by op instead of fs_feat_tail (feat, cfg3)")
     ap.add_argument("--json", action="store_true", help="also print one JSON line {value, unit, ms_per_step, steps} of the last config run")
@@ -128,13 +129,13 @@ def main():
         rows.append(("configs[2] DeepLabv3-R101 keyframe + logit warp", N / t, t * 1e3))
         del dl3
     if want("cfg3"):
-        vit = VITSegmentModel(5, 704, patch_size=16, d_model=384, n_layers=12, dec_layers=2, **{w: True for w in HP.OPTIONS}).eval()
+        vit = VITSegmentModel(5, 704, patch_size=16, d_model=384, n_layers=12, dec_layers=2, **{w.partition("=")[0]: (int(w.partition("=")[2]) if "=" in w else True) for w in HP.OPTIONS}).eval()
         vit.load_state_dict(synth.make_vit_state(5, 704, 16, 384, 12, 2, seed=0))
         t = timeit(window(FlowModel(vit, feature_based=True, no_warp=False).eval(), (wl, wr)), st)
         rows.append(("configs[3] Segmenter ViT-S/16 keyframe + feature flow (extension)", N / t, t * 1e3))
         del vit
     if want("vitb"):
-        vitb = VITSegmentModel(5, 704, **{w: True for w in HP.OPTIONS}).eval()
+        vitb = VITSegmentModel(5, 704, **{w.partition("=")[0]: (int(w.partition("=")[2]) if "=" in w else True) for w in HP.OPTIONS}).eval()
         vitb.load_state_dict(synth.make_vit_state(5, 704, seed=0))
 
         def vit_single(i):
