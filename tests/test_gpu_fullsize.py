@@ -13,7 +13,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from conftest import load_golden, note, rel_err
+from conftest import memo_by_content, load_golden, note, rel_err
 from flood_uav_video_segmentation_amd import ops, synth
 from flood_uav_video_segmentation_amd.flow import crops
 from flood_uav_video_segmentation_amd.flow.model import FlowModel, KeyframeCache
@@ -54,6 +54,17 @@ def memo(fn):
             cache[key] = fn(x)
         return cache[key]
     return wrapped
+
+
+_CROP_SEG = {}
+
+
+def _crop_oracle_seg(state):
+    """pspnet_oracle's decoder(encoder(.)) for `state`, memoised by input content across the tests of this module."""
+    key = id(state)
+    if key not in _CROP_SEG:
+        _CROP_SEG[key] = (state, memo_by_content(lambda x: pspnet_oracle.decoder(pspnet_oracle.encoder(x, state, 50), state)))
+    return _CROP_SEG[key][1]
 
 
 @pytest.fixture(scope="module")
@@ -434,8 +445,9 @@ def test_sliding_crops_1072x1920_pspnet_batched_route_against_oracle(full_hd, no
     fn = lambda p, q, ml, mr: fm.predict(p, q, ml, mr, N, None)["pred"]  # noqa: E731
     canvas_g, mask_g = crops.compute_output(fm, N, prev.cuda(), nxt.cuda(), cu(mvl), cu(mvr), 713, 713, 5, want_mask=True, function=fn)
     assert torch.equal(canvas, canvas_g) and torch.equal(mask, mask_g)  # same arithmetic per crop, bit for bit
-    # (no memo here: the oracle clones every crop, and a freed clone's address may be reused by the next one)
-    seg = lambda x: pspnet_oracle.decoder(pspnet_oracle.encoder(x, state, 50), state)  # noqa: E731
+    # memoised on the crops' CONTENT (the oracle clones every crop: addresses repeat, contents do not lie): the 16 oracle forwards are
+    # the same for the warp and the no_warp run of this test -- only the tail differs
+    seg = _crop_oracle_seg(state)
     pred = lambda p, q, ml, mr: flow_oracle.predict_segmentation(lambda x: x, seg, p, q, ml, mr, N, no_warp)["pred"]  # noqa: E731
     ref = crops_oracle.compute_output(pred, N, prev, nxt, mvl, mvr, 713, 713, 5)
     tag = "nowarp" if no_warp else "warp"
