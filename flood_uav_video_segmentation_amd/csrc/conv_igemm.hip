@@ -408,15 +408,15 @@ __device__ __forceinline__ void conv_tile(ConvParams p, const int m0, const int 
                 FS_DMA_ADVANCE()
             }
             if (kc == touch_kc) {
-                // the residual tile is BM rows x BN * 4 / 128 lines; thread t touches lines (t & 1) * 2 + {0, 1} of row t >> 1 (+ 128 per pass)
+                // the residual tile is BM rows x LPR = BN * 4 / 128 lines; thread t touches lines t and t + NT of the tile's BM * LPR (by
+                // line, not by row pair: on the 128 x 96 tile a row has three lines -- ADVICE r5)
                 const __amdgpu_buffer_rsrc_t t_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.res, 0, (unsigned)((long long)M * p.ld_res * 4), 0x00020000);
                 constexpr int LPR = BN / 32;  // lines per row
-                const int tl = t * 2;
-                const int trow = tl / LPR, tline = tl % LPR;
-                const bool ok = trow < BM && n0 + tline * 32 < p.Cout;
-                const unsigned vo = ok ? (unsigned)((m0 + trow) * p.ld_res + n0 + tline * 32) * 4u : 0x80000000u;
-                touch0 = __builtin_amdgcn_raw_buffer_load_b32(t_rsrc, vo, 0, 0);
-                touch1 = __builtin_amdgcn_raw_buffer_load_b32(t_rsrc, (ok && tline + 1 < LPR && n0 + (tline + 1) * 32 < p.Cout) ? vo + 128u : 0x80000000u, 0, 0);
+                const int l0 = t, l1 = t + NT;
+                const int r0t = l0 / LPR, c0t = l0 % LPR, r1t = l1 / LPR, c1t = l1 % LPR;
+                const bool ok0 = l0 < BM * LPR && n0 + c0t * 32 < p.Cout, ok1 = l1 < BM * LPR && n0 + c1t * 32 < p.Cout;
+                touch0 = __builtin_amdgcn_raw_buffer_load_b32(t_rsrc, ok0 ? (unsigned)((m0 + r0t) * p.ld_res + n0 + c0t * 32) * 4u : 0x80000000u, 0, 0);
+                touch1 = __builtin_amdgcn_raw_buffer_load_b32(t_rsrc, ok1 ? (unsigned)((m0 + r1t) * p.ld_res + n0 + c1t * 32) * 4u : 0x80000000u, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
             FS_READ3(cur ^ 1, 0, araw, B3)  // (after the last chunk: a stale stage, read and never used)

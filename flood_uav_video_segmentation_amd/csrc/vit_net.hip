@@ -48,13 +48,14 @@ int make_block(fs_net* h, VitBlock& b, const std::string& p, int D, hipStream_t 
 // them with two and the rest with one) while its K is long: cut K into `split` slices -- grouped launch, group g multiplies
 // columns g*K/split .. of the [out][in] weight rows (ConvParams::ld_wgt) into its own partial buffer -- and merge the partials
 // with bias + residual in one small pass.  S/16 fc2 59 -> 4x us (profiles/r02_experiments.txt).  0 = no split.
-int linear_splits(const Linear& l, int rows_per_image, int act) {
+int linear_splits(const Linear& l, int rows_per_image, int act, bool split_route) {
     // decided on ONE image's rows (for the usual batch of two key frames: ~768 workgroups), never on the batch: a frame's
     // result must not depend on the batch it is computed in (the key-frame cache relies on it)
     if (act != 0 || l.in < 768) return 0;
-    // the tile the launch will get (conv_igemm.hip::pick_tile): 128 x 96 where 96 divides the columns, else 64 x 64; aim at two
-    // workgroups per CU for a pair of images
-    const bool t96 = l.out % 96 == 0;
+    // the tile the launch will get (conv_igemm.hip::pick_tile): 128 x 96 where 96 divides the columns -- a tile of the split-operand
+    // route only (the fp32-MFMA route keeps the 64 x 64 estimate it was fitted with) -- else 64 x 64; aim at two workgroups
+    // per CU for a pair of images
+    const bool t96 = split_route && l.out % 96 == 0;
     const long tiles = t96 ? (long)cdiv(rows_per_image, 128) * (l.out / 96) : (long)cdiv(rows_per_image, 64) * cdiv(l.out, 64);
     const long want = t96 ? 256 : 384;
     int split = (int)std::min<long>(4, (want + tiles / 2) / std::max<long>(tiles, 1));
@@ -67,7 +68,7 @@ int linear_splits(const Linear& l, int rows_per_image, int act) {
 // *ln_done is set; otherwise the caller runs that LayerNorm itself.
 int run_linear(fs_net* h, const Linear& l, const float* in, int rows, float* out, const float* res, int act, hipStream_t s, float* part = nullptr,
                int rows_per_image = 0, const LNorm* ln = nullptr, float* ln_out = nullptr, bool* ln_done = nullptr) {
-    const int split = part ? linear_splits(l, rows_per_image ? rows_per_image : rows, act) : 0;
+    const int split = part ? linear_splits(l, rows_per_image ? rows_per_image : rows, act, h->use_split) : 0;
     if (ln_done) *ln_done = false;
     if (split) {
         ConvParams p{};

@@ -14,7 +14,7 @@ which = sys.argv[1] if len(sys.argv) > 1 else "s16"
 if len(sys.argv) > 2 and sys.argv[2] != "-":
     _lib.LIB_PATH, _lib.ALLOW_MISSING = os.path.abspath(sys.argv[2]), True
 cfg = dict(patch=16, d=384) if which == "s16" else dict(patch=32, d=768)
-opts = {w: True for w in sys.argv[3:]}  # e.g. hip_att_pipelined
+opts = {w: True for w in sys.argv[3:]}  # e.g. hip_no_fused_qkv
 net = VITSegmentModel(5, 704, patch_size=cfg["patch"], d_model=cfg["d"], **opts).eval()
 net.load_state_dict(synth.make_vit_state(5, 704, cfg["patch"], cfg["d"], 12, 2, seed=0))
 x = synth.make_clip(2, 713, seed=3).cuda()
