@@ -2,7 +2,7 @@
 # Copy what the last tools/gpu_round.sh left under gpurun_out/ into the tracked profiles/ directory (round tag as $1, e.g. r02).
 set -e
 cd "$(dirname "$0")/.."
-T=${1:-r04}; O=gpurun_out/prof_$T
+T=${1:-r06}; O=gpurun_out/prof_$T
 [ -d "$O" ] || { echo "no $O: run ROUND=$T tools/gpu_round.sh first (this script never copies another round's artefacts)"; exit 1; }
 cp $O/bench_kernel_stats.csv profiles/${T}_bench_kernel_stats.csv
 cp $O/cfg2_kernel_stats.csv profiles/${T}_cfg2_deeplabv3_r101_kernel_stats.csv

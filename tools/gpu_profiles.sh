@@ -3,7 +3,7 @@
 # (tools/bench_configs.py --only cfgN), + the per-layer HIP-event tables.  Outputs under gpurun_out/prof_$ROUND/ (ROUND: round tag, default r03).
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-/root/repo}
-ROUND=${ROUND:-r04}
+ROUND=${ROUND:-r06}
 O=$R/gpurun_out/prof_$ROUND
 rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
