@@ -24,7 +24,9 @@ def is_channels_last_dense(t):
     if t.dim() != 4:
         return False
     b, c, h, w = t.shape
-    return t.stride() == (h * w * c, 1, w * c, c) or (c == 1 and t.is_contiguous())
+    want = (h * w * c, 1, w * c, c)
+    # (the stride of a size-1 dimension is arbitrary: torch keeps whatever the tensor was made with)
+    return all(n == 1 or s == ws for n, s, ws in zip(t.shape, t.stride(), want)) or (c == 1 and t.is_contiguous())
 
 
 def as_nhwc(t):

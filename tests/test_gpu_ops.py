@@ -427,6 +427,30 @@ def test_feat_tail_is_bit_identical_to_the_op_by_op_route(case, no_warp, single)
         assert rel(got, torch.cat(ref, 0)) < INTERP_TOL
 
 
+def test_feat_tail_on_seeded_random_geometries():
+    """40 seeded random geometries through fs_feat_tail against the op-by-op route, bit for bit: grids larger AND smaller than the map
+    (the run loop's down-sampling branch reloads both register sets), 1-pixel maps and grids, channel counts that leave the last XCD's
+    slab short or empty, n = 1 (no chain at all) .. 7."""
+    import random
+    rnd = random.Random(606)
+    for it in range(40):
+        C = 4 * rnd.choice([16, 17, 24, 31, 32, 33, 64, 96, 130])
+        fh, fw = rnd.choice([(1, 1), (1, 9), (7, 1), (5, 6), (13, 11), (23, 31)])
+        Hg, Wg = rnd.choice([(1, 1), (2, 3), (fh, fw), (2 * fh + 1, 3 * fw), (9, 4)])
+        H0, W0 = rnd.choice([(1, 1), (fh, fw), (3, 5), (11, 17)])
+        n = rnd.choice([1, 2, 3, 5, 7])
+        no_warp, single = rnd.random() < 0.25, rnd.random() < 0.2
+        g = torch.Generator().manual_seed(1000 + it)
+        f = (torch.randn(1, C, fh, fw, generator=g) * 2).to(DEV).contiguous(memory_format=torch.channels_last)
+        f_next = None if single else (torch.randn(1, C, fh, fw, generator=g) * 2).to(DEV).contiguous(memory_format=torch.channels_last)
+        mk = lambda: (torch.rand(1, Hg, Wg, 2, generator=g) * 2.4 - 1.2).to(DEV)  # noqa: E731
+        mvl, mvr = [mk() for _ in range(n - 1)], [mk() for _ in range(n - 1)]
+        g0 = (torch.rand(1, H0, W0, 2, generator=g) * 2.4 - 1.2).to(DEV)
+        got = ops.feat_tail(f, f_next, mvl, mvr, n, no_warp, None if no_warp else g0)
+        want = _feature_tail_op_by_op(f, f_next, mvl, mvr, n, no_warp, g0)
+        assert torch.equal(got, want), (it, C, fh, fw, Hg, Wg, H0, W0, n, no_warp, single)
+
+
 def test_feat_tail_refuses_what_it_cannot_address():
     f = torch.randn(1, 64, 8, 8, device=DEV).contiguous(memory_format=torch.channels_last)
     g = [torch.zeros(1, 4, 4, 2, device=DEV)]
