@@ -95,9 +95,8 @@ template <int BM, int BN, bool SPLIT, int WAVES = 4>
 constexpr int conv_tile_lds_floats() { return 2 * (BM * 32 + (SPLIT ? 3 * conv_split_rows(BN, WAVES) * 16 : BN * 32)); }
 
 // One BM x BN output tile at (m0, n0): prologue, main loop, epilogue.  `lds` = conv_tile_lds_floats() floats, 1 KiB aligned; every
-// wave of the workgroup calls it with the same arguments.  A_AUX: cache-policy bits of the PIXEL operand's DMA loads (16 = sc1,
-// served by L2 past this CU's L1: conv_chain_dma_f32 below reads rows the same workgroup stored a moment ago).
-template <int BM, int BN, int WGM, int WGN, bool DUAL, bool SPLIT, int A_AUX = 0>
+// wave of the workgroup calls it with the same arguments.
+template <int BM, int BN, int WGM, int WGN, bool DUAL, bool SPLIT>
 __device__ __forceinline__ void conv_tile(ConvParams p, const int m0, const int n0, float* __restrict__ lds, const int bid) {
 #if defined(__HIP_DEVICE_COMPILE__)  // the buffer-resource builtins do not exist in the host pass, which only needs the launch stub
     constexpr int BK = 32;
@@ -227,11 +226,11 @@ __device__ __forceinline__ void conv_tile(ConvParams p, const int m0, const int 
         if (DUAL && second) {                                                                                     \
             const unsigned vo = (a_mask[j] & 1u) ? a2_voff[DUAL ? j : 0] : SENT;                                  \
             __builtin_amdgcn_raw_ptr_buffer_load_lds(a2_rsrc, (__attribute__((address_space(3))) void*)(lds + (STG) * STAGE + (8 * wv_u + RSTEP * j) * BK), \
-                                                     16, vo, a_soff, 0, A_AUX);                                   \
+                                                     16, vo, a_soff, 0, 0);                                       \
         } else {                                                                                                  \
             const unsigned vo = ((a_mask[j] >> tap_bit) & 1u) ? a_voff[j] : SENT;                                 \
             __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (__attribute__((address_space(3))) void*)(lds + (STG) * STAGE + (8 * wv_u + RSTEP * j) * BK), \
-                                                     16, vo, a_soff, 0, A_AUX);                                   \
+                                                     16, vo, a_soff, 0, 0);                                       \
         }                                                                                                         \
     } else if (SPLIT) {                                                                                           \
         const int jj = (ROW_) >= RA ? (ROW_) - RA : 0;                                                            \

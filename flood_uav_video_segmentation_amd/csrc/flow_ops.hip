@@ -405,9 +405,9 @@ int launch_seg_tail(const SegTailParams& p, hipStream_t s) {
 //   warp chains   w_1 = warp(f, g_0), w_j = warp(w_{j-1}, g_{j-1})  kept at GRID resolution [Hg][Wg][C]         (:135-151)
 //   stack[0]    = up(grid_sample(f, default grid [H0][W0], align_corners=True))                                 (:154-159)
 //   stack[p]    = (n-p)/n * up(fwd[p-1]) + p/n * up(bwd[n-p-1]),  up = bilinear align_corners=True to fh x fw   (:166-171)
-// The reference (and the op-by-op route) materialises the eight upsampled maps and the H0 x W0 resample; here the steps of a
-// chain are one launch for both directions and ONE launch writes every map of the decoder's batch straight from the low-resolution
-// chains.  Same operations in the same order per element (gs_combine, bilerp, separate mul / add roundings): bit-identical to
+// The reference (and the op-by-op route) materialises the eight upsampled maps and the H0 x W0 resample; here a step of the two
+// chains is one launch and two launches (key map; maps 1..n-1) write the decoder's batch straight from the low-resolution chains.
+// Same operations in the same order per element (gs_combine, bilerp, separate mul / add roundings): bit-identical to
 // fs_grid_sample_nhwc -> fs_resize_bilinear_nhwc -> fs_blend.
 __global__ __launch_bounds__(256) void feat_warp_step_kernel(const float* __restrict__ src_f, const float* __restrict__ src_b, int Hs, int Ws,
                                                              const float* __restrict__ grid_f, const float* __restrict__ grid_b,
@@ -417,17 +417,15 @@ __global__ __launch_bounds__(256) void feat_warp_step_kernel(const float* __rest
     const float* __restrict__ grid = dir ? grid_b : grid_f;
     float* __restrict__ dst = dir ? dst_b : dst_f;
     const int ld = C4 * 4;
-    {
-        // channel slab per XCD, cells in raster order (see feat_fuse_kernel): the four taps of neighbouring cells meet in one L2
-        const unsigned xcd = blockIdx.x & 7u;
-        const unsigned e = (blockIdx.x >> 3) * 256u + threadIdx.x;
-        const unsigned m = e / (unsigned)S;
-        const int c4 = (int)(xcd * (unsigned)S + (e - m * (unsigned)S));
-        if (m >= total || c4 >= C4) return;   // total = cells of the grid
-        const float gx = grid[m * 2 + 0], gy = grid[m * 2 + 1];
-        const GsTaps t = gs_taps(gx, gy, Ws, Hs, 0);
-        *reinterpret_cast<f32x4*>(dst + (size_t)m * ld + c4 * 4) = gs_gather_nhwc(src + c4 * 4, Ws, ld, t);
-    }
+    // channel slab per XCD, cells in raster order (see the map kernels below): the four taps of neighbouring cells meet in one L2
+    const unsigned xcd = blockIdx.x & 7u;
+    const unsigned e = (blockIdx.x >> 3) * 256u + threadIdx.x;
+    const unsigned m = e / (unsigned)S;
+    const int c4 = (int)(xcd * (unsigned)S + (e - m * (unsigned)S));
+    if (m >= total || c4 >= C4) return;   // total = cells of the grid
+    const float gx = grid[m * 2 + 0], gy = grid[m * 2 + 1];
+    const GsTaps t = gs_taps(gx, gy, Ws, Hs, 0);
+    *reinterpret_cast<f32x4*>(dst + (size_t)m * ld + c4 * 4) = gs_gather_nhwc(src + c4 * 4, Ws, ld, t);
 }
 
 struct FeatFuseArgs {
@@ -452,10 +450,7 @@ struct FeatFuseArgs {
 //   * XCD-aware split in both parts: XCD x = blockIdx % 8 owns the channel slab [x * S, (x + 1) * S) float4s of every pixel and walks
 //     the pixels in raster order, so all readers of a tap share one L2 and follow each other closely.
 // Same loads, same operations in the same order per element as the op-by-op route: bit-identical.
-#ifndef FS_FEAT_RUN
-#define FS_FEAT_RUN 10
-#endif
-constexpr int FEAT_RUN = FS_FEAT_RUN;
+constexpr int FEAT_RUN = 10;   // (3 .. 30 measured within 4 % of each other: profiles/r06_experiments.txt section 1)
 
 // One cell of the default grid as the key-map kernel uses it: the four taps as element offsets into the key frame's map, the four
 // weights, and which taps lie inside the image -- computed ONCE per thread and applied to FEAT_KEY_CH float4s of channels (the
@@ -551,10 +546,7 @@ __global__ __launch_bounds__(256) void feat_fuse_key_kernel(FeatFuseArgs a, unsi
 
 // ---- maps 1..n-1: (map, row, run) per thread, S float4 lanes of the XCD's slab side by side.  Its own kernel: 6 waves per SIMD (the
 // key-map kernel holds 16 taps in registers), since what this loop waits for is the latency of its 4-load groups.
-#ifndef FS_FEAT_WAVES
-#define FS_FEAT_WAVES 6
-#endif
-__global__ __launch_bounds__(256, FS_FEAT_WAVES) void feat_fuse_warp_kernel(FeatFuseArgs a, int S, int nruns) {
+__global__ __launch_bounds__(256, 6) void feat_fuse_warp_kernel(FeatFuseArgs a, int S, int nruns) {
     const int ld = a.C4 * 4;
     const size_t map = (size_t)a.fh * a.fw * ld;
     const unsigned bid = blockIdx.x;

@@ -1,4 +1,4 @@
-// Epilogue of the matrix-core GEMM kernels (conv_igemm.hip, gemm_planes.hip): y = act(acc * scale + shift (+ residual)) for the 32x32
+// Epilogue of the matrix-core GEMM kernel (conv_igemm.hip): y = act(acc * scale + shift (+ residual)) for the 32x32
 // accumulator blocks of v_mfma_f32_32x32x*: col(n) = lane & 31, row(m) = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
 #pragma once
 #include "kernels.h"

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-launch table (HIP events inside the library) of one key-frame batch at 713x713:
-    python tools/layer_profile.py [B=2] [pspnet50 | deeplab101] [hip_plane_operands ...]   (further words: hparams options set True)"""
+    python tools/layer_profile.py [B=2] [pspnet50 | deeplab101] [hip_no_winograd ...]   (further words: hparams options set True; model/hipnet.py::HIP_OPTIONS)"""
 import os
 import sys
 
