@@ -111,6 +111,8 @@ __global__ __launch_bounds__(256) void stem_conv_mfma_kernel(StemParams p, int k
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 31, h = lane >> 5;
     const int M = p.B * p.Ho * p.Wo, hw = p.Ho * p.Wo;
+    // rows >= M fall outside the descriptor's range: the stores are dropped (launcher: M * ld_out * 4 < 2 GiB)
+    const __amdgpu_buffer_rsrc_t o_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.out, 0, (unsigned)((long long)M * p.ld_out * 4), 0x00020000);
     const int tiles = (M + 31) / 32;
     for (int tile = blockIdx.x * 4 + wave; tile < tiles; tile += gridDim.x * 4) {
         const int m = tile * 32 + i;
@@ -155,10 +157,13 @@ __global__ __launch_bounds__(256) void stem_conv_mfma_kernel(StemParams p, int k
         for (int j = 0; j < NT; ++j) {
             const int n = j * 32 + i;
             const float sc = p.scale[n], sh = p.shift[n];
+            // (straight-line stores through a buffer descriptor whose range check is the row guard: written as `if (mr < M) store` every
+            //  store sat in a basic block of its own behind an s_waitcnt vmcnt(0), which also waits for the previous store: round 6)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int mr = tile * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                if (mr < M) p.out[(size_t)mr * p.ld_out + n] = fmaxf(acc[j][e] * sc + sh, 0.f);
+                const float v = fmaxf(acc[j][e] * sc + sh, 0.f);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), o_rsrc, (unsigned)(mr * p.ld_out + n) * 4u, 0, 0);
             }
         }
     }
@@ -219,6 +224,8 @@ __global__ __launch_bounds__(256) void stem_conv_split_kernel(StemParams p, int 
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 31, h = lane >> 5;
     const int M = p.B * p.Ho * p.Wo, hw = p.Ho * p.Wo;
+    // rows >= M fall outside the descriptor's range: the stores are dropped (launcher: M * ld_out * 4 < 2 GiB)
+    const __amdgpu_buffer_rsrc_t o_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.out, 0, (unsigned)((long long)M * p.ld_out * 4), 0x00020000);
     const int tiles = (M + 31) / 32;
     for (int tile = blockIdx.x * 4 + wave; tile < tiles; tile += gridDim.x * 4) {
         const int m = tile * 32 + i;
@@ -282,10 +289,13 @@ __global__ __launch_bounds__(256) void stem_conv_split_kernel(StemParams p, int 
         for (int j = 0; j < NT; ++j) {
             const int n = j * 32 + i;
             const float sc = p.scale[n], sh = p.shift[n];
+            // (straight-line stores through a buffer descriptor whose range check is the row guard: written as `if (mr < M) store` every
+            //  store sat in a basic block of its own behind an s_waitcnt vmcnt(0), which also waits for the previous store: round 6)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int mr = tile * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                if (mr < M) p.out[(size_t)mr * p.ld_out + n] = fmaxf(acc[j][e] * sc + sh, 0.f);
+                const float v = fmaxf(acc[j][e] * sc + sh, 0.f);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), o_rsrc, (unsigned)(mr * p.ld_out + n) * 4u, 0, 0);
             }
         }
     }
@@ -295,6 +305,7 @@ __global__ __launch_bounds__(256) void stem_conv_split_kernel(StemParams p, int 
 int launch_stem_conv(const StemParams& p, hipStream_t s) {
     FS_REQUIRE(p.Cout >= 16 && p.Cout <= 256 && p.Cout % 16 == 0, "stem_conv: unsupported Cout=%d", p.Cout);
     FS_REQUIRE(p.ld_out % 4 == 0, "stem_conv: ld_out must be a multiple of 4");
+    FS_REQUIRE((long long)p.B * p.Ho * p.Wo * p.ld_out * 4 < (1ll << 31), "stem_conv: output tensor must be smaller than 2 GiB");
     const FrameSrc& f = p.src;
     if (f.ncrops) {
         FS_REQUIRE(f.ncrops <= 32 && f.in && (p.B == f.ncrops || (p.B == 2 * f.ncrops && f.in2)), "stem_conv: bad crop batch (%d crops, B=%d)", f.ncrops, p.B);

@@ -56,6 +56,7 @@ int launch_winograd_filter(const float* w_oihw, float* U, int O, int I, int mt, 
 // this way the same map is 3600 waves of 8 loads each.)  The arithmetic (B^T d B, A^T m A; which products are formed and in
 // which order) is unchanged.
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned wo_u32x4 __attribute__((ext_vector_type(4)));
 
 template <int MT>
 __global__ __launch_bounds__((MT + 2) * 32) void winograd_input_kernel(const float* __restrict__ in, int ld_in, float* __restrict__ V, int B, int H,
@@ -140,7 +141,8 @@ template <int MT>
 __global__ __launch_bounds__((MT + 2) * 32) void winograd_output_kernel(const float* __restrict__ M, const float* __restrict__ scale,
                                                                         const float* __restrict__ shift, float* __restrict__ out, int ld_out, int B,
                                                                         int H, int W, int N4, int th, int tw, int relu, int dil, long long s_pos,
-                                                                        long long s_tile) {
+                                                                        long long s_tile, unsigned out_bytes) {
+#if defined(__HIP_DEVICE_COMPILE__)  // (the buffer-resource builtins do not exist in the host pass, which only needs the launch stub)
     constexpr int A = Wino<MT>::A;
     __shared__ f32x4 tmp[MT][A][32];  // [a][q][channel quad]
     const unsigned T = (unsigned)(B * dil * dil * th * tw);
@@ -171,19 +173,23 @@ __global__ __launch_bounds__((MT + 2) * 32) void winograd_output_kernel(const fl
             const f32x4 sc = scale ? *reinterpret_cast<const f32x4*>(scale + (size_t)n4 * 4) : f32x4(1.f);
             const f32x4 sh = shift ? *reinterpret_cast<const f32x4*>(shift + (size_t)n4 * 4) : f32x4(0.f);
             const int oy = py + dil * (ty * MT + a);
-            if (oy < H) {
+            // Straight-line stores through a buffer descriptor whose range check drops the pixels beyond the map's edge (sentinel offset):
+            // written as `if (ox >= W) continue; store` every store sat in a basic block of its own behind an s_waitcnt vmcnt(0) -- which on
+            // gfx9 also waits for the PREVIOUS store's acknowledgement: six serial round trips per thread (round 6).
+            const __amdgpu_buffer_rsrc_t o_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)out, 0, out_bytes, 0x00020000);
+            const unsigned rowoff = (unsigned)(((b * H + oy) * W) * ld_out + n4 * 4) * 4u;
 #pragma unroll
-                for (int c = 0; c < MT; ++c) {
-                    const int ox = px + dil * (tx * MT + c);
-                    if (ox >= W) continue;
-                    f32x4 v = y[c] * sc + sh;
-                    if (relu) v = __builtin_elementwise_max(v, f32x4(0.f));
-                    *reinterpret_cast<f32x4*>(out + ((size_t)(b * H + oy) * W + ox) * ld_out + (size_t)n4 * 4) = v;
-                }
+            for (int c = 0; c < MT; ++c) {
+                const int ox = px + dil * (tx * MT + c);
+                f32x4 v = y[c] * sc + sh;
+                if (relu) v = __builtin_elementwise_max(v, f32x4(0.f));
+                const unsigned vo = (oy < H && ox < W) ? rowoff + (unsigned)(ox * ld_out) * 4u : 0x80000000u;
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(wo_u32x4, v), o_rsrc, vo, 0, 0);
             }
         }
         __syncthreads();
     }
+#endif
 }
 
 int launch_winograd_output(const float* M, const float* scale, const float* shift, float* out, int ld_out, int B, int H, int W, int N,
@@ -195,14 +201,17 @@ int launch_winograd_output(const float* M, const float* scale, const float* shif
     const int th = (cdiv(H, dil) + mt - 1) / mt, tw = (cdiv(W, dil) + mt - 1) / mt;
     const long long T = (long long)B * dil * dil * th * tw;
     FS_REQUIRE(T < (1ll << 31), "winograd_output: too many tiles");
+    // the stores go through a buffer descriptor with 32-bit byte offsets (as the implicit-GEMM epilogue's do)
+    const long long out_bytes = ((long long)B * H * W - 1) * ld_out * 4 + (long long)N * 4;
+    FS_REQUIRE(out_bytes < (1ll << 31), "winograd_output: output tensor must be smaller than 2 GiB");
     const dim3 grid((unsigned)cdiv(N / 4, 32), (unsigned)std::min<long long>(T, 65535));
     const WinoLayout lay = winograd_layout(mt, T, N);
     if (mt == 4)
         hipLaunchKernelGGL(winograd_output_kernel<4>, grid, dim3(6 * 32), 0, s, M, scale, shift, out, ld_out, B, H, W, N / 4, th, tw, relu, dil,
-                           lay.s_pos, lay.s_tile);
+                           lay.s_pos, lay.s_tile, (unsigned)out_bytes);
     else
         hipLaunchKernelGGL(winograd_output_kernel<6>, grid, dim3(8 * 32), 0, s, M, scale, shift, out, ld_out, B, H, W, N / 4, th, tw, relu, dil,
-                           lay.s_pos, lay.s_tile);
+                           lay.s_pos, lay.s_tile, (unsigned)out_bytes);
     FS_HIP(hipGetLastError());
     return 0;
 }
