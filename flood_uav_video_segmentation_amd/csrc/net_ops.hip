@@ -384,20 +384,27 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const float* __restri
     const int ox = (int)(r / (unsigned)C4), c4 = (int)(r - (unsigned)ox * (unsigned)C4);
     for (int b = blockIdx.z; b < B; b += gridDim.z) {
         for (int oy = blockIdx.y; oy < Ho; oy += gridDim.y) {
-            f32x4 best = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+            // all nine taps are loaded from clamped (always valid) addresses and the ones outside the map replaced by -inf afterwards:
+            // `if (outside) continue; load` is a branch and an s_waitcnt vmcnt(0) per tap -- nine serial round trips (round 6)
+            f32x4 tap[9];
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky) {
-                const int iy = oy * 2 - 1 + ky;
-                if ((unsigned)iy >= (unsigned)H) continue;
+                const int iy = min(max(oy * 2 - 1 + ky, 0), H - 1);
 #pragma unroll
                 for (int kx = 0; kx < 3; ++kx) {
-                    const int ix = ox * 2 - 1 + kx;
-                    if ((unsigned)ix >= (unsigned)W) continue;
-                    const f32x4 v = *reinterpret_cast<const f32x4*>(in + ((size_t)(b * H + iy) * W + ix) * ld_in + c4 * 4);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) best[e] = fmaxf(best[e], v[e]);
+                    const int ix = min(max(ox * 2 - 1 + kx, 0), W - 1);
+                    tap[ky * 3 + kx] = *reinterpret_cast<const f32x4*>(in + ((size_t)(b * H + iy) * W + ix) * ld_in + c4 * 4);
                 }
             }
+            f32x4 best = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const bool ok = (unsigned)(oy * 2 - 1 + ky) < (unsigned)H && (unsigned)(ox * 2 - 1 + kx) < (unsigned)W;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) best[e] = fmaxf(best[e], ok ? tap[ky * 3 + kx][e] : -INFINITY);
+                }
             *reinterpret_cast<f32x4*>(out + ((size_t)(b * Ho + oy) * Wo + ox) * ld_out + c4 * 4) = best;
         }
     }

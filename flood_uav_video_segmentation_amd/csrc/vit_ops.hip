@@ -869,6 +869,9 @@ int launch_splitk_combine(const float* part, int nsplit, const float* bias, cons
 // of norm1 of block i + 1): one wave per row, D <= 1024; the merged row goes to `out`, its LayerNorm to `ln_out`.  The row never
 // returns from HBM between the two, and a launch disappears per block.  Same operations in the same order as splitk_combine_kernel
 // followed by layernorm_kernel, hence bit-identical to the two launches.
+// NS > 0: the number of partials at compile time (2, 3, 4: what linear_splits returns) -- the loads of all of them, of the bias and of the
+// shortcut are then issued together; with a run-time count every load waited for its predecessor (round 6).  NS = 0: run-time count.
+template <int NS>
 __global__ __launch_bounds__(256) void splitk_combine_ln_kernel(const float* __restrict__ part, int nsplit, const float* __restrict__ bias,
                                                                 const float* __restrict__ res, float* __restrict__ out, const float* __restrict__ gamma,
                                                                 const float* __restrict__ beta, float* __restrict__ ln_out, int rows, int D4) {
@@ -884,10 +887,25 @@ __global__ __launch_bounds__(256) void splitk_combine_ln_kernel(const float* __r
         v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (c < D4) {
             const int64_t idx = (int64_t)row * D4 + c;
-            f32x4 a = reinterpret_cast<const f32x4*>(part)[idx];
-            for (int sidx = 1; sidx < nsplit; ++sidx) a += reinterpret_cast<const f32x4*>(part)[(int64_t)sidx * total4 + idx];
-            if (bias) a += reinterpret_cast<const f32x4*>(bias)[c];
-            if (res) a += reinterpret_cast<const f32x4*>(res)[idx];
+            f32x4 a;
+            if (NS > 0) {  // same sums in the same order, the operands requested up front
+                f32x4 pv[NS > 0 ? NS : 1];
+#pragma unroll
+                for (int sidx = 0; sidx < NS; ++sidx) pv[sidx] = reinterpret_cast<const f32x4*>(part)[(int64_t)sidx * total4 + idx];
+                const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                const f32x4 bv = bias ? reinterpret_cast<const f32x4*>(bias)[c] : z;
+                const f32x4 rv = res ? reinterpret_cast<const f32x4*>(res)[idx] : z;
+                a = pv[0];
+#pragma unroll
+                for (int sidx = 1; sidx < NS; ++sidx) a += pv[sidx];
+                if (bias) a += bv;
+                if (res) a += rv;
+            } else {
+                a = reinterpret_cast<const f32x4*>(part)[idx];
+                for (int sidx = 1; sidx < nsplit; ++sidx) a += reinterpret_cast<const f32x4*>(part)[(int64_t)sidx * total4 + idx];
+                if (bias) a += reinterpret_cast<const f32x4*>(bias)[c];
+                if (res) a += reinterpret_cast<const f32x4*>(res)[idx];
+            }
             reinterpret_cast<f32x4*>(out)[idx] = a;
             v[i] = a;
         }
@@ -927,7 +945,13 @@ __global__ __launch_bounds__(256) void splitk_combine_ln_kernel(const float* __r
 int launch_splitk_combine_ln(const float* part, int nsplit, const float* bias, const float* res, float* out, const float* gamma, const float* beta,
                              float* ln_out, int rows, int N, hipStream_t s) {
     FS_REQUIRE(part && out && ln_out && gamma && beta && nsplit >= 2 && rows >= 1 && N % 4 == 0 && N <= 1024, "splitk_combine_ln: bad arguments");
-    hipLaunchKernelGGL(splitk_combine_ln_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, s, part, nsplit, bias, res, out, gamma, beta, ln_out, rows, N / 4);
+    const dim3 grid(cdiv(rows, 4)), block(256);
+    switch (nsplit) {
+        case 2: hipLaunchKernelGGL(splitk_combine_ln_kernel<2>, grid, block, 0, s, part, nsplit, bias, res, out, gamma, beta, ln_out, rows, N / 4); break;
+        case 3: hipLaunchKernelGGL(splitk_combine_ln_kernel<3>, grid, block, 0, s, part, nsplit, bias, res, out, gamma, beta, ln_out, rows, N / 4); break;
+        case 4: hipLaunchKernelGGL(splitk_combine_ln_kernel<4>, grid, block, 0, s, part, nsplit, bias, res, out, gamma, beta, ln_out, rows, N / 4); break;
+        default: hipLaunchKernelGGL(splitk_combine_ln_kernel<0>, grid, block, 0, s, part, nsplit, bias, res, out, gamma, beta, ln_out, rows, N / 4); break;
+    }
     FS_HIP(hipGetLastError());
     return 0;
 }
