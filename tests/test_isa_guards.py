@@ -74,3 +74,30 @@ def test_no_float_atomics_anywhere_and_the_fused_maxpool_uses_integer_max(tmp_pa
     # every other atomic in the library is an integer one as well (histograms: iou_hist / mv_to_grids)
     for h, a in with_atomics.items():
         assert all(re.search(r"atomic_(add|smax|umax|umin|smin|inc|or|and|cmpswap|swap)(_x2)?(_u32|_u64|_i32|_b32|_b64)?$", x) for x in a), (h, a)
+
+
+def test_no_kernel_puts_each_of_its_stores_behind_a_wait_of_its_own(tmp_path):
+    """Round 6: `if (row_ok) out[..] = v` inside an unrolled epilogue loop compiles to one basic block per store, each behind an
+    `s_waitcnt vmcnt(0)` -- and gfx9 has ONE in-order counter for loads and stores, so that wait is also a wait for the previous store's
+    acknowledgement: the stem kernels had 30 of 32 stores of a lane serialised that way, winograd_output all six.  They now store in a
+    straight line through a buffer descriptor whose range check drops the out-of-range rows.  The guard: in no kernel may more than two
+    stores sit behind a vmcnt(0) wait that has no load between it and the previous store (a wait that covers loads is doing its job)."""
+    dis = _device_disassembly(str(tmp_path))
+    bad = {}
+    for k in re.split(r"\n(?=[0-9a-f]+ <[^>]+>:)", dis):
+        head = k.split("\n", 1)[0]
+        ops = [re.sub(r"\s*//.*", "", l.split("\t", 1)[-1]).strip() for l in k.splitlines()[1:] if "\t" in l]
+        serial = stores = 0
+        have_prev = seen_wait = seen_load = False
+        for o in ops:
+            if re.match(r"(global|buffer|flat)_(store|atomic)", o):
+                stores += 1
+                serial += have_prev and seen_wait and not seen_load
+                have_prev, seen_wait, seen_load = True, False, False
+            elif re.match(r"(global|buffer|flat|scratch)_load", o):
+                seen_load = True
+            elif o.startswith("s_waitcnt") and "vmcnt(0)" in o:
+                seen_wait = True
+        if serial > 2:
+            bad[head] = (serial, stores)
+    assert not bad, f"stores serialised behind their own vmcnt(0) waits: {bad}"
