@@ -855,8 +855,7 @@ def variants(args, dev, rdev, net, state, fm, windows, dl, dr, host_masks, host_
 
     def step_cfg3(i):
         prev, nxt = windows[i % 4]
-        out_ = fmv.predict(prev, nxt, wl, wr, N_DELTA, None)["pred"]
-        host_masks.copy_(ops.argmax_u8(out_), non_blocking=True)
+        host_masks.copy_(fmv.predict(prev, nxt, wl, wr, N_DELTA, None, with_mask=True)["mask"], non_blocking=True)
         torch.cuda.current_stream().synchronize()
     run("fps_config3_vit_s16_feature_flow", step_cfg3, few, N_DELTA)
     return out

@@ -75,6 +75,7 @@ _SIGNATURES = {
     "fs_crops_fuse": (c_int, [c_void, c_void, c_void, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int)] + [c_int] * 9 + [c_void, c_void, c_int, c_int,
                               c_void, c_void]),
     "fs_argmax_u8": (c_int, [c_void, c_int, c_int, c_i64, c_void, c_void]),
+    "fs_resize_crop": (c_int, [c_void, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void, c_void, c_int, c_int, c_void]),
     "fs_resize_argmax_u8": (c_int, [c_void, c_int, c_int, c_int, c_int, c_void, c_int, c_int, c_void]),
     "fs_iou_hist": (c_int, [c_void, c_void, c_i64, c_int, c_int, c_void, c_void]),
     "fs_colorize": (c_int, [c_void, c_void, c_int, c_void, c_i64, c_void]),

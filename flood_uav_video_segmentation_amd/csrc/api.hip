@@ -205,6 +205,11 @@ FS_API int fs_canvas_finish(double* canvas, const double* count, int n, int K, i
     return fs::launch_canvas_finish(canvas, count, n, K, HW, mask, S(stream));
 }
 
+FS_API int fs_resize_crop(const float* in, int B, int K, int Hi, int Wi, int Hfull, int Wfull, int align_corners, float* logits,
+                          uint8_t* mask, int Ho, int Wo, fs_stream stream) {
+    if (!in || B < 1 || K < 1 || Hi < 1 || Wi < 1 || Ho < 1 || Wo < 1 || Hfull < 1 || Wfull < 1) return fs::fail("fs_resize_crop: bad arguments");
+    return fs::launch_resize_crop(in, B, K, Hi, Wi, Hfull, Wfull, align_corners, logits, mask, Ho, Wo, S(stream));
+}
 FS_API int fs_canvas_resize_argmax(const double* canvas, int n, int K, int Hi, int Wi, uint8_t* mask, int Ho, int Wo, fs_stream stream) {
     if (!canvas || !mask || n < 1 || K < 1 || Hi < 1 || Wi < 1 || Ho < 1 || Wo < 1) return fs::fail("fs_canvas_resize_argmax: bad arguments");
     return fs::launch_canvas_resize_argmax(canvas, n, K, Hi, Wi, mask, Ho, Wo, S(stream));

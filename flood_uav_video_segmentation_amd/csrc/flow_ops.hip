@@ -951,6 +951,48 @@ int launch_resize_argmax_u8(const float* in, int B, int K, int Hi, int Wi, uint8
     return 0;
 }
 
+// F.interpolate(in, (Hfull, Wfull), bilinear, ac)[:, :, :Ho, :Wo] -- the Segmenter's decoder tail (segm/model/segmenter.py:45-46:
+// upsample the class masks to the padded frame, then crop the padding) -- as dense logits and / or their channel argmax, in one
+// launch: the scale is the padded size's, only the kept pixels are computed, and the crop is never a strided view that something
+// downstream has to copy.  Values and tie-breaking are resize_bilinear_nchw's and argmax_u8's.
+template <bool LOGITS, bool MASK>
+__global__ __launch_bounds__(256) void resize_crop_kernel(const float* __restrict__ in, int B, int K, int Hi, int Wi, int ac, float sy,
+                                                          float sx, float* __restrict__ logits, uint8_t* __restrict__ mask, int Ho,
+                                                          int Wo) {
+    const int64_t HWo = (int64_t)Ho * Wo, total = (int64_t)B * HWo;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t b = i / HWo, px = i - b * HWo;
+        const int oy = (int)(px / Wo), ox = (int)(px - (int64_t)oy * Wo);
+        const LinCoord cy = lin_coord(oy, Hi, sy, ac), cx = lin_coord(ox, Wi, sx, ac);
+        const int o00 = cy.i0 * Wi + cx.i0, o01 = cy.i0 * Wi + cx.i1, o10 = cy.i1 * Wi + cx.i0, o11 = cy.i1 * Wi + cx.i1;
+        float best = 0.f;
+        int arg = 0;
+        for (int k = 0; k < K; ++k) {
+            const float* pl = in + ((size_t)b * K + k) * Hi * Wi;
+            const float v = bilerp(pl[o00], pl[o01], pl[o10], pl[o11], cy, cx);
+            if (LOGITS) logits[((size_t)b * K + k) * HWo + px] = v;
+            if (MASK && (k == 0 || v > best)) { best = v; arg = k; }
+        }
+        if (MASK) mask[i] = (uint8_t)arg;
+    }
+}
+
+int launch_resize_crop(const float* in, int B, int K, int Hi, int Wi, int Hfull, int Wfull, int align_corners, float* logits,
+                       uint8_t* mask, int Ho, int Wo, hipStream_t s) {
+    FS_REQUIRE(Ho <= Hfull && Wo <= Wfull, "resize_crop: the kept region must lie inside the resized frame");
+    FS_REQUIRE((int64_t)Hi * Wi < ((int64_t)1 << 31), "resize_crop: input plane too large");
+    FS_REQUIRE(!mask || (K >= 1 && K <= 255), "resize_crop: K out of range for a uint8 mask");
+    FS_REQUIRE(logits || mask, "resize_crop: no output requested");
+    const int64_t total = (int64_t)B * Ho * Wo;
+    const dim3 grid((unsigned)std::min<int64_t>(cdiv64(total, 256), 16384));
+    const float sy = resize_scale(Hi, Hfull, align_corners), sx = resize_scale(Wi, Wfull, align_corners);
+    if (logits && mask) hipLaunchKernelGGL((resize_crop_kernel<true, true>), grid, dim3(256), 0, s, in, B, K, Hi, Wi, align_corners, sy, sx, logits, mask, Ho, Wo);
+    else if (logits) hipLaunchKernelGGL((resize_crop_kernel<true, false>), grid, dim3(256), 0, s, in, B, K, Hi, Wi, align_corners, sy, sx, logits, mask, Ho, Wo);
+    else hipLaunchKernelGGL((resize_crop_kernel<false, true>), grid, dim3(256), 0, s, in, B, K, Hi, Wi, align_corners, sy, sx, logits, mask, Ho, Wo);
+    FS_HIP(hipGetLastError());
+    return 0;
+}
+
 // ------------------------------------------------------------------ sliding-crop accumulation (flow/base.py:182-234)
 // canvas[f][k][y0+y][x0+x] += softmax_k(logits[f][:, y, x]);  count[y0+y][x0+x] += 1   (float64 canvas, :190-191)
 __global__ __launch_bounds__(256) void softmax_accumulate_kernel(const float* __restrict__ logits, int n, int K, int h, int w,

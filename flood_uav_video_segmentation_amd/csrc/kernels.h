@@ -233,6 +233,8 @@ int launch_softmax_accumulate(const float* logits, int n, int K, int h, int w, d
                               int x0, hipStream_t s);
 int launch_canvas_finish(double* canvas, const double* count, int n, int K, int64_t HW, uint8_t* mask, hipStream_t s);
 // argmax over K of the align_corners=True bilinear resize (in float64) of the crop-averaged canvas (flow/base.py:275-276)
+int launch_resize_crop(const float* in, int B, int K, int Hi, int Wi, int Hfull, int Wfull, int align_corners, float* logits,
+                       uint8_t* mask, int Ho, int Wo, hipStream_t s);
 int launch_canvas_resize_argmax(const double* canvas, int n, int K, int Hi, int Wi, uint8_t* mask, int Ho, int Wo, hipStream_t s);
 // crop_motion_vector (flow/transform.py:215-261) for every crop x every grid of a window in one launch
 struct CropGridParams {

@@ -147,6 +147,15 @@ class FlowModel(nn.Module):
         fit = getattr(self.model, "fit_output", None)
         return fit(out, h, w) if fit is not None else self._fit(out, h, w)
 
+    def _decode_fit(self, stack, h, w, with_mask=False):
+        """decoder -> frame size (-> argmax): (logits, mask or None).  A network whose decoder ends in upsample + unpadding (the
+        Segmenter mirror's `decode_fit`) does the three in one launch; bit-identical to the steps taken one by one."""
+        fused = getattr(self.model, "decode_fit", None)
+        if fused is not None:
+            return fused(stack, h, w, with_mask)
+        out = self._fit_out(self.model.decoder(stack), h, w)
+        return out, (ops.argmax_u8(out) if with_mask else None)
+
     def warp(self, frame, motion_vectors):
         """grid_sample(bilinear, border, align_corners=False); identity when no_warp (reference :244-249)."""
         if self.no_warp:
@@ -172,7 +181,7 @@ class FlowModel(nn.Module):
         feats = self._encode(frame_prev, frame_next)
         mixed = ops.blend(self.warp_batch(feats[:nb], mvs_left, left_index, n_list), 1.0,
                           self.warp_batch(feats[nb:], mvs_right, right_index, n_list), 1.0)
-        return {"pred": self._fit_out(self.model.decoder(mixed), h, w)}
+        return {"pred": self._decode_fit(mixed, h, w)[0]}
 
     def forward_segmentation(self, frame_prev, frame_next, mvs_left, mvs_right, left_index, right_index, n_list):
         """Segment the two key frames, warp + weight the LOGITS and add them (reference :73-88)."""
@@ -247,8 +256,8 @@ class FlowModel(nn.Module):
             with _region(profiler, "predict_warp"), _region(profiler, "predict_fusion"):
                 stack = ops.feat_tail(f, f_next, mvs_left, mvs_right, n, self.no_warp, None if self.no_warp else self.default_motion_vector)
             with _region(profiler, "predict_decoder"):
-                out = self._fit_out(self.model.decoder(stack), h, w)
-            return {"pred": out, "mask": ops.argmax_u8(out)} if with_mask else {"pred": out}
+                out, mask = self._decode_fit(stack, h, w, with_mask)
+            return {"pred": out, "mask": mask} if with_mask else {"pred": out}
         stack = (ops.empty_nhwc(nmaps, f.shape[1], f_h, f_w, f.device) if nhwc else
                  torch.empty((nmaps, f.shape[1], f_h, f_w), dtype=torch.float32, device=f.device))
         fwd, bwd = [], []
@@ -281,5 +290,5 @@ class FlowModel(nn.Module):
                     else:
                         ops.blend(fwd[p - 1], (n - p) / n, bwd[n - p - 1], p / n, out=stack[p:p + 1])
         with _region(profiler, "predict_decoder"):
-            out = self._fit_out(self.model.decoder(stack), h, w)
-        return {"pred": out, "mask": ops.argmax_u8(out)} if with_mask else {"pred": out}
+            out, mask = self._decode_fit(stack, h, w, with_mask)
+        return {"pred": out, "mask": mask} if with_mask else {"pred": out}

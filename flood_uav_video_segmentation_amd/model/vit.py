@@ -59,8 +59,17 @@ class VITSegmentModel(HipSegNet):
         """Decoder output -> frame size: crop the right/bottom zero padding (segm/model/utils.py:79-89)."""
         return out[:, :, :h, :w]
 
+    def decode_fit(self, f, h, w, with_mask=False):
+        """fit_output(decoder(f), h, w) as ONE launch after the mask transformer: the upsample computes only the pixels the
+        unpadding keeps and writes them dense (bit-identical to the two steps; no strided view for the caller to copy).
+        Returns (logits [B,K,h,w], uint8 argmax [B,h,w] or None)."""
+        masks = self._hip_net.decode(f)  # [B, K, gh, gw]
+        gh, gw = masks.shape[2], masks.shape[3]
+        return ops.resize_crop(masks, (gh * self.patch_size, gw * self.patch_size), (h, w), align_corners=False,
+                               want_logits=True, want_mask=with_mask)
+
     def forward(self, x):
         if self.training:
             raise NotImplementedError("VITSegmentModel(HIP) is an inference path; call .eval()")
         h, w = x.shape[2], x.shape[3]
-        return {"pred": self.fit_output(self._decode_map(self._hip_net.encode(x)), h, w)}
+        return {"pred": self.decode_fit(self._hip_net.encode(x), h, w)[0]}

@@ -358,6 +358,27 @@ def resize_argmax_u8(logits, size):
     return out
 
 
+def resize_crop(logits, full_size, size, align_corners=False, want_logits=True, want_mask=False):
+    """F.interpolate(logits, full_size, bilinear, align_corners)[:, :, :size[0], :size[1]] as a DENSE tensor, and / or its
+    .max(1)[1] as uint8 -- the Segmenter's upsample + unpadding (segm/model/segmenter.py:45-46, segm/model/utils.py:79-89) in
+    one launch.  Returns (logits or None, mask or None)."""
+    lib = _lib.load()
+    if not (want_logits or want_mask):
+        raise RuntimeError("floodseg.resize_crop: no output requested")
+    with torch.cuda.device(one_device(logits, what="floodseg.resize_crop")):
+        x = _f32c(logits)
+        b, k, hi, wi = x.shape
+        hf, wf, ho, wo = int(full_size[0]), int(full_size[1]), int(size[0]), int(size[1])
+        if ho > hf or wo > wf or min(ho, wo) < 1:
+            raise RuntimeError(f"floodseg.resize_crop: kept region {ho}x{wo} is not inside the resized frame {hf}x{wf}")
+        out = torch.empty((b, k, ho, wo), dtype=torch.float32, device=x.device) if want_logits else None
+        mask = torch.empty((b, ho, wo), dtype=torch.uint8, device=x.device) if want_mask else None
+        if b:
+            check(lib.fs_resize_crop(ptr(x), b, k, hi, wi, hf, wf, int(align_corners), ptr(out) if want_logits else None,
+                                     ptr(mask) if want_mask else None, ho, wo, stream_ptr()))
+    return out, mask
+
+
 def iou_hist(pred_u8, target_u8, classes, ignore_index=255, hist=None):
     """Accumulate int64[3,K] = (intersection, |pred|, |target|) (util/util.py:52-63)."""
     lib = _lib.load()

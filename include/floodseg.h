@@ -183,6 +183,11 @@ int fs_seg_tail_accumulate(const float* lo_prev, const float* lo_next, const flo
 
 int fs_argmax_u8(const float* in, int B, int K, int64_t HW, uint8_t* out, fs_stream stream);
 int fs_resize_argmax_u8(const float* in, int B, int K, int Hi, int Wi, uint8_t* out, int Ho, int Wo, fs_stream stream);
+/* F.interpolate(in, (Hfull, Wfull), bilinear, align_corners)[:, :, :Ho, :Wo] -- the Segmenter's upsample-then-unpad decoder tail
+ * (segm/model/segmenter.py:45-46) -- in one launch: dense logits [B][K][Ho][Wo] (may be NULL) and / or their channel argmax
+ * uint8 [B][Ho][Wo] (may be NULL).  Bit-identical to fs_resize_bilinear_nchw at the full size, cropped, then fs_argmax_u8. */
+int fs_resize_crop(const float* in, int B, int K, int Hi, int Wi, int Hfull, int Wfull, int align_corners, float* logits,
+                   uint8_t* mask, int Ho, int Wo, fs_stream stream);
 /* hist3K: int64[3][K] = {intersection, |pred|, |target|}, accumulated (caller zeroes). */
 int fs_iou_hist(const uint8_t* pred, const uint8_t* target, int64_t numel, int K, int ignore_index, long long* hist3K,
                 fs_stream stream);

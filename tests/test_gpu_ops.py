@@ -485,6 +485,39 @@ def test_argmax_resize_argmax_and_iou_hist():
         assert hist[2, k] == (t == k).sum()
 
 
+@pytest.mark.parametrize("geom", [
+    # b, k, hi, wi, full, keep, align_corners
+    (5, 5, 45, 45, (720, 720), (713, 713), False),   # configs[3]: the Segmenter's 16x upsample of a 713 frame padded to 720
+    (2, 5, 44, 44, (704, 704), (704, 704), False),   # nothing to crop
+    (1, 7, 9, 13, (36, 52), (33, 41), True),
+    (3, 1, 5, 4, (17, 9), (1, 1), False),            # K = 1: the mask is all zeros
+])
+def test_resize_crop_is_the_resize_then_the_crop_then_the_argmax(geom):
+    """fs_resize_crop: upsample at the padded size's scale, only the kept pixels, dense -- bit-identical to resize_bilinear at the
+    full size, cropped, and to argmax_u8 of that; each output alone equals the pair."""
+    b, k, hi, wi, full, keep, ac = geom
+    x = torch.randn(b, k, hi, wi, generator=torch.Generator().manual_seed(5)).to(DEV)
+    x[0, :, 0, 0] = 0.25  # a tie: the first class wins
+    two_steps = ops.resize_bilinear(x, full, align_corners=ac)[:, :, :keep[0], :keep[1]].contiguous()
+    logits, mask = ops.resize_crop(x, full, keep, align_corners=ac, want_logits=True, want_mask=True)
+    assert logits.is_contiguous() and torch.equal(logits, two_steps)
+    assert torch.equal(mask, ops.argmax_u8(two_steps)) and mask[0, 0, 0] == 0
+    assert torch.equal(ops.resize_crop(x, full, keep, align_corners=ac)[0], two_steps)
+    only_mask = ops.resize_crop(x, full, keep, align_corners=ac, want_logits=False, want_mask=True)
+    assert only_mask[0] is None and torch.equal(only_mask[1], mask)
+    ref = F.interpolate(x.cpu(), size=full, mode="bilinear", align_corners=ac)[:, :, :keep[0], :keep[1]]
+    assert (logits.cpu() - ref).abs().max() < 1e-5
+
+
+def test_resize_crop_refuses_a_region_outside_the_frame_and_an_empty_request():
+    x = torch.randn(1, 5, 8, 8).to(DEV)
+    with pytest.raises(RuntimeError, match="not inside"):
+        ops.resize_crop(x, (32, 32), (33, 32))
+    with pytest.raises(RuntimeError, match="no output"):
+        ops.resize_crop(x, (32, 32), (32, 32), want_logits=False, want_mask=False)
+    assert ops.resize_crop(x[:0], (32, 32), (30, 30), want_mask=True)[1].shape == (0, 30, 30)
+
+
 WINO_TOL = 5e-5  # F(4x4,3x3) in fp32: ~7e-6 relative on unit-scale data, F(6x6,3x3) ~1.5x that; the tolerance leaves room for K = 1024
 # The error grows ~sqrt(Cin).  Cin = 2048 with F(6,3) measures 6.7e-5 on a single conv (round 2, gpurun_out/r02_pytest_gpu_1.txt) --
 # and F(6,3) IS what the network runs for the 2048-channel PSPNet head at 713x713 (90x90 = exactly 15x15 tiles of 6x6, DESIGN 3.2), so

@@ -106,6 +106,16 @@ def test_vit_feature_flow_extension_against_oracle_parity_unpinned():
     ref = flow_oracle.predict_feature(enc, dec, clip[0:1], clip[1:2], mvl, mvr, n, False)["pred"]
     assert got.shape == ref.shape == (3, 5, size, size)
     assert rel_err(got.cpu(), ref) < VIT_TOL
+    # round 6: decoder -> upsample -> unpadding (-> argmax) is ONE launch after the mask transformer (decode_fit); it must equal the
+    # steps taken one by one, for a frame that is padded (90 -> 96) as for one that is not, and the mask must be pred.max(1)[1]
+    both = fm.predict(clip[0:1].cuda(), clip[1:2].cuda(), [m.cuda() for m in mvl], [m.cuda() for m in mvr], n, None, with_mask=True)
+    assert torch.equal(both["pred"], got) and got.is_contiguous()
+    assert torch.equal(both["mask"], got.max(1)[1].to(torch.uint8))
+    small = clip[0:1, :, :90, :90].contiguous().cuda()
+    tokens = net.encoder(small)
+    assert torch.equal(net(small)["pred"], net.fit_output(net.decoder(tokens), 90, 90))
+    logits, mask = net.decode_fit(tokens, 90, 90, with_mask=True)
+    assert logits.shape == (1, 5, 90, 90) and torch.equal(mask, logits.max(1)[1].to(torch.uint8))
 
 
 def test_vit_frame_result_does_not_depend_on_its_batch():

@@ -51,6 +51,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--opt", action="append", default=[], help="hip_no_split_bf16 | hip_no_winograd | hip_winograd_tile=4 | ... (repeatable; model/hipnet.py::HIP_OPTIONS)")
     ap.add_argument("--lib", default=None, help="development A/B: load this build of the library instead of the in-tree one")
+    ap.add_argument("--vit-two-step", action="store_true", help="A/B: the Segmenter's upsample, unpadding and argmax as separate steps (cfg3)")
     ap.add_argument("--feat-op-by-op", action="store_true", help="A/B: predict_feature's tail op by op instead of fs_feat_tail (feat, cfg3)")
     ap.add_argument("--json", action="store_true", help="also print one JSON line {value, unit, ms_per_step, steps} of the last config run")
     args = ap.parse_args()
@@ -70,8 +71,8 @@ def main():
         fm.fused_feature_tail = not args.feat_op_by_op
 
         def step(i):
-            out = fm.predict(keys[i % 4:i % 4 + 1], keys[i % 4 + 1:i % 4 + 2], grids[0], grids[1], N, None)["pred"]
-            host.copy_(ops.argmax_u8(out), non_blocking=True)
+            r = fm.predict(keys[i % 4:i % 4 + 1], keys[i % 4 + 1:i % 4 + 2], grids[0], grids[1], N, None, with_mask=True)
+            host.copy_(r["mask"], non_blocking=True)  # logits AND masks are produced; the masks go to the host
             torch.cuda.current_stream().synchronize()
         return step
 
@@ -131,6 +132,8 @@ def main():
     if want("cfg3"):
         vit = VITSegmentModel(5, 704, patch_size=16, d_model=384, n_layers=12, dec_layers=2, **{w.partition("=")[0]: (int(w.partition("=")[2]) if "=" in w else True) for w in HP.OPTIONS}).eval()
         vit.load_state_dict(synth.make_vit_state(5, 704, 16, 384, 12, 2, seed=0))
+        if args.vit_two_step:
+            vit.decode_fit = None  # FlowModel._decode_fit then takes decoder -> fit_output -> argmax_u8 one by one
         t = timeit(window(FlowModel(vit, feature_based=True, no_warp=False).eval(), (wl, wr)), st)
         rows.append(("configs[3] Segmenter ViT-S/16 keyframe + feature flow (extension)", N / t, t * 1e3))
         del vit
@@ -140,7 +143,7 @@ def main():
 
         def vit_single(i):
             out = vitb(keys[i % 5:i % 5 + 1])["pred"]
-            host[:1].copy_(ops.argmax_u8(out.contiguous()), non_blocking=True)
+            host[:1].copy_(ops.argmax_u8(out), non_blocking=True)
             torch.cuda.current_stream().synchronize()
         t = timeit(vit_single, st)
         rows.append(("(extra) Segmenter ViT-B/32 per-frame (as model/vit.py builds it)", 1 / t, t * 1e3))
