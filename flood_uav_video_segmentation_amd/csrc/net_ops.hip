@@ -182,8 +182,9 @@ typedef __bf16 bf16x8s __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2s __attribute__((ext_vector_type(2)));
 typedef float f32x2s __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4s __attribute__((ext_vector_type(4)));
+typedef int i32x4s __attribute__((ext_vector_type(4)));
 
-template <int NT /* 32-channel sub-tiles */>
+template <int NT /* 32-channel sub-tiles */, int PF /* steps whose taps are in flight together */>
 __global__ __launch_bounds__(256) void stem_conv_split_kernel(StemParams p, int nsteps) {
 #if defined(__HIP_DEVICE_COMPILE__)
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -196,14 +197,14 @@ __global__ __launch_bounds__(256) void stem_conv_split_kernel(StemParams p, int 
     for (int idx = threadIdx.x; idx < nsteps * 2 * p.Cout; idx += 256) {
         const int n = idx % p.Cout, sh_ = idx / p.Cout, hh = sh_ & 1, st = sh_ >> 1;
         u32x4s q[3];
+        float wv[8];  // all eight loads in flight at once, from clamped addresses; padding taps carry zero weights
+#pragma unroll
+        for (int e = 0; e < 8; ++e) wv[e] = p.wgt[min(16 * st + 8 * hh + e, taps - 1) * p.Cout + n];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) wv[e] = 16 * st + 8 * hh + e < taps ? wv[e] : 0.f;
 #pragma unroll
         for (int e = 0; e < 8; e += 2) {
-            float w[2];
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int k = 16 * st + 8 * hh + e + u;
-                w[u] = k < taps ? p.wgt[k * p.Cout + n] : 0.f;  // padding taps carry zero weights
-            }
+            float w[2] = {wv[e], wv[e + 1]};
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl) {
                 const unsigned pk = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2s){w[0], w[1]}, bf16x2s));
@@ -247,42 +248,60 @@ __global__ __launch_bounds__(256) void stem_conv_split_kernel(StemParams p, int 
         for (int j = 0; j < NT; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
-        auto gather = [&](int st, float (&av)[8]) {
+        // Branch-free, in chunks of PF steps (round 6).  Written as `ok ? origin[koff[k]] : 0`, one step ahead, every tap was a basic
+        // block of its own -- exec mask, LDS read of its offset, wait, load -- and a 7 x 7 tile paid ten exposed round trips.  Now the
+        // offsets and row / column pairs of a step are two 16-B LDS reads each, every tap loads unconditionally (a tap outside the
+        // frame reads the patch's centre instead, which every output pixel has inside the frame), ALL loads of PF steps are issued
+        // before the first is used, and the out-of-frame taps are zeroed when their step is split (a select next to the load would
+        // make the wave wait there).  No `mok` in the test: rows >= M compute pixel 0's values and their stores are dropped; with it
+        // the compiler wraps the taps in an `if (mok)` region and waits for every load inside it.
+        const int centre = p.pad * rowW + p.pad;
+        auto gather = [&](int st, float (&av)[8]) -> unsigned {
+            const i32x4s* ko = reinterpret_cast<const i32x4s*>(koff + 16 * st + 8 * h);
+            const i32x4s* ky = reinterpret_cast<const i32x4s*>(kyx + 16 * st + 8 * h);
+            const i32x4s o4[2] = {ko[0], ko[1]}, y4[2] = {ky[0], ky[1]};
+            unsigned okbits = 0;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                const int k = 16 * st + 8 * h + e;
-                const int yx = kyx[k];
+                const int yx = y4[e >> 2][e & 3];
                 const int iy = iy0 + (yx >> 16), ix = ix0 + (yx & 0xffff);
-                const bool ok = mok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-                av[e] = ok ? origin[koff[k]] : 0.f;
+                const bool ok = ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
+                av[e] = origin[ok ? o4[e >> 2][e & 3] : centre];
+                okbits |= (unsigned)ok << e;
             }
+            return okbits;
         };
-        float cur[8], nxt[8];
-        gather(0, cur);
-        for (int st = 0; st < nsteps; ++st) {
-            if (st + 1 < nsteps) gather(st + 1, nxt);  // in flight under this step's split + MFMAs
-            u32x4s a3[3];
+        for (int c0 = 0; c0 < nsteps; c0 += PF) {
+            float raw[PF][8];
+            unsigned okb[PF];
 #pragma unroll
-            for (int e = 0; e < 8; e += 2) {
-                float x0 = cur[e], x1 = cur[e + 1];
+            for (int j = 0; j < PF; ++j) okb[j] = gather(min(c0 + j, nsteps - 1), raw[j]);
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl) {
-                    const unsigned pk = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2s){x0, x1}, bf16x2s));
-                    a3[pl][e >> 1] = pk;
-                    x0 -= __builtin_bit_cast(float, pk << 16);
-                    x1 -= __builtin_bit_cast(float, pk & 0xffff0000u);
+            for (int j = 0; j < PF; ++j) {
+                const int st = c0 + j;
+                if (st < nsteps) {  // uniform
+                    u32x4s a3[3];
+#pragma unroll
+                    for (int e = 0; e < 8; e += 2) {
+                        float x0 = (okb[j] >> e) & 1 ? raw[j][e] : 0.f, x1 = (okb[j] >> (e + 1)) & 1 ? raw[j][e + 1] : 0.f;
+#pragma unroll
+                        for (int pl = 0; pl < 3; ++pl) {
+                            const unsigned pk = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2s){x0, x1}, bf16x2s));
+                            a3[pl][e >> 1] = pk;
+                            x0 -= __builtin_bit_cast(float, pk << 16);
+                            x1 -= __builtin_bit_cast(float, pk & 0xffff0000u);
+                        }
+                    }
+                    // the six products of order <= 2^-16, smallest first: l h', h l', m m', m h', h m', h h'
+                    constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+                    for (int term = 0; term < 6; ++term)
+#pragma unroll
+                        for (int jn = 0; jn < NT; ++jn)
+                            acc[jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8s, a3[PA[term]]),
+                                                                              __builtin_bit_cast(bf16x8s, wl[((PB[term] * nsteps + st) * 2 + h) * p.Cout + jn * 32 + i]), acc[jn], 0, 0, 0);
                 }
             }
-            // the six products of order <= 2^-16, smallest first: l h', h l', m m', m h', h m', h h'
-            constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
-#pragma unroll
-            for (int term = 0; term < 6; ++term)
-#pragma unroll
-                for (int j = 0; j < NT; ++j)
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8s, a3[PA[term]]),
-                                                                     __builtin_bit_cast(bf16x8s, wl[((PB[term] * nsteps + st) * 2 + h) * p.Cout + j * 32 + i]), acc[j], 0, 0, 0);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) cur[e] = nxt[e];
         }
         // D layout: col n = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * h: every store instruction writes two 128-B channel runs
 #pragma unroll
@@ -323,12 +342,20 @@ int launch_stem_conv(const StemParams& p, hipStream_t s) {
         FS_REQUIRE(lds <= 150 * 1024, "stem_conv: filter planes %zu B exceed the LDS budget", lds);
         FS_REQUIRE((long long)3 * (f.ncrops ? (long long)f.FH * f.FW : (long long)p.H * p.W) < (1ll << 31), "stem_conv: frame too large for 32-bit tap offsets");
         const int tiles = cdiv(M, 32);
-        const dim3 grid((unsigned)std::min(cdiv(tiles, 4), 256 * 8));
-#define FS_STEM_SPLIT(NT_)                                                                                                       \
+        // every workgroup splits the whole filter bank into LDS before its first tile (a 7 x 7 x 64 bank: 1280 rows of eight weights):
+        // no more workgroups than a CU can hold at once (LDS), so that a wave walks several tiles behind one prologue (round 6: the 7 x 7
+        // stem ran 1992 workgroups of ONE tile per wave, four rounds of prologue)
+        const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (size_t)160 * 1024 / lds));
+        const dim3 grid((unsigned)std::min(cdiv(tiles, 4), 256 * per_cu));
+#define FS_STEM_SPLIT_PF(NT_, PF_)                                                                                               \
     {                                                                                                                            \
         if (lds > 64 * 1024)                                                                                                     \
-            FS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_conv_split_kernel<NT_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        hipLaunchKernelGGL((stem_conv_split_kernel<NT_>), grid, dim3(256), lds, s, p, nsteps);                                   \
+            FS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&stem_conv_split_kernel<NT_, PF_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL((stem_conv_split_kernel<NT_, PF_>), grid, dim3(256), lds, s, p, nsteps);                              \
+    }
+#define FS_STEM_SPLIT(NT_)                                                                                                       \
+    {                                                                                                                            \
+        if (nsteps <= 2) FS_STEM_SPLIT_PF(NT_, 2) else FS_STEM_SPLIT_PF(NT_, 5)                                                  \
     }
         switch (p.Cout / 32) {
             case 1: FS_STEM_SPLIT(1) break;
@@ -337,6 +364,7 @@ int launch_stem_conv(const StemParams& p, hipStream_t s) {
             default: FS_STEM_SPLIT(4) break;
         }
 #undef FS_STEM_SPLIT
+#undef FS_STEM_SPLIT_PF
         FS_HIP(hipGetLastError());
         return 0;
     }
