@@ -81,6 +81,10 @@ int launch_dec_assemble(const float* Y, const float* cls_emb, float* Z, int B, i
 }
 
 // ------------------------------------------------------------------ LayerNorm: one wave per row, D <= 1024
+// NI = chunks of 64 float4 a row has.  Everything a row needs -- its values, gamma, beta -- is requested before anything is used
+// (round 6: the gamma / beta loads sat behind the two reductions, a second memory round trip in a kernel that is one round trip
+// long); lanes past the row's end load from clamped addresses and contribute exact zeros, as before.
+template <int NI>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ in, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, float* __restrict__ out, int rows, int D4,
                                                         int rows_per_batch, int drop_first) {
@@ -94,26 +98,37 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
         orow = b * (rows_per_batch - 1) + t - 1;
     }
     const f32x4* x = reinterpret_cast<const f32x4*>(in) + (size_t)row * D4;
-    f32x4 v[4];
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    f32x4 v[NI], g[NI], bt[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int cc = min(lane + 64 * i, D4 - 1);
+        v[i] = x[cc];
+        g[i] = reinterpret_cast<const f32x4*>(gamma)[cc];
+        bt[i] = reinterpret_cast<const f32x4*>(beta)[cc];
+    }
+    // an empty asm that "reads" gamma and beta: the compiler otherwise sinks their loads into the conditional store at the end; the
+    // scheduling barrier keeps all nine loads in front of the first use of any of them
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < NI; ++i) asm volatile("" ::"v"(g[i]), "v"(bt[i]));
     float sum = 0.f;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int c = lane + 64 * i;
-        v[i] = c < D4 ? x[c] : f32x4{0.f, 0.f, 0.f, 0.f};
-        sum += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+    for (int i = 0; i < 4; ++i) {  // four terms whatever NI is: the sum is then the same float for every instantiation
+        if (i < NI) v[i] = lane + 64 * i < D4 ? v[i] : z;
+        sum += i < NI ? v[i][0] + v[i][1] + v[i][2] + v[i][3] : 0.f;
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
     const float mean = sum / (float)(D4 * 4);
     float sq = 0.f;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        if (lane + 64 * i < D4) {
+    for (int i = 0; i < NI; ++i) {  // element by element into ONE running sum, valid chunks only (as the round-1 kernel did)
+        const bool ok = lane + 64 * i < D4;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float d = v[i][e] - mean;
-                sq += d * d;
-            }
+        for (int e = 0; e < 4; ++e) {
+            const float d = v[i][e] - mean;
+            sq = ok ? sq + d * d : sq;
         }
     }
 #pragma unroll
@@ -121,23 +136,25 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     const float rstd = 1.f / sqrtf(sq / (float)(D4 * 4) + 1e-5f);
     f32x4* y = reinterpret_cast<f32x4*>(out) + (size_t)orow * D4;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NI; ++i) {
         const int c = lane + 64 * i;
-        if (c < D4) {
-            const f32x4 g = reinterpret_cast<const f32x4*>(gamma)[c], bt = reinterpret_cast<const f32x4*>(beta)[c];
-            f32x4 r;
+        f32x4 r;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) r[e] = (v[i][e] - mean) * rstd * g[e] + bt[e];
-            y[c] = r;
-        }
+        for (int e = 0; e < 4; ++e) r[e] = (v[i][e] - mean) * rstd * g[i][e] + bt[i][e];
+        if (c < D4) y[c] = r;
     }
 }
 
 int launch_layernorm(const float* in, const float* gamma, const float* beta, float* out, int rows, int D, int rows_per_batch,
                      int drop_first, hipStream_t s) {
-    FS_REQUIRE(D % 4 == 0 && D <= 1024, "layernorm: D=%d must be a multiple of 4 and <= 1024", D);
-    hipLaunchKernelGGL(layernorm_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, s, in, gamma, beta, out, rows, D / 4, rows_per_batch,
-                       drop_first);
+    FS_REQUIRE(D % 4 == 0 && D >= 4 && D <= 1024, "layernorm: D=%d must be a multiple of 4 and <= 1024", D);
+    const dim3 grid(cdiv(rows, 4)), block(256);
+    switch (cdiv(D / 4, 64)) {
+        case 1: hipLaunchKernelGGL(layernorm_kernel<1>, grid, block, 0, s, in, gamma, beta, out, rows, D / 4, rows_per_batch, drop_first); break;
+        case 2: hipLaunchKernelGGL(layernorm_kernel<2>, grid, block, 0, s, in, gamma, beta, out, rows, D / 4, rows_per_batch, drop_first); break;
+        case 3: hipLaunchKernelGGL(layernorm_kernel<3>, grid, block, 0, s, in, gamma, beta, out, rows, D / 4, rows_per_batch, drop_first); break;
+        default: hipLaunchKernelGGL(layernorm_kernel<4>, grid, block, 0, s, in, gamma, beta, out, rows, D / 4, rows_per_batch, drop_first); break;
+    }
     FS_HIP(hipGetLastError());
     return 0;
 }
@@ -736,6 +753,11 @@ __global__ __launch_bounds__(64 * ATT_NW, 3) void attention_bf16x3_kernel(const 
 }
 
 // merge the key splits of one query: O = sum_s e^(m_s - M) O_s / sum_s e^(m_s - M) l_s ; thread = (query row, float4 of dh)
+// NS > 0: the split count at compile time -- every (max, sum) pair and partial row is requested before the first is used (round 6: the maxima
+// were one pass of loads, the weighted sum a second one with each split's loads behind the previous split's arithmetic).  Same operations in
+// the same order as the generic form (NS == 0).
+typedef float f32x2c __attribute__((ext_vector_type(2)));
+template <int NS>
 __global__ __launch_bounds__(256) void attention_combine_kernel(const float* __restrict__ part_o, const float* __restrict__ part_ml,
                                                                 float* __restrict__ out, int B, int N, int heads, int nsplit) {
     const int64_t total = (int64_t)B * heads * N * 16;
@@ -746,22 +768,54 @@ __global__ __launch_bounds__(256) void attention_combine_kernel(const float* __r
     const int q = (int)(r % N);
     const int bh = (int)(r / N);
     const int b = bh / heads, head = bh - b * heads;
-    float M = -INFINITY;
-    for (int sp = 0; sp < nsplit; ++sp) M = fmaxf(M, part_ml[2 * (((size_t)bh * nsplit + sp) * N + q)]);
     float L = 0.f;
     f32x4 o = {0.f, 0.f, 0.f, 0.f};
-    for (int sp = 0; sp < nsplit; ++sp) {
-        const size_t row = ((size_t)bh * nsplit + sp) * N + q;
-        const float w = __builtin_amdgcn_exp2f(part_ml[2 * row] - M);   // the partial maxima are in log2 units (see the kernel)
-        L += w * part_ml[2 * row + 1];
-        const f32x4 v = *reinterpret_cast<const f32x4*>(part_o + row * ATT_DH + c4 * 4);
+    if (NS > 0) {
+        f32x2c ml[NS > 0 ? NS : 1];
+        f32x4 v[NS > 0 ? NS : 1];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] += w * v[e];
+        for (int sp = 0; sp < NS; ++sp) {
+            const size_t row = ((size_t)bh * NS + sp) * N + q;
+            ml[sp] = *reinterpret_cast<const f32x2c*>(part_ml + 2 * row);
+            v[sp] = *reinterpret_cast<const f32x4*>(part_o + row * ATT_DH + c4 * 4);
+        }
+        float M = -INFINITY;
+#pragma unroll
+        for (int sp = 0; sp < NS; ++sp) M = fmaxf(M, ml[sp][0]);
+#pragma unroll
+        for (int sp = 0; sp < NS; ++sp) {
+            const float w = __builtin_amdgcn_exp2f(ml[sp][0] - M);   // the partial maxima are in log2 units (see the kernel)
+            L += w * ml[sp][1];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] += w * v[sp][e];
+        }
+    } else {
+        float M = -INFINITY;
+        for (int sp = 0; sp < nsplit; ++sp) M = fmaxf(M, part_ml[2 * (((size_t)bh * nsplit + sp) * N + q)]);
+        for (int sp = 0; sp < nsplit; ++sp) {
+            const size_t row = ((size_t)bh * nsplit + sp) * N + q;
+            const float w = __builtin_amdgcn_exp2f(part_ml[2 * row] - M);
+            L += w * part_ml[2 * row + 1];
+            const f32x4 v = *reinterpret_cast<const f32x4*>(part_o + row * ATT_DH + c4 * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] += w * v[e];
+        }
     }
     const float inv = 1.f / L;
 #pragma unroll
     for (int e = 0; e < 4; ++e) o[e] *= inv;
     *reinterpret_cast<f32x4*>(out + ((size_t)b * N + q) * (heads * ATT_DH) + head * ATT_DH + c4 * 4) = o;
+}
+
+static void launch_attention_combine(const float* part_o, const float* part_ml, float* out, int B, int N, int heads, int ns, hipStream_t s) {
+    const int64_t tot = (int64_t)B * heads * N * 16;
+    const dim3 grid((unsigned)cdiv64(tot, 256)), block(256);
+    switch (ns) {
+        case 2: hipLaunchKernelGGL(attention_combine_kernel<2>, grid, block, 0, s, part_o, part_ml, out, B, N, heads, ns); break;
+        case 3: hipLaunchKernelGGL(attention_combine_kernel<3>, grid, block, 0, s, part_o, part_ml, out, B, N, heads, ns); break;
+        case 4: hipLaunchKernelGGL(attention_combine_kernel<4>, grid, block, 0, s, part_o, part_ml, out, B, N, heads, ns); break;
+        default: hipLaunchKernelGGL(attention_combine_kernel<0>, grid, block, 0, s, part_o, part_ml, out, B, N, heads, ns); break;
+    }
 }
 
 int attention_splits(int /*B*/, int N, int heads) {
@@ -812,8 +866,7 @@ int launch_attention_split(const float* qkv, float* out, int B, int N, int heads
     hipLaunchKernelGGL(attention_bf16x3_kernel<true>, dim3(qtiles * ns, heads, B), dim3(64 * ATT_NW), 0, s, qkv, Kp, Vtp, out, part_o, part_ml, N, Npad,
                        heads, scale, ns, plane_bytes);
     FS_HIP(hipGetLastError());
-    const int64_t tot = (int64_t)B * heads * N * 16;
-    hipLaunchKernelGGL(attention_combine_kernel, dim3((unsigned)cdiv64(tot, 256)), dim3(256), 0, s, part_o, part_ml, out, B, N, heads, ns);
+    launch_attention_combine(part_o, part_ml, out, B, N, heads, ns, s);
     FS_HIP(hipGetLastError());
     return 0;
 }
@@ -838,8 +891,7 @@ int launch_attention_f32(const float* qkv, float* out, int B, int N, int heads, 
     else hipLaunchKernelGGL(attention_f32_kernel<true>, dim3(qtiles * ns, heads, B), dim3(64 * ATT_NW), 0, s, qkv, out, part_o, part_ml, N, heads,
                        scale, ns);
     FS_HIP(hipGetLastError());
-    const int64_t total = (int64_t)B * heads * N * 16;
-    hipLaunchKernelGGL(attention_combine_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, s, part_o, part_ml, out, B, N, heads, ns);
+    launch_attention_combine(part_o, part_ml, out, B, N, heads, ns, s);
     FS_HIP(hipGetLastError());
     return 0;
 }
@@ -871,7 +923,7 @@ int launch_splitk_combine(const float* part, int nsplit, const float* bias, cons
 // followed by layernorm_kernel, hence bit-identical to the two launches.
 // NS > 0: the number of partials at compile time (2, 3, 4: what linear_splits returns) -- the loads of all of them, of the bias and of the
 // shortcut are then issued together; with a run-time count every load waited for its predecessor (round 6).  NS = 0: run-time count.
-template <int NS>
+template <int NS, int NI>
 __global__ __launch_bounds__(256) void splitk_combine_ln_kernel(const float* __restrict__ part, int nsplit, const float* __restrict__ bias,
                                                                 const float* __restrict__ res, float* __restrict__ out, const float* __restrict__ gamma,
                                                                 const float* __restrict__ beta, float* __restrict__ ln_out, int rows, int D4) {
@@ -879,50 +931,69 @@ __global__ __launch_bounds__(256) void splitk_combine_ln_kernel(const float* __r
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const int64_t total4 = (int64_t)rows * D4;
-    f32x4 v[4];
-    float sum = 0.f;
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    f32x4 v[NI], g[NI], bt[NI];
+    // NS > 0: the partial sums, bias, residual, gamma and beta of the whole row are requested before anything is used (round 6: they came
+    // chunk by chunk, each chunk's six loads behind the previous chunk's store, and gamma / beta behind both reductions -- four to five
+    // memory round trips in a 10-us kernel).  Lanes past the row's end read clamped addresses and contribute exact zeros.  Same sums in
+    // the same order as the generic form (NS == 0: any number of partials, loaded as they are added).
+    if (NS > 0) {
+        f32x4 pv[NI][NS > 0 ? NS : 1], bv[NI], rv[NI];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int c = lane + 64 * i;
-        v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (c < D4) {
-            const int64_t idx = (int64_t)row * D4 + c;
-            f32x4 a;
-            if (NS > 0) {  // same sums in the same order, the operands requested up front
-                f32x4 pv[NS > 0 ? NS : 1];
+        for (int i = 0; i < NI; ++i) {
+            const int cc = min(lane + 64 * i, D4 - 1);
+            const int64_t idx = (int64_t)row * D4 + cc;
 #pragma unroll
-                for (int sidx = 0; sidx < NS; ++sidx) pv[sidx] = reinterpret_cast<const f32x4*>(part)[(int64_t)sidx * total4 + idx];
-                const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-                const f32x4 bv = bias ? reinterpret_cast<const f32x4*>(bias)[c] : z;
-                const f32x4 rv = res ? reinterpret_cast<const f32x4*>(res)[idx] : z;
-                a = pv[0];
+            for (int sidx = 0; sidx < NS; ++sidx) pv[i][sidx] = reinterpret_cast<const f32x4*>(part)[(int64_t)sidx * total4 + idx];
+            bv[i] = bias ? reinterpret_cast<const f32x4*>(bias)[cc] : z;
+            rv[i] = res ? reinterpret_cast<const f32x4*>(res)[idx] : z;
+            g[i] = reinterpret_cast<const f32x4*>(gamma)[cc];
+            bt[i] = reinterpret_cast<const f32x4*>(beta)[cc];
+        }
 #pragma unroll
-                for (int sidx = 1; sidx < NS; ++sidx) a += pv[sidx];
-                if (bias) a += bv;
-                if (res) a += rv;
-            } else {
-                a = reinterpret_cast<const f32x4*>(part)[idx];
+        for (int i = 0; i < NI; ++i) {
+            f32x4 a = pv[i][0];
+#pragma unroll
+            for (int sidx = 1; sidx < NS; ++sidx) a += pv[i][sidx];
+            if (bias) a += bv[i];
+            if (res) a += rv[i];
+            const int c = lane + 64 * i;
+            if (c < D4) reinterpret_cast<f32x4*>(out)[(int64_t)row * D4 + c] = a;
+            v[i] = c < D4 ? a : z;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int c = lane + 64 * i;
+            v[i] = z;
+            g[i] = bt[i] = z;
+            if (c < D4) {
+                const int64_t idx = (int64_t)row * D4 + c;
+                f32x4 a = reinterpret_cast<const f32x4*>(part)[idx];
                 for (int sidx = 1; sidx < nsplit; ++sidx) a += reinterpret_cast<const f32x4*>(part)[(int64_t)sidx * total4 + idx];
                 if (bias) a += reinterpret_cast<const f32x4*>(bias)[c];
                 if (res) a += reinterpret_cast<const f32x4*>(res)[idx];
+                reinterpret_cast<f32x4*>(out)[idx] = a;
+                v[i] = a;
+                g[i] = reinterpret_cast<const f32x4*>(gamma)[c];
+                bt[i] = reinterpret_cast<const f32x4*>(beta)[c];
             }
-            reinterpret_cast<f32x4*>(out)[idx] = a;
-            v[i] = a;
         }
-        sum += v[i][0] + v[i][1] + v[i][2] + v[i][3];
     }
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) sum += i < NI ? v[i < NI ? i : 0][0] + v[i < NI ? i : 0][1] + v[i < NI ? i : 0][2] + v[i < NI ? i : 0][3] : 0.f;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
     const float mean = sum / (float)(D4 * 4);
     float sq = 0.f;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        if (lane + 64 * i < D4) {
+    for (int i = 0; i < NI; ++i) {
+        const bool ok = lane + 64 * i < D4;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float d = v[i][e] - mean;
-                sq += d * d;
-            }
+        for (int e = 0; e < 4; ++e) {
+            const float d = v[i][e] - mean;
+            sq = ok ? sq + d * d : sq;
         }
     }
 #pragma unroll
@@ -930,13 +1001,12 @@ __global__ __launch_bounds__(256) void splitk_combine_ln_kernel(const float* __r
     const float rstd = 1.f / sqrtf(sq / (float)(D4 * 4) + 1e-5f);
     f32x4* y = reinterpret_cast<f32x4*>(ln_out) + (size_t)row * D4;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NI; ++i) {
         const int c = lane + 64 * i;
         if (c < D4) {
-            const f32x4 g = reinterpret_cast<const f32x4*>(gamma)[c], bt = reinterpret_cast<const f32x4*>(beta)[c];
             f32x4 r;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) r[e] = (v[i][e] - mean) * rstd * g[e] + bt[e];
+            for (int e = 0; e < 4; ++e) r[e] = (v[i][e] - mean) * rstd * g[i][e] + bt[i][e];
             y[c] = r;
         }
     }
@@ -944,14 +1014,21 @@ __global__ __launch_bounds__(256) void splitk_combine_ln_kernel(const float* __r
 
 int launch_splitk_combine_ln(const float* part, int nsplit, const float* bias, const float* res, float* out, const float* gamma, const float* beta,
                              float* ln_out, int rows, int N, hipStream_t s) {
-    FS_REQUIRE(part && out && ln_out && gamma && beta && nsplit >= 2 && rows >= 1 && N % 4 == 0 && N <= 1024, "splitk_combine_ln: bad arguments");
+    FS_REQUIRE(part && out && ln_out && gamma && beta && nsplit >= 2 && rows >= 1 && N % 4 == 0 && N >= 4 && N <= 1024, "splitk_combine_ln: bad arguments");
     const dim3 grid(cdiv(rows, 4)), block(256);
-    switch (nsplit) {
-        case 2: hipLaunchKernelGGL(splitk_combine_ln_kernel<2>, grid, block, 0, s, part, nsplit, bias, res, out, gamma, beta, ln_out, rows, N / 4); break;
-        case 3: hipLaunchKernelGGL(splitk_combine_ln_kernel<3>, grid, block, 0, s, part, nsplit, bias, res, out, gamma, beta, ln_out, rows, N / 4); break;
-        case 4: hipLaunchKernelGGL(splitk_combine_ln_kernel<4>, grid, block, 0, s, part, nsplit, bias, res, out, gamma, beta, ln_out, rows, N / 4); break;
-        default: hipLaunchKernelGGL(splitk_combine_ln_kernel<0>, grid, block, 0, s, part, nsplit, bias, res, out, gamma, beta, ln_out, rows, N / 4); break;
+    const bool narrow = N <= 512;  // two chunks of 64 float4 per row (ViT-S 384, ViT-B 768 takes four)
+#define FS_CLN(NS_)                                                                                                                              \
+    {                                                                                                                                            \
+        if (narrow) hipLaunchKernelGGL((splitk_combine_ln_kernel<NS_, 2>), grid, block, 0, s, part, nsplit, bias, res, out, gamma, beta, ln_out, rows, N / 4); \
+        else hipLaunchKernelGGL((splitk_combine_ln_kernel<NS_, 4>), grid, block, 0, s, part, nsplit, bias, res, out, gamma, beta, ln_out, rows, N / 4);        \
     }
+    switch (nsplit) {
+        case 2: FS_CLN(2) break;
+        case 3: FS_CLN(3) break;
+        case 4: FS_CLN(4) break;
+        default: FS_CLN(0) break;
+    }
+#undef FS_CLN
     FS_HIP(hipGetLastError());
     return 0;
 }
