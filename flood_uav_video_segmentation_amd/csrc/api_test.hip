@@ -81,7 +81,7 @@ static int fs_attention(const float* qkv, float* out, int B, int N, int heads, f
     return fs::launch_attention_split(qkv, out, B, N, heads, scale, scratch, planes, S(stream));
 }
 static size_t fs_winograd_workspace_floats(int B, int H, int W, int Cin, int Cout, int dil, int tile_m) {
-    if (B < 1 || H < 1 || W < 1 || dil < 1 || !(tile_m == 0 || tile_m == 4 || tile_m == 6)) return 0;
+    if (B < 1 || H < 1 || W < 1 || dil < 1 || !(tile_m == 0 || tile_m == 3 || tile_m == 4 || tile_m == 6)) return 0;
     const int mt = tile_m ? tile_m : fs::winograd_pick_m(B, H, W, dil);
     const size_t G = (size_t)(mt + 2) * (mt + 2), T = (size_t)fs::winograd_tiles(B, H, W, dil, mt);
     return G * T * ((size_t)Cin + (size_t)Cout) + G * (size_t)Cout * Cin;
@@ -90,8 +90,8 @@ static int fs_conv3x3_winograd_nhwc(const float* in, int ld_in, const float* wgt
                                     float* out, int ld_out, int B, int H, int W, int Cin, int Cout, int dil, int relu, int tile_m,
                                     float* workspace, fs_stream stream) {
     if (!in || !wgt_oihw || !out || !workspace || B < 1 || H < 1 || W < 1 || dil < 1 || Cin % 32 != 0 || Cout % 4 != 0 ||
-        !(tile_m == 0 || tile_m == 4 || tile_m == 6))
-        return fs::fail("fs_conv3x3_winograd_nhwc: bad arguments (Cin %% 32, Cout %% 4, tile_m in {0, 4, 6} required)");
+        !(tile_m == 0 || tile_m == 3 || tile_m == 4 || tile_m == 6))
+        return fs::fail("fs_conv3x3_winograd_nhwc: bad arguments (Cin %% 32, Cout %% 4, tile_m in {0, 3, 4, 6} required)");
     const int mt = tile_m ? tile_m : fs::winograd_pick_m(B, H, W, dil);
     const size_t G = (size_t)(mt + 2) * (mt + 2), T = (size_t)fs::winograd_tiles(B, H, W, dil, mt);
     float* U = workspace;

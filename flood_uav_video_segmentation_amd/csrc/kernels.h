@@ -329,8 +329,10 @@ static inline double winograd_gemm_rows(int B, int H, int W, int dil, int mt) {
 }
 // the cheaper tile size for this map (a 90x90 map is 15x15 tiles of 6x6 exactly, but 23x23 of 4x4).  Decided on the
 // geometry of ONE image, so that a frame's result does not depend on the batch it is processed in.
+// Round 6: F(3,3) joins where BOTH larger forms are mostly empty tiles (lattices of <= 3 pixels: ASPP's dilation 36 on a 90x90 map).
 static inline int winograd_pick_m(int /*B*/, int H, int W, int dil) {
-    return winograd_gemm_rows(1, H, W, dil, 6) < winograd_gemm_rows(1, H, W, dil, 4) ? 6 : 4;
+    const int m = winograd_gemm_rows(1, H, W, dil, 6) < winograd_gemm_rows(1, H, W, dil, 4) ? 6 : 4;
+    return winograd_gemm_rows(1, H, W, dil, 3) < winograd_gemm_rows(1, H, W, dil, m) ? 3 : m;
 }
 
 // ---------------------------------------------------------------------------------

@@ -27,10 +27,11 @@ struct RawTensor {
 struct WinoBank {
     float* U4 = nullptr;  // [36][Cout][Cin]  F(4x4,3x3)
     float* U6 = nullptr;  // [64][Cout][Cin]  F(6x6,3x3)
-    // recorded on the stream the bank was built on, right behind the filter transform; [0] = U4, [1] = U6.  A forward on any
+    float* U3 = nullptr;  // [25][Cout][Cin]  F(3x3,3x3)
+    // recorded on the stream the bank was built on, right behind the filter transform; [0] = U4, [1] = U6, [2] = U3.  A forward on any
     // other stream waits for it before its first read (the events belong to the handle: fs_net::bank_events)
-    hipEvent_t ready[2] = {nullptr, nullptr};
-    hipStream_t built_on[2] = {nullptr, nullptr};
+    hipEvent_t ready[3] = {nullptr, nullptr, nullptr};
+    hipStream_t built_on[3] = {nullptr, nullptr, nullptr};
 };
 
 // conv + (eval BatchNorm | bias) + optional ReLU, ready to launch
@@ -130,7 +131,7 @@ struct fs_net {
     size_t ws_allocs = 0;                 // workspace / bank allocations made so far (none after fs_reserve, tests/test_gpu_net.py)
     // explicit options of fs_config (include/floodseg.h): nothing is read from the environment
     bool use_winograd = true;    // !(flags & FS_OPT_NO_WINOGRAD)
-    int wino_force_m = 0;        // winograd_tile: 4 | 6 forces F(4,3) / F(6,3); 0 = the cheaper one for the map at hand
+    int wino_force_m = 0;        // winograd_tile: 3 | 4 | 6 forces F(3,3) / F(4,3) / F(6,3); 0 = the cheapest one for the map at hand
     bool use_fused_head = true;  // !(flags & FS_OPT_NO_FUSED_HEAD)
     bool use_fused_shortcut = true;  // !(flags & FS_OPT_NO_FUSED_SHORTCUT)
     bool use_fused_winograd = true;  // !(flags & FS_OPT_NO_FUSED_WINOGRAD)

@@ -90,8 +90,8 @@ bool wino_eligible(const ConvBN& c, bool hwio) {
 // A forward on ANOTHER stream than the one the bank was built on waits for the build's event first (fs_reserve builds the
 // banks ahead of time; without it the first forward that needs a bank allocates and builds it -- never under graph capture).
 int wino_bank(fs_net* h, const ConvBN& c, int mt, hipStream_t s, const float** U) {
-    const int k = mt == 6 ? 1 : 0;
-    float*& slot = mt == 6 ? c.wino->U6 : c.wino->U4;
+    const int k = mt == 6 ? 1 : mt == 3 ? 2 : 0;
+    float*& slot = mt == 6 ? c.wino->U6 : mt == 3 ? c.wino->U3 : c.wino->U4;
     if (!slot) {
         FS_REQUIRE(c.korder == 1, "winograd: conv '%s' has no chunk-major filter bank", c.name.c_str());
         float* bank = nullptr;  // published only once the transform has been enqueued: a failed launch must not leave a half-built bank behind
@@ -390,7 +390,8 @@ int net_create(const fs_config* cfg, fs_handle* out) {
     FS_REQUIRE((cfg->flags & ~(FS_OPT_NO_WINOGRAD | FS_OPT_NO_FUSED_HEAD | FS_OPT_NO_FUSED_SHORTCUT | FS_OPT_NO_FUSED_WINOGRAD | FS_OPT_NO_SPLIT_BF16 |
                                FS_OPT_NO_RES_TOUCH | FS_OPT_NO_FUSED_POOL | FS_OPT_NO_FUSED_QKV)) == 0,
                "fs_create: unknown option bits 0x%x", cfg->flags);
-    FS_REQUIRE(cfg->winograd_tile == 0 || cfg->winograd_tile == 4 || cfg->winograd_tile == 6, "fs_create: winograd_tile must be 0, 4 or 6");
+    FS_REQUIRE(cfg->winograd_tile == 0 || cfg->winograd_tile == 3 || cfg->winograd_tile == 4 || cfg->winograd_tile == 6,
+               "fs_create: winograd_tile must be 0, 3, 4 or 6");
     fs_net* h = new fs_net();
     h->cfg = *cfg;
     h->use_winograd = !(cfg->flags & FS_OPT_NO_WINOGRAD);

@@ -1,10 +1,36 @@
-// Winograd F(m x m, 3x3) transform matrices, m = 4 (Lavin & Gray) or m = 6 (points 0, +-1, +-2, +-1/2, inf, the NNPACK set):
+// Winograd F(m x m, 3x3) transform matrices, m = 3 (points 0, +-1, 2, inf), m = 4 (Lavin & Gray) or m = 6 (points 0, +-1, +-2, +-1/2, inf, the NNPACK set):
 // B^T d (input), A^T m (output), G g (filter).  Shared by the transform kernels (winograd.hip) and the fused kernel (wino_fused.hip).
 #pragma once
 
 namespace fs {
 
 template <int MT> struct Wino;
+
+// ---------------------------------------------------------------- F(3,3): points 0, 1, -1, 2, inf (Cook-Toom; round 6)
+// 25 products per 9 outputs (2.78 per output, against 2.25 / 1.78) -- it pays where the tiles of the larger forms are mostly empty: the
+// dilation-36 branch of DeepLab's ASPP on a 90 x 90 map is 36 x 36 lattices of 3 x 3 (or 2 x 2) pixels, ONE 3 x 3 tile each.
+template <> struct Wino<3> {
+    static constexpr int A = 5;
+    template <typename T> __device__ static __forceinline__ void bt(const T d[5], T t[5]) {  // B^T d
+        t[0] = 2.f * (d[0] - d[2]) - d[1] + d[3];
+        t[1] = -2.f * d[1] - d[2] + d[3];
+        t[2] = 2.f * d[1] - 3.f * d[2] + d[3];
+        t[3] = d[3] - d[1];
+        t[4] = 2.f * (d[1] - d[3]) - d[2] + d[4];
+    }
+    template <typename T> __device__ static __forceinline__ void at(const T m[5], T y[3]) {  // A^T m
+        y[0] = m[0] + m[1] + m[2] + m[3];
+        y[1] = m[1] - m[2] + 2.f * m[3];
+        y[2] = m[1] + m[2] + 4.f * m[3] + m[4];
+    }
+    __device__ static __forceinline__ void g(double g0, double g1, double g2, double u[5]) {  // G g
+        u[0] = g0 / 2;
+        u[1] = -(g0 + g1 + g2) / 2;
+        u[2] = (-g0 + g1 - g2) / 6;
+        u[3] = g0 / 6 + g1 / 3 + 2 * g2 / 3;
+        u[4] = g2;
+    }
+};
 
 // ---------------------------------------------------------------- F(4,3)
 template <> struct Wino<4> {

@@ -38,11 +38,12 @@ __global__ __launch_bounds__(256) void winograd_filter_kernel(const float* __res
 }
 
 int launch_winograd_filter(const float* w_oihw, float* U, int O, int I, int mt, hipStream_t s, int chunk_major) {
-    FS_REQUIRE(mt == 4 || mt == 6, "winograd: tile size must be 4 or 6");
+    FS_REQUIRE(mt == 3 || mt == 4 || mt == 6, "winograd: tile size must be 3, 4 or 6");
     FS_REQUIRE(!chunk_major || I % 32 == 0, "winograd_filter: a chunk-major bank needs Cin %% 32 == 0");
     const int64_t total = (int64_t)O * I;
     const dim3 grid((unsigned)std::min<int64_t>(cdiv64(total, 256), 65535));
-    if (mt == 4) hipLaunchKernelGGL(winograd_filter_kernel<4>, grid, dim3(256), 0, s, w_oihw, U, O, I, chunk_major);
+    if (mt == 3) hipLaunchKernelGGL(winograd_filter_kernel<3>, grid, dim3(256), 0, s, w_oihw, U, O, I, chunk_major);
+    else if (mt == 4) hipLaunchKernelGGL(winograd_filter_kernel<4>, grid, dim3(256), 0, s, w_oihw, U, O, I, chunk_major);
     else hipLaunchKernelGGL(winograd_filter_kernel<6>, grid, dim3(256), 0, s, w_oihw, U, O, I, chunk_major);
     FS_HIP(hipGetLastError());
     return 0;
@@ -122,14 +123,15 @@ WinoLayout winograd_layout(int mt, long long T, int C) {
 
 int launch_winograd_input(const float* in, int ld_in, float* V, int B, int H, int W, int C, int dil, int mt, hipStream_t s) {
     FS_REQUIRE(C % 4 == 0 && ld_in % 4 == 0 && dil >= 1, "winograd_input: C must be a multiple of 4");
-    FS_REQUIRE(mt == 4 || mt == 6, "winograd: tile size must be 4 or 6");
+    FS_REQUIRE(mt == 3 || mt == 4 || mt == 6, "winograd: tile size must be 3, 4 or 6");
     FS_REQUIRE(((uintptr_t)in & 15) == 0 && ((uintptr_t)V & 15) == 0, "winograd_input: unaligned operand");
     const int th = (cdiv(H, dil) + mt - 1) / mt, tw = (cdiv(W, dil) + mt - 1) / mt;
     const long long T = (long long)B * dil * dil * th * tw;
     FS_REQUIRE(T < (1ll << 31), "winograd_input: too many tiles");
     const dim3 grid((unsigned)cdiv(C / 4, 32), (unsigned)std::min<long long>(T, 65535));
     const WinoLayout lay = winograd_layout(mt, T, C);
-    if (mt == 4) hipLaunchKernelGGL((winograd_input_kernel<4>), grid, dim3(6 * 32), 0, s, in, ld_in, V, B, H, W, C / 4, th, tw, dil, lay.s_pos, lay.s_tile);
+    if (mt == 3) hipLaunchKernelGGL((winograd_input_kernel<3>), grid, dim3(5 * 32), 0, s, in, ld_in, V, B, H, W, C / 4, th, tw, dil, lay.s_pos, lay.s_tile);
+    else if (mt == 4) hipLaunchKernelGGL((winograd_input_kernel<4>), grid, dim3(6 * 32), 0, s, in, ld_in, V, B, H, W, C / 4, th, tw, dil, lay.s_pos, lay.s_tile);
     else hipLaunchKernelGGL((winograd_input_kernel<6>), grid, dim3(8 * 32), 0, s, in, ld_in, V, B, H, W, C / 4, th, tw, dil, lay.s_pos, lay.s_tile);
     FS_HIP(hipGetLastError());
     return 0;
@@ -195,7 +197,7 @@ __global__ __launch_bounds__((MT + 2) * 32) void winograd_output_kernel(const fl
 int launch_winograd_output(const float* M, const float* scale, const float* shift, float* out, int ld_out, int B, int H, int W, int N,
                            int relu, int dil, int mt, hipStream_t s) {
     FS_REQUIRE(N % 4 == 0 && ld_out % 4 == 0 && dil >= 1, "winograd_output: N must be a multiple of 4");
-    FS_REQUIRE(mt == 4 || mt == 6, "winograd: tile size must be 4 or 6");
+    FS_REQUIRE(mt == 3 || mt == 4 || mt == 6, "winograd: tile size must be 3, 4 or 6");
     FS_REQUIRE(((uintptr_t)M & 15) == 0 && ((uintptr_t)out & 15) == 0 && ((uintptr_t)scale & 15) == 0 && ((uintptr_t)shift & 15) == 0,
                "winograd_output: unaligned operand");
     const int th = (cdiv(H, dil) + mt - 1) / mt, tw = (cdiv(W, dil) + mt - 1) / mt;
@@ -206,7 +208,10 @@ int launch_winograd_output(const float* M, const float* scale, const float* shif
     FS_REQUIRE(out_bytes < (1ll << 31), "winograd_output: output tensor must be smaller than 2 GiB");
     const dim3 grid((unsigned)cdiv(N / 4, 32), (unsigned)std::min<long long>(T, 65535));
     const WinoLayout lay = winograd_layout(mt, T, N);
-    if (mt == 4)
+    if (mt == 3)
+        hipLaunchKernelGGL(winograd_output_kernel<3>, grid, dim3(5 * 32), 0, s, M, scale, shift, out, ld_out, B, H, W, N / 4, th, tw, relu, dil,
+                           lay.s_pos, lay.s_tile, (unsigned)out_bytes);
+    else if (mt == 4)
         hipLaunchKernelGGL(winograd_output_kernel<4>, grid, dim3(6 * 32), 0, s, M, scale, shift, out, ld_out, B, H, W, N / 4, th, tw, relu, dil,
                            lay.s_pos, lay.s_tile, (unsigned)out_bytes);
     else

@@ -54,7 +54,7 @@ typedef struct fs_config {
     /* Explicit A/B options of the convolutional networks (0 = the shipped default).  They select between arithmetically
      * different but parity-tested evaluation routes; nothing is read from the process environment.                     */
     int flags;          /* FS_OPT_* bits                                                                                */
-    int winograd_tile;  /* 0 = per-map choice of F(4x4,3x3) / F(6x6,3x3); 4 or 6 forces one tile size                   */
+    int winograd_tile;  /* 0 = per-map choice of F(3x3,3x3) / F(4x4,3x3) / F(6x6,3x3); 3, 4 or 6 forces one tile size       */
 } fs_config;
 
 enum {

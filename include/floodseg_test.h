@@ -56,7 +56,7 @@ typedef struct fs_test_api {
                      fs_stream stream);
 
     /* 3x3 stride-1 conv with padding == dilation as Winograd F(m x m,3x3) (transforms + (m+2)^2 grouped MFMA GEMMs); the networks use
-     * it for every such conv with Cin >= 256.  tile_m: 4, 6, or 0 = whichever needs fewer GEMM rows for this map (a 90x90 map is
+     * it for every such conv with Cin >= 256.  tile_m: 3, 4, 6, or 0 = whichever needs the fewest GEMM rows for this map (a 90x90 map is
      * exactly 15x15 tiles of 6x6).  workspace: winograd_workspace_floats(..., same tile_m) floats of device memory. */
     size_t (*winograd_workspace_floats)(int B, int H, int W, int Cin, int Cout, int dil, int tile_m);
     int (*conv3x3_winograd_nhwc)(const float* in, int ld_in, const float* wgt_oihw, const float* scale, const float* shift, float* out,

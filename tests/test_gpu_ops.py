@@ -192,7 +192,7 @@ def test_conv_and_winograd_on_seeded_random_shapes():
         got = ops.conv2d_nhwc(x.to(DEV), wt.to(DEV), sc.to(DEV), sh.to(DEV), r.to(DEV) if res else None, stride, pad, dil, relu, 0)
         assert rel(got, ref) < CONV_TOL, (it, b, h, w, cin, cout, k, stride, dil, relu, res)
         if k == 3 and stride == 1 and not res and cout % 4 == 0:
-            for tile_m in (4, 6):
+            for tile_m in (3, 4, 6):
                 out = torch.empty((b, h, w, cout), device=DEV)
                 ws = torch.empty(lib.fs_winograd_workspace_floats(b, h, w, cin, cout, dil, tile_m), device=DEV)
                 xd = ops.as_nhwc(x.to(DEV))
@@ -542,10 +542,11 @@ WINO_TOL_2048 = 1.5e-4
     (2, 90, 90, 2048, 512, 1, True),    # THE PSPNet head conv of a 713x713 window (decoder.0 over the backbone channels, B = 2): with
                                         #   tile_m = 0 the library picks F(6,3) here, as the network does
 ])
-@pytest.mark.parametrize("tile_m", [4, 6, 0])
+@pytest.mark.parametrize("tile_m", [3, 4, 6, 0])
 def test_winograd_conv3x3(case, tile_m):
-    """F(4x4,3x3) / F(6x6,3x3): input/filter/output transforms + 36 / 64 grouped MFMA GEMMs vs torch conv2d (direct) on ragged
-    maps, batch > 1, dilation lattices; tile_m = 0 lets the library take the cheaper tiling for the map."""
+    """F(3x3,3x3) / F(4x4,3x3) / F(6x6,3x3): input/filter/output transforms + 25 / 36 / 64 grouped MFMA GEMMs vs torch conv2d (direct)
+    on ragged maps, batch > 1, dilation lattices; tile_m = 0 lets the library take the cheapest tiling for the map (F(3,3) for the
+    dilation-36 ASPP case: its lattices are 3 x 3 pixels, one tile each)."""
     lib = _lib.load()
     b, h, w, cin, cout, dil, relu = case
     g = torch.Generator().manual_seed(h * 100 + cin + dil)
