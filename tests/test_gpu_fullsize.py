@@ -270,7 +270,7 @@ def test_pspnet_r101_713_against_the_reference():
 
 
 # ------------------------------------------------------------------------------------------------ A/B options at full size
-@pytest.mark.parametrize("opts", [dict(hip_no_winograd=True), dict(hip_winograd_tile=4), dict(hip_winograd_tile=6),
+@pytest.mark.parametrize("opts", [dict(hip_no_winograd=True), dict(hip_winograd_tile=3), dict(hip_winograd_tile=4), dict(hip_winograd_tile=6),
                                   dict(hip_no_fused_head=True), dict(hip_no_fused_shortcut=True), dict(hip_no_fused_winograd=True),
                                   dict(hip_no_split_bf16=True),  # the fp32-MFMA kernels (round 2's arithmetic)
                                   dict(hip_no_fused_pool=True),   # round 5 A/B switch: layer0.6 and the max-pool as two launches again
@@ -278,7 +278,7 @@ def test_pspnet_r101_713_against_the_reference():
                                   dict(hip_no_split_bf16=True, hip_no_winograd=True),
                                   dict(hip_no_winograd=True, hip_no_fused_head=True, hip_no_fused_shortcut=True)])
 def test_every_shipped_option_matches_the_reference_golden_at_713(psp, opts):
-    """Each arithmetic-changing route the library ships (direct conv instead of Winograd, F(4,3) / F(6,3) forced, head over
+    """Each arithmetic-changing route the library ships (direct conv instead of Winograd, F(3,3) / F(4,3) / F(6,3) forced, head over
     the 4096-channel concat instead of the fused pyramid term, projection shortcut + conv3 as two launches instead of one
     concatenated-K GEMM, the small-Cin 3x3 convs on the direct kernel instead of the one-kernel Winograd) against the
     reference's own 713x713 outputs."""
