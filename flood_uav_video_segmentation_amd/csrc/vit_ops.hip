@@ -26,9 +26,37 @@ __global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__
     }
 }
 
+// P % 4 == 0: a thread moves four consecutive pixels of a patch row (four scalar loads -- frame rows are not 16-B aligned -- one 16-B store)
+// with 32-bit index arithmetic; the element-wise kernel above spent its time on 64-bit divisions (20 us for 2 x 12 MB).
+__global__ __launch_bounds__(256) void patchify4_kernel(const float* __restrict__ in, const float* __restrict__ in2, int B1,
+                                                        float* __restrict__ out, unsigned total4, int H, int W, int P, int gh, int gw) {
+    const unsigned P4 = (unsigned)P / 4, Kc4 = 3u * P * P4;
+    for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < total4; i += gridDim.x * 256) {
+        const unsigned col4 = i % Kc4, row = i / Kc4;
+        const unsigned px4 = col4 % P4, t = col4 / P4, py = t % (unsigned)P, c = t / (unsigned)P;
+        const unsigned gx = row % (unsigned)gw, r2 = row / (unsigned)gw, gy = r2 % (unsigned)gh, b = r2 / (unsigned)gh;
+        const int y = (int)(gy * P + py), x = (int)(gx * P + 4 * px4);
+        const float* src = ((int)b < B1 ? in + (size_t)b * 3 * H * W : in2 + (size_t)(b - B1) * 3 * H * W) + (size_t)c * H * W;
+        const int yc = min(y, H - 1);
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float q = src[(size_t)yc * W + min(x + e, W - 1)];  // clamped: always a valid address; zero padding by the select
+            v[e] = (y < H && x + e < W) ? q : 0.f;
+        }
+        reinterpret_cast<f32x4*>(out)[i] = v;
+    }
+}
+
 int launch_patchify(const float* in, const float* in2, int B1, float* out, int B, int H, int W, int P, int gh, int gw, hipStream_t s) {
     FS_REQUIRE(B1 >= 0 && B1 <= B && (B1 == B || in2) && (B1 == 0 || in), "patchify: bad frame split B1=%d of B=%d", B1, B);
     const int64_t total = (int64_t)B * gh * gw * 3 * P * P;
+    if (P % 4 == 0 && total / 4 < ((int64_t)1 << 31) && ((uintptr_t)out & 15) == 0) {
+        hipLaunchKernelGGL(patchify4_kernel, dim3((unsigned)std::min<int64_t>(cdiv64(total / 4, 256), 16384)), dim3(256), 0, s, in, in2, B1, out,
+                           (unsigned)(total / 4), H, W, P, gh, gw);
+        FS_HIP(hipGetLastError());
+        return 0;
+    }
     hipLaunchKernelGGL(patchify_kernel, dim3((unsigned)std::min<int64_t>(cdiv64(total, 256), 16384)), dim3(256), 0, s, in, in2, B1,
                        out, B, H, W, P, gh, gw);
     FS_HIP(hipGetLastError());
@@ -114,10 +142,12 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     for (int i = 0; i < NI; ++i) asm volatile("" ::"v"(g[i]), "v"(bt[i]));
     float sum = 0.f;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {  // four terms whatever NI is: the sum is then the same float for every instantiation
-        if (i < NI) v[i] = lane + 64 * i < D4 ? v[i] : z;
-        sum += i < NI ? v[i][0] + v[i][1] + v[i][2] + v[i][3] : 0.f;
+    for (int i = 0; i < NI; ++i) {
+        v[i] = lane + 64 * i < D4 ? v[i] : z;
+        sum += v[i][0] + v[i][1] + v[i][2] + v[i][3];
     }
+#pragma unroll
+    for (int i = NI; i < 4; ++i) sum += 0.f;  // four terms whatever NI is (x + 0.0 is not x for x = -0.0): the same float in every instantiation
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
     const float mean = sum / (float)(D4 * 4);
@@ -982,7 +1012,9 @@ __global__ __launch_bounds__(256) void splitk_combine_ln_kernel(const float* __r
     }
     float sum = 0.f;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) sum += i < NI ? v[i < NI ? i : 0][0] + v[i < NI ? i : 0][1] + v[i < NI ? i : 0][2] + v[i < NI ? i : 0][3] : 0.f;
+    for (int i = 0; i < NI; ++i) sum += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+#pragma unroll
+    for (int i = NI; i < 4; ++i) sum += 0.f;  // four terms whatever NI is (x + 0.0 is not x for x = -0.0): the same float in every instantiation
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
     const float mean = sum / (float)(D4 * 4);
